@@ -1,0 +1,319 @@
+"""ctypes front-end of the CPU oracle (oracle/liboracle.so) and of oracle/_ref.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg — never from the product package ``dynfu_amd``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+
+def build(force=False):
+    """Compile liboracle.so (and _ref/ when the reference checkout is present)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc", ".cpp"))]
+    stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    ref_so = os.path.join(_HERE, "_ref", "libref_knn.so")
+    if stale or (not os.path.exists(ref_so) and os.path.exists("/root/reference/include/nanoflann/nanoflann.hpp")):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _declare(_LIB)
+    return _LIB
+
+
+def ref_lib():
+    """The reference's own nanoflann k-NN (oracle/_ref/libref_knn.so); None if not built."""
+    global _REF
+    if _REF is None:
+        p = os.path.join(_HERE, "_ref", "libref_knn.so")
+        if not os.path.exists(p):
+            build()
+        if not os.path.exists(p):
+            return None
+        _REF = C.CDLL(p)
+        _REF.ref_knn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _REF.ref_knn.restype = None
+    return _REF
+
+
+class SolveParams(C.Structure):
+    _fields_ = [
+        ("num_iter", C.c_int),
+        ("nonlinear_iter", C.c_int),
+        ("linear_iter", C.c_int),
+        ("tukey_offset", C.c_float),
+        ("psi_data", C.c_float),
+        ("lambda_", C.c_float),
+        ("psi_reg", C.c_float),
+        ("pcg_tol", C.c_float),
+        ("gn_tol", C.c_float),
+        ("use_double", C.c_int),
+        ("threads", C.c_int),
+    ]
+
+
+class SolveStats(C.Structure):
+    _fields_ = [
+        ("initial_cost", C.c_double),
+        ("final_cost", C.c_double),
+        ("grad_first", C.c_double),
+        ("gn_iters", C.c_int),
+        ("pcg_iters", C.c_int),
+    ]
+
+
+def _declare(L):
+    vp, i, f = C.c_void_p, C.c_int, C.c_float
+    L.orc_float_to_half.argtypes = [f]
+    L.orc_float_to_half.restype = C.c_uint16
+    L.orc_half_to_float.argtypes = [C.c_uint16]
+    L.orc_half_to_float.restype = f
+    L.orc_compute_dists.argtypes = [vp, i, vp, i, i, i, f, f, f, f]
+    L.orc_compute_dists.restype = None
+    L.orc_tsdf_clear.argtypes = [vp, i, i, i]
+    L.orc_tsdf_clear.restype = None
+    L.orc_tsdf_integrate.argtypes = [vp, i, i, i, vp, i, i, i, vp, f, i, vp, f, f, f, f, i]
+    L.orc_tsdf_integrate.restype = C.c_long
+    L.orc_tsdf_raycast_points.argtypes = [vp, i, i, i, vp, f, vp, vp, f, f, f, f, f, f, vp, i, vp, i, i, i, i]
+    L.orc_tsdf_raycast_points.restype = None
+    L.orc_tsdf_raycast_depth.argtypes = [vp, i, i, i, vp, f, vp, vp, f, f, f, f, f, f, vp, i, vp, i, i, i, i]
+    L.orc_tsdf_raycast_depth.restype = None
+    L.orc_dq_from_euler.argtypes = [f, f, f, f, f, f, vp]
+    L.orc_dq_from_quat_trans.argtypes = [vp, vp, vp]
+    L.orc_dq_from_rodrigues.argtypes = [vp, vp, vp]
+    for n in ("add", "sub", "mul"):
+        getattr(L, "orc_dq_" + n).argtypes = [vp, vp, vp]
+    L.orc_dq_scale.argtypes = [vp, f, vp]
+    L.orc_dq_normalize.argtypes = [vp, vp]
+    L.orc_dq_get_translation.argtypes = [vp, vp]
+    L.orc_dq_transform_vertex.argtypes = [vp, vp, vp]
+    L.orc_dq_get_rodrigues.argtypes = [vp, vp]
+    for n in ("roll", "pitch", "yaw"):
+        getattr(L, "orc_dq_" + n).argtypes = [vp]
+        getattr(L, "orc_dq_" + n).restype = f
+    L.orc_knn.argtypes = [vp, i, vp, i, i, vp, i]
+    L.orc_transformation_weight.argtypes = [vp, f, vp]
+    L.orc_transformation_weight.restype = f
+    L.orc_calc_dqb.argtypes = [vp, vp, vp, i, i, vp, vp]
+    L.orc_warp_to_live.argtypes = [vp, vp, vp, i, i, vp, vp, i, vp, vp, i]
+    L.orc_solve_ref.argtypes = [vp, vp, vp, i, i, vp, vp, i, C.POINTER(SolveParams), vp, vp, C.POINTER(SolveStats)]
+    L.orc_tukey_weights.argtypes = [vp, vp, vp, i, i, vp, vp, i, f, f, vp, i]
+    L.orc_huber_weights.argtypes = [vp, vp, vp, i, i, f, vp]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ------------------------------------------------------------------ half / TSDF ----
+def float_to_half(x):
+    return int(lib().orc_float_to_half(float(np.float32(x))))
+
+
+def half_to_float(h):
+    return float(lib().orc_half_to_float(int(h)))
+
+
+def compute_dists(depth, fx, fy, cx, cy):
+    depth = np.ascontiguousarray(depth, dtype=np.uint16)
+    rows, cols = depth.shape
+    out = np.empty_like(depth)
+    lib().orc_compute_dists(_p(depth), depth.strides[0], _p(out), out.strides[0], cols, rows, fx, fy, cx, cy)
+    return out
+
+
+def tsdf_integrate(vol, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, cx, cy, threads=1):
+    """vol: uint32 (Z,Y,X) contiguous, updated in place. Returns #updated voxels."""
+    assert vol.dtype == np.uint32 and vol.flags.c_contiguous
+    Z, Y, X = vol.shape
+    dists = np.ascontiguousarray(dists, dtype=np.uint16)
+    rows, cols = dists.shape
+    vs, a = _f32(voxel_size), _f32(vol2cam).reshape(-1)
+    return int(lib().orc_tsdf_integrate(_p(dists), dists.strides[0], cols, rows, _p(vol), X, Y, Z, _p(vs), trunc,
+                                        max_weight, _p(a), fx, fy, cx, cy, threads))
+
+
+def tsdf_raycast_points(vol, voxel_size, trunc, cam2vol, Rinv, fx, fy, cx, cy, step_factor, delta_factor, cols,
+                        rows, threads=1):
+    Z, Y, X = vol.shape
+    pts = np.empty((rows, cols, 4), np.float32)
+    nrm = np.empty((rows, cols, 4), np.float32)
+    vs, a, ri = _f32(voxel_size), _f32(cam2vol).reshape(-1), _f32(Rinv).reshape(-1)
+    lib().orc_tsdf_raycast_points(_p(vol), X, Y, Z, _p(vs), trunc, _p(a), _p(ri), fx, fy, cx, cy, step_factor,
+                                  delta_factor, _p(pts), pts.strides[0], _p(nrm), nrm.strides[0], cols, rows, threads)
+    return pts, nrm
+
+
+def tsdf_raycast_depth(vol, voxel_size, trunc, cam2vol, Rinv, fx, fy, cx, cy, step_factor, delta_factor, cols, rows,
+                       threads=1):
+    Z, Y, X = vol.shape
+    dep = np.empty((rows, cols), np.uint16)
+    nrm = np.empty((rows, cols, 4), np.float32)
+    vs, a, ri = _f32(voxel_size), _f32(cam2vol).reshape(-1), _f32(Rinv).reshape(-1)
+    lib().orc_tsdf_raycast_depth(_p(vol), X, Y, Z, _p(vs), trunc, _p(a), _p(ri), fx, fy, cx, cy, step_factor,
+                                 delta_factor, _p(dep), dep.strides[0], _p(nrm), nrm.strides[0], cols, rows, threads)
+    return dep, nrm
+
+
+# ------------------------------------------------------------------ dual quaternion -
+def dq_from_euler(yaw, pitch, roll, x, y, z):
+    out = np.empty(8, np.float32)
+    lib().orc_dq_from_euler(yaw, pitch, roll, x, y, z, _p(out))
+    return out
+
+
+def dq_from_rodrigues(rod, t):
+    out = np.empty(8, np.float32)
+    lib().orc_dq_from_rodrigues(_p(_f32(rod)), _p(_f32(t)), _p(out))
+    return out
+
+
+def _dq_bin(name, a, b):
+    out = np.empty(8, np.float32)
+    getattr(lib(), "orc_dq_" + name)(_p(_f32(a)), _p(_f32(b)), _p(out))
+    return out
+
+
+def dq_add(a, b):
+    return _dq_bin("add", a, b)
+
+
+def dq_sub(a, b):
+    return _dq_bin("sub", a, b)
+
+
+def dq_mul(a, b):
+    return _dq_bin("mul", a, b)
+
+
+def dq_scale(a, s):
+    out = np.empty(8, np.float32)
+    lib().orc_dq_scale(_p(_f32(a)), s, _p(out))
+    return out
+
+
+def dq_normalize(a):
+    out = np.empty(8, np.float32)
+    lib().orc_dq_normalize(_p(_f32(a)), _p(out))
+    return out
+
+
+def dq_transform_vertex(a, v):
+    out = np.empty(3, np.float32)
+    lib().orc_dq_transform_vertex(_p(_f32(a)), _p(_f32(v)), _p(out))
+    return out
+
+
+def dq_get_translation(a):
+    out = np.empty(3, np.float32)
+    lib().orc_dq_get_translation(_p(_f32(a)), _p(out))
+    return out
+
+
+def dq_get_rodrigues(a):
+    out = np.empty(3, np.float32)
+    lib().orc_dq_get_rodrigues(_p(_f32(a)), _p(out))
+    return out
+
+
+def dq_roll(a):
+    return float(lib().orc_dq_roll(_p(_f32(a))))
+
+
+def dq_pitch(a):
+    return float(lib().orc_dq_pitch(_p(_f32(a))))
+
+
+def dq_yaw(a):
+    return float(lib().orc_dq_yaw(_p(_f32(a))))
+
+
+# ------------------------------------------------------------------ warp field -----
+def knn(nodes, query, k, threads=1):
+    nodes, query = _f32(nodes), _f32(query)
+    idx = np.empty((len(query), k), np.int32)
+    lib().orc_knn(_p(nodes), len(nodes), _p(query), len(query), k, _p(idx), threads)
+    return idx
+
+
+def ref_knn(nodes, query, k):
+    """k-NN by the reference's vendored nanoflann. Returns (idx, dist_sqr)."""
+    R = ref_lib()
+    if R is None:
+        return None
+    nodes, query = _f32(nodes), _f32(query)
+    idx = np.empty((len(query), k), np.int32)
+    d = np.empty((len(query), k), np.float32)
+    R.ref_knn(_p(nodes), len(nodes), _p(query), len(query), k, _p(idx), _p(d))
+    return idx, d
+
+
+def transformation_weight(g, dg_w, v):
+    return float(lib().orc_transformation_weight(_p(_f32(g)), dg_w, _p(_f32(v))))
+
+
+def calc_dqb(node_pos, node_dq, node_w, k, p):
+    node_pos, node_dq, node_w = _f32(node_pos), _f32(node_dq), _f32(node_w)
+    out = np.empty(8, np.float32)
+    lib().orc_calc_dqb(_p(node_pos), _p(node_dq), _p(node_w), len(node_pos), k, _p(_f32(p)), _p(out))
+    return out
+
+
+def warp_to_live(node_pos, node_dq, node_w, k, verts, normals=None, threads=1):
+    node_pos, node_dq, node_w, verts = _f32(node_pos), _f32(node_dq), _f32(node_w), _f32(verts)
+    ov = np.empty_like(verts)
+    on = None
+    if normals is not None:
+        normals = _f32(normals)
+        on = np.empty_like(normals)
+    lib().orc_warp_to_live(_p(node_pos), _p(node_dq), _p(node_w), len(node_pos), k, _p(verts), _p(normals),
+                           len(verts), _p(ov), _p(on), threads)
+    return ov, on
+
+
+def tukey_weights(node_pos, node_dq, node_w, k, canon, live, tukey_offset, psi_data, threads=1):
+    node_pos, node_dq, node_w, canon, live = map(_f32, (node_pos, node_dq, node_w, canon, live))
+    out = np.empty(len(canon), np.float32)
+    lib().orc_tukey_weights(_p(node_pos), _p(node_dq), _p(node_w), len(node_pos), k, _p(canon), _p(live), len(canon),
+                            tukey_offset, psi_data, _p(out), threads)
+    return out
+
+
+def huber_weights(node_pos, node_dq, node_w, k, psi_reg):
+    node_pos, node_dq, node_w = map(_f32, (node_pos, node_dq, node_w))
+    out = np.empty(len(node_pos), np.float32)
+    lib().orc_huber_weights(_p(node_pos), _p(node_dq), _p(node_w), len(node_pos), k, psi_reg, _p(out))
+    return out
+
+
+def solve_ref(node_pos, node_dq, node_w, k, canon, live, num_iter=1, nonlinear_iter=1, linear_iter=256,
+              tukey_offset=4.652, psi_data=0.01, lambda_=0.0, psi_reg=1e-4, pcg_tol=0.0, gn_tol=0.0, use_double=True,
+              threads=1):
+    """Returns (translations Dx3, node_dq_out Dx8, stats dict)."""
+    node_pos, node_dq, node_w, canon, live = map(_f32, (node_pos, node_dq, node_w, canon, live))
+    D, N = len(node_pos), len(canon)
+    prm = SolveParams(num_iter, nonlinear_iter, linear_iter, tukey_offset, psi_data, lambda_, psi_reg, pcg_tol, gn_tol,
+                      1 if use_double else 0, threads)
+    st = SolveStats()
+    t = np.zeros((D, 3), np.float32)
+    dq_out = np.zeros((D, 8), np.float32)
+    lib().orc_solve_ref(_p(node_pos), _p(node_dq), _p(node_w), D, k, _p(canon), _p(live), N, C.byref(prm), _p(t),
+                        _p(dq_out), C.byref(st))
+    return t, dq_out, dict(initial_cost=st.initial_cost, final_cost=st.final_cost, gn_iters=st.gn_iters,
+                           pcg_iters=st.pcg_iters)

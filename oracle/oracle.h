@@ -1,0 +1,157 @@
+/*
+ * oracle.h — CPU restatement of the dynfu warp-solve + TSDF-fuse hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load liboracle.so; the product path
+ * (dynfu_amd/, include/dynfu_amd.h) never links or calls anything in this directory.
+ *
+ * Each function cites the reference file:line it restates (paths relative to the
+ * reference checkout, swarth100/dynfu).  Arithmetic conventions (shared with the HIP
+ * kernels so integer/half results can be compared bit-exactly):
+ *   - IEEE-754 binary32, round-to-nearest-even, subnormals kept, no FMA contraction
+ *     except where written as fmaf() — those are the places where nvcc's default
+ *     -fmad=true would fuse the reference's a*b+c;
+ *   - the reference's approximate CUDA intrinsics (__fdividef, rsqrt, --prec-div=false,
+ *     CMakeLists.txt:76-78) are replaced by the correctly-rounded operation they
+ *     approximate ( / , 1/sqrtf );
+ *   - half conversion is software round-to-nearest-even (== __float2half_rn).
+ *
+ * Pinning status:
+ *   dual quaternions  : pinned  — 21 known-answer tests of test/quaternion_test.cpp
+ *   k-NN graph        : pinned  — against the reference's own vendored nanoflann
+ *                                 (oracle/_ref, built from /root/reference/include/nanoflann)
+ *   warp-field solve  : pinned  — the 8 OptTest end-state assertions of
+ *                                 test/opt_optimisation_test.cpp (tolerance 1e-3)
+ *   TSDF / raycast / compute_dists : PARITY UNPINNED — the reference has no tests,
+ *                                 golden vectors or CPU path for them and its CUDA
+ *                                 sources cannot be built here.
+ */
+#ifndef DYNFU_ORACLE_H
+#define DYNFU_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- half ---- */
+uint16_t orc_float_to_half(float f);  /* __float2half_rn, device.hpp:59-61 */
+float orc_half_to_float(uint16_t h);  /* __half2float,    device.hpp:63-67 */
+
+/* ---------------------------------------------------------------- TSDF ---- */
+/* Volume element = {u16 half-bits tsdf, u16 weight} packed little-endian in a
+ * uint32 (internal.hpp:36-55, device.hpp:59-67); idx = x + y*X + z*X*Y
+ * (device.hpp:20-35). Affine = 12 floats: R row-major (9) then t (3). */
+
+/* imgproc.cu:233-245 (+ host imgproc.cpp:38-41). Steps are in BYTES. */
+void orc_compute_dists(const uint16_t* depth, int depth_step, uint16_t* dists, int dists_step, int cols, int rows,
+                       float fx, float fy, float cx, float cy);
+
+/* tsdf_volume.cu:11-22 */
+void orc_tsdf_clear(uint32_t* vol, int X, int Y, int Z);
+
+/* tsdf_volume.cu:43-121. Returns number of voxels updated. threads<=1: serial. */
+long orc_tsdf_integrate(const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* vol, int X, int Y, int Z,
+                        const float voxel_size[3], float trunc_dist, int max_weight, const float vol2cam[12], float fx,
+                        float fy, float cx, float cy, int threads);
+
+/* tsdf_volume.cu:128-386 (points variant :258-318): points/normals are float4
+ * images, steps in BYTES; misses are quiet-NaN. */
+void orc_tsdf_raycast_points(const uint32_t* vol, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
+                             const float cam2vol[12], const float Rinv[9], float fx, float fy, float cx, float cy,
+                             float step_factor, float delta_factor, float* points, int points_step, float* normals,
+                             int normals_step, int cols, int rows, int threads);
+
+/* depth variant :195-256: depth u16 millimetres (0 on miss) + normals float4. */
+void orc_tsdf_raycast_depth(const uint32_t* vol, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
+                            const float cam2vol[12], const float Rinv[9], float fx, float fy, float cx, float cy,
+                            float step_factor, float delta_factor, uint16_t* depth, int depth_step, float* normals,
+                            int normals_step, int cols, int rows, int threads);
+
+/* ------------------------------------------------------- dual quaternion -- */
+/* DualQuaternion<float> (include/dynfu/utils/dual_quaternion.hpp). Storage:
+ * 8 floats = real (w,x,y,z) then dual (w,x,y,z); Hamilton product as
+ * boost::math::quaternion. */
+void orc_dq_from_euler(float yaw, float pitch, float roll, float x, float y, float z, float out[8]); /* :48-67 */
+void orc_dq_from_quat_trans(const float q[4], const float t[3], float out[8]);                       /* :42-45 */
+void orc_dq_from_rodrigues(const float rod[3], const float t[3], float out[8]);                      /* :70-86 */
+void orc_dq_add(const float a[8], const float b[8], float out[8]);                                   /* :99-107 */
+void orc_dq_sub(const float a[8], const float b[8], float out[8]);                                   /* :109-117 */
+void orc_dq_scale(const float a[8], float s, float out[8]);                                          /* :120-125 */
+void orc_dq_mul(const float a[8], const float b[8], float out[8]);                                   /* :127-135 */
+void orc_dq_normalize(const float a[8], float out[8]);                                               /* :139-144 */
+void orc_dq_get_translation(const float a[8], float out[3]);                                         /* :94-97 */
+void orc_dq_transform_vertex(const float a[8], const float v[3], float out[3]);                      /* :204-215 */
+float orc_dq_roll(const float a[8]);                                                                 /* :148-160 */
+float orc_dq_pitch(const float a[8]);                                                                /* :162-176 */
+float orc_dq_yaw(const float a[8]);                                                                  /* :178-190 */
+void orc_dq_get_rodrigues(const float a[8], float out[3]);                                           /* :194-200 */
+
+/* ------------------------------------------------------------ warp field -- */
+/* Exact k-NN, ascending L2^2, ties broken by lower node index (nanoflann keeps
+ * the first-found candidate on ties, nanoflann.hpp:104-111; equal to this
+ * except on exact distance ties). warp_field.cpp:111-122. idx is (n_query x k)
+ * row-major int32, -1 padded when D<k. Returns nothing. */
+void orc_knn(const float* nodes, int D, const float* query, int n_query, int k, int32_t* idx, int threads);
+
+/* node.cpp:29-36: w = exp(-|g-v|^2 / (2 dg_w^2)), evaluated in double, rounded to float. */
+float orc_transformation_weight(const float g[3], float dg_w, const float v[3]);
+
+/* warp_field.cpp:127-148: DQ "blend" = ordered product of the k neighbours'
+ * dual-scaled transforms, real part normalised. node_dq is D x 8. */
+void orc_calc_dqb(const float* node_pos, const float* node_dq, const float* node_w, int D, int k, const float p[3],
+                  float out[8]);
+
+/* warp_field.cpp:150-171: warped vertices and "normals" (normals transformed as
+ * points — reference quirk). */
+void orc_warp_to_live(const float* node_pos, const float* node_dq, const float* node_w, int D, int k,
+                      const float* verts, const float* normals, int N, float* out_verts, float* out_normals,
+                      int threads);
+
+/* ----------------------------------------------------------------- solve -- */
+typedef struct {
+    int num_iter;        /* outer iterations: Tukey/Huber re-weighting (CombinedSolverParameters.numIter)      */
+    int nonlinear_iter;  /* Gauss-Newton iterations per outer iteration (nonLinearIter)                        */
+    int linear_iter;     /* max PCG iterations per GN iteration (linearIter)                                   */
+    float tukey_offset;  /* opt_solver.cpp:204-212 */
+    float psi_data;      /* Tukey cut-off c */
+    float lambda;        /* regularisation weight; w_reg = sqrt(lambda/(D*k)) opt_solver.cpp:30 */
+    float psi_reg;       /* Huber k (computed, unused by energy.t) */
+    float pcg_tol;       /* relative preconditioned-residual tolerance, 0 = run linear_iter iterations */
+    float gn_tol;        /* relative cost-decrease tolerance, 0 = run all GN iterations */
+    int use_double;      /* 1: accumulate in double (reference tests: optDoublePrecision=true) */
+    int threads;
+} orc_solve_params;
+
+typedef struct {
+    double initial_cost;
+    double final_cost;
+    double grad_first; /* g.M^-1.g of the first linearisation (scale for the convergence floor) */
+    int gn_iters;      /* total GN iterations executed */
+    int pcg_iters;     /* total PCG iterations executed */
+} orc_solve_stats;
+
+/* Reference-parity solve (energy.t:19-78 + opt_solver.cpp:15-285).
+ *   node_pos D x 3, node_dq D x 8 (current dg_se3, used for the Tukey weights
+ *   exactly as updateTukeyBiweights does), node_w D;
+ *   canon/live N x 3. Output: translations D x 3 (the Opt unknown), and — if
+ *   node_dq_out != NULL — the written-back transforms DQ(t_i) * dg_se3_i
+ *   (opt_solver.cpp:270-285, node.cpp:19-23), composed ONCE. */
+void orc_solve_ref(const float* node_pos, const float* node_dq, const float* node_w, int D, int k, const float* canon,
+                   const float* live, int N, const orc_solve_params* prm, float* translations, float* node_dq_out,
+                   orc_solve_stats* stats);
+
+/* Building blocks, exposed for kernel-level parity tests. */
+/* opt_solver.cpp:204-231 */
+void orc_tukey_weights(const float* node_pos, const float* node_dq, const float* node_w, int D, int k,
+                       const float* canon, const float* live, int N, float tukey_offset, float psi_data, float* tukey,
+                       int threads);
+/* opt_solver.cpp:233-268 */
+void orc_huber_weights(const float* node_pos, const float* node_dq, const float* node_w, int D, int k, float psi_reg,
+                       float* huber);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,106 @@
+/*
+ * warp_oracle.c — CPU restatement of the warp-field model: k-NN of deformation nodes,
+ * radial-basis transformation weight, the reference's dual-quaternion "blend"
+ * (an ordered product, see below) and warpToLive.
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * Follows src/dynfu/warp_field.cpp:99-171, src/dynfu/utils/node.cpp:19-36.
+ * k-NN is pinned against the reference's vendored nanoflann (oracle/_ref/libref_knn.so,
+ * tests/test_oracle_knn.py); the DQ algebra by tests/test_oracle_dq.py.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "oracle.h"
+
+/* ------------------------------------------------------------------------------------ */
+/* warp_field.cpp:111-122 (nanoflann knnSearch, L2_Simple_Adaptor: squared distance
+ * accumulated as d0*d0 + d1*d1 + d2*d2 in float, nanoflann.hpp L2_Simple_Adaptor::accum_dist) */
+
+static inline float dist2(const float* a, const float* b) {
+    float d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
+    return (d0 * d0 + d1 * d1) + d2 * d2;
+}
+
+static void knn_one(const float* nodes, int D, const float* q, int k, int32_t* idx, float* dist) {
+    int count = 0;
+    for (int i = 0; i < D; ++i) {
+        float d = dist2(q, nodes + 3 * i);
+        /* KNNResultSet::addPoint (nanoflann.hpp:88-122): stable insertion, ascending;
+         * an equal distance is placed AFTER the ones already held */
+        int j;
+        for (j = count; j > 0; --j) {
+            if (dist[j - 1] > d) {
+                if (j < k) {
+                    dist[j] = dist[j - 1];
+                    idx[j]  = idx[j - 1];
+                }
+            } else
+                break;
+        }
+        if (j < k) {
+            dist[j] = d;
+            idx[j]  = i;
+        }
+        if (count < k) count++;
+    }
+    for (int j = count; j < k; ++j) idx[j] = -1;
+}
+
+void orc_knn(const float* nodes, int D, const float* query, int n_query, int k, int32_t* idx, int threads) {
+    (void)threads;
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+    for (int v = 0; v < n_query; ++v) {
+        float dist[64];
+        knn_one(nodes, D, query + 3 * (size_t)v, k, idx + (size_t)v * k, dist);
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* node.cpp:29-36 — pow(float,int) and exp() are evaluated in double, result stored to float */
+
+float orc_transformation_weight(const float g[3], float dg_w, const float v[3]) {
+    double dx = (double)(g[0] - v[0]), dy = (double)(g[1] - v[1]), dz = (double)(g[2] - v[2]);
+    double dist_sq = dx * dx + dy * dy + dz * dz;
+    double w       = (double)dg_w;
+    return (float)exp(-dist_sq / (2 * (w * w)));
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* warp_field.cpp:127-148 */
+
+void orc_calc_dqb(const float* node_pos, const float* node_dq, const float* node_w, int D, int k, const float p[3],
+                  float out[8]) {
+    int32_t idx[64];
+    float dist[64];
+    knn_one(node_pos, D, p, k, idx, dist);
+    /* transformationSum(0,0,0,0,0,0) = identity (:133) */
+    float sum[8] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < k; ++j) {
+        int n = idx[j];
+        if (n < 0) break;
+        float w = orc_transformation_weight(node_pos + 3 * n, node_w[n], p);
+        float weighted[8], prod[8];
+        orc_dq_scale(node_dq + 8 * n, w, weighted); /* :139 dual part scaled only */
+        orc_dq_mul(sum, weighted, prod);            /* :141 transformationSum *= weighted */
+        memcpy(sum, prod, sizeof(sum));
+    }
+    orc_dq_normalize(sum, out); /* :145 */
+}
+
+/* warp_field.cpp:150-171 */
+void orc_warp_to_live(const float* node_pos, const float* node_dq, const float* node_w, int D, int k,
+                      const float* verts, const float* normals, int N, float* out_verts, float* out_normals,
+                      int threads) {
+    (void)threads;
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+    for (int i = 0; i < N; ++i) {
+        float dq[8];
+        orc_calc_dqb(node_pos, node_dq, node_w, D, k, verts + 3 * (size_t)i, dq);
+        orc_dq_transform_vertex(dq, verts + 3 * (size_t)i, out_verts + 3 * (size_t)i);
+        /* transformNormal uses the same formula as transformVertex (dual_quaternion.hpp:217-228) */
+        if (normals && out_normals)
+            orc_dq_transform_vertex(dq, normals + 3 * (size_t)i, out_normals + 3 * (size_t)i);
+    }
+}
