@@ -1,0 +1,15 @@
+"""dynfu_amd — MI355X-native (gfx950) TSDF fusion + warp-field solve behind a C ABI.
+
+This package is plumbing only: it loads ``libdynfu_amd.so`` (hand-written HIP kernels +
+the C ABI of ``include/dynfu_amd.h``) and exposes the entry points on torch CUDA tensors
+(torch is used for device memory and streams, nothing else).  There is NO CPU fallback: if
+the library is missing or no GPU is visible every compute call raises.
+"""
+from . import _lib
+from ._lib import (DynfuAmdError, SolveParams, Solver, compute_dists, knn, lib_path, load, tsdf_clear,
+                   tsdf_clear_integrate, tsdf_integrate, tsdf_raycast_depth, tsdf_raycast_points, version,
+                   warp_to_live)
+
+__all__ = ["DynfuAmdError", "SolveParams", "Solver", "compute_dists", "knn", "lib_path", "load", "tsdf_clear",
+           "tsdf_clear_integrate", "tsdf_integrate", "tsdf_raycast_depth", "tsdf_raycast_points", "version",
+           "warp_to_live", "_lib"]

@@ -1,0 +1,292 @@
+"""ctypes binding of include/dynfu_amd.h.  Tensors are torch CUDA tensors (device memory +
+stream plumbing only); every function launches on torch's current stream."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# every symbol include/dynfu_amd.h declares (tests/test_capi_symbols.py checks the .so exports them)
+SYMBOLS = [
+    "dfa_last_error", "dfa_version", "dfa_compute_dists", "dfa_tsdf_clear", "dfa_tsdf_integrate",
+    "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_knn", "dfa_warp_to_live",
+    "dfa_solver_create", "dfa_solver_destroy", "dfa_solver_set_problem", "dfa_solver_solve",
+    "dfa_solver_translations", "dfa_solver_node_dq", "dfa_solver_tukey_weights", "dfa_solver_huber_weights",
+    "dfa_solver_data_graph", "dfa_solver_reg_graph", "dfa_solver_get_stats",
+]
+
+
+class DynfuAmdError(RuntimeError):
+    pass
+
+
+class SolveParams(C.Structure):
+    """dfa_solve_params"""
+    _fields_ = [("num_iter", C.c_int), ("nonlinear_iter", C.c_int), ("linear_iter", C.c_int),
+                ("tukey_offset", C.c_float), ("psi_data", C.c_float), ("lambda_", C.c_float), ("psi_reg", C.c_float),
+                ("pcg_tol", C.c_float), ("gn_tol", C.c_float)]
+
+
+class _SolveStats(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("gn_iters", C.c_int),
+                ("pcg_iters", C.c_int), ("max_row_nnz", C.c_int), ("reserved", C.c_int)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libdynfu_amd.so")
+
+
+def load():
+    """Loads libdynfu_amd.so; raises (never falls back) when it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    # torch first: its bundled libamdhip64 (SONAME libamdhip64.so.7) must be the HIP runtime this
+    # library binds to, so that torch's streams and device pointers are valid inside it
+    import torch  # noqa: F401
+    p = lib_path()
+    if not os.path.exists(p):
+        raise DynfuAmdError("%s not found: build it with `python dynfu_amd/build.py` "
+                            "(__graft_entry__.build()). There is no CPU fallback." % p)
+    L = C.CDLL(p)
+    vp, i, f = C.c_void_p, C.c_int, C.c_float
+    L.dfa_last_error.restype = C.c_char_p
+    L.dfa_version.restype = C.c_char_p
+    L.dfa_compute_dists.argtypes = [vp, i, vp, i, i, i, f, f, f, f, vp]
+    L.dfa_tsdf_clear.argtypes = [vp, i, i, i, vp]
+    integ = [vp, i, i, i, vp, i, i, i, vp, f, i, vp, f, f, f, f, vp]
+    L.dfa_tsdf_integrate.argtypes = integ
+    L.dfa_tsdf_clear_integrate.argtypes = integ
+    ray = [vp, i, i, i, vp, f, vp, vp, f, f, f, f, f, f, vp, i, vp, i, i, i, vp]
+    L.dfa_tsdf_raycast_points.argtypes = ray
+    L.dfa_tsdf_raycast_depth.argtypes = ray
+    L.dfa_knn.argtypes = [vp, vp, i, vp, i, i, vp, vp, vp]
+    L.dfa_warp_to_live.argtypes = [vp, vp, vp, i, i, vp, vp, i, vp, vp, vp]
+    L.dfa_solver_create.argtypes = [i, i, i, C.POINTER(vp)]
+    L.dfa_solver_destroy.argtypes = [vp]
+    L.dfa_solver_destroy.restype = None
+    L.dfa_solver_set_problem.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, i, vp]
+    L.dfa_solver_solve.argtypes = [vp, C.POINTER(SolveParams), vp]
+    for n in ("translations", "node_dq", "tukey_weights", "huber_weights", "data_graph", "reg_graph"):
+        fn = getattr(L, "dfa_solver_" + n)
+        fn.argtypes = [vp]
+        fn.restype = vp
+    L.dfa_solver_get_stats.argtypes = [vp, C.POINTER(_SolveStats), vp]
+    runtimes = set()
+    with open("/proc/self/maps") as maps:
+        for line in maps:
+            if "libamdhip64" in line:
+                runtimes.add(line.split()[-1])
+    if len(runtimes) > 1:
+        raise DynfuAmdError("two HIP runtimes are mapped in this process: %s" % sorted(runtimes))
+    _LIB = L
+    return L
+
+
+def version():
+    return load().dfa_version().decode()
+
+
+def _check(rc):
+    if rc != 0:
+        raise DynfuAmdError("dynfu_amd error %d: %s" % (rc, load().dfa_last_error().decode()))
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise DynfuAmdError("no GPU visible: dynfu_amd has no CPU path")
+    return torch
+
+
+def _stream():
+    return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype=None, name="tensor"):
+    torch = _torch()
+    if t is None:
+        return None
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise DynfuAmdError("%s must be a CUDA tensor" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise DynfuAmdError("%s must have dtype %s, got %s" % (name, dtype, t.dtype))
+    return C.c_void_p(t.data_ptr())
+
+
+def _farr(vals, n):
+    a = (C.c_float * n)(*[float(v) for v in vals])
+    return a
+
+
+def _aff12(m):
+    """accepts 12 floats (R row-major then t) or a (3x4)/(4x4) array [R|t]"""
+    import numpy as np
+    m = np.asarray(m, dtype=np.float32)
+    if m.size == 12 and m.ndim == 1:
+        return _farr(m, 12)
+    m = m.reshape(-1, 4)[:3]
+    return _farr(list(m[:, :3].reshape(-1)) + list(m[:, 3]), 12)
+
+
+# ------------------------------------------------------------------------------- TSDF seam
+def compute_dists(depth, dists, fx, fy, cx, cy):
+    torch = _torch()
+    rows, cols = depth.shape
+    _check(load().dfa_compute_dists(_dev(depth, torch.uint16, "depth"), depth.stride(0) * 2,
+                                    _dev(dists, torch.uint16, "dists"), dists.stride(0) * 2, cols, rows, fx, fy, cx, cy,
+                                    _stream()))
+
+
+def _vol_dims(vol):
+    torch = _torch()
+    if vol.dtype not in (torch.uint32, torch.int32) or vol.dim() != 3 or not vol.is_contiguous():
+        raise DynfuAmdError("volume must be a contiguous (Z, Y, X) 32-bit tensor")
+    Z, Y, X = vol.shape
+    return X, Y, Z
+
+
+def tsdf_clear(vol):
+    X, Y, Z = _vol_dims(vol)
+    _check(load().dfa_tsdf_clear(_dev(vol), X, Y, Z, _stream()))
+
+
+def _integrate(fn, vol, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, cx, cy):
+    torch = _torch()
+    X, Y, Z = _vol_dims(vol)
+    rows, cols = dists.shape
+    _check(fn(_dev(dists, torch.uint16, "dists"), dists.stride(0) * 2, cols, rows, _dev(vol), X, Y, Z,
+              _farr(voxel_size, 3), trunc, max_weight, _aff12(vol2cam), fx, fy, cx, cy, _stream()))
+
+
+def tsdf_integrate(vol, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, cx, cy):
+    _integrate(load().dfa_tsdf_integrate, vol, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, cx, cy)
+
+
+def tsdf_clear_integrate(vol, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, cx, cy):
+    _integrate(load().dfa_tsdf_clear_integrate, vol, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, cx, cy)
+
+
+def tsdf_raycast_points(vol, voxel_size, trunc, cam2vol, Rinv, fx, fy, cx, cy, step_factor, delta_factor, points,
+                        normals):
+    torch = _torch()
+    X, Y, Z = _vol_dims(vol)
+    rows, cols = points.shape[:2]
+    _check(load().dfa_tsdf_raycast_points(_dev(vol), X, Y, Z, _farr(voxel_size, 3), trunc, _aff12(cam2vol),
+                                          _farr(list(map(float, _flat(Rinv))), 9), fx, fy, cx, cy, step_factor,
+                                          delta_factor, _dev(points, torch.float32, "points"), points.stride(0) * 4,
+                                          _dev(normals, torch.float32, "normals"), normals.stride(0) * 4, cols, rows,
+                                          _stream()))
+
+
+def tsdf_raycast_depth(vol, voxel_size, trunc, cam2vol, Rinv, fx, fy, cx, cy, step_factor, delta_factor, depth,
+                       normals):
+    torch = _torch()
+    X, Y, Z = _vol_dims(vol)
+    rows, cols = depth.shape[:2]
+    _check(load().dfa_tsdf_raycast_depth(_dev(vol), X, Y, Z, _farr(voxel_size, 3), trunc, _aff12(cam2vol),
+                                         _farr(list(map(float, _flat(Rinv))), 9), fx, fy, cx, cy, step_factor,
+                                         delta_factor, _dev(depth, torch.uint16, "depth"), depth.stride(0) * 2,
+                                         _dev(normals, torch.float32, "normals"), normals.stride(0) * 4, cols, rows,
+                                         _stream()))
+
+
+def _flat(m):
+    import numpy as np
+    return np.asarray(m, dtype=np.float32).reshape(-1)
+
+
+# -------------------------------------------------------------------------- warp-field seam
+def knn(node_pos, node_w, query, k, want_weights=True):
+    torch = _torch()
+    D, n = node_pos.shape[0], query.shape[0]
+    idx = torch.empty((n, k), dtype=torch.int32, device=query.device)
+    w = torch.empty((n, k), dtype=torch.float32, device=query.device) if want_weights else None
+    _check(load().dfa_knn(_dev(node_pos, torch.float32, "node_pos"), _dev(node_w, torch.float32, "node_w"), D,
+                          _dev(query, torch.float32, "query"), n, k, _dev(idx), _dev(w), _stream()))
+    return idx, w
+
+
+def warp_to_live(node_pos, node_dq, node_w, k, verts, normals=None):
+    torch = _torch()
+    out_v = torch.empty_like(verts)
+    out_n = torch.empty_like(normals) if normals is not None else None
+    _check(load().dfa_warp_to_live(_dev(node_pos, torch.float32, "node_pos"), _dev(node_dq, torch.float32, "node_dq"),
+                                   _dev(node_w, torch.float32, "node_w"), node_pos.shape[0], k,
+                                   _dev(verts, torch.float32, "verts"), _dev(normals, torch.float32, "normals"),
+                                   verts.shape[0], _dev(out_v), _dev(out_n), _stream()))
+    return out_v, out_n
+
+
+# ------------------------------------------------------------------------------ solver seam
+class Solver:
+    """dfa_solver plan.  Mirrors CombinedSolver's life cycle: set_problem == initializeProblemInstance,
+    solve == solveAll; results stay on the device."""
+
+    def __init__(self, max_D, max_N, k):
+        _torch()
+        self._h = C.c_void_p()
+        self.k, self.max_D, self.max_N = k, max_D, max_N
+        _check(load().dfa_solver_create(max_D, max_N, k, C.byref(self._h)))
+        self._keep = None
+        self.D = self.N = 0
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            load().dfa_solver_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def set_problem(self, node_pos, node_dq, node_w, canon, live, canon_normals=None, live_normals=None):
+        torch = _torch()
+        f32 = torch.float32
+        self.D, self.N = node_pos.shape[0], canon.shape[0]
+        self._keep = (node_pos, node_dq, node_w, canon, live, canon_normals, live_normals)  # borrowed by the plan
+        _check(load().dfa_solver_set_problem(self._h, _dev(node_pos, f32, "node_pos"), _dev(node_dq, f32, "node_dq"),
+                                             _dev(node_w, f32, "node_w"), self.D, _dev(canon, f32, "canon"),
+                                             _dev(canon_normals, f32), _dev(live, f32, "live"),
+                                             _dev(live_normals, f32), self.N, _stream()))
+
+    def solve(self, params):
+        _check(load().dfa_solver_solve(self._h, C.byref(params), _stream()))
+
+    def _view(self, name, shape, dtype):
+        """Copy of a plan-owned device array as a torch tensor (zero-copy view, then clone)."""
+        torch = _torch()
+        n = 1
+        for d in shape:
+            n *= d
+        if n == 0:
+            return torch.empty(shape, dtype=dtype, device="cuda")
+        ptr = getattr(load(), "dfa_solver_" + name)(self._h)
+        typestr = {torch.float32: "<f4", torch.int32: "<i4"}[dtype]
+
+        class _Holder:
+            __cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(int(ptr), False), version=2)
+
+        return torch.as_tensor(_Holder(), device="cuda").clone()
+
+    def translations(self):
+        return self._view("translations", (self.D, 3), _torch().float32)
+
+    def node_dq(self):
+        return self._view("node_dq", (self.D, 8), _torch().float32)
+
+    def tukey_weights(self):
+        return self._view("tukey_weights", (self.N,), _torch().float32)
+
+    def huber_weights(self):
+        return self._view("huber_weights", (self.D,), _torch().float32)
+
+    def data_graph(self):
+        return self._view("data_graph", (self.N, self.k), _torch().int32)
+
+    def reg_graph(self):
+        return self._view("reg_graph", (self.D, self.k), _torch().int32)
+
+    def stats(self):
+        st = _SolveStats()
+        _check(load().dfa_solver_get_stats(self._h, C.byref(st), _stream()))
+        return dict(initial_cost=st.initial_cost, final_cost=st.final_cost, gn_iters=st.gn_iters,
+                    pcg_iters=st.pcg_iters, max_row_nnz=st.max_row_nnz)

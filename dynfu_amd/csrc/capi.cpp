@@ -1,0 +1,313 @@
+// capi.cpp — the C ABI declared in include/dynfu_amd.h: argument checking, error strings,
+// the solver plan's device memory, and the per-frame launch sequences.  No arithmetic lives
+// here; the kernels are in tsdf.hip / warp.hip / solve.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/dynfu_amd.h"
+#include "kernels.hpp"
+#include "solve.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    return fail(e == hipErrorNoDevice ? DFA_ERR_NO_GPU : DFA_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define REQUIRE(cond, msg) \
+    if (!(cond)) return fail(DFA_ERR_INVALID, "%s: %s", __func__, msg)
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t e_ = (expr);                        \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+    } while (0)
+
+inline hipStream_t S(dfa_stream_t s) { return (hipStream_t)s; }
+
+bool volume_args_ok(const void* vol, int X, int Y, int Z) { return vol && X > 0 && Y > 0 && Z > 0; }
+
+}  // namespace
+
+struct dfa_solver {
+    int max_D, max_N, k;
+    size_t max_R;
+    int ell_cap;
+    dfa::SolveView v;          // pointers into `blocks`
+    dfa::SolveState* state;    // device
+    double* cost_partials;     // device
+    std::vector<void*> blocks;  // every hipMalloc of this plan
+    bool has_problem;
+};
+
+namespace {
+template <class T>
+int plan_alloc(dfa_solver* s, T** out, size_t count) {
+    void* p       = nullptr;
+    hipError_t e  = hipMalloc(&p, sizeof(T) * (count ? count : 1));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc (solver plan)");
+    s->blocks.push_back(p);
+    *out = (T*)p;
+    return DFA_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* dfa_last_error(void) { return g_err; }
+
+const char* dfa_version(void) { return "dynfu_amd 0.1 (gfx950, HIP)"; }
+
+// ---------------------------------------------------------------------------------- TSDF seam
+
+int dfa_compute_dists(const uint16_t* depth, int depth_step, uint16_t* dists, int dists_step, int cols, int rows,
+                      float fx, float fy, float cx, float cy, dfa_stream_t stream) {
+    REQUIRE(depth && dists, "null image");
+    REQUIRE(cols > 0 && rows > 0, "empty image");
+    REQUIRE(depth_step >= cols * 2 && dists_step >= cols * 2, "row step smaller than a row");
+    REQUIRE(fx != 0.f && fy != 0.f, "zero focal length");
+    HIP_TRY(dfa::launch_compute_dists(depth, depth_step, dists, dists_step, cols, rows, fx, fy, cx, cy, S(stream)));
+    return DFA_OK;
+}
+
+int dfa_tsdf_clear(uint32_t* volume, int X, int Y, int Z, dfa_stream_t stream) {
+    REQUIRE(volume_args_ok(volume, X, Y, Z), "bad volume");
+    HIP_TRY(dfa::launch_tsdf_clear(volume, X, Y, Z, S(stream)));
+    return DFA_OK;
+}
+
+static int integrate_common(bool fused, const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* volume,
+                            int X, int Y, int Z, const float voxel_size[3], float trunc_dist, int max_weight,
+                            const float vol2cam[12], float fx, float fy, float cx, float cy, dfa_stream_t stream) {
+    REQUIRE(volume_args_ok(volume, X, Y, Z), "bad volume");
+    REQUIRE(dists && cols > 0 && rows > 0 && dists_step >= cols * 2, "bad dists image");
+    REQUIRE(voxel_size && vol2cam, "null parameter block");
+    REQUIRE(trunc_dist > 0.f, "trunc_dist must be positive");
+    REQUIRE(max_weight >= 0 && max_weight <= 65535, "max_weight must fit the 16-bit weight");
+    HIP_TRY(dfa::launch_tsdf_integrate(fused, dists, dists_step, cols, rows, volume, X, Y, Z, voxel_size, trunc_dist,
+                                       max_weight, vol2cam, fx, fy, cx, cy, S(stream)));
+    return DFA_OK;
+}
+
+int dfa_tsdf_integrate(const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* volume, int X, int Y, int Z,
+                       const float voxel_size[3], float trunc_dist, int max_weight, const float vol2cam[12], float fx,
+                       float fy, float cx, float cy, dfa_stream_t stream) {
+    return integrate_common(false, dists, dists_step, cols, rows, volume, X, Y, Z, voxel_size, trunc_dist, max_weight,
+                            vol2cam, fx, fy, cx, cy, stream);
+}
+
+int dfa_tsdf_clear_integrate(const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* volume, int X, int Y,
+                             int Z, const float voxel_size[3], float trunc_dist, int max_weight,
+                             const float vol2cam[12], float fx, float fy, float cx, float cy, dfa_stream_t stream) {
+    return integrate_common(true, dists, dists_step, cols, rows, volume, X, Y, Z, voxel_size, trunc_dist, max_weight,
+                            vol2cam, fx, fy, cx, cy, stream);
+}
+
+int dfa_tsdf_raycast_points(const uint32_t* volume, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
+                            const float cam2vol[12], const float Rinv[9], float fx, float fy, float cx, float cy,
+                            float step_factor, float delta_factor, float* points, int points_step, float* normals,
+                            int normals_step, int cols, int rows, dfa_stream_t stream) {
+    REQUIRE(volume_args_ok(volume, X, Y, Z), "bad volume");
+    REQUIRE(X >= 2 && Y >= 2 && Z >= 2, "volume needs at least 2 voxels per axis");
+    REQUIRE(points && normals && cols > 0 && rows > 0, "bad output images");
+    REQUIRE(points_step >= cols * 16 && normals_step >= cols * 16, "row step smaller than a float4 row");
+    REQUIRE(voxel_size && cam2vol && Rinv, "null parameter block");
+    REQUIRE(trunc_dist > 0.f && step_factor > 0.f, "non-positive ray step");
+    HIP_TRY(dfa::launch_raycast_points(volume, X, Y, Z, voxel_size, trunc_dist, cam2vol, Rinv, fx, fy, cx, cy,
+                                       step_factor, delta_factor, points, points_step, normals, normals_step, cols,
+                                       rows, S(stream)));
+    return DFA_OK;
+}
+
+int dfa_tsdf_raycast_depth(const uint32_t* volume, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
+                           const float cam2vol[12], const float Rinv[9], float fx, float fy, float cx, float cy,
+                           float step_factor, float delta_factor, uint16_t* depth, int depth_step, float* normals,
+                           int normals_step, int cols, int rows, dfa_stream_t stream) {
+    REQUIRE(volume_args_ok(volume, X, Y, Z), "bad volume");
+    REQUIRE(X >= 2 && Y >= 2 && Z >= 2, "volume needs at least 2 voxels per axis");
+    REQUIRE(depth && normals && cols > 0 && rows > 0, "bad output images");
+    REQUIRE(depth_step >= cols * 2 && normals_step >= cols * 16, "row step smaller than a row");
+    REQUIRE(voxel_size && cam2vol && Rinv, "null parameter block");
+    REQUIRE(trunc_dist > 0.f && step_factor > 0.f, "non-positive ray step");
+    HIP_TRY(dfa::launch_raycast_depth(volume, X, Y, Z, voxel_size, trunc_dist, cam2vol, Rinv, fx, fy, cx, cy,
+                                      step_factor, delta_factor, depth, depth_step, normals, normals_step, cols, rows,
+                                      S(stream)));
+    return DFA_OK;
+}
+
+// ---------------------------------------------------------------------------- warp-field seam
+
+int dfa_knn(const float* node_pos, const float* node_w, int D, const float* query, int n_query, int k, int32_t* idx,
+            float* weights, dfa_stream_t stream) {
+    REQUIRE(node_pos && D > 0, "no nodes");
+    REQUIRE(n_query >= 0 && (n_query == 0 || (query && idx)), "bad query / output");
+    REQUIRE(k >= 1 && k <= DFA_MAX_KNN, "k out of range 1..16");
+    REQUIRE(!weights || node_w, "weights requested without node_w");
+    HIP_TRY(dfa::launch_knn(node_pos, node_w, D, query, n_query, k, idx, weights, S(stream)));
+    return DFA_OK;
+}
+
+int dfa_warp_to_live(const float* node_pos, const float* node_dq, const float* node_w, int D, int k,
+                     const float* vertices, const float* normals, int N, float* out_vertices, float* out_normals,
+                     dfa_stream_t stream) {
+    REQUIRE(node_pos && node_dq && node_w && D > 0, "no nodes");
+    REQUIRE(N >= 0 && (N == 0 || (vertices && out_vertices)), "bad vertices / output");
+    REQUIRE(k >= 1 && k <= DFA_MAX_KNN, "k out of range 1..16");
+    HIP_TRY(dfa::launch_warp_to_live(node_pos, node_dq, node_w, D, k, vertices, normals, N, out_vertices,
+                                     out_normals, S(stream)));
+    return DFA_OK;
+}
+
+// ------------------------------------------------------------------------------- solver seam
+
+int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
+    REQUIRE(out, "null out");
+    *out = nullptr;
+    REQUIRE(max_D > 0 && max_N >= 0, "bad sizes");
+    REQUIRE(k >= 1 && k <= DFA_MAX_KNN, "k out of range 1..16");
+    REQUIRE(max_D <= dfa::solve_pcg_max_nodes(), "more nodes than the single-workgroup PCG supports (8192)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DFA_ERR_NO_GPU, "no HIP device");
+    dfa_solver* s = new (std::nothrow) dfa_solver();
+    REQUIRE(s, "out of host memory");
+    s->max_D = max_D, s->max_N = max_N, s->k = k;
+    s->max_R       = (size_t)max_N + (size_t)max_D * k;
+    s->ell_cap     = 256;
+    s->has_problem = false;
+    std::memset(&s->v, 0, sizeof(s->v));
+    const size_t R = s->max_R, D = (size_t)max_D;
+    int rc = DFA_OK;
+#define A(field, count) \
+    if (rc == DFA_OK) rc = plan_alloc(s, &s->v.field, (count))
+    A(ridx, R * k);
+    A(rw, R * k);
+    A(rtau, R);
+    A(rb, R * 3);
+    A(re, R * 3);
+    A(reg_idx, D * k);
+    A(node_cnt, D);
+    A(node_ptr, D + 1);
+    A(cursor, D);
+    A(node_list, R * k);
+    A(ell_cols, D * s->ell_cap);
+    A(ell_vals, D * s->ell_cap);
+    A(ell_cnt, D);
+    A(diag, D);
+    A(g, D * 3);
+    A(t, D * 3);
+    A(huber, D);
+    A(node_dq_out, D * 8);
+#undef A
+    if (rc == DFA_OK) rc = plan_alloc(s, &s->state, 1);
+    if (rc == DFA_OK) rc = plan_alloc(s, &s->cost_partials, (R + 255) / 256 + 1);
+    if (rc != DFA_OK) {
+        dfa_solver_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return DFA_OK;
+}
+
+void dfa_solver_destroy(dfa_solver* s) {
+    if (!s) return;
+    for (void* p : s->blocks) (void)hipFree(p);
+    delete s;
+}
+
+int dfa_solver_set_problem(dfa_solver* s, const float* node_pos, const float* node_dq, const float* node_w, int D,
+                           const float* canon_vertices, const float* canon_normals, const float* live_vertices,
+                           const float* live_normals, int N, dfa_stream_t stream) {
+    (void)canon_normals;
+    (void)live_normals;  // declared by energy.t:28-31, never read by an Energy term
+    REQUIRE(s, "null plan");
+    REQUIRE(node_pos && node_dq && node_w && D > 0, "no nodes");
+    REQUIRE(N >= 0 && (N == 0 || (canon_vertices && live_vertices)), "bad vertex arrays");
+    if (D > s->max_D || N > s->max_N)
+        return fail(DFA_ERR_CAPACITY, "dfa_solver_set_problem: D=%d N=%d exceed the plan (max_D=%d max_N=%d)", D, N,
+                    s->max_D, s->max_N);
+    dfa::SolveView& v = s->v;
+    v.N = N, v.D = D, v.k = s->k, v.Dpad = (D + 3) & ~3, v.ell_cap = s->ell_cap;
+    v.node_pos = node_pos, v.node_dq = node_dq, v.node_w = node_w;
+    v.canon = canon_vertices, v.live = live_vertices;
+    hipStream_t st = S(stream);
+    // initializeDataGraph (opt_solver.cpp:56-72): rows [0, N) = k-NN of the canonical vertices + RBF weights
+    if (N > 0) HIP_TRY(dfa::launch_knn(node_pos, node_w, D, canon_vertices, N, s->k, v.ridx, v.rw, st));
+    // initializeRegGraph (:74-105): k-NN of every node among the nodes (itself included at distance 0)
+    HIP_TRY(dfa::launch_knn(node_pos, node_w, D, node_pos, D, s->k, v.reg_idx, nullptr, st));
+    HIP_TRY(dfa::solve_build_graph(v, st));
+    // resetGPUMemory (:149-202): unknowns start at zero
+    HIP_TRY(hipMemsetAsync(v.t, 0, sizeof(float) * 3 * (size_t)D, st));
+    s->has_problem = true;
+    return DFA_OK;
+}
+
+int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stream) {
+    REQUIRE(s && p, "null plan / params");
+    REQUIRE(s->has_problem, "set_problem has not been called");
+    REQUIRE(p->num_iter >= 0 && p->nonlinear_iter >= 0 && p->linear_iter >= 0, "negative iteration count");
+    REQUIRE(p->tukey_offset > 0.f && p->psi_data > 0.f, "tukey_offset / psi_data must be positive");
+    REQUIRE(p->lambda >= 0.f, "lambda must be non-negative");
+    const dfa::SolveView& v = s->v;
+    hipStream_t st          = S(stream);
+    HIP_TRY(hipMemsetAsync(s->state, 0, sizeof(dfa::SolveState), st));
+    HIP_TRY(hipMemsetAsync(v.t, 0, sizeof(float) * 3 * (size_t)v.D, st));
+    // w_reg = sqrt(lambda / (D * KNN))  (opt_solver.cpp:30); rows carry tau = w_reg^2
+    const double w_reg    = std::sqrt((double)p->lambda / ((double)v.D * (double)v.k));
+    const float w_reg_f   = (float)w_reg;
+    const float w_reg_sq  = w_reg_f * w_reg_f;
+    for (int outer = 0; outer < p->num_iter; ++outer) {
+        // preNonlinearSolve (opt_solver.cpp:135-140)
+        HIP_TRY(dfa::solve_weights(v, p->tukey_offset, p->psi_data, w_reg_sq, p->psi_reg, st));
+        for (int gn = 0; gn < p->nonlinear_iter; ++gn) {
+            HIP_TRY(dfa::solve_residual(v, s->state, s->cost_partials, gn == 0 ? 0 : 1, p->gn_tol, st));
+            HIP_TRY(dfa::solve_assemble(v, s->state, st));
+            HIP_TRY(dfa::solve_pcg(v, s->state, p->linear_iter, p->pcg_tol, st));
+        }
+    }
+    if (p->num_iter == 0) HIP_TRY(dfa::solve_weights(v, p->tukey_offset, p->psi_data, w_reg_sq, p->psi_reg, st));
+    HIP_TRY(dfa::solve_residual(v, s->state, s->cost_partials, 2, 0.f, st));
+    // postSingleSolve -> copyResultToCPUFromFloat3 (opt_solver.cpp:133,270-285), composed once
+    HIP_TRY(dfa::solve_writeback(v, st));
+    return DFA_OK;
+}
+
+const float* dfa_solver_translations(const dfa_solver* s) { return s ? s->v.t : nullptr; }
+const float* dfa_solver_node_dq(const dfa_solver* s) { return s ? s->v.node_dq_out : nullptr; }
+const float* dfa_solver_tukey_weights(const dfa_solver* s) { return s ? s->v.rtau : nullptr; }
+const float* dfa_solver_huber_weights(const dfa_solver* s) { return s ? s->v.huber : nullptr; }
+const int32_t* dfa_solver_data_graph(const dfa_solver* s) { return s ? s->v.ridx : nullptr; }
+const int32_t* dfa_solver_reg_graph(const dfa_solver* s) { return s ? s->v.reg_idx : nullptr; }
+
+int dfa_solver_get_stats(dfa_solver* s, dfa_solve_stats* host_out, dfa_stream_t stream) {
+    REQUIRE(s && host_out, "null plan / out");
+    dfa::SolveState h;
+    HIP_TRY(hipMemcpyAsync(&h, s->state, sizeof(h), hipMemcpyDeviceToHost, S(stream)));
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    host_out->initial_cost = h.initial_cost;
+    host_out->final_cost   = h.final_cost;
+    host_out->gn_iters     = h.gn_iters;
+    host_out->pcg_iters    = h.pcg_iters;
+    host_out->max_row_nnz  = h.max_row_nnz;
+    host_out->reserved     = 0;
+    if (h.overflow)
+        return fail(DFA_ERR_CAPACITY, "normal-matrix row wider than the plan's ELL capacity (%d > %d)", h.max_row_nnz,
+                    s->ell_cap);
+    return DFA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// device_math.hpp — small float3 / half helpers for the gfx950 kernels.
+//
+// Arithmetic contract: every file including this header is compiled
+// with -ffp-contract=off; a fused multiply-add happens exactly where fmaf() is written.
+// Division and sqrtf are the correctly rounded HIP defaults.  This makes the TSDF kernels
+// bit-reproducible against the IEEE restatement used by the parity tests.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dfa {
+
+struct f3 {
+    float x, y, z;
+};
+
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+// x*x' + y*y' + z*z' with the two trailing products fused (kfusion dot(), temp_utils.hpp:32-34)
+__device__ __forceinline__ float dot(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+
+// 3x3 row-major matrix + translation, passed by value as kernel arguments (SGPRs)
+struct Mat3 {
+    float m[9];
+};
+struct Aff3 {
+    float m[9];
+    float t[3];
+};
+__device__ __forceinline__ f3 mul(const Mat3& R, f3 v) {
+    return mk3(dot(mk3(R.m[0], R.m[1], R.m[2]), v), dot(mk3(R.m[3], R.m[4], R.m[5]), v),
+               dot(mk3(R.m[6], R.m[7], R.m[8]), v));
+}
+__device__ __forceinline__ f3 mulR(const Aff3& A, f3 v) {
+    return mk3(dot(mk3(A.m[0], A.m[1], A.m[2]), v), dot(mk3(A.m[3], A.m[4], A.m[5]), v),
+               dot(mk3(A.m[6], A.m[7], A.m[8]), v));
+}
+// kfusion normalized(): v * rsqrt(dot(v,v)), with the correctly rounded reciprocal square root
+__device__ __forceinline__ f3 normalized(f3 v) { return v * (1.0f / sqrtf(dot(v, v))); }
+
+// half <-> float: v_cvt_f16_f32 (round-to-nearest-even, f16 subnormals kept) / v_cvt_f32_f16
+__device__ __forceinline__ uint32_t float_to_half_bits(float f) {
+    _Float16 h = (_Float16)f;
+    return (uint32_t)__builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float half_bits_to_float(uint32_t bits) {
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)(bits & 0xffffu));
+}
+
+// TSDF voxel packing (kfusion pack_tsdf / unpack_tsdf): low half = tsdf (fp16), high = weight
+__device__ __forceinline__ uint32_t pack_tsdf(float tsdf, int weight) {
+    return float_to_half_bits(tsdf) | ((uint32_t)weight << 16);
+}
+__device__ __forceinline__ float unpack_tsdf(uint32_t v) { return half_bits_to_float(v); }
+
+// 64-lane wave reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;  // valid in lane 0
+}
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;  // valid in every lane
+}
+__device__ __forceinline__ double wave_sum_all(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace dfa

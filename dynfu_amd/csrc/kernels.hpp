@@ -1,0 +1,34 @@
+// kernels.hpp — host-callable launchers of the gfx950 kernels (internal; the public surface
+// is include/dynfu_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dfa {
+
+// tsdf.hip
+hipError_t launch_compute_dists(const uint16_t* depth, int depth_step, uint16_t* dists, int dists_step, int cols,
+                                int rows, float fx, float fy, float cx, float cy, hipStream_t s);
+hipError_t launch_tsdf_clear(uint32_t* vol, int X, int Y, int Z, hipStream_t s);
+hipError_t launch_tsdf_integrate(bool fused_clear, const uint16_t* dists, int dists_step, int cols, int rows,
+                                 uint32_t* vol, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
+                                 int max_weight, const float vol2cam[12], float fx, float fy, float cx, float cy,
+                                 hipStream_t s);
+hipError_t launch_raycast_points(const uint32_t* vol, int X, int Y, int Z, const float voxel_size[3],
+                                 float trunc_dist, const float cam2vol[12], const float Rinv[9], float fx, float fy,
+                                 float cx, float cy, float step_factor, float delta_factor, float* points,
+                                 int points_step, float* normals, int normals_step, int cols, int rows,
+                                 hipStream_t s);
+hipError_t launch_raycast_depth(const uint32_t* vol, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
+                                const float cam2vol[12], const float Rinv[9], float fx, float fy, float cx, float cy,
+                                float step_factor, float delta_factor, uint16_t* depth, int depth_step,
+                                float* normals, int normals_step, int cols, int rows, hipStream_t s);
+
+// warp.hip
+hipError_t launch_knn(const float* node_pos, const float* node_w, int D, const float* query, int n_query, int k,
+                      int32_t* idx, float* weights, hipStream_t s);
+hipError_t launch_warp_to_live(const float* node_pos, const float* node_dq, const float* node_w, int D, int k,
+                               const float* verts, const float* normals, int N, float* out_verts, float* out_normals,
+                               hipStream_t s);
+
+}  // namespace dfa

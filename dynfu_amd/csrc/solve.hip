@@ -1,0 +1,535 @@
+// solve.hip — gfx950 kernels of the warp-field solve: residual rows, Tukey / Huber
+// re-weighting, assembly of the sparse normal equations, block-Jacobi PCG, write-back.
+//
+// Replaces what the reference runs through Opt (include/dynfu/utils/terra/energy.t, driven by
+// src/dynfu/utils/opt_solver.cpp) plus the CPU loops updateTukeyBiweights / updateHuberWeights.
+//
+// Formulation.  Unknown t_i in R^3 per node.  Every residual of
+// energy.t is a "row"  r = sqrt(tau) * (b - sum_j w_j t_{n_j})  with at most k node slots:
+//   data row v   (energy.t:50-55): slots = k-NN of the canonical vertex, w = RBF weights,
+//                                  b = live - canonical, tau = Tukey biweight;
+//   reg row (n,i)(energy.t:75-78): slots = {v_i: -1, n: +1}, b = 0, tau = w_reg^2
+//                                  (r = w_reg (t_{v_i} - t_n)); the self edge is empty.
+// J^T J has the block structure D x D with blocks s*I_3, so ONE scalar sparse matrix A
+// (D x D) serves the x, y and z systems:  A = sum_rows tau w w^T,  g = sum_rows tau w e,
+// e = b - sum w t.
+//
+// MI355X mapping
+//   * Opt re-walks all N*k graph edges with global atomics in every PCG iteration; here A is
+//     assembled once per linearisation and the PCG iterates on ~20 D non-zeros that never
+//     leave the chip's caches.
+//   * assembly is a gather, not a scatter: a node -> rows transpose graph is built once per
+//     frame, then ONE WAVE PER NODE reduces its ~128 k rows into an LDS hash keyed by column
+//     (LDS float atomics stay on the CU; no global atomics on the matrix at all) and writes
+//     one ELL row + one rhs entry + the Jacobi diagonal.
+//   * the PCG is a single persistent 1024-thread workgroup: at 2 k - 8 k nodes the solve is
+//     bound by synchronisation latency, not bandwidth — a workgroup barrier
+//     costs ~0.1 us where a grid-wide barrier costs 4-5 us — with the direction vector in
+//     LDS (16 B / node, ds_read_b128 gathers), x / r / p of the thread's own rows in
+//     registers and dot products reduced by wave shuffles in double.
+#include <hip/hip_runtime.h>
+
+#include <float.h>
+
+#include "dq_device.hpp"
+#include "solve.hpp"
+
+namespace dfa {
+
+// ------------------------------------------------------------------------------------------
+// row construction
+
+// reg rows (opt_solver.cpp:74-105 + energy.t:75-78): row N + n*k + i  <-  {reg_idx[n][i]: -1, n: +1}
+__global__ __launch_bounds__(256) void build_reg_rows_kernel(const int32_t* __restrict__ reg_idx, int D, int k, int N,
+                                                             int32_t* __restrict__ ridx, float* __restrict__ rw,
+                                                             float* __restrict__ rb) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= D * k) return;
+    const int n = e / k;
+    const int m = reg_idx[e];
+    const size_t row = (size_t)N + e;
+    for (int j = 0; j < k; ++j) ridx[row * k + j] = -1, rw[row * k + j] = 0.f;
+    if (m >= 0 && m != n) {
+        // k >= 2 whenever a non-self neighbour exists
+        ridx[row * k + 0] = m, rw[row * k + 0] = -1.f;
+        ridx[row * k + 1] = n, rw[row * k + 1] = +1.f;
+    }
+    rb[row * 3 + 0] = rb[row * 3 + 1] = rb[row * 3 + 2] = 0.f;
+}
+
+// data rows: b = live - canonical (energy.t:55)
+__global__ __launch_bounds__(256) void build_data_rhs_kernel(const float* __restrict__ canon,
+                                                             const float* __restrict__ live, int N,
+                                                             float* __restrict__ rb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * N) rb[i] = live[i] - canon[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// transpose graph node -> (row, slot): count / scan / fill
+
+__global__ __launch_bounds__(256) void count_kernel(const int32_t* __restrict__ ridx, size_t total,
+                                                    int32_t* __restrict__ node_cnt) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int n = ridx[e];
+    if (n >= 0) atomicAdd(&node_cnt[n], 1);
+}
+
+// single workgroup exclusive scan of node_cnt[0..D) -> node_ptr[0..D]; also zeroes the cursors
+__global__ __launch_bounds__(1024) void scan_kernel(const int32_t* __restrict__ node_cnt, int D,
+                                                    int32_t* __restrict__ node_ptr, int32_t* __restrict__ cursor) {
+    __shared__ int32_t wave_tot[16];
+    __shared__ int32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < D; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < D ? node_cnt[i] : 0;
+        int incl    = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int wave_off = 0;
+        for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
+        const int c = carry;
+        if (i < D) {
+            node_ptr[i] = c + wave_off + incl - v;
+            cursor[i]   = 0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + wave_off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) node_ptr[D] = carry;
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(const int32_t* __restrict__ ridx, size_t total,
+                                                   const int32_t* __restrict__ node_ptr,
+                                                   int32_t* __restrict__ cursor, uint32_t* __restrict__ node_list) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int n = ridx[e];
+    if (n >= 0) node_list[node_ptr[n] + atomicAdd(&cursor[n], 1)] = (uint32_t)e;
+}
+
+// ------------------------------------------------------------------------------------------
+// per outer iteration: Tukey biweights (opt_solver.cpp:204-231) from the current warp
+//   warp(c) = calcDQB(c)(c) with node transforms DQ(t_i) * dg_se3_i   (:270-285, node.cpp:19-23)
+
+template <int K>
+__global__ __launch_bounds__(256) void tukey_kernel(SolveView s, float tukey_offset, float psi_data) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= s.N) return;
+    const f3 c = mk3(s.canon[3 * (size_t)v], s.canon[3 * (size_t)v + 1], s.canon[3 * (size_t)v + 2]);
+    DQ sum     = dq_identity();
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        if (j < s.k) {
+            const int n = s.ridx[(size_t)v * s.k + j];
+            if (n >= 0) {
+                const float w = s.rw[(size_t)v * s.k + j];
+                const DQ cur  = dq_mul(dq_from_translation(s.t[3 * n], s.t[3 * n + 1], s.t[3 * n + 2]),
+                                       dq_load(s.node_dq + 8 * (size_t)n));
+                sum           = dq_mul(sum, dq_scale(cur, w));
+            }
+        }
+    }
+    const f3 warped = dq_transform(dq_normalize(sum), c);
+    const float ex = s.live[3 * (size_t)v] - warped.x, ey = s.live[3 * (size_t)v + 1] - warped.y,
+                ez = s.live[3 * (size_t)v + 2] - warped.z;
+    // calcTukeyBiweight (:204-212)
+    const float d = sqrtf(ex * ex + ey * ey + ez * ez) / tukey_offset;
+    float tau     = 0.f;
+    if (d < psi_data) {
+        const double q = 1.0 - ((double)d * (double)d) / ((double)psi_data * (double)psi_data);
+        tau            = (float)(q * q);
+    }
+    s.rtau[v] = tau;
+}
+
+// reg rows' tau = w_reg^2 (opt_solver.cpp:30) and Huber weights (opt_solver.cpp:233-268,
+// computed for interface parity; energy.t:70 never uses them)
+__global__ __launch_bounds__(256) void reg_weights_kernel(SolveView s, float w_reg_sq, float psi_reg) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < s.D * s.k) s.rtau[(size_t)s.N + e] = w_reg_sq;
+    if (e < s.D) {
+        const int i   = e;
+        const DQ dq_i = dq_mul(dq_from_translation(s.t[3 * i], s.t[3 * i + 1], s.t[3 * i + 2]),
+                               dq_load(s.node_dq + 8 * (size_t)i));
+        float h = 0.f;
+        for (int j = 0; j < s.k; ++j) {
+            const int m = s.reg_idx[(size_t)i * s.k + j];
+            if (m < 0) break;
+            const f3 pm   = mk3(s.node_pos[3 * m], s.node_pos[3 * m + 1], s.node_pos[3 * m + 2]);
+            const DQ dq_m = dq_mul(dq_from_translation(s.t[3 * m], s.t[3 * m + 1], s.t[3 * m + 2]),
+                                   dq_load(s.node_dq + 8 * (size_t)m));
+            const f3 a = dq_transform(dq_i, pm), b = dq_transform(dq_m, pm);
+            const float ex = a.x - b.x, ey = a.y - b.y, ez = a.z - b.z;
+            const float err = sqrtf(ex * ex + ey * ey + ez * ez);
+            h               = fabsf(err) <= psi_reg ? 1.f : psi_reg / fabsf(err);  // last neighbour wins (:263)
+        }
+        s.huber[i] = h;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// per linearisation: e_r = b_r - sum_j w_rj t_{n_rj},  cost = sum tau |e|^2
+
+template <int K>
+__global__ __launch_bounds__(256) void residual_kernel(SolveView s, double* __restrict__ cost_partials) {
+    __shared__ double wsum[4];
+    const size_t R = (size_t)s.N + (size_t)s.D * s.k;
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double c       = 0.0;
+    if (r < R) {
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (j < s.k) {
+                const int n = s.ridx[r * s.k + j];
+                if (n >= 0) {
+                    const float w = s.rw[r * s.k + j];
+                    sx += w * s.t[3 * n], sy += w * s.t[3 * n + 1], sz += w * s.t[3 * n + 2];
+                }
+            }
+        }
+        const float ex = s.rb[3 * r] - sx, ey = s.rb[3 * r + 1] - sy, ez = s.rb[3 * r + 2] - sz;
+        s.re[3 * r] = ex, s.re[3 * r + 1] = ey, s.re[3 * r + 2] = ez;
+        c = (double)s.rtau[r] * ((double)ex * ex + (double)ey * ey + (double)ez * ez);
+    }
+    c = wave_sum_all(c);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cost_partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// one thread-block: sums the partials in a fixed order (deterministic), Gauss-Newton control
+__global__ __launch_bounds__(256) void control_kernel(SolveState* __restrict__ st,
+                                                      const double* __restrict__ cost_partials, int nparts,
+                                                      int mode /*0 first of outer, 1 later GN, 2 final*/,
+                                                      float gn_tol) {
+    __shared__ double sm[256];
+    double c = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) c += cost_partials[i];
+    sm[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double cost = sm[0];
+        if (!st->have_initial) st->initial_cost = cost, st->have_initial = 1;
+        if (mode == 0) st->done = 0;
+        // Gauss-Newton early-out: relative cost decrease of the previous step below gn_tol
+        if (mode == 1 && !st->done && gn_tol > 0.f && (st->cost - cost) <= (double)gn_tol * st->cost) st->done = 1;
+        st->cost       = cost;
+        st->final_cost = cost;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// assembly: one wave per node.  LDS hash (HASH entries) keyed by column -> ELL row.
+
+constexpr int HASH      = 512;
+constexpr int HASH_MASK = HASH - 1;
+
+template <int K>
+__global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* __restrict__ st) {
+    __shared__ int hkey[4][HASH];
+    __shared__ float hval[4][HASH];
+    if (st->done) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int a    = blockIdx.x * 4 + wave;
+    if (a >= s.D) return;
+    int* key   = hkey[wave];
+    float* val = hval[wave];
+    for (int i = lane; i < HASH; i += 64) key[i] = -1, val[i] = 0.f;
+    // wave-private LDS region: a wave-level fence is enough, lanes of a wave run in lockstep
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const int beg = s.node_ptr[a], end = s.node_ptr[a + 1];
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    bool overflow = false;
+    for (int p = beg + lane; p < end; p += 64) {
+        const uint32_t e = s.node_list[p];
+        const size_t r   = e / (uint32_t)s.k;
+        const float tau  = s.rtau[r];
+        const float wa   = s.rw[e];
+        const float tw   = tau * wa;
+        gx += tw * s.re[3 * r], gy += tw * s.re[3 * r + 1], gz += tw * s.re[3 * r + 2];
+        if (tau != 0.f) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                if (j < s.k) {
+                    const int b = s.ridx[r * s.k + j];
+                    if (b >= 0) {
+                        const float v = tw * s.rw[r * s.k + j];
+                        uint32_t h    = ((uint32_t)b * 2654435761u) >> (32 - 9);
+                        int probes    = 0;
+                        for (;; h = (h + 1) & HASH_MASK) {
+                            const int cur = atomicCAS(&key[h], -1, b);
+                            if (cur == -1 || cur == b) {
+                                atomicAdd(&val[h], v);
+                                break;
+                            }
+                            if (++probes >= HASH) {
+                                overflow = true;
+                                break;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    gx = wave_sum_all(gx), gy = wave_sum_all(gy), gz = wave_sum_all(gz);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // compact the hash into the ELL row (slot-major: entry s of row a at [s*D + a])
+    int cnt = 0;
+    float diag = 0.f;
+    for (int base = 0; base < HASH; base += 64) {
+        const int kk       = key[base + lane];
+        const float vv     = val[base + lane];
+        const bool valid   = kk >= 0;
+        const uint64_t m   = __ballot(valid);
+        const int pos      = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        if (valid) {
+            if (pos < s.ell_cap) {
+                s.ell_cols[(size_t)pos * s.D + a] = kk;
+                s.ell_vals[(size_t)pos * s.D + a] = vv;
+            }
+            if (kk == a) diag = vv;
+        }
+        cnt += __popcll(m);
+    }
+    diag = wave_sum_all(diag);
+    if (lane == 0) {
+        s.ell_cnt[a] = min(cnt, s.ell_cap);
+        s.diag[a]    = diag;
+        s.g[3 * a] = gx, s.g[3 * a + 1] = gy, s.g[3 * a + 2] = gz;
+        atomicMax(&st->max_row_nnz, cnt);
+        if (cnt > s.ell_cap) st->overflow = 1;
+    }
+    if (__ballot(overflow) && lane == 0) st->overflow = 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// block-Jacobi PCG, one persistent workgroup of 1024 threads; thread owns rows tid + 1024*i.
+
+__device__ __forceinline__ double block_sum(double v, double* red /*[16]*/) {
+    v = wave_sum_all(v);
+    __syncthreads();  // protect red[] against the previous reduction's readers
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += red[w];
+    return tot;
+}
+
+template <int RPT>
+__global__ __launch_bounds__(1024) void pcg_kernel(SolveView s, SolveState* __restrict__ st, int max_iter,
+                                                   float pcg_tol) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* p_s = (float4*)smem;                                // D entries
+    double* red = (double*)(smem + sizeof(float4) * (size_t)s.Dpad);  // 16 doubles
+    if (st->done) return;
+    const int tid = threadIdx.x;
+    const int D   = s.D;
+
+    float x[RPT][3], r[RPT][3], p[RPT][3], minv[RPT];
+    double rz_loc = 0.0;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int row = tid + 1024 * i;
+        if (row < D) {
+            const float d = s.diag[row];
+            minv[i]       = d > FLT_EPSILON ? 1.0f / d : 1.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                x[i][c] = 0.f;
+                r[i][c] = s.g[3 * row + c];
+                p[i][c] = minv[i] * r[i][c];
+                rz_loc += (double)r[i][c] * (double)p[i][c];
+            }
+            p_s[row] = make_float4(p[i][0], p[i][1], p[i][2], 0.f);
+        } else {
+            minv[i] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x[i][c] = r[i][c] = p[i][c] = 0.f;
+        }
+    }
+    double rz        = block_sum(rz_loc, red);  // also publishes p_s (barriers inside)
+    const double rz0 = rz;
+    const double floor_ = 1e-12;  // squared-residual-ratio floor of float arithmetic
+    const double tol2   = (double)pcg_tol * (double)pcg_tol > floor_ ? (double)pcg_tol * (double)pcg_tol : floor_;
+    int it              = 0;
+    const bool skip     = st->grad_first > 0.0 && rz0 <= floor_ * st->grad_first;
+    if (!skip) {
+        while (it < max_iter) {
+            if (!(rz > 0.0)) break;
+            // Ap for own rows
+            float ap[RPT][3];
+            double pap_loc = 0.0;
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int row = tid + 1024 * i;
+                float ax = 0.f, ay = 0.f, az = 0.f;
+                if (row < D) {
+                    const int cnt = s.ell_cnt[row];
+                    for (int q = 0; q < cnt; ++q) {
+                        const int col   = s.ell_cols[(size_t)q * D + row];
+                        const float v   = s.ell_vals[(size_t)q * D + row];
+                        const float4 pc = p_s[col];
+                        ax = fmaf(v, pc.x, ax), ay = fmaf(v, pc.y, ay), az = fmaf(v, pc.z, az);
+                    }
+                }
+                ap[i][0] = ax, ap[i][1] = ay, ap[i][2] = az;
+                pap_loc += (double)p[i][0] * ax + (double)p[i][1] * ay + (double)p[i][2] * az;
+            }
+            const double pAp = block_sum(pap_loc, red);
+            if (!(pAp > 0.0)) break;
+            const float alpha = (float)(rz / pAp);
+            double rzn_loc    = 0.0;
+            float z[RPT][3];
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    x[i][c] = fmaf(alpha, p[i][c], x[i][c]);
+                    r[i][c] = fmaf(-alpha, ap[i][c], r[i][c]);
+                    z[i][c] = minv[i] * r[i][c];
+                    rzn_loc += (double)r[i][c] * (double)z[i][c];
+                }
+            }
+            const double rz_new = block_sum(rzn_loc, red);
+            ++it;
+            if (rz_new <= tol2 * rz0) break;
+            const float beta = (float)(rz_new / rz);
+            // every thread has read p_s for this iteration (two barriers passed since)
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int row = tid + 1024 * i;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) p[i][c] = fmaf(beta, p[i][c], z[i][c]);
+                if (row < D) p_s[row] = make_float4(p[i][0], p[i][1], p[i][2], 0.f);
+            }
+            rz = rz_new;
+            __syncthreads();
+        }
+    }
+    // t += delta
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int row = tid + 1024 * i;
+        if (row < D) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s.t[3 * row + c] += x[i][c];
+        }
+    }
+    if (tid == 0) {
+        if (st->grad_first == 0.0) st->grad_first = rz0;
+        st->pcg_iters += it;
+        st->gn_iters += 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// write-back: dg_se3_i <- DQ(0,0,0,t_i) * dg_se3_i  (opt_solver.cpp:270-285, node.cpp:19-23)
+__global__ __launch_bounds__(256) void writeback_kernel(SolveView s) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.D) return;
+    const DQ out = dq_mul(dq_from_translation(s.t[3 * i], s.t[3 * i + 1], s.t[3 * i + 2]),
+                          dq_load(s.node_dq + 8 * (size_t)i));
+    dq_store(s.node_dq_out + 8 * (size_t)i, out);
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+
+#define KDISPATCH(kernel, k, ...)                      \
+    do {                                               \
+        if ((k) <= 4) kernel<4> __VA_ARGS__;           \
+        else if ((k) <= 8) kernel<8> __VA_ARGS__;      \
+        else kernel<16> __VA_ARGS__;                   \
+    } while (0)
+
+hipError_t solve_build_graph(const SolveView& s, hipStream_t st) {
+    const int D = s.D, N = s.N, k = s.k;
+    const size_t R = (size_t)N + (size_t)D * k, total = R * k;
+    hipError_t e;
+    build_reg_rows_kernel<<<(D * k + 255) / 256, 256, 0, st>>>(s.reg_idx, D, k, N, s.ridx, s.rw, s.rb);
+    if (N > 0) build_data_rhs_kernel<<<(3 * N + 255) / 256, 256, 0, st>>>(s.canon, s.live, N, s.rb);
+    if ((e = hipMemsetAsync(s.node_cnt, 0, sizeof(int32_t) * (size_t)D, st)) != hipSuccess) return e;
+    count_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(s.ridx, total, s.node_cnt);
+    scan_kernel<<<1, 1024, 0, st>>>(s.node_cnt, D, s.node_ptr, s.cursor);
+    fill_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(s.ridx, total, s.node_ptr, s.cursor, s.node_list);
+    return hipGetLastError();
+}
+
+hipError_t solve_weights(const SolveView& s, float tukey_offset, float psi_data, float w_reg_sq, float psi_reg,
+                         hipStream_t st) {
+    if (s.N > 0) KDISPATCH(tukey_kernel, s.k, <<<(s.N + 255) / 256, 256, 0, st>>>(s, tukey_offset, psi_data));
+    reg_weights_kernel<<<(s.D * s.k + 255) / 256, 256, 0, st>>>(s, w_reg_sq, psi_reg);
+    return hipGetLastError();
+}
+
+int solve_residual_blocks(const SolveView& s) {
+    const size_t R = (size_t)s.N + (size_t)s.D * s.k;
+    return (int)((R + 255) / 256);
+}
+
+hipError_t solve_residual(const SolveView& s, SolveState* state, double* cost_partials, int mode, float gn_tol,
+                          hipStream_t st) {
+    const int nb = solve_residual_blocks(s);
+    KDISPATCH(residual_kernel, s.k, <<<nb, 256, 0, st>>>(s, cost_partials));
+    control_kernel<<<1, 256, 0, st>>>(state, cost_partials, nb, mode, gn_tol);
+    return hipGetLastError();
+}
+
+hipError_t solve_assemble(const SolveView& s, SolveState* state, hipStream_t st) {
+    KDISPATCH(assemble_kernel, s.k, <<<(s.D + 3) / 4, 256, 0, st>>>(s, state));
+    return hipGetLastError();
+}
+
+int solve_pcg_max_nodes() { return 1024 * 8; }
+
+hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, hipStream_t st) {
+    const size_t shmem = sizeof(float4) * (size_t)s.Dpad + 16 * sizeof(double);
+    const int rpt      = (s.D + 1023) / 1024;
+#define PCG_LAUNCH(R)                                                                                              \
+    do {                                                                                                           \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set) {                                                                                           \
+            hipError_t e = hipFuncSetAttribute((const void*)pcg_kernel<R>,                                         \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);    \
+            if (e != hipSuccess) return e;                                                                         \
+            attr_set = true;                                                                                       \
+        }                                                                                                          \
+        pcg_kernel<R><<<1, 1024, shmem, st>>>(s, state, max_iter, pcg_tol);                                        \
+    } while (0)
+    if (rpt <= 1) PCG_LAUNCH(1);
+    else if (rpt <= 2) PCG_LAUNCH(2);
+    else if (rpt <= 4) PCG_LAUNCH(4);
+    else if (rpt <= 8) PCG_LAUNCH(8);
+    else return hipErrorInvalidValue;
+#undef PCG_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t solve_writeback(const SolveView& s, hipStream_t st) {
+    writeback_kernel<<<(s.D + 255) / 256, 256, 0, st>>>(s);
+    return hipGetLastError();
+}
+
+}  // namespace dfa

@@ -1,0 +1,472 @@
+// tsdf.hip — gfx950 kernels for the TSDF seam: compute_dists, clear, integrate,
+// fused clear+integrate, raycast (points / depth).
+//
+// What they compute is kfusion's src/kfusion/cuda/tsdf_volume.cu + imgproc.cu:233-245
+// (cited per kernel); how they are laid out is MI355X-specific:
+//   * the volume is x-fastest, 4 B / voxel; one lane owns FOUR consecutive x voxels, so a
+//     64-lane wave moves 1 KiB per load / store instruction (global_load/store_dwordx4);
+//   * a 256-thread block = 4 waves = 4 consecutive y rows of one 256-voxel x segment;
+//   * z is cut into chunks (grid.z) so that even a 256^3 volume launches >> 256 workgroups;
+//     inside a chunk the z loop is software-pipelined 4 slices deep (4 KiB in flight per
+//     wave) instead of relying on occupancy alone;
+//   * the reference's running `vc += zstep` (tsdf_volume.cu:64) is kept bit-for-bit: a
+//     chunk that starts at slice z0 replays the z0 additions in registers first (12 VALU
+//     adds per skipped slice, a few % of the chunk's work) rather than using z0*zstep;
+//   * the depth ("dists") image is gathered with plain 2-byte loads: 600 KiB at VGA, it
+//     stays in every XCD's 4 MiB L2 while the volume streams past it.
+// Every kernel is HBM-bound integer/half work; nothing here is GEMM-shaped, no MFMA.
+#include <hip/hip_runtime.h>
+
+#include "device_math.hpp"
+#include "kernels.hpp"
+
+namespace dfa {
+
+// ------------------------------------------------------------------------------------------
+// compute_dists — imgproc.cu:233-245.  2 pixels per lane (one dword in, one dword out).
+__global__ __launch_bounds__(256) void compute_dists_kernel(const uint16_t* __restrict__ depth, int depth_step,
+                                                            uint16_t* __restrict__ dists, int dists_step, int cols,
+                                                            int rows, float finvx, float finvy, float cx, float cy) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= cols || y >= rows) return;
+    const uint16_t* drow = (const uint16_t*)((const char*)depth + (size_t)y * depth_step);
+    uint16_t* orow       = (uint16_t*)((char*)dists + (size_t)y * dists_step);
+    float xl             = ((float)x - cx) * finvx;
+    float yl             = ((float)y - cy) * finvy;
+    float lambda         = sqrtf(fmaf(yl, yl, xl * xl) + 1.f);
+    orow[x]              = (uint16_t)float_to_half_bits(((float)drow[x] * lambda) * 0.001f);
+}
+
+// ------------------------------------------------------------------------------------------
+// clear — tsdf_volume.cu:11-22: pack_tsdf(0.f, 0) == 0.  Grid-stride 16-byte stores.
+__global__ __launch_bounds__(256) void clear_kernel(uint4* __restrict__ vol4, size_t n4, uint32_t* __restrict__ tail,
+                                                    int ntail) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+        vol4[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0u;
+}
+
+// ------------------------------------------------------------------------------------------
+// integrate — tsdf_volume.cu:43-96
+struct IntegrateArgs {
+    const uint16_t* dists;
+    int dists_step, cols, rows;
+    uint32_t* vol;
+    int X, Y, Z;
+    float vsx, vsy, vsz;
+    float trunc, trunc_inv;
+    int max_weight;
+    Aff3 vol2cam;
+    float fx, fy, cx, cy;
+    int zchunk;
+};
+
+// One voxel of one slice (tsdf_volume.cu:65-91).  `old` is the packed voxel (0 when the clear
+// is fused); returns the packed voxel after the update and sets `changed`.
+template <bool FUSED_CLEAR>
+__device__ __forceinline__ uint32_t integrate_voxel(const IntegrateArgs& a, f3 vc, uint32_t old, bool& changed) {
+    // :74 `vc.z <= 0` is tested first here: the reference tests it after the (side-effect
+    // free) projection and texture fetch, the outcome is the same and NaN/inf never form.
+    if (!(vc.z > 0.f)) return old;
+    // Projector (device.hpp:40-45): correctly rounded divisions stand in for __fdividef
+    const float coox = fmaf(a.fx, vc.x / vc.z, a.cx);
+    const float cooy = fmaf(a.fy, vc.y / vc.z, a.cy);
+    if (!(coox >= 0.f && cooy >= 0.f && coox < (float)a.cols && cooy < (float)a.rows)) return old;  // :70
+    // :73 point-sampled, un-normalised texture fetch == texel (floor x, floor y); coordinates
+    // are non-negative here so the truncating convert is the floor
+    const int px         = (int)coox;
+    const int py         = (int)cooy;
+    const uint16_t* drow = (const uint16_t*)((const char*)a.dists + (size_t)py * a.dists_step);
+    const float Dp       = half_bits_to_float(drow[px]);
+    if (Dp == 0.f) return old;                      // :74
+    const float sdf = Dp - sqrtf(dot(vc, vc));      // :77
+    if (!(sdf >= -a.trunc)) return old;             // :79
+    const float tsdf = fminf(1.f, sdf * a.trunc_inv);  // :80
+    int weight_prev;
+    float tsdf_prev;
+    if (FUSED_CLEAR) {
+        weight_prev = 0;
+        tsdf_prev   = 0.f;
+    } else {
+        weight_prev = (int)(old >> 16);
+        tsdf_prev   = unpack_tsdf(old);
+    }
+    const float tsdf_new = fmaf(tsdf_prev, (float)weight_prev, tsdf) / (float)(weight_prev + 1);  // :86
+    const int weight_new = min(weight_prev + 1, a.max_weight);                                   // :87
+    changed              = true;
+    return pack_tsdf(tsdf_new, weight_new);
+}
+
+template <int VX>
+struct VoxVec;
+template <>
+struct VoxVec<4> {
+    uint4 v;
+    __device__ __forceinline__ uint32_t get(int i) const { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+    __device__ __forceinline__ void set(int i, uint32_t x) {
+        if (i == 0) v.x = x;
+        else if (i == 1) v.y = x;
+        else if (i == 2) v.z = x;
+        else v.w = x;
+    }
+    __device__ __forceinline__ void load(const uint32_t* p) { v = *(const uint4*)p; }
+    __device__ __forceinline__ void store(uint32_t* p) const { *(uint4*)p = v; }
+    __device__ __forceinline__ void zero() { v = make_uint4(0u, 0u, 0u, 0u); }
+};
+template <>
+struct VoxVec<1> {
+    uint32_t v;
+    __device__ __forceinline__ uint32_t get(int) const { return v; }
+    __device__ __forceinline__ void set(int, uint32_t x) { v = x; }
+    __device__ __forceinline__ void load(const uint32_t* p) { v = *p; }
+    __device__ __forceinline__ void store(uint32_t* p) const { *p = v; }
+    __device__ __forceinline__ void zero() { v = 0u; }
+};
+
+// block = (64, 4): a wave spans 64*VX voxels in x, the block 4 rows in y; grid.z = z chunks.
+template <bool FUSED_CLEAR, int VX>
+__global__ __launch_bounds__(256) void integrate_kernel(const IntegrateArgs a) {
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * VX;
+    const int y  = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= a.X || y >= a.Y) return;
+    const int z0 = blockIdx.z * a.zchunk;
+    const int z1 = min(z0 + a.zchunk, a.Z);
+
+    // :58
+    const f3 zstep = mk3(a.vol2cam.m[2], a.vol2cam.m[5], a.vol2cam.m[8]) * a.vsz;
+    const f3 t     = mk3(a.vol2cam.t[0], a.vol2cam.t[1], a.vol2cam.t[2]);
+    f3 vc[VX];
+#pragma unroll
+    for (int v = 0; v < VX; ++v) {
+        const f3 vx = mk3((float)(x0 + v) * a.vsx, (float)y * a.vsy, 0.f);  // :60
+        vc[v]       = mulR(a.vol2cam, vx) + t;                              // :61
+    }
+    // replay the z0 running additions of :64 so the chunk starts on the reference's value
+    for (int i = 0; i < z0; ++i) {
+#pragma unroll
+        for (int v = 0; v < VX; ++v) vc[v] = vc[v] + zstep;
+    }
+
+    const size_t slice = (size_t)a.X * a.Y;
+    uint32_t* ptr      = a.vol + (size_t)x0 + (size_t)a.X * y + slice * z0;
+
+    constexpr int U = 4;  // slices in flight per lane
+    int z           = z0;
+    for (; z + U <= z1; z += U, ptr += slice * U) {
+        VoxVec<VX> cur[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (FUSED_CLEAR) cur[u].zero();
+            else cur[u].load(ptr + slice * u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bool changed = FUSED_CLEAR;  // the fused sweep writes every voxel
+#pragma unroll
+            for (int v = 0; v < VX; ++v) {
+                cur[u].set(v, integrate_voxel<FUSED_CLEAR>(a, vc[v], cur[u].get(v), changed));
+                vc[v] = vc[v] + zstep;  // :64, also for skipped voxels
+            }
+            if (changed) cur[u].store(ptr + slice * u);
+        }
+    }
+    for (; z < z1; ++z, ptr += slice) {
+        VoxVec<VX> cur;
+        if (FUSED_CLEAR) cur.zero();
+        else cur.load(ptr);
+        bool changed = FUSED_CLEAR;
+#pragma unroll
+        for (int v = 0; v < VX; ++v) {
+            cur.set(v, integrate_voxel<FUSED_CLEAR>(a, vc[v], cur.get(v), changed));
+            vc[v] = vc[v] + zstep;
+        }
+        if (changed) cur.store(ptr);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// raycast — tsdf_volume.cu:128-337
+struct RaycastArgs {
+    const uint32_t* vol;
+    int X, Y, Z;
+    float vsx, vsy, vsz;        // voxel size
+    float vix, viy, viz;        // 1 / voxel size          (:362)
+    float sx, sy, sz;           // volume size = voxel*dims (:359)
+    float gdx, gdy, gdz;        // gradient delta           (:361)
+    float time_step;            // trunc * step_factor      (:360)
+    Aff3 cam2vol;
+    Mat3 Rinv;
+    float finvx, finvy, cx, cy;  // Reprojector
+    int cols, rows;
+};
+
+__device__ __forceinline__ float qnan() { return __uint_as_float(0x7fffffffu); }  // temp_utils.hpp:22
+
+// :187-193 nearest voxel (round-half-even).  The clamp is memory safety only: rays are kept
+// inside [0, size - voxel] by the slab test.
+__device__ __forceinline__ float fetch_tsdf(const RaycastArgs& a, f3 p) {
+    int x = (int)rintf(p.x * a.vix);
+    int y = (int)rintf(p.y * a.viy);
+    int z = (int)rintf(p.z * a.viz);
+    x     = min(max(x, 0), a.X - 1);
+    y     = min(max(y, 0), a.Y - 1);
+    z     = min(max(z, 0), a.Z - 1);
+    return unpack_tsdf(a.vol[(size_t)x + (size_t)a.X * y + (size_t)a.X * a.Y * z]);
+}
+
+// :146-171 trilinear interpolation, voxel centres at integer coordinates
+__device__ __forceinline__ float interpolate(const RaycastArgs& a, f3 cf) {
+    if (!(cf.x >= 0.f && cf.x < (float)(a.X - 1) && cf.y >= 0.f && cf.y < (float)(a.Y - 1) && cf.z >= 0.f &&
+          cf.z < (float)(a.Z - 1)))
+        return qnan();
+    const int gx = (int)cf.x, gy = (int)cf.y, gz = (int)cf.z;  // floor of a non-negative value
+    const float fa = cf.x - (float)gx, fb = cf.y - (float)gy, fc = cf.z - (float)gz;
+    const size_t sy = (size_t)a.X, sz = (size_t)a.X * a.Y;
+    const uint32_t* b = a.vol + (size_t)gx + sy * gy + sz * gz;
+    // 8 independent gathers issued together
+    const float v000 = unpack_tsdf(b[0]), v001 = unpack_tsdf(b[sz]);
+    const float v010 = unpack_tsdf(b[sy]), v011 = unpack_tsdf(b[sy + sz]);
+    const float v100 = unpack_tsdf(b[1]), v101 = unpack_tsdf(b[1 + sz]);
+    const float v110 = unpack_tsdf(b[1 + sy]), v111 = unpack_tsdf(b[1 + sy + sz]);
+    float tsdf = 0.f;
+    tsdf = fmaf((v000 * (1.f - fa)) * (1.f - fb), (1.f - fc), tsdf);
+    tsdf = fmaf((v001 * (1.f - fa)) * (1.f - fb), fc, tsdf);
+    tsdf = fmaf((v010 * (1.f - fa)) * fb, (1.f - fc), tsdf);
+    tsdf = fmaf((v011 * (1.f - fa)) * fb, fc, tsdf);
+    tsdf = fmaf((v100 * fa) * (1.f - fb), (1.f - fc), tsdf);
+    tsdf = fmaf((v101 * fa) * (1.f - fb), fc, tsdf);
+    tsdf = fmaf((v110 * fa) * fb, (1.f - fc), tsdf);
+    tsdf = fmaf((v111 * fa) * fb, fc, tsdf);
+    return tsdf;
+}
+
+// :320-336
+__device__ __forceinline__ f3 compute_normal(const RaycastArgs& a, f3 p) {
+    const f3 vi = mk3(a.vix, a.viy, a.viz);
+    f3 n;
+    const float Fx1 = interpolate(a, mk3(p.x + a.gdx, p.y, p.z) * vi);
+    const float Fx2 = interpolate(a, mk3(p.x - a.gdx, p.y, p.z) * vi);
+    n.x             = (Fx1 - Fx2) / a.gdx;
+    const float Fy1 = interpolate(a, mk3(p.x, p.y + a.gdy, p.z) * vi);
+    const float Fy2 = interpolate(a, mk3(p.x, p.y - a.gdy, p.z) * vi);
+    n.y             = (Fy1 - Fy2) / a.gdy;
+    const float Fz1 = interpolate(a, mk3(p.x, p.y, p.z + a.gdz) * vi);
+    const float Fz2 = interpolate(a, mk3(p.x, p.y, p.z - a.gdz) * vi);
+    n.z             = (Fz1 - Fz2) / a.gdz;
+    return normalized(n);
+}
+
+// shared body of the two TsdfRaycaster::operator() overloads (:195-318)
+__device__ __forceinline__ bool cast_ray(const RaycastArgs& a, int x, int y, f3& vertex_cam, f3& normal_cam) {
+    const f3 ray_org = mk3(a.cam2vol.t[0], a.cam2vol.t[1], a.cam2vol.t[2]);
+    const f3 pix     = mk3((1.f * ((float)x - a.cx)) * a.finvx, (1.f * ((float)y - a.cy)) * a.finvy, 1.f);
+    const f3 ray_dir = normalized(mulR(a.cam2vol, pix));
+    const f3 box_max = mk3(a.sx - a.vsx, a.sy - a.vsy, a.sz - a.vsz);  // :213
+    // intersect (:128-144), including the reference's asymmetric max/min
+    const f3 invR = mk3(1.f / ray_dir.x, 1.f / ray_dir.y, 1.f / ray_dir.z);
+    const f3 tbot = invR * (mk3(0.f, 0.f, 0.f) - ray_org);
+    const f3 ttop = invR * (box_max - ray_org);
+    const f3 tmn  = mk3(fminf(ttop.x, tbot.x), fminf(ttop.y, tbot.y), fminf(ttop.z, tbot.z));
+    const f3 tmx  = mk3(fmaxf(ttop.x, tbot.x), fmaxf(ttop.y, tbot.y), fmaxf(ttop.z, tbot.z));
+    float tmin    = fmaxf(fmaxf(tmn.x, tmn.y), fmaxf(tmn.x, tmn.z));
+    float tmax    = fminf(fminf(tmx.x, tmx.y), fminf(tmx.x, tmx.z));
+    tmin          = fmaxf(0.f, tmin);  // :219
+    if (!(tmin < tmax)) return false;  // :220
+    tmax -= a.time_step;
+    const f3 vstep  = ray_dir * a.time_step;
+    f3 next         = ray_org + ray_dir * tmin;
+    float tsdf_next = fetch_tsdf(a, next);
+    const f3 vi     = mk3(a.vix, a.viy, a.viz);
+    for (float tcurr = tmin; tcurr < tmax; tcurr += a.time_step) {
+        const float tsdf_curr = tsdf_next;
+        const f3 curr         = next;
+        next                  = next + vstep;
+        tsdf_next             = fetch_tsdf(a, next);
+        if (tsdf_curr < 0.f && tsdf_next > 0.f) break;  // :234
+        if (tsdf_curr > 0.f && tsdf_next < 0.f) {       // :237
+            const float Ft   = interpolate(a, curr * vi);
+            const float Ftdt = interpolate(a, next * vi);
+            const float Ts   = tcurr - (a.time_step * Ft) / (Ftdt - Ft);  // :241
+            const f3 vertex  = ray_org + ray_dir * Ts;
+            const f3 normal  = compute_normal(a, vertex);
+            const float prod = normal.x * normal.y * normal.z;
+            if (prod == prod) {  // :246 !isnan
+                normal_cam = mul(a.Rinv, normal);
+                vertex_cam = mul(a.Rinv, vertex - ray_org);
+                return true;
+            }
+            break;
+        }
+    }
+    return false;
+}
+
+// A wave covers an 8x8 pixel tile (rays of a tile walk neighbouring voxels -> shared cache
+// lines); a 256-thread block covers 16x16 pixels.
+__device__ __forceinline__ void tile_pixel(int& x, int& y) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+}
+
+__global__ __launch_bounds__(256) void raycast_points_kernel(const RaycastArgs a, float* __restrict__ points,
+                                                             int points_step, float* __restrict__ normals,
+                                                             int normals_step) {
+    int x, y;
+    tile_pixel(x, y);
+    if (x >= a.cols || y >= a.rows) return;
+    float4* prow = (float4*)((char*)points + (size_t)y * points_step);
+    float4* nrow = (float4*)((char*)normals + (size_t)y * normals_step);
+    f3 v, n;
+    if (cast_ray(a, x, y, v, n)) {
+        prow[x] = make_float4(v.x, v.y, v.z, 0.f);  // :312-313
+        nrow[x] = make_float4(n.x, n.y, n.z, 0.f);
+    } else {
+        const float q = qnan();
+        prow[x] = nrow[x] = make_float4(q, q, q, q);  // :267
+    }
+}
+
+__global__ __launch_bounds__(256) void raycast_depth_kernel(const RaycastArgs a, uint16_t* __restrict__ depth,
+                                                            int depth_step, float* __restrict__ normals,
+                                                            int normals_step) {
+    int x, y;
+    tile_pixel(x, y);
+    if (x >= a.cols || y >= a.rows) return;
+    uint16_t* drow = (uint16_t*)((char*)depth + (size_t)y * depth_step);
+    float4* nrow   = (float4*)((char*)normals + (size_t)y * normals_step);
+    f3 v, n;
+    if (cast_ray(a, x, y, v, n)) {
+        nrow[x]  = make_float4(n.x, n.y, n.z, 0.f);  // :250
+        float mm = v.z * 1000.f;                     // :251, saturating truncation
+        mm       = mm < 0.f ? 0.f : (mm > 65535.f ? 65535.f : mm);
+        drow[x]  = (uint16_t)(int)mm;
+    } else {
+        const float q = qnan();
+        drow[x]       = 0;  // :204-205
+        nrow[x]       = make_float4(q, q, q, q);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launchers (called by the C ABI, capi.cpp)
+
+static inline hipError_t launch_status() { return hipGetLastError(); }
+
+hipError_t launch_compute_dists(const uint16_t* depth, int depth_step, uint16_t* dists, int dists_step, int cols,
+                                int rows, float fx, float fy, float cx, float cy, hipStream_t s) {
+    dim3 block(64, 4), grid((cols + 63) / 64, (rows + 3) / 4);
+    // host wrapper passes finv = 1/f (imgproc.cu:252)
+    compute_dists_kernel<<<grid, block, 0, s>>>(depth, depth_step, dists, dists_step, cols, rows, 1.f / fx, 1.f / fy,
+                                                cx, cy);
+    return launch_status();
+}
+
+hipError_t launch_tsdf_clear(uint32_t* vol, int X, int Y, int Z, hipStream_t s) {
+    const size_t n = (size_t)X * Y * Z;
+    // head/tail so the 16-byte stores are aligned whatever pointer the caller passes
+    size_t head = ((16 - ((uintptr_t)vol & 15)) & 15) / 4;
+    if (head > n) head = n;
+    if (head) {
+        hipError_t e = hipMemsetAsync(vol, 0, head * 4, s);
+        if (e != hipSuccess) return e;
+    }
+    uint32_t* body  = vol + head;
+    const size_t nb = n - head;
+    const size_t n4 = nb / 4;
+    const int ntail = (int)(nb - n4 * 4);
+    size_t blocks   = (n4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;  // 16 blocks per CU, grid-stride the rest
+    if (blocks == 0) blocks = 1;
+    clear_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>((uint4*)body, n4, body + n4 * 4, ntail);
+    return launch_status();
+}
+
+// z-chunk heuristic: enough workgroups to fill 256 CUs several times over, while keeping the
+// replayed-additions prologue (z0 adds per chunk) a small fraction of a chunk's work.
+static int pick_zchunk(int X, int Y, int Z, int vx) {
+    const long columns_wg = (long)((X + 64 * vx - 1) / (64 * vx)) * ((Y + 3) / 4);
+    int zchunk            = Z;
+    // want >= 8 workgroups per CU (2048 in total), chunks no shorter than 32 slices
+    while (columns_wg * ((Z + zchunk - 1) / zchunk) < 2048 && zchunk > 32) zchunk /= 2;
+    zchunk = (zchunk + 3) & ~3;
+    if (const char* e = getenv("DFA_TSDF_ZCHUNK")) {
+        int v = atoi(e);
+        if (v > 0) zchunk = v;
+    }
+    return zchunk;
+}
+
+hipError_t launch_tsdf_integrate(bool fused_clear, const uint16_t* dists, int dists_step, int cols, int rows,
+                                 uint32_t* vol, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
+                                 int max_weight, const float vol2cam[12], float fx, float fy, float cx, float cy,
+                                 hipStream_t s) {
+    IntegrateArgs a;
+    a.dists = dists, a.dists_step = dists_step, a.cols = cols, a.rows = rows;
+    a.vol = vol, a.X = X, a.Y = Y, a.Z = Z;
+    a.vsx = voxel_size[0], a.vsy = voxel_size[1], a.vsz = voxel_size[2];
+    a.trunc      = trunc_dist;
+    a.trunc_inv  = 1.f / trunc_dist;  // tsdf_volume.cu:106
+    a.max_weight = max_weight;
+    for (int i = 0; i < 9; ++i) a.vol2cam.m[i] = vol2cam[i];
+    for (int i = 0; i < 3; ++i) a.vol2cam.t[i] = vol2cam[9 + i];
+    a.fx = fx, a.fy = fy, a.cx = cx, a.cy = cy;
+    const bool vec4 = (X % 4 == 0) && (((uintptr_t)vol & 15) == 0);
+    const int vx    = vec4 ? 4 : 1;
+    a.zchunk        = pick_zchunk(X, Y, Z, vx);
+    dim3 block(64, 4), grid((X + 64 * vx - 1) / (64 * vx), (Y + 3) / 4, (Z + a.zchunk - 1) / a.zchunk);
+    if (vec4) {
+        if (fused_clear) integrate_kernel<true, 4><<<grid, block, 0, s>>>(a);
+        else integrate_kernel<false, 4><<<grid, block, 0, s>>>(a);
+    } else {
+        if (fused_clear) integrate_kernel<true, 1><<<grid, block, 0, s>>>(a);
+        else integrate_kernel<false, 1><<<grid, block, 0, s>>>(a);
+    }
+    return launch_status();
+}
+
+static RaycastArgs make_raycast_args(const uint32_t* vol, int X, int Y, int Z, const float voxel_size[3],
+                                     float trunc_dist, const float cam2vol[12], const float Rinv[9], float fx,
+                                     float fy, float cx, float cy, float step_factor, float delta_factor, int cols,
+                                     int rows) {
+    RaycastArgs a;
+    a.vol = vol, a.X = X, a.Y = Y, a.Z = Z;
+    a.vsx = voxel_size[0], a.vsy = voxel_size[1], a.vsz = voxel_size[2];
+    // tsdf_volume.cu:359-362 (host, plain float arithmetic)
+    a.sx = voxel_size[0] * (float)X, a.sy = voxel_size[1] * (float)Y, a.sz = voxel_size[2] * (float)Z;
+    a.time_step = trunc_dist * step_factor;
+    a.gdx = voxel_size[0] * delta_factor, a.gdy = voxel_size[1] * delta_factor, a.gdz = voxel_size[2] * delta_factor;
+    a.vix = 1.f / voxel_size[0], a.viy = 1.f / voxel_size[1], a.viz = 1.f / voxel_size[2];
+    for (int i = 0; i < 9; ++i) a.cam2vol.m[i] = cam2vol[i], a.Rinv.m[i] = Rinv[i];
+    for (int i = 0; i < 3; ++i) a.cam2vol.t[i] = cam2vol[9 + i];
+    a.finvx = 1.f / fx, a.finvy = 1.f / fy, a.cx = cx, a.cy = cy;
+    a.cols = cols, a.rows = rows;
+    return a;
+}
+
+hipError_t launch_raycast_points(const uint32_t* vol, int X, int Y, int Z, const float voxel_size[3],
+                                 float trunc_dist, const float cam2vol[12], const float Rinv[9], float fx, float fy,
+                                 float cx, float cy, float step_factor, float delta_factor, float* points,
+                                 int points_step, float* normals, int normals_step, int cols, int rows,
+                                 hipStream_t s) {
+    RaycastArgs a = make_raycast_args(vol, X, Y, Z, voxel_size, trunc_dist, cam2vol, Rinv, fx, fy, cx, cy,
+                                      step_factor, delta_factor, cols, rows);
+    dim3 block(256), grid((cols + 15) / 16, (rows + 15) / 16);
+    raycast_points_kernel<<<grid, block, 0, s>>>(a, points, points_step, normals, normals_step);
+    return launch_status();
+}
+
+hipError_t launch_raycast_depth(const uint32_t* vol, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
+                                const float cam2vol[12], const float Rinv[9], float fx, float fy, float cx, float cy,
+                                float step_factor, float delta_factor, uint16_t* depth, int depth_step,
+                                float* normals, int normals_step, int cols, int rows, hipStream_t s) {
+    RaycastArgs a = make_raycast_args(vol, X, Y, Z, voxel_size, trunc_dist, cam2vol, Rinv, fx, fy, cx, cy,
+                                      step_factor, delta_factor, cols, rows);
+    dim3 block(256), grid((cols + 15) / 16, (rows + 15) / 16);
+    raycast_depth_kernel<<<grid, block, 0, s>>>(a, depth, depth_step, normals, normals_step);
+    return launch_status();
+}
+
+}  // namespace dfa

@@ -1,0 +1,174 @@
+/*
+ * dynfu_amd.h — C ABI of the MI355X-native (gfx950) implementation of dynfu's per-frame hot
+ * path: TSDF clear / integrate / raycast + compute_dists, and the warp-field solve
+ * (k-NN graph, RBF weights, DQ warp, Tukey re-weighting, Gauss-Newton / block-Jacobi PCG).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ / torch / OpenCV types.
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * swarth100/dynfu checkout).  INTEGRATION.md shows the reference-side bindings.
+ *
+ * Conventions
+ *   - all data pointers are DEVICE pointers (hipMalloc / torch CUDA tensors) unless the
+ *     parameter is documented as host; the caller owns them, kernels allocate nothing
+ *     (same ownership as kfusion::cuda::DeviceMemory, device_memory.cpp:50-113);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is
+ *     asynchronous on it.  NOTE the reference's device::integrate ends with
+ *     cudaDeviceSynchronize (tsdf_volume.cu:120); the adaptor class syncs where the caller
+ *     relied on that;
+ *   - return value: DFA_OK or an error code; dfa_last_error() gives the message for the
+ *     calling thread (the reference prints and exit(0)s instead, safe_call.hpp:11-22 — the
+ *     C++ adaptor may translate);
+ *   - affine transforms are 12 floats: R row-major (9) then t (3) == device::Aff3f
+ *     (internal.hpp:28-34); image `step`s are in BYTES == PtrStep (kernel_containers.hpp);
+ *   - TSDF voxel = uint32: low 16 bits half-float tsdf (RNE), high 16 bits weight
+ *     == ushort2{x,y} (internal.hpp:38, device.hpp:59-67); idx = x + y*X + z*X*Y.
+ */
+#ifndef DYNFU_AMD_H
+#define DYNFU_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dfa_stream_t;
+
+enum {
+    DFA_OK           = 0,
+    DFA_ERR_INVALID  = 1, /* bad argument (null pointer, non-positive size, unsupported k, ...) */
+    DFA_ERR_HIP      = 2, /* a HIP runtime call or kernel launch failed */
+    DFA_ERR_CAPACITY = 3, /* a solver plan is too small for the problem handed to it */
+    DFA_ERR_NO_GPU   = 4  /* no HIP device visible */
+};
+
+/* message of the last failing call on this thread ("" if none) */
+const char* dfa_last_error(void);
+/* library / device identification: "dynfu_amd <ver> gfx950 ..." ; static storage */
+const char* dfa_version(void);
+
+/* ===================================================================================== */
+/* TSDF seam — replaces the free functions of namespace kfusion::device                  */
+/* (include/kfusion/internal.hpp:158-166,204)                                            */
+
+/* compute_dists — internal.hpp:204, imgproc.cu:233-254.
+ * dists(y,x) = half(depth_mm * sqrt(((x-cx)/fx)^2 + ((y-cy)/fy)^2 + 1) * 0.001) */
+int dfa_compute_dists(const uint16_t* depth, int depth_step, uint16_t* dists, int dists_step, int cols, int rows,
+                      float fx, float fy, float cx, float cy, dfa_stream_t stream);
+
+/* clear_volume — internal.hpp:159, tsdf_volume.cu:11-34 */
+int dfa_tsdf_clear(uint32_t* volume, int X, int Y, int Z, dfa_stream_t stream);
+
+/* integrate — internal.hpp:160, tsdf_volume.cu:43-121.
+ * dists: half-float ray lengths in metres (cols x rows, dists_step bytes per row). */
+int dfa_tsdf_integrate(const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* volume, int X, int Y, int Z,
+                       const float voxel_size[3], float trunc_dist, int max_weight, const float vol2cam[12], float fx,
+                       float fy, float cx, float cy, dfa_stream_t stream);
+
+/* clear_volume + integrate in one sweep (what DynFusion::operator() does every frame,
+ * src/dynfu/dyn_fusion.cpp:113-116): bit-identical to dfa_tsdf_clear followed by
+ * dfa_tsdf_integrate, with half the HBM traffic (no read of the old volume). */
+int dfa_tsdf_clear_integrate(const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* volume, int X, int Y,
+                             int Z, const float voxel_size[3], float trunc_dist, int max_weight,
+                             const float vol2cam[12], float fx, float fy, float cx, float cy, dfa_stream_t stream);
+
+/* raycast (points variant) — internal.hpp:165-166, tsdf_volume.cu:258-318,371-386.
+ * points / normals: float4 images; misses are quiet NaN. */
+int dfa_tsdf_raycast_points(const uint32_t* volume, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
+                            const float cam2vol[12], const float Rinv[9], float fx, float fy, float cx, float cy,
+                            float step_factor, float delta_factor, float* points, int points_step, float* normals,
+                            int normals_step, int cols, int rows, dfa_stream_t stream);
+
+/* raycast (depth variant) — internal.hpp:162-163, tsdf_volume.cu:195-256,354-369.
+ * depth: u16 millimetres, 0 on miss. */
+int dfa_tsdf_raycast_depth(const uint32_t* volume, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
+                           const float cam2vol[12], const float Rinv[9], float fx, float fy, float cx, float cy,
+                           float step_factor, float delta_factor, uint16_t* depth, int depth_step, float* normals,
+                           int normals_step, int cols, int rows, dfa_stream_t stream);
+
+/* ===================================================================================== */
+/* Warp-field seam — replaces the per-vertex CPU loops of class Warpfield                */
+/* (src/dynfu/warp_field.cpp:99-171, src/dynfu/utils/node.cpp:29-36)                     */
+
+#define DFA_MAX_KNN 16
+
+/* Warpfield::findNeighborsIndex for n_query points at once (warp_field.cpp:111-122; the
+ * reference's KNN is the compile-time constant 8, warp_field.hpp:27 — here 1 <= k <= 16).
+ * idx: n_query x k int32, ascending squared distance, ties to the lower node index,
+ * -1 padded when D < k.  weights (optional, may be NULL): Node::getTransformationWeight
+ * (node.cpp:29-36) of each neighbour, 0 for padding. */
+int dfa_knn(const float* node_pos, const float* node_w, int D, const float* query, int n_query, int k, int32_t* idx,
+            float* weights, dfa_stream_t stream);
+
+/* Warpfield::warpToLive (warp_field.cpp:150-171) = per vertex calcDQB (:127-148) +
+ * DualQuaternion::transformVertex / transformNormal (dual_quaternion.hpp:204-228).
+ * node_dq: D x 8 floats (real w,x,y,z ; dual w,x,y,z).  normals / out_normals may be NULL. */
+int dfa_warp_to_live(const float* node_pos, const float* node_dq, const float* node_w, int D, int k,
+                     const float* vertices, const float* normals, int N, float* out_vertices, float* out_normals,
+                     dfa_stream_t stream);
+
+/* ===================================================================================== */
+/* Solver seam — replaces class CombinedSolver (include/dynfu/utils/opt_solver.hpp:19-110, */
+/* src/dynfu/utils/opt_solver.cpp) and the Opt GN/PCG it drives with energy.t            */
+
+typedef struct dfa_solver dfa_solver; /* opaque plan: owns all scratch device memory */
+
+typedef struct {
+    int num_iter;       /* outer iterations with Tukey/Huber re-weighting (CombinedSolverParameters.numIter) */
+    int nonlinear_iter; /* Gauss-Newton iterations per outer iteration (nonLinearIter)                       */
+    int linear_iter;    /* max PCG iterations per GN iteration (linearIter)                                  */
+    float tukey_offset; /* CombinedSolver ctor, opt_solver.cpp:3-13                                          */
+    float psi_data;
+    float lambda;
+    float psi_reg;
+    float pcg_tol; /* relative preconditioned-residual tolerance; 0 = machine floor only */
+    float gn_tol;  /* relative cost-decrease tolerance; 0 = run all GN iterations         */
+} dfa_solve_params;
+
+typedef struct {
+    double initial_cost; /* sum |r|^2 at t = 0 (Opt convention) */
+    double final_cost;
+    int gn_iters;  /* Gauss-Newton iterations executed in total */
+    int pcg_iters; /* PCG iterations executed in total */
+    int max_row_nnz; /* widest row of the assembled normal matrix (blocks) */
+    int reserved;
+} dfa_solve_stats;
+
+/* Plan for up to max_D nodes / max_N vertices with k neighbours (1..16). */
+int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out);
+void dfa_solver_destroy(dfa_solver* s);
+
+/* CombinedSolver::initializeProblemInstance (opt_solver.cpp:15-54): uploads nothing (inputs
+ * are already device-resident), builds the data graph (vertex -> k nodes, :56-72), the
+ * regularisation graph (node -> k nodes, :74-105) and the RBF weights on the device.
+ * node_dq are the nodes' current transforms dg_se3 (used by the Tukey weights exactly as
+ * updateTukeyBiweights :214-231 uses calcDQB).  Normals are accepted for interface parity
+ * (energy.t declares them, :28-31) and unused by the reference energy; may be NULL. */
+int dfa_solver_set_problem(dfa_solver* s, const float* node_pos, const float* node_dq, const float* node_w, int D,
+                           const float* canon_vertices, const float* canon_normals, const float* live_vertices,
+                           const float* live_normals, int N, dfa_stream_t stream);
+
+/* CombinedSolverBase::solveAll() with the hooks of opt_solver.cpp:107-147: per outer
+ * iteration Tukey + Huber weights, then Gauss-Newton with a block-Jacobi PCG on the normal
+ * equations of energy.t.  Everything is enqueued on `stream`; no host synchronisation. */
+int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* params, dfa_stream_t stream);
+
+/* Results (device pointers, valid until the next set_problem/solve on this plan):
+ *   translations : D x 3, the Opt unknown (energy.t:24)
+ *   node_dq      : D x 8, DQ(0,0,0,t_i) * dg_se3_i — copyResultToCPUFromFloat3 +
+ *                  Node::updateTransformation (opt_solver.cpp:270-285, node.cpp:19-23), once
+ *   tukey        : N, huber : D (opt_solver.cpp:204-268) */
+const float* dfa_solver_translations(const dfa_solver* s);
+const float* dfa_solver_node_dq(const dfa_solver* s);
+const float* dfa_solver_tukey_weights(const dfa_solver* s);
+const float* dfa_solver_huber_weights(const dfa_solver* s);
+const int32_t* dfa_solver_data_graph(const dfa_solver* s); /* N x k */
+const int32_t* dfa_solver_reg_graph(const dfa_solver* s);  /* D x k */
+
+/* Copies the statistics of the last solve to host memory; synchronises `stream`. */
+int dfa_solver_get_stats(dfa_solver* s, dfa_solve_stats* host_out, dfa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYNFU_AMD_H */

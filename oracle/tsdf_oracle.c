@@ -209,6 +209,14 @@ typedef struct {
     float finvx, finvy, cx, cy;
 } raycaster;
 
+/* numeric_limits<float>::quiet_NaN() of temp_utils.hpp:22 is the bit pattern 0x7fffffff */
+static inline float qnan(void) {
+    const uint32_t bits = 0x7fffffffu;
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
 static inline float unpack_tsdf(uint32_t p) { return orc_half_to_float((uint16_t)(p & 0xffffu)); }
 
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -233,7 +241,7 @@ static inline float interpolate(const raycaster* rc, f3 cf) {
      * the same NaN result). */
     if (!(cf.x >= 0.f && cf.x < (float)(rc->X - 1) && cf.y >= 0.f && cf.y < (float)(rc->Y - 1) && cf.z >= 0.f &&
           cf.z < (float)(rc->Z - 1)))
-        return NAN;
+        return qnan();
     int gx = (int)floorf(cf.x), gy = (int)floorf(cf.y), gz = (int)floorf(cf.z);
     float a = cf.x - (float)gx, b = cf.y - (float)gy, c = cf.z - (float)gz;
     const size_t sx = 1, sy = (size_t)rc->X, sz = (size_t)rc->X * rc->Y;
@@ -358,7 +366,7 @@ void orc_tsdf_raycast_points(const uint32_t* vol, int X, int Y, int Z, const flo
                 prow[4 * x + 0] = v.x, prow[4 * x + 1] = v.y, prow[4 * x + 2] = v.z, prow[4 * x + 3] = 0.f;
                 nrow[4 * x + 0] = n.x, nrow[4 * x + 1] = n.y, nrow[4 * x + 2] = n.z, nrow[4 * x + 3] = 0.f;
             } else {
-                for (int c = 0; c < 4; ++c) prow[4 * x + c] = nrow[4 * x + c] = NAN;
+                for (int c = 0; c < 4; ++c) prow[4 * x + c] = nrow[4 * x + c] = qnan();
             }
         }
     }
@@ -386,7 +394,7 @@ void orc_tsdf_raycast_depth(const uint32_t* vol, int X, int Y, int Z, const floa
                 drow[x]  = (uint16_t)(int)mm;
             } else {
                 drow[x] = 0;
-                for (int c = 0; c < 4; ++c) nrow[4 * x + c] = NAN;
+                for (int c = 0; c < 4; ++c) nrow[4 * x + c] = qnan();
             }
         }
     }

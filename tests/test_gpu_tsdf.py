@@ -1,0 +1,227 @@
+"""-m gpu parity tests of the TSDF seam: HIP kernels (through the C ABI) vs the CPU oracle.
+
+Bar: BIT-EXACT — voxel indices touched, 16-bit weights and half-float tsdf bits; raycast
+outputs compared as raw float bits (misses are the 0x7fffffff NaN of the reference).
+The TSDF oracle itself is unpinned (the reference has no TSDF tests), see oracle/oracle.h.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle as O  # noqa: E402
+from dynfu_amd import synth  # noqa: E402
+from gpu_util import aff12, bits, dev, host, rot  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def A():
+    import dynfu_amd
+    dynfu_amd.load()
+    return dynfu_amd
+
+
+def _scene(name, frame=0):
+    cfg = synth.CONFIGS[name]
+    fx, fy, cx, cy = synth.intrinsics(cfg)
+    voxel, trunc, vol2cam, cam2vol, rinv = synth.volume_params(cfg)
+    depth = synth.depth_frame(cfg, frame)
+    return cfg, (fx, fy, cx, cy), voxel, trunc, vol2cam, cam2vol, rinv, depth
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (37, 53), (1, 1), (8, 130)])
+def test_compute_dists_bit_exact(A, shape):
+    import torch
+    rng = np.random.default_rng(1)
+    rows, cols = shape
+    depth = rng.integers(0, 6000, (rows, cols)).astype(np.uint16)
+    depth[rng.random(depth.shape) < 0.1] = 0
+    # pitched input and output (PtrStep semantics): wider row stride than cols
+    pitch = cols + 6
+    d_in = torch.zeros((rows, pitch), dtype=torch.uint16, device="cuda")
+    d_in[:, :cols] = dev(depth)
+    d_out = torch.full((rows, pitch), 0x5555, dtype=torch.uint16, device="cuda")
+    fx, fy, cx, cy = 525.0, 520.0, cols / 2 - 0.5, rows / 2 - 0.5
+    A.compute_dists(d_in[:, :cols], d_out[:, :cols], fx, fy, cx, cy)
+    got = host(d_out)
+    assert np.array_equal(got[:, :cols], O.compute_dists(depth, fx, fy, cx, cy))
+    assert np.all(got[:, cols:] == 0x5555)  # padding untouched
+
+
+@pytest.mark.parametrize("dims", [(64, 64, 64), (50, 38, 44), (4, 4, 4), (128, 32, 72)])
+def test_clear(A, dims):
+    import torch
+    X, Y, Z = dims
+    vol = torch.full((Z, Y, X), 0x12345678, dtype=torch.int32, device="cuda")
+    A.tsdf_clear(vol)
+    assert int(vol.abs().max()) == 0
+
+
+def _integrate_both(A, vol_np, dists, voxel, trunc, maxw, vol2cam, intr, fused=False):
+    import torch
+    v = dev(vol_np)
+    d = dev(dists)
+    (A.tsdf_clear_integrate if fused else A.tsdf_integrate)(v, d, voxel, trunc, maxw, vol2cam, *intr)
+    torch.cuda.synchronize()
+    ref = np.zeros_like(vol_np) if fused else vol_np.copy()
+    n = O.tsdf_integrate(ref, dists, voxel, trunc, maxw, vol2cam, *intr, threads=8)
+    return host(v, np.uint32), ref, n
+
+
+@pytest.mark.parametrize("name", ["T0", "T1"])
+def test_integrate_bit_exact_synthetic_frames(A, name):
+    cfg, intr, voxel, trunc, vol2cam, _, _, _ = _scene(name)
+    dim = cfg["dim"]
+    vol = np.zeros((dim, dim, dim), np.uint32)
+    for f in range(3):  # running average over three different frames, weight clamp at 2
+        dists = O.compute_dists(synth.depth_frame(cfg, f * 7, noise_mm=1.0), *intr)
+        got, ref, n = _integrate_both(A, vol, dists, voxel, trunc, 2, vol2cam, intr)
+        assert n > 0.05 * vol.size
+        assert np.array_equal(got, ref), "frame %d: %d voxels differ" % (f, int((got != ref).sum()))
+        vol = ref
+    assert set(np.unique(vol >> 16)) == {0, 1, 2}
+
+
+@pytest.mark.parametrize("dims", [(50, 38, 44), (36, 20, 9), (64, 8, 130), (4, 4, 4)])
+def test_integrate_bit_exact_ragged_dims_and_rotated_camera(A, dims):
+    # X not a multiple of 4 (scalar path), tiny volumes, camera inside the volume looking
+    # along a tilted axis (voxels behind the camera, rays leaving the image on all sides)
+    X, Y, Z = dims
+    rng = np.random.default_rng(X * 1000 + Y)
+    rows, cols = 61, 83
+    depth = (rng.uniform(400, 2500, (rows, cols))).astype(np.uint16)
+    depth[rng.random(depth.shape) < 0.2] = 0
+    intr = (70.0, 65.0, cols / 2 - 0.5, rows / 2 - 0.5)
+    dists = O.compute_dists(depth, *intr)
+    voxel = np.array([0.04, 0.05, 0.03], np.float32)
+    R = rot([0.3, 1.0, 0.2], 0.4)
+    vol2cam = aff12(R, [-0.9, -0.8, -0.3])
+    vol = rng.integers(0, 2 ** 32, (Z, Y, X), dtype=np.uint64).astype(np.uint32)
+    vol = (vol & 0x0003FFFF) | 0x3000  # plausible half tsdf + small weights
+    got, ref, n = _integrate_both(A, vol, dists, voxel, 0.1, 5, vol2cam, intr)
+    assert n > 0
+    assert np.array_equal(got, ref)
+    got, ref, _ = _integrate_both(A, vol, dists, voxel, 0.1, 5, vol2cam, intr, fused=True)
+    assert np.array_equal(got, ref)
+
+
+def test_fused_clear_integrate_equals_clear_then_integrate(A):
+    cfg, intr, voxel, trunc, vol2cam, _, _, depth = _scene("T1")
+    dim = cfg["dim"]
+    dists = O.compute_dists(depth, *intr)
+    junk = np.full((dim, dim, dim), 0xDEADBEEF, np.uint32)
+    got, ref, _ = _integrate_both(A, junk, dists, voxel, trunc, 64, vol2cam, intr, fused=True)
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("zchunk", ["4", "7", "20", "1000"])
+def test_integrate_independent_of_z_chunking(A, zchunk, monkeypatch):
+    # the kernel replays the running `vc += zstep` additions for chunks that start at z0 > 0
+    cfg, intr, voxel, trunc, vol2cam, _, _, depth = _scene("T0")
+    dim = cfg["dim"]
+    dists = O.compute_dists(depth, *intr)
+    R = rot([1, 0.2, 0], 0.15)
+    vol2cam = aff12(R, vol2cam[9:])
+    monkeypatch.setenv("DFA_TSDF_ZCHUNK", zchunk)
+    vol = np.zeros((dim, dim, dim), np.uint32)
+    got, ref, _ = _integrate_both(A, vol, dists, voxel, trunc, 64, vol2cam, intr)
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("name", ["T0", "T1"])
+def test_raycast_bit_exact(A, name):
+    import torch
+    cfg, intr, voxel, trunc, vol2cam, cam2vol, rinv, depth = _scene(name)
+    dim, W, H = cfg["dim"], cfg["width"], cfg["height"]
+    vol = np.zeros((dim, dim, dim), np.uint32)
+    dists = O.compute_dists(depth, *intr)
+    for _ in range(2):
+        O.tsdf_integrate(vol, dists, voxel, trunc, 64, vol2cam, *intr, threads=8)
+    v = dev(vol)
+    # slightly moved camera so rays are not axis aligned with the integration frame
+    R = rot([0, 1, 0], 0.05)
+    cam2vol_m = aff12(R, cam2vol[9:] + np.array([0.02, -0.01, 0.0], np.float32))
+    rinv_m = np.linalg.inv(R).astype(np.float32).reshape(-1)
+    for c2v, ri in ((cam2vol, rinv), (cam2vol_m, rinv_m)):
+        pts = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        nrm = torch.zeros_like(pts)
+        A.tsdf_raycast_points(v, voxel, trunc, c2v, ri, *intr, synth.RAYCAST_STEP_FACTOR,
+                              synth.GRADIENT_DELTA_FACTOR, pts, nrm)
+        rp, rn = O.tsdf_raycast_points(vol, voxel, trunc, c2v, ri, *intr, synth.RAYCAST_STEP_FACTOR,
+                                       synth.GRADIENT_DELTA_FACTOR, W, H, threads=8)
+        hits = ~np.isnan(rp[..., 0])
+        assert hits.mean() > 0.5
+        assert np.array_equal(bits(host(pts)), bits(rp))
+        assert np.array_equal(bits(host(nrm)), bits(rn))
+        dep = torch.full((H, W), 7, dtype=torch.uint16, device="cuda")
+        nrm2 = torch.zeros_like(pts)
+        A.tsdf_raycast_depth(v, voxel, trunc, c2v, ri, *intr, synth.RAYCAST_STEP_FACTOR,
+                             synth.GRADIENT_DELTA_FACTOR, dep, nrm2)
+        rd, rn2 = O.tsdf_raycast_depth(vol, voxel, trunc, c2v, ri, *intr, synth.RAYCAST_STEP_FACTOR,
+                                       synth.GRADIENT_DELTA_FACTOR, W, H, threads=8)
+        assert np.array_equal(host(dep), rd)
+        assert np.array_equal(bits(host(nrm2)), bits(rn2))
+
+
+def test_raycast_miss_everywhere_on_empty_volume(A):
+    import torch
+    cfg, intr, voxel, trunc, _, cam2vol, rinv, _ = _scene("T0")
+    dim, W, H = cfg["dim"], cfg["width"], cfg["height"]
+    v = torch.zeros((dim, dim, dim), dtype=torch.int32, device="cuda")
+    pts = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    nrm = torch.zeros_like(pts)
+    A.tsdf_raycast_points(v, voxel, trunc, cam2vol, rinv, *intr, 0.75, 0.5, pts, nrm)
+    assert np.all(bits(host(pts)) == 0x7FFFFFFF) and np.all(bits(host(nrm)) == 0x7FFFFFFF)
+
+
+def test_full_size_properties_512(A):
+    """BASELINE config C2 volume (512^3): size-independent properties instead of the oracle
+    (which needs ~10 s per sweep): fused == clear+integrate; W sweeps of one frame give weight
+    min(W, max_weight) on exactly the voxels of the first sweep with the tsdf unchanged
+    (running average of identical samples); checksum independent of the z chunking."""
+    import torch
+    cfg, intr, voxel, trunc, vol2cam, _, _, depth = _scene("C2")
+    dim = cfg["dim"]
+    dists = dev(O.compute_dists(depth, *intr))
+    a = torch.full((dim, dim, dim), -1, dtype=torch.int32, device="cuda")
+    A.tsdf_clear_integrate(a, dists, voxel, trunc, 3, vol2cam, *intr)
+    b = torch.full((dim, dim, dim), -1, dtype=torch.int32, device="cuda")
+    A.tsdf_clear(b)
+    A.tsdf_integrate(b, dists, voxel, trunc, 3, vol2cam, *intr)
+    assert torch.equal(a, b)
+    touched = (a >> 16) == 1
+    frac = float(touched.float().mean())
+    assert 0.05 < frac < 0.9
+    assert int((a[~touched]).abs().max()) == 0
+    for sweep in range(2, 6):
+        A.tsdf_integrate(b, dists, voxel, trunc, 3, vol2cam, *intr)
+        w = b >> 16
+        assert torch.equal(w == min(sweep, 3), touched) and int(w[~touched].max()) == 0
+        # averaging identical samples: (F*W + F)/(W+1) stays within one half ulp step of F
+        diff = ((b & 0xFFFF) - (a & 0xFFFF)).abs()
+        assert int(diff.max()) <= 1
+    os.environ["DFA_TSDF_ZCHUNK"] = "48"
+    try:
+        c = torch.empty_like(a)
+        A.tsdf_clear_integrate(c, dists, voxel, trunc, 3, vol2cam, *intr)
+    finally:
+        del os.environ["DFA_TSDF_ZCHUNK"]
+    assert torch.equal(a, c)
+    # spot-check one z-slab of the 512^3 result against the oracle (bit exact)
+    ref = np.zeros((dim, dim, dim), np.uint32)
+    O.tsdf_integrate(ref, host(dists), voxel, trunc, 3, vol2cam, *intr, threads=8)
+    assert np.array_equal(host(a, np.uint32), ref)
+
+
+def test_argument_errors_are_loud(A):
+    import torch
+    v = torch.zeros((8, 8, 8), dtype=torch.int32, device="cuda")
+    d = torch.zeros((4, 4), dtype=torch.uint16, device="cuda")
+    with pytest.raises(A.DynfuAmdError):
+        A.tsdf_integrate(v, d, [0.1, 0.1, 0.1], -1.0, 64, np.eye(4)[:3], 1, 1, 0, 0)  # trunc <= 0
+    with pytest.raises(A.DynfuAmdError):
+        A.tsdf_integrate(v, d, [0.1, 0.1, 0.1], 0.1, 70000, np.eye(4)[:3], 1, 1, 0, 0)  # weight overflow
+    with pytest.raises(A.DynfuAmdError):
+        A.tsdf_integrate(v.cpu(), d, [0.1, 0.1, 0.1], 0.1, 64, np.eye(4)[:3], 1, 1, 0, 0)  # host pointer

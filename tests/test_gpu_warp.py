@@ -1,0 +1,83 @@
+"""-m gpu parity tests of the warp-field seam (k-NN graph, RBF weights, DQ warp) vs the oracle.
+
+Bar: k-NN indices bit-exact (integer work); weights within 1 float ulp (double exp on two
+different libms, rounded to float); warped vertices within 2e-6 m absolute (float DQ algebra
+with identical operation order, exp as above)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle as O  # noqa: E402
+from dynfu_amd import synth  # noqa: E402
+from gpu_util import dev, host  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def A():
+    import dynfu_amd
+    dynfu_amd.load()
+    return dynfu_amd
+
+
+def _ulp_diff(a, b):
+    ia = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    ib = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    return np.abs(ia - ib)
+
+
+@pytest.mark.parametrize("D,k,n", [(2048, 4, 20000), (500, 8, 5000), (3000, 16, 3000), (5, 8, 100), (1, 4, 10),
+                                    (1025, 5, 777)])
+def test_knn_bit_exact_and_weights(A, D, k, n):
+    rng = np.random.default_rng(D + k)
+    nodes = rng.uniform(-1, 1, (D, 3)).astype(np.float32)
+    node_w = rng.uniform(0.05, 0.5, D).astype(np.float32)
+    q = rng.uniform(-1.2, 1.2, (n, 3)).astype(np.float32)
+    q[: min(n, D)] = nodes[: min(n, D)]  # queries sitting exactly on nodes (distance 0)
+    idx, w = A.knn(dev(nodes), dev(node_w), dev(q), k)
+    ref = O.knn(nodes, q, k, threads=8)
+    assert np.array_equal(host(idx), ref)
+    wref = np.zeros((n, k), np.float32)
+    for v in range(0, n, max(1, n // 500)):
+        for j in range(k):
+            if ref[v, j] >= 0:
+                wref[v, j] = O.transformation_weight(nodes[ref[v, j]], float(node_w[ref[v, j]]), q[v])
+        assert _ulp_diff(host(w)[v], wref[v]).max() <= 1
+    assert np.all(host(w)[ref < 0] == 0)
+
+
+def test_knn_exact_ties_keep_lower_index(A):
+    # integer lattice: many exactly equal distances
+    g = np.stack(np.meshgrid(*[np.arange(6.0)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    q = (g[::5] + np.float32(0.5)).astype(np.float32)
+    idx, _ = A.knn(dev(g), dev(np.ones(len(g), np.float32)), dev(q), 8)
+    assert np.array_equal(host(idx), O.knn(g, q, 8))
+
+
+@pytest.mark.parametrize("name", ["T0", "T1"])
+def test_warp_to_live_matches_oracle(A, name):
+    cfg = synth.CONFIGS[name]
+    c = synth.canonical(cfg)
+    D, k = cfg["D"], cfg["k"]
+    rng = np.random.default_rng(5)
+    # general rigid node transforms (rotation + translation), not only the solver's translations
+    dq = np.stack([O.dq_from_euler(*rng.uniform(-0.2, 0.2, 3), *rng.uniform(-0.05, 0.05, 3)) for _ in range(D)])
+    verts, normals = c["verts"][:20000], c["normals"][:20000]
+    ov, on = A.warp_to_live(dev(c["node_pos"]), dev(dq), dev(c["node_w"]), k, dev(verts), dev(normals))
+    rv, rn = O.warp_to_live(c["node_pos"], dq, c["node_w"], k, verts, normals, threads=8)
+    np.testing.assert_allclose(host(ov), rv, atol=2e-6, rtol=0)
+    np.testing.assert_allclose(host(on), rn, atol=2e-6, rtol=0)
+    # identity transforms warp nothing
+    ov, _ = A.warp_to_live(dev(c["node_pos"]), dev(c["node_dq"]), dev(c["node_w"]), k, dev(verts))
+    assert np.array_equal(host(ov), verts)
+
+
+def test_warp_empty_and_errors(A):
+    import torch
+    nodes = torch.zeros((4, 3), device="cuda")
+    dq = torch.zeros((4, 8), device="cuda")
+    w = torch.ones(4, device="cuda")
+    ov, _ = A.warp_to_live(nodes, dq, w, 4, torch.zeros((0, 3), device="cuda"))
+    assert ov.shape == (0, 3)
+    with pytest.raises(A.DynfuAmdError):
+        A.knn(nodes, w, torch.zeros((3, 3), device="cuda"), 17)
