@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def lib():
+    import torch  # noqa: F401  (torch's bundled HIP runtime must be the one the library binds to)
     from dynfu_amd import build as B
     return ctypes.CDLL(B.build())
 
