@@ -42,7 +42,12 @@ __device__ __forceinline__ f3 mulR(const Aff3& A, f3 v) {
 __device__ __forceinline__ f3 normalized(f3 v) { return v * (1.0f / sqrtf(dot(v, v))); }
 
 // half <-> float: v_cvt_f16_f32 (round-to-nearest-even, f16 subnormals kept) / v_cvt_f32_f16
+// The empty asm makes the float opaque to instruction selection: without it the backend folds
+// a preceding fp32 multiply into v_fma_mixlo_f16, which rounds the exact product ONCE to half
+// instead of fp32-then-half (observed on compute_dists; differs from __float2half_rn(a*b) in
+// ~1e-4 of the pixels).
 __device__ __forceinline__ uint32_t float_to_half_bits(float f) {
+    asm("" : "+v"(f));
     _Float16 h = (_Float16)f;
     return (uint32_t)__builtin_bit_cast(unsigned short, h);
 }

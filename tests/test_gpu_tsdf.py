@@ -97,7 +97,10 @@ def test_integrate_bit_exact_ragged_dims_and_rotated_camera(A, dims):
     dists = O.compute_dists(depth, *intr)
     voxel = np.array([0.04, 0.05, 0.03], np.float32)
     R = rot([0.3, 1.0, 0.2], 0.4)
-    vol2cam = aff12(R, [-0.9, -0.8, -0.3])
+    # camera sits inside / just behind the volume whatever its size: part of the voxels have
+    # vc.z <= 0, part project outside the image, part land on invalid (0) depth
+    centre = 0.5 * voxel * np.array([X, Y, Z], np.float32)
+    vol2cam = aff12(R, np.array([0.05, -0.03, 0.9], np.float32) - (R @ centre).astype(np.float32))
     vol = rng.integers(0, 2 ** 32, (Z, Y, X), dtype=np.uint64).astype(np.uint32)
     vol = (vol & 0x0003FFFF) | 0x3000  # plausible half tsdf + small weights
     got, ref, n = _integrate_both(A, vol, dists, voxel, 0.1, 5, vol2cam, intr)
