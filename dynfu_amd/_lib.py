@@ -12,7 +12,8 @@ SYMBOLS = [
     "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_knn", "dfa_warp_to_live",
     "dfa_solver_create", "dfa_solver_destroy", "dfa_solver_set_problem", "dfa_solver_solve",
     "dfa_solver_translations", "dfa_solver_node_dq", "dfa_solver_tukey_weights", "dfa_solver_huber_weights",
-    "dfa_solver_data_graph", "dfa_solver_reg_graph", "dfa_solver_get_stats",
+    "dfa_solver_data_graph", "dfa_solver_reg_graph", "dfa_solver_get_stats", "dfa_solver_enable_timing",
+    "dfa_solver_get_timing",
 ]
 
 
@@ -30,6 +31,11 @@ class SolveParams(C.Structure):
 class _SolveStats(C.Structure):
     _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("gn_iters", C.c_int),
                 ("pcg_iters", C.c_int), ("max_row_nnz", C.c_int), ("reserved", C.c_int)]
+
+
+class _SolveTiming(C.Structure):
+    _fields_ = [("pcg_ms", C.c_float), ("assemble_ms", C.c_float), ("pcg_launches", C.c_int),
+                ("assemble_launches", C.c_int), ("matrix_nnz", C.c_longlong)]
 
 
 def lib_path():
@@ -72,6 +78,8 @@ def load():
         fn.argtypes = [vp]
         fn.restype = vp
     L.dfa_solver_get_stats.argtypes = [vp, C.POINTER(_SolveStats), vp]
+    L.dfa_solver_enable_timing.argtypes = [vp, i]
+    L.dfa_solver_get_timing.argtypes = [vp, C.POINTER(_SolveTiming), vp]
     runtimes = set()
     with open("/proc/self/maps") as maps:
         for line in maps:
@@ -284,6 +292,15 @@ class Solver:
 
     def reg_graph(self):
         return self._view("reg_graph", (self.D, self.k), _torch().int32)
+
+    def enable_timing(self, on=True):
+        _check(load().dfa_solver_enable_timing(self._h, 1 if on else 0))
+
+    def timing(self):
+        t = _SolveTiming()
+        _check(load().dfa_solver_get_timing(self._h, C.byref(t), _stream()))
+        return dict(pcg_ms=t.pcg_ms, assemble_ms=t.assemble_ms, pcg_launches=t.pcg_launches,
+                    assemble_launches=t.assemble_launches, matrix_nnz=t.matrix_nnz)
 
     def stats(self):
         st = _SolveStats()

@@ -18,7 +18,8 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libdynfu_amd.so")
 SOURCES = ["tsdf.hip", "warp.hip", "solve.hip", "capi.cpp"]
 ARCH = "gfx950"
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function",
+EXTRA = os.environ.get("DFA_EXTRA_CXXFLAGS", "").split()
+FLAGS = EXTRA + ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc"]
 
 

@@ -42,6 +42,38 @@ inline hipStream_t S(dfa_stream_t s) { return (hipStream_t)s; }
 
 bool volume_args_ok(const void* vol, int X, int Y, int Z) { return vol && X > 0 && Y > 0 && Z > 0; }
 
+// device scratch of one node grid (warp.hip); grows on demand, never shrinks
+struct GridScratch {
+    dfa::KnnGridView v{};
+    int cap_nodes = 0;
+    void release() {
+        (void)hipFree(v.desc), (void)hipFree(v.cell_count), (void)hipFree(v.cell_start);
+        (void)hipFree(v.node_cell), (void)hipFree(v.sorted);
+        v         = dfa::KnnGridView{};
+        cap_nodes = 0;
+    }
+    hipError_t reserve(int D) {
+        if (D <= cap_nodes) return hipSuccess;
+        release();
+        hipError_t e;
+        if ((e = hipMalloc((void**)&v.desc, sizeof(dfa::KnnGridDesc))) != hipSuccess) return e;
+        if ((e = hipMalloc((void**)&v.cell_count, sizeof(int32_t) * dfa::KNN_GRID_MAX_CELLS)) != hipSuccess) return e;
+        if ((e = hipMalloc((void**)&v.cell_start, sizeof(int32_t) * (dfa::KNN_GRID_MAX_CELLS + 1))) != hipSuccess)
+            return e;
+        if ((e = hipMalloc((void**)&v.node_cell, sizeof(int32_t) * (size_t)D)) != hipSuccess) return e;
+        if ((e = hipMalloc((void**)&v.sorted, sizeof(float4) * (size_t)D)) != hipSuccess) return e;
+        cap_nodes = D;
+        return hipSuccess;
+    }
+};
+
+// The standalone entry points (dfa_knn, dfa_warp_to_live) have no plan to keep scratch in:
+// one grid per host thread, reused across calls (stream-ordered use; grows synchronously).
+thread_local GridScratch g_thread_grid;
+
+// exhaustive scan below this many distance evaluations (grid build = 4 small launches)
+bool want_grid(int D, long n_query) { return D >= 64 && (long)D * n_query >= (1L << 22); }
+
 }  // namespace
 
 struct dfa_solver {
@@ -52,10 +84,33 @@ struct dfa_solver {
     dfa::SolveState* state;    // device
     double* cost_partials;     // device
     std::vector<void*> blocks;  // every hipMalloc of this plan
+    GridScratch grid;           // node grid of the current problem
     bool has_problem;
+    bool timing;
+    std::vector<hipEvent_t> events;  // pool of timing events, reused every solve
+    std::vector<int> ev_pcg, ev_asm; // indices of the begin events of each bracketed launch
+    size_t ev_used;
 };
 
 namespace {
+// returns the index of a fresh event pair's begin event, recorded on st
+int timing_begin(dfa_solver* s, hipStream_t st) {
+    if (s->ev_used + 2 > s->events.size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return -1;
+            s->events.push_back(e);
+        }
+    }
+    const int idx = (int)s->ev_used;
+    s->ev_used += 2;
+    (void)hipEventRecord(s->events[idx], st);
+    return idx;
+}
+void timing_end(dfa_solver* s, int idx, hipStream_t st) {
+    if (idx >= 0) (void)hipEventRecord(s->events[idx + 1], st);
+}
+
 template <class T>
 int plan_alloc(dfa_solver* s, T** out, size_t count) {
     void* p       = nullptr;
@@ -158,7 +213,13 @@ int dfa_knn(const float* node_pos, const float* node_w, int D, const float* quer
     REQUIRE(n_query >= 0 && (n_query == 0 || (query && idx)), "bad query / output");
     REQUIRE(k >= 1 && k <= DFA_MAX_KNN, "k out of range 1..16");
     REQUIRE(!weights || node_w, "weights requested without node_w");
-    HIP_TRY(dfa::launch_knn(node_pos, node_w, D, query, n_query, k, idx, weights, S(stream)));
+    const dfa::KnnGridView* grid = nullptr;
+    if (want_grid(D, n_query)) {
+        HIP_TRY(g_thread_grid.reserve(D));
+        HIP_TRY(dfa::knn_grid_build(g_thread_grid.v, node_pos, D, S(stream)));
+        grid = &g_thread_grid.v;
+    }
+    HIP_TRY(dfa::launch_knn(node_pos, node_w, D, query, n_query, k, idx, weights, grid, S(stream)));
     return DFA_OK;
 }
 
@@ -168,8 +229,14 @@ int dfa_warp_to_live(const float* node_pos, const float* node_dq, const float* n
     REQUIRE(node_pos && node_dq && node_w && D > 0, "no nodes");
     REQUIRE(N >= 0 && (N == 0 || (vertices && out_vertices)), "bad vertices / output");
     REQUIRE(k >= 1 && k <= DFA_MAX_KNN, "k out of range 1..16");
+    const dfa::KnnGridView* grid = nullptr;
+    if (want_grid(D, N)) {
+        HIP_TRY(g_thread_grid.reserve(D));
+        HIP_TRY(dfa::knn_grid_build(g_thread_grid.v, node_pos, D, S(stream)));
+        grid = &g_thread_grid.v;
+    }
     HIP_TRY(dfa::launch_warp_to_live(node_pos, node_dq, node_w, D, k, vertices, normals, N, out_vertices,
-                                     out_normals, S(stream)));
+                                     out_normals, grid, S(stream)));
     return DFA_OK;
 }
 
@@ -189,6 +256,8 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
     s->max_R       = (size_t)max_N + (size_t)max_D * k;
     s->ell_cap     = 256;
     s->has_problem = false;
+    s->timing      = false;
+    s->ev_used     = 0;
     std::memset(&s->v, 0, sizeof(s->v));
     const size_t R = s->max_R, D = (size_t)max_D;
     int rc = DFA_OK;
@@ -213,6 +282,10 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
     A(huber, D);
     A(node_dq_out, D * 8);
 #undef A
+    if (rc == DFA_OK) {
+        hipError_t e = s->grid.reserve(max_D);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMalloc (node grid)");
+    }
     if (rc == DFA_OK) rc = plan_alloc(s, &s->state, 1);
     if (rc == DFA_OK) rc = plan_alloc(s, &s->cost_partials, (R + 255) / 256 + 1);
     if (rc != DFA_OK) {
@@ -226,6 +299,8 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
 void dfa_solver_destroy(dfa_solver* s) {
     if (!s) return;
     for (void* p : s->blocks) (void)hipFree(p);
+    s->grid.release();
+    for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     delete s;
 }
 
@@ -246,9 +321,14 @@ int dfa_solver_set_problem(dfa_solver* s, const float* node_pos, const float* no
     v.canon = canon_vertices, v.live = live_vertices;
     hipStream_t st = S(stream);
     // initializeDataGraph (opt_solver.cpp:56-72): rows [0, N) = k-NN of the canonical vertices + RBF weights
-    if (N > 0) HIP_TRY(dfa::launch_knn(node_pos, node_w, D, canon_vertices, N, s->k, v.ridx, v.rw, st));
+    const dfa::KnnGridView* grid = nullptr;
+    if (want_grid(D, (long)N + D)) {
+        HIP_TRY(dfa::knn_grid_build(s->grid.v, node_pos, D, st));
+        grid = &s->grid.v;
+    }
+    if (N > 0) HIP_TRY(dfa::launch_knn(node_pos, node_w, D, canon_vertices, N, s->k, v.ridx, v.rw, grid, st));
     // initializeRegGraph (:74-105): k-NN of every node among the nodes (itself included at distance 0)
-    HIP_TRY(dfa::launch_knn(node_pos, node_w, D, node_pos, D, s->k, v.reg_idx, nullptr, st));
+    HIP_TRY(dfa::launch_knn(node_pos, node_w, D, node_pos, D, s->k, v.reg_idx, nullptr, grid, st));
     HIP_TRY(dfa::solve_build_graph(v, st));
     // resetGPUMemory (:149-202): unknowns start at zero
     HIP_TRY(hipMemsetAsync(v.t, 0, sizeof(float) * 3 * (size_t)D, st));
@@ -270,13 +350,22 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
     const double w_reg    = std::sqrt((double)p->lambda / ((double)v.D * (double)v.k));
     const float w_reg_f   = (float)w_reg;
     const float w_reg_sq  = w_reg_f * w_reg_f;
+    s->ev_used = 0;
+    s->ev_pcg.clear();
+    s->ev_asm.clear();
     for (int outer = 0; outer < p->num_iter; ++outer) {
         // preNonlinearSolve (opt_solver.cpp:135-140)
         HIP_TRY(dfa::solve_weights(v, p->tukey_offset, p->psi_data, w_reg_sq, p->psi_reg, st));
         for (int gn = 0; gn < p->nonlinear_iter; ++gn) {
             HIP_TRY(dfa::solve_residual(v, s->state, s->cost_partials, gn == 0 ? 0 : 1, p->gn_tol, st));
+            int ev = s->timing ? timing_begin(s, st) : -1;
             HIP_TRY(dfa::solve_assemble(v, s->state, st));
+            timing_end(s, ev, st);
+            if (ev >= 0) s->ev_asm.push_back(ev);
+            ev = s->timing ? timing_begin(s, st) : -1;
             HIP_TRY(dfa::solve_pcg(v, s->state, p->linear_iter, p->pcg_tol, st));
+            timing_end(s, ev, st);
+            if (ev >= 0) s->ev_pcg.push_back(ev);
         }
     }
     if (p->num_iter == 0) HIP_TRY(dfa::solve_weights(v, p->tukey_offset, p->psi_data, w_reg_sq, p->psi_reg, st));
@@ -304,9 +393,44 @@ int dfa_solver_get_stats(dfa_solver* s, dfa_solve_stats* host_out, dfa_stream_t 
     host_out->pcg_iters    = h.pcg_iters;
     host_out->max_row_nnz  = h.max_row_nnz;
     host_out->reserved     = 0;
+    if (getenv("DFA_PCG_PROFILE_PRINT"))
+        fprintf(stderr, "pcg phase cycles: spmv %lld  red_pAp %lld  update %lld  red_rz %lld  p_update+barrier %lld  loop %lld  (iters %d)\n",
+                h.prof[0], h.prof[1], h.prof[2], h.prof[3], h.prof[4], h.prof[5], h.pcg_iters);
     if (h.overflow)
         return fail(DFA_ERR_CAPACITY, "normal-matrix row wider than the plan's ELL capacity (%d > %d)", h.max_row_nnz,
                     s->ell_cap);
+    return DFA_OK;
+}
+
+int dfa_solver_enable_timing(dfa_solver* s, int enable) {
+    REQUIRE(s, "null plan");
+    s->timing = enable != 0;
+    return DFA_OK;
+}
+
+int dfa_solver_get_timing(dfa_solver* s, dfa_solve_timing* out, dfa_stream_t stream) {
+    REQUIRE(s && out, "null plan / out");
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    std::memset(out, 0, sizeof(*out));
+    for (int idx : s->ev_pcg) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->events[idx], s->events[idx + 1]));
+        out->pcg_ms += ms;
+    }
+    for (int idx : s->ev_asm) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->events[idx], s->events[idx + 1]));
+        out->assemble_ms += ms;
+    }
+    out->pcg_launches      = (int)s->ev_pcg.size();
+    out->assemble_launches = (int)s->ev_asm.size();
+    if (s->has_problem && s->v.D > 0) {
+        std::vector<int32_t> cnt((size_t)s->v.D);
+        HIP_TRY(hipMemcpy(cnt.data(), s->v.ell_cnt, sizeof(int32_t) * cnt.size(), hipMemcpyDeviceToHost));
+        long long nnz = 0;
+        for (int32_t c : cnt) nnz += c;
+        out->matrix_nnz = nnz;
+    }
     return DFA_OK;
 }
 

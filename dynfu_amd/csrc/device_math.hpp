@@ -61,6 +61,24 @@ __device__ __forceinline__ uint32_t pack_tsdf(float tsdf, int weight) {
 }
 __device__ __forceinline__ float unpack_tsdf(uint32_t v) { return half_bits_to_float(v); }
 
+// 64-lane wave total by DPP (no LDS traffic, ~6 dependent VALU ops): Hillis-Steele inclusive scan
+// inside each row of 16 lanes (row_shr 1,2,4,8), then row_bcast15 / row_bcast31 carry the row
+// totals across rows; lane 63 ends up with the wave total, returned wave-uniformly.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_total(float v) {
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // 64-lane wave reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -25,10 +25,27 @@ hipError_t launch_raycast_depth(const uint32_t* vol, int X, int Y, int Z, const 
                                 float* normals, int normals_step, int cols, int rows, hipStream_t s);
 
 // warp.hip
+// Uniform grid over the deformation nodes (device-resident, geometry computed on the device).
+constexpr int KNN_GRID_MAX_DIM   = 32;
+constexpr int KNN_GRID_MAX_CELLS = KNN_GRID_MAX_DIM * KNN_GRID_MAX_DIM * KNN_GRID_MAX_DIM;
+struct KnnGridDesc {
+    float bmin[3];
+    float cs, inv_cs;
+    int dim[3];
+};
+struct KnnGridView {
+    KnnGridDesc* desc;
+    int32_t* cell_count;  // KNN_GRID_MAX_CELLS   (counts, then fill cursors)
+    int32_t* cell_start;  // KNN_GRID_MAX_CELLS + 1
+    int32_t* node_cell;   // D
+    float4* sorted;       // D   (x, y, z, node index bits), grouped by cell
+};
+hipError_t knn_grid_build(const KnnGridView& g, const float* node_pos, int D, hipStream_t s);
+// grid == nullptr: exhaustive scan
 hipError_t launch_knn(const float* node_pos, const float* node_w, int D, const float* query, int n_query, int k,
-                      int32_t* idx, float* weights, hipStream_t s);
+                      int32_t* idx, float* weights, const KnnGridView* grid, hipStream_t s);
 hipError_t launch_warp_to_live(const float* node_pos, const float* node_dq, const float* node_w, int D, int k,
                                const float* verts, const float* normals, int N, float* out_verts, float* out_normals,
-                               hipStream_t s);
+                               const KnnGridView* grid, hipStream_t s);
 
 }  // namespace dfa

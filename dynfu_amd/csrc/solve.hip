@@ -326,32 +326,64 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
 // ------------------------------------------------------------------------------------------
 // block-Jacobi PCG, one persistent workgroup of 1024 threads; thread owns rows tid + 1024*i.
 
-__device__ __forceinline__ double block_sum(double v, double* red /*[16]*/) {
-    v = wave_sum_all(v);
-    __syncthreads();  // protect red[] against the previous reduction's readers
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+// Workgroup total: DPP wave totals (float) -> one LDS slot per wave -> ONE barrier -> every
+// thread adds the NWAVES partials in double.  `red` must alternate between two buffers on
+// successive calls so that no second barrier is needed to protect the slots.
+template <int NWAVES>
+__device__ __forceinline__ double block_sum(float v, float* red) {
+    const float w = wave_total(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
     __syncthreads();
     double tot = 0.0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) tot += red[w];
+    for (int i = 0; i < NWAVES; ++i) tot += (double)red[i];
     return tot;
 }
 
-template <int RPT>
-__global__ __launch_bounds__(1024) void pcg_kernel(SolveView s, SolveState* __restrict__ st, int max_iter,
+// S = matrix entries per row kept in registers for the whole solve (values as fp32, columns as
+// packed u16): the matrix is constant over the PCG iterations, so the only per-iteration
+// memory traffic left is the LDS gather of the direction vector.  Rows longer than S read the
+// excess from global memory (L2).  S = 0 streams the whole matrix from L2 every iteration.
+template <int NT, int RPT, int S>
+__global__ __launch_bounds__(NT) void pcg_kernel(SolveView s, SolveState* __restrict__ st, int max_iter,
                                                    float pcg_tol) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* p_s = (float4*)smem;                                // D entries
-    double* red = (double*)(smem + sizeof(float4) * (size_t)s.Dpad);  // 16 doubles
+    float* red0 = (float*)(smem + sizeof(float4) * (size_t)s.Dpad);  // 2 x 16 wave partials
+    float* red1 = red0 + 16;
     if (st->done) return;
     const int tid = threadIdx.x;
     const int D   = s.D;
 
     float x[RPT][3], r[RPT][3], p[RPT][3], minv[RPT];
-    double rz_loc = 0.0;
+    float mval[RPT][S > 0 ? S : 1];
+    uint32_t mcol[RPT][S > 0 ? (S + 1) / 2 : 1];
+    int rcnt[RPT];
+    int wmax = 0;  // longest row among this wave's rows (wave-uniform loop bound)
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-        const int row = tid + 1024 * i;
+        const int row = tid + NT * i;
+        rcnt[i]       = row < D ? s.ell_cnt[row] : 0;
+        if (S > 0) {
+#pragma unroll
+            for (int q = 0; q < S; ++q) {
+                const int rowc = row < D ? row : 0;
+                float v        = s.ell_vals[(size_t)q * D + rowc];
+                int col        = s.ell_cols[(size_t)q * D + rowc];
+                if (!(q < rcnt[i])) v = 0.f, col = 0;
+                mval[i][q] = v;
+                if (q & 1) mcol[i][q >> 1] |= (uint32_t)col << 16;
+                else mcol[i][q >> 1] = (uint32_t)col;
+            }
+        }
+        wmax = max(wmax, rcnt[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
+    float rz_loc = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int row = tid + NT * i;
         if (row < D) {
             const float d = s.diag[row];
             minv[i]       = d > FLT_EPSILON ? 1.0f / d : 1.0f;
@@ -360,7 +392,7 @@ __global__ __launch_bounds__(1024) void pcg_kernel(SolveView s, SolveState* __re
                 x[i][c] = 0.f;
                 r[i][c] = s.g[3 * row + c];
                 p[i][c] = minv[i] * r[i][c];
-                rz_loc += (double)r[i][c] * (double)p[i][c];
+                rz_loc = fmaf(r[i][c], p[i][c], rz_loc);
             }
             p_s[row] = make_float4(p[i][0], p[i][1], p[i][2], 0.f);
         } else {
@@ -369,69 +401,124 @@ __global__ __launch_bounds__(1024) void pcg_kernel(SolveView s, SolveState* __re
             for (int c = 0; c < 3; ++c) x[i][c] = r[i][c] = p[i][c] = 0.f;
         }
     }
-    double rz        = block_sum(rz_loc, red);  // also publishes p_s (barriers inside)
+    double rz        = block_sum<NT / 64>(rz_loc, red1);  // the barrier inside also publishes p_s
     const double rz0 = rz;
     const double floor_ = 1e-12;  // squared-residual-ratio floor of float arithmetic
     const double tol2   = (double)pcg_tol * (double)pcg_tol > floor_ ? (double)pcg_tol * (double)pcg_tol : floor_;
     int it              = 0;
     const bool skip     = st->grad_first > 0.0 && rz0 <= floor_ * st->grad_first;
+#ifdef DFA_PCG_PROFILE
+    long long pc_[6] = {0, 0, 0, 0, 0, 0};
+#define PROF_MARK(i)                      \
+    do {                                  \
+        const long long now_ = clock64(); \
+        pc_[i] += now_ - last_;           \
+        last_ = now_;                     \
+    } while (0)
+    long long last_ = clock64();
+#else
+#define PROF_MARK(i)
+#endif
     if (!skip) {
         while (it < max_iter) {
             if (!(rz > 0.0)) break;
+            PROF_MARK(5);
             // Ap for own rows
             float ap[RPT][3];
-            double pap_loc = 0.0;
+            float pap_loc = 0.f;
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
-                const int row = tid + 1024 * i;
+                const int row = tid + NT * i;
                 float ax = 0.f, ay = 0.f, az = 0.f;
-                if (row < D) {
-                    const int cnt = s.ell_cnt[row];
-                    for (int q = 0; q < cnt; ++q) {
-                        const int col   = s.ell_cols[(size_t)q * D + row];
-                        const float v   = s.ell_vals[(size_t)q * D + row];
-                        const float4 pc = p_s[col];
-                        ax = fmaf(v, pc.x, ax), ay = fmaf(v, pc.y, ay), az = fmaf(v, pc.z, az);
+                if (S > 0) {
+                    // chunks of 8 gathers; the scheduling barrier keeps the compiler from hoisting
+                    // all S ds_read_b128 (4 VGPRs each) ahead of the FMAs
+#pragma unroll
+                    for (int q0 = 0; q0 < S; q0 += 8) {
+                        if (q0 < wmax) {  // wave-uniform; padded entries have value 0 and column 0
+#pragma unroll
+                            for (int q = q0; q < q0 + 8 && q < S; ++q) {
+                                const uint32_t cw = mcol[i][q >> 1];
+                                const int col     = (q & 1) ? (int)(cw >> 16) : (int)(cw & 0xffffu);
+                                const float4 pc   = p_s[col];
+                                const float v     = mval[i][q];
+                                ax = fmaf(v, pc.x, ax), ay = fmaf(v, pc.y, ay), az = fmaf(v, pc.z, az);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                // entries beyond the register slots stream from L2, 8 (coalesced, slot-major) loads
+                // in flight per lane; wmax is wave-uniform so the loop has no divergence
+                for (int q0 = S; q0 < wmax; q0 += 8) {
+                    int colv[8];
+                    float valv[8];
+                    // unconditional loads (slots up to the ELL capacity are valid memory), masked
+                    // AFTER the load: a load under a per-element condition makes hipcc branch around
+                    // it and wait vmcnt(0) each time — 16 serial L2 round trips per chunk
+                    const int rowc = row < D ? row : 0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        colv[u] = s.ell_cols[(size_t)(q0 + u) * D + rowc];
+                        valv[u] = s.ell_vals[(size_t)(q0 + u) * D + rowc];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const bool ok = q0 + u < rcnt[i];
+                        colv[u]       = ok ? colv[u] : 0;
+                        valv[u]       = ok ? valv[u] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float4 pc = p_s[colv[u]];
+                        ax = fmaf(valv[u], pc.x, ax), ay = fmaf(valv[u], pc.y, ay), az = fmaf(valv[u], pc.z, az);
                     }
                 }
                 ap[i][0] = ax, ap[i][1] = ay, ap[i][2] = az;
-                pap_loc += (double)p[i][0] * ax + (double)p[i][1] * ay + (double)p[i][2] * az;
+                pap_loc = fmaf(p[i][0], ax, fmaf(p[i][1], ay, fmaf(p[i][2], az, pap_loc)));
             }
-            const double pAp = block_sum(pap_loc, red);
+            PROF_MARK(0);
+            const double pAp = block_sum<NT / 64>(pap_loc, red0);
+            PROF_MARK(1);
             if (!(pAp > 0.0)) break;
             const float alpha = (float)(rz / pAp);
-            double rzn_loc    = 0.0;
-            float z[RPT][3];
+            float rzn_loc     = 0.f;
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     x[i][c] = fmaf(alpha, p[i][c], x[i][c]);
                     r[i][c] = fmaf(-alpha, ap[i][c], r[i][c]);
-                    z[i][c] = minv[i] * r[i][c];
-                    rzn_loc += (double)r[i][c] * (double)z[i][c];
+                    rzn_loc = fmaf(r[i][c], minv[i] * r[i][c], rzn_loc);
                 }
             }
-            const double rz_new = block_sum(rzn_loc, red);
+            PROF_MARK(2);
+            const double rz_new = block_sum<NT / 64>(rzn_loc, red1);
+            PROF_MARK(3);
             ++it;
             if (rz_new <= tol2 * rz0) break;
             const float beta = (float)(rz_new / rz);
-            // every thread has read p_s for this iteration (two barriers passed since)
+            // every thread has read p_s for this iteration (two barriers passed since the SpMV)
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
-                const int row = tid + 1024 * i;
+                const int row = tid + NT * i;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) p[i][c] = fmaf(beta, p[i][c], z[i][c]);
+                for (int c = 0; c < 3; ++c) p[i][c] = fmaf(beta, p[i][c], minv[i] * r[i][c]);
                 if (row < D) p_s[row] = make_float4(p[i][0], p[i][1], p[i][2], 0.f);
             }
             rz = rz_new;
             __syncthreads();
+            PROF_MARK(4);
         }
     }
+#ifdef DFA_PCG_PROFILE
+    if (tid == 0)
+        for (int i = 0; i < 6; ++i) st->prof[i] += pc_[i];
+#endif
     // t += delta
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-        const int row = tid + 1024 * i;
+        const int row = tid + NT * i;
         if (row < D) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) s.t[3 * row + c] += x[i][c];
@@ -505,23 +592,32 @@ hipError_t solve_assemble(const SolveView& s, SolveState* state, hipStream_t st)
 int solve_pcg_max_nodes() { return 1024 * 8; }
 
 hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, hipStream_t st) {
-    const size_t shmem = sizeof(float4) * (size_t)s.Dpad + 16 * sizeof(double);
-    const int rpt      = (s.D + 1023) / 1024;
-#define PCG_LAUNCH(R)                                                                                              \
+    const size_t shmem = sizeof(float4) * (size_t)s.Dpad + 32 * sizeof(float);
+#define PCG_LAUNCH(NT, R, SS)                                                                                      \
     do {                                                                                                           \
         static bool attr_set = false;                                                                              \
         if (!attr_set) {                                                                                           \
-            hipError_t e = hipFuncSetAttribute((const void*)pcg_kernel<R>,                                         \
+            hipError_t e = hipFuncSetAttribute((const void*)pcg_kernel<NT, R, SS>,                                 \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);    \
             if (e != hipSuccess) return e;                                                                         \
             attr_set = true;                                                                                       \
         }                                                                                                          \
-        pcg_kernel<R><<<1, 1024, shmem, st>>>(s, state, max_iter, pcg_tol);                                        \
+        pcg_kernel<NT, R, SS><<<1, NT, shmem, st>>>(s, state, max_iter, pcg_tol);                                  \
     } while (0)
-    if (rpt <= 1) PCG_LAUNCH(1);
-    else if (rpt <= 2) PCG_LAUNCH(2);
-    else if (rpt <= 4) PCG_LAUNCH(4);
-    else if (rpt <= 8) PCG_LAUNCH(8);
+    // Geometry: the fewer waves, the more registers per lane for matrix rows (512 VGPRs / waves
+    // per SIMD) and the cheaper the barriers; the LDS gather rate is reached from 4 waves per CU.
+    static const int variant = getenv("DFA_PCG_VARIANT") ? atoi(getenv("DFA_PCG_VARIANT")) : -1;
+    const int D = s.D;
+    if (D <= 512) PCG_LAUNCH(512, 1, 32);
+    else if (D <= 1024) PCG_LAUNCH(1024, 1, 32);
+    else if (D <= 2048) {
+        if (variant == 0) PCG_LAUNCH(1024, 2, 0);
+        else if (variant == 2) PCG_LAUNCH(512, 4, 16);
+        else if (variant == 3) PCG_LAUNCH(1024, 2, 8);
+        else if (variant == 4) PCG_LAUNCH(512, 4, 8);
+        else PCG_LAUNCH(1024, 2, 0);
+    } else if (D <= 4096) PCG_LAUNCH(1024, 4, 0);
+    else if (D <= 8192) PCG_LAUNCH(1024, 8, 0);
     else return hipErrorInvalidValue;
 #undef PCG_LAUNCH
     return hipGetLastError();

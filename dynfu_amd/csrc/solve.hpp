@@ -17,6 +17,7 @@ struct SolveState {
     int pcg_iters;
     int max_row_nnz;
     int overflow;       // a row of the normal matrix did not fit the plan's ELL capacity
+    long long prof[8];  // DFA_PCG_PROFILE builds: shader cycles per PCG phase (thread 0)
 };
 
 // All pointers are device pointers owned by the plan unless marked (borrowed).

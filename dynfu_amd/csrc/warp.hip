@@ -1,14 +1,22 @@
 // warp.hip — gfx950 kernels for the warp-field seam: exact k-NN of the deformation nodes,
 // RBF transformation weights, the reference's ordered dual-quaternion "blend" and warpToLive.
 //
-// Reference semantics: src/dynfu/warp_field.cpp:99-171 (nanoflann k-NN per vertex on the
-// CPU, three std::vector allocations per query) and src/dynfu/utils/node.cpp:29-36.
-// MI355X layout: one lane per query vertex, the node positions are staged through LDS in
-// 1024-node tiles (16 KiB, every lane of a wave reads the same node -> LDS broadcast, no bank
-// conflicts), the k best candidates live in registers as a sorted list updated by a fully
-// unrolled compare-exchange chain (no dynamic register indexing -> no scratch).  With at
-// most a few thousand nodes the exhaustive scan (N*D distance evaluations, 0.5 G at
-// 262 k vertices x 2 k nodes) is cheaper than any tree walk and is exact by construction.
+// Reference semantics: src/dynfu/warp_field.cpp:99-171 (nanoflann KD-tree k-NN per vertex on
+// the CPU, three std::vector allocations per query) and src/dynfu/utils/node.cpp:29-36.
+//
+// MI355X design.  The result contract is "the k nodes with the smallest (squared distance,
+// node index) pairs, ascending" — what nanoflann returns up to the order of exact ties.  Two
+// exact searches produce it:
+//   * brute force (small problems): one lane per query, node positions staged through LDS in
+//     1024-node tiles (a wave reads one node per step -> LDS broadcast), the k best kept in
+//     registers as a sorted list updated by an unrolled compare-exchange chain;
+//   * uniform grid (n_query * D large): nodes are bucketed by a counting sort into at most 32^3
+//     cells sized ~2 node spacings (the grid geometry is computed ON the device from the node
+//     bounding box, no host round trip); a query walks Chebyshev shells of cells around its own
+//     cell and stops once its k-th distance is below the distance to the next shell.  At
+//     262 k vertices x 2 k nodes that is ~50 candidates per query instead of 2048.
+// Both use the same distance expression (nanoflann L2_Simple_Adaptor order of operations) so
+// the neighbour lists are bit-identical to the CPU oracle's.
 #include <hip/hip_runtime.h>
 
 #include "dq_device.hpp"
@@ -18,23 +26,24 @@ namespace dfa {
 
 constexpr int KNN_TILE = 1024;
 
-// sorted (ascending) list of the K nearest candidates; equal distances keep scan order
-// (== nanoflann KNNResultSet::addPoint without NANOFLANN_FIRST_MATCH, nanoflann.hpp:100-122,
-// when candidates arrive in ascending node index)
+// sorted (ascending by (distance, index)) list of the K nearest candidates
 template <int K>
 struct KnnList {
     float d[K];
     int i[K];
     __device__ __forceinline__ void init() {
 #pragma unroll
-        for (int j = 0; j < K; ++j) d[j] = __builtin_inff(), i[j] = -1;
+        for (int j = 0; j < K; ++j) d[j] = __builtin_inff(), i[j] = 0x7fffffff;
+    }
+    __device__ __forceinline__ static bool before(float da, int ia, float db, int ib) {
+        return da < db || (da == db && ia < ib);
     }
     __device__ __forceinline__ void push(float dist, int idx) {
-        if (dist < d[K - 1]) {
+        if (before(dist, idx, d[K - 1], i[K - 1])) {
             d[K - 1] = dist, i[K - 1] = idx;
 #pragma unroll
             for (int j = K - 1; j > 0; --j) {
-                if (d[j] < d[j - 1]) {
+                if (before(d[j], i[j], d[j - 1], i[j - 1])) {
                     const float td = d[j];
                     d[j] = d[j - 1], d[j - 1] = td;
                     const int ti = i[j];
@@ -43,8 +52,16 @@ struct KnnList {
             }
         }
     }
+    __device__ __forceinline__ int index(int j) const { return i[j] == 0x7fffffff ? -1 : i[j]; }
 };
 
+// L2_Simple_Adaptor::evalMetric (nanoflann.hpp:338-345): ((0 + d0^2) + d1^2) + d2^2
+__device__ __forceinline__ float dist2(f3 q, float gx, float gy, float gz) {
+    const float d0 = q.x - gx, d1 = q.y - gy, d2 = q.z - gz;
+    return (d0 * d0 + d1 * d1) + d2 * d2;
+}
+
+// ---------------------------------------------------------------------------- brute force
 // scans all D nodes (block-cooperative LDS staging); every thread of the block must call it
 template <int K>
 __device__ __forceinline__ void knn_scan(const float* __restrict__ node_pos, int D, f3 q, KnnList<K>& best,
@@ -60,31 +77,174 @@ __device__ __forceinline__ void knn_scan(const float* __restrict__ node_pos, int
         __syncthreads();
         for (int j = 0; j < n; ++j) {
             const float4 g = tile[j];
-            // L2_Simple_Adaptor::evalMetric (nanoflann.hpp:338-345): ((0 + d0^2) + d1^2) + d2^2
-            const float d0 = q.x - g.x, d1 = q.y - g.y, d2 = q.z - g.z;
-            const float dist = (d0 * d0 + d1 * d1) + d2 * d2;
-            best.push(dist, base + j);
+            best.push(dist2(q, g.x, g.y, g.z), base + j);
         }
     }
 }
 
+// ------------------------------------------------------------------------------ uniform grid
+__global__ __launch_bounds__(1024) void grid_setup_kernel(const float* __restrict__ node_pos, int D,
+                                                          KnnGridDesc* __restrict__ desc,
+                                                          int32_t* __restrict__ cell_count) {
+    __shared__ float smin[3][16], smax[3][16];
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int i = threadIdx.x; i < D; i += blockDim.x)
+        for (int c = 0; c < 3; ++c) {
+            const float v = node_pos[3 * (size_t)i + c];
+            mn[c] = fminf(mn[c], v), mx[c] = fmaxf(mx[c], v);
+        }
+    for (int c = 0; c < 3; ++c) {
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o, 64));
+            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) smin[c][threadIdx.x >> 6] = mn[c], smax[c][threadIdx.x >> 6] = mx[c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < KNN_GRID_MAX_CELLS; i += blockDim.x) cell_count[i] = 0;
+    if (threadIdx.x == 0) {
+        float ext[3];
+        for (int c = 0; c < 3; ++c) {
+            float a = smin[c][0], b = smax[c][0];
+            for (int w = 1; w < (int)(blockDim.x >> 6); ++w) a = fminf(a, smin[c][w]), b = fmaxf(b, smax[c][w]);
+            desc->bmin[c] = a;
+            ext[c]        = fmaxf(b - a, 0.f);
+        }
+        const float emax = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
+        // ~2 node spacings for nodes on a surface; never more than 32 cells per axis
+        float cs = cbrtf((ext[0] * ext[1] * ext[2]) / (float)D);
+        cs       = fmaxf(cs, emax / (float)KNN_GRID_MAX_DIM);
+        if (!(cs > 0.f)) cs = 1.f;  // all nodes coincide
+        desc->cs     = cs;
+        desc->inv_cs = 1.f / cs;
+        for (int c = 0; c < 3; ++c) {
+            int n = (int)(ext[c] * desc->inv_cs) + 1;
+            desc->dim[c] = min(max(n, 1), KNN_GRID_MAX_DIM);
+        }
+    }
+}
+
+__device__ __forceinline__ void cell_of(const KnnGridDesc& g, f3 p, int& cx, int& cy, int& cz) {
+    // clamped: queries outside the node bounding box are projected onto it (the projection is
+    // never farther from any node than the query itself, so shell bounds stay valid)
+    cx = min(max((int)floorf((p.x - g.bmin[0]) * g.inv_cs), 0), g.dim[0] - 1);
+    cy = min(max((int)floorf((p.y - g.bmin[1]) * g.inv_cs), 0), g.dim[1] - 1);
+    cz = min(max((int)floorf((p.z - g.bmin[2]) * g.inv_cs), 0), g.dim[2] - 1);
+}
+
+__global__ __launch_bounds__(256) void grid_count_kernel(const float* __restrict__ node_pos, int D,
+                                                         const KnnGridDesc* __restrict__ desc,
+                                                         int32_t* __restrict__ cell_count,
+                                                         int32_t* __restrict__ node_cell) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    const KnnGridDesc g = *desc;
+    int cx, cy, cz;
+    cell_of(g, mk3(node_pos[3 * (size_t)i], node_pos[3 * (size_t)i + 1], node_pos[3 * (size_t)i + 2]), cx, cy, cz);
+    const int c  = cx + g.dim[0] * (cy + g.dim[1] * cz);
+    node_cell[i] = c;
+    atomicAdd(&cell_count[c], 1);
+}
+
+// exclusive scan of KNN_GRID_MAX_CELLS counts by one workgroup (32 consecutive cells per thread)
+__global__ __launch_bounds__(1024) void grid_scan_kernel(int32_t* __restrict__ cell_count /* in: counts, out: cursors */,
+                                                         int32_t* __restrict__ cell_start) {
+    __shared__ int32_t wave_tot[16];
+    constexpr int PER = KNN_GRID_MAX_CELLS / 1024;
+    const int base    = threadIdx.x * PER;
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) loc[j] = cell_count[base + j], sum += loc[j];
+    int incl        = sum;
+    const int lane  = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int off = incl - sum;
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        cell_start[base + j] = off;
+        cell_count[base + j] = off;  // running cursor for the fill pass
+        off += loc[j];
+    }
+    if (threadIdx.x == 1023) cell_start[KNN_GRID_MAX_CELLS] = off;
+}
+
+__global__ __launch_bounds__(256) void grid_fill_kernel(const float* __restrict__ node_pos, int D,
+                                                        const int32_t* __restrict__ node_cell,
+                                                        int32_t* __restrict__ cursor,
+                                                        float4* __restrict__ sorted) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    const int slot = atomicAdd(&cursor[node_cell[i]], 1);
+    sorted[slot]   = make_float4(node_pos[3 * (size_t)i], node_pos[3 * (size_t)i + 1], node_pos[3 * (size_t)i + 2],
+                                 __int_as_float(i));
+}
+
+// exact k-NN through the grid: Chebyshev shells r = 0, 1, 2, ... around the query's cell
 template <int K>
+__device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32_t* __restrict__ cell_start,
+                                               const float4* __restrict__ sorted, f3 q, KnnList<K>& best) {
+    best.init();
+    int cx, cy, cz;
+    cell_of(g, q, cx, cy, cz);
+    const int rmax = max(g.dim[0], max(g.dim[1], g.dim[2]));
+    for (int r = 0; r < rmax; ++r) {
+        const int z0 = max(cz - r, 0), z1 = min(cz + r, g.dim[2] - 1);
+        const int y0 = max(cy - r, 0), y1 = min(cy + r, g.dim[1] - 1);
+        const int x0 = max(cx - r, 0), x1 = min(cx + r, g.dim[0] - 1);
+        for (int z = z0; z <= z1; ++z)
+            for (int y = y0; y <= y1; ++y) {
+                const bool face = (abs(z - cz) == r) || (abs(y - cy) == r);
+                // on a z/y face of the shell every x belongs to it; otherwise only the two x ends
+                const int xstep = face ? 1 : max(x1 - x0, 1);
+                for (int x = x0; x <= x1; x += xstep) {
+                    if (!face && abs(x - cx) != r) continue;
+                    const int c   = x + g.dim[0] * (y + g.dim[1] * z);
+                    const int beg = cell_start[c], end = cell_start[c + 1];
+                    for (int j = beg; j < end; ++j) {
+                        const float4 n = sorted[j];
+                        best.push(dist2(q, n.x, n.y, n.z), __float_as_int(n.w));
+                    }
+                }
+            }
+        // every node not visited yet is at least r*cs away (from the query's projection onto
+        // the grid, hence from the query); stop when the k-th candidate is strictly closer,
+        // with a relative margin that absorbs the rounding of the cell assignment
+        const float bound = (float)r * g.cs;
+        if (best.d[K - 1] < bound * bound * 0.9999f) break;
+    }
+}
+
+template <int K, bool GRID>
 __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ node_pos,
                                                   const float* __restrict__ node_w, int D,
                                                   const float* __restrict__ query, int n_query, int k,
-                                                  int32_t* __restrict__ idx, float* __restrict__ weights) {
-    __shared__ float4 tile[KNN_TILE];
+                                                  int32_t* __restrict__ idx, float* __restrict__ weights,
+                                                  KnnGridView grid) {
+    __shared__ float4 tile[GRID ? 1 : KNN_TILE];
     const int v       = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = v < n_query;
     f3 q              = mk3(0.f, 0.f, 0.f);
     if (active) q = mk3(query[3 * (size_t)v], query[3 * (size_t)v + 1], query[3 * (size_t)v + 2]);
     KnnList<K> best;
-    knn_scan<K>(node_pos, D, q, best, tile);
-    if (!active) return;
+    if (GRID) {
+        if (!active) return;
+        knn_grid_query<K>(*grid.desc, grid.cell_start, grid.sorted, q, best);
+    } else {
+        knn_scan<K>(node_pos, D, q, best, tile);
+        if (!active) return;
+    }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         if (j < k) {
-            const int n                = best.i[j];
+            const int n            = best.index(j);
             idx[(size_t)v * k + j] = n;
             if (weights) {
                 float w = 0.f;
@@ -104,8 +264,8 @@ __device__ __forceinline__ DQ calc_dqb(const KnnList<K>& nb, int k, const float*
     DQ sum = dq_identity();  // :133
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        if (j < k && nb.i[j] >= 0) {
-            const int n   = nb.i[j];
+        if (j < k && nb.index(j) >= 0) {
+            const int n   = nb.index(j);
             const float w = transformation_weight(mk3(node_pos[3 * n], node_pos[3 * n + 1], node_pos[3 * n + 2]),
                                                   node_w[n], p);
             sum = dq_mul(sum, dq_scale(dq_load(node_dq + 8 * (size_t)n), w));  // :139-141
@@ -115,22 +275,27 @@ __device__ __forceinline__ DQ calc_dqb(const KnnList<K>& nb, int k, const float*
 }
 
 // Warpfield::warpToLive (warp_field.cpp:150-171)
-template <int K>
+template <int K, bool GRID>
 __global__ __launch_bounds__(256) void warp_to_live_kernel(const float* __restrict__ node_pos,
                                                            const float* __restrict__ node_dq,
                                                            const float* __restrict__ node_w, int D, int k,
                                                            const float* __restrict__ verts,
                                                            const float* __restrict__ normals, int N,
                                                            float* __restrict__ out_verts,
-                                                           float* __restrict__ out_normals) {
-    __shared__ float4 tile[KNN_TILE];
+                                                           float* __restrict__ out_normals, KnnGridView grid) {
+    __shared__ float4 tile[GRID ? 1 : KNN_TILE];
     const int v       = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = v < N;
     f3 p              = mk3(0.f, 0.f, 0.f);
     if (active) p = mk3(verts[3 * (size_t)v], verts[3 * (size_t)v + 1], verts[3 * (size_t)v + 2]);
     KnnList<K> best;
-    knn_scan<K>(node_pos, D, p, best, tile);
-    if (!active) return;
+    if (GRID) {
+        if (!active) return;
+        knn_grid_query<K>(*grid.desc, grid.cell_start, grid.sorted, p, best);
+    } else {
+        knn_scan<K>(node_pos, D, p, best, tile);
+        if (!active) return;
+    }
     const DQ dq = calc_dqb<K>(best, k, node_pos, node_dq, node_w, p);
     const f3 o  = dq_transform(dq, p);
     out_verts[3 * (size_t)v] = o.x, out_verts[3 * (size_t)v + 1] = o.y, out_verts[3 * (size_t)v + 2] = o.z;
@@ -143,30 +308,48 @@ __global__ __launch_bounds__(256) void warp_to_live_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------ launchers
+
+hipError_t knn_grid_build(const KnnGridView& g, const float* node_pos, int D, hipStream_t s) {
+    grid_setup_kernel<<<1, 1024, 0, s>>>(node_pos, D, g.desc, g.cell_count);
+    grid_count_kernel<<<(D + 255) / 256, 256, 0, s>>>(node_pos, D, g.desc, g.cell_count, g.node_cell);
+    grid_scan_kernel<<<1, 1024, 0, s>>>(g.cell_count, g.cell_start);
+    grid_fill_kernel<<<(D + 255) / 256, 256, 0, s>>>(node_pos, D, g.node_cell, g.cell_count, g.sorted);
+    return hipGetLastError();
+}
+
+#define KGDISPATCH(kernel, k, use_grid, ...)                         \
+    do {                                                             \
+        if (use_grid) {                                              \
+            if ((k) <= 4) kernel<4, true> __VA_ARGS__;               \
+            else if ((k) <= 8) kernel<8, true> __VA_ARGS__;          \
+            else kernel<16, true> __VA_ARGS__;                       \
+        } else {                                                     \
+            if ((k) <= 4) kernel<4, false> __VA_ARGS__;              \
+            else if ((k) <= 8) kernel<8, false> __VA_ARGS__;         \
+            else kernel<16, false> __VA_ARGS__;                      \
+        }                                                            \
+    } while (0)
+
 hipError_t launch_knn(const float* node_pos, const float* node_w, int D, const float* query, int n_query, int k,
-                      int32_t* idx, float* weights, hipStream_t s) {
+                      int32_t* idx, float* weights, const KnnGridView* grid, hipStream_t s) {
     if (n_query == 0) return hipSuccess;
-    dim3 block(256), grid((n_query + 255) / 256);
-    if (k <= 4) knn_kernel<4><<<grid, block, 0, s>>>(node_pos, node_w, D, query, n_query, k, idx, weights);
-    else if (k <= 8) knn_kernel<8><<<grid, block, 0, s>>>(node_pos, node_w, D, query, n_query, k, idx, weights);
-    else knn_kernel<16><<<grid, block, 0, s>>>(node_pos, node_w, D, query, n_query, k, idx, weights);
+    dim3 block(256), gridDim((n_query + 255) / 256);
+    const bool use_grid = grid != nullptr;
+    KnnGridView g       = use_grid ? *grid : KnnGridView{};
+    KGDISPATCH(knn_kernel, k, use_grid, <<<gridDim, block, 0, s>>>(node_pos, node_w, D, query, n_query, k, idx, weights, g));
     return hipGetLastError();
 }
 
 hipError_t launch_warp_to_live(const float* node_pos, const float* node_dq, const float* node_w, int D, int k,
                                const float* verts, const float* normals, int N, float* out_verts, float* out_normals,
-                               hipStream_t s) {
+                               const KnnGridView* grid, hipStream_t s) {
     if (N == 0) return hipSuccess;
-    dim3 block(256), grid((N + 255) / 256);
-    if (k <= 4)
-        warp_to_live_kernel<4><<<grid, block, 0, s>>>(node_pos, node_dq, node_w, D, k, verts, normals, N, out_verts,
-                                                       out_normals);
-    else if (k <= 8)
-        warp_to_live_kernel<8><<<grid, block, 0, s>>>(node_pos, node_dq, node_w, D, k, verts, normals, N, out_verts,
-                                                       out_normals);
-    else
-        warp_to_live_kernel<16><<<grid, block, 0, s>>>(node_pos, node_dq, node_w, D, k, verts, normals, N, out_verts,
-                                                        out_normals);
+    dim3 block(256), gridDim((N + 255) / 256);
+    const bool use_grid = grid != nullptr;
+    KnnGridView g       = use_grid ? *grid : KnnGridView{};
+    KGDISPATCH(warp_to_live_kernel, k, use_grid,
+               <<<gridDim, block, 0, s>>>(node_pos, node_dq, node_w, D, k, verts, normals, N, out_verts, out_normals, g));
     return hipGetLastError();
 }
 

@@ -168,6 +168,20 @@ const int32_t* dfa_solver_reg_graph(const dfa_solver* s);  /* D x k */
 /* Copies the statistics of the last solve to host memory; synchronises `stream`. */
 int dfa_solver_get_stats(dfa_solver* s, dfa_solve_stats* host_out, dfa_stream_t stream);
 
+/* Optional per-kernel timing for roofline reports (no reference counterpart; Opt has
+ * profileSolve, opt_solver.cpp:144-147).  When enabled, dfa_solver_solve brackets every PCG
+ * and assembly launch with hipEvents on the launch stream.  dfa_solver_get_timing synchronises
+ * the stream and returns, for the LAST solve: summed kernel milliseconds and launch counts. */
+typedef struct {
+    float pcg_ms;
+    float assemble_ms;
+    int pcg_launches;
+    int assemble_launches;
+    long long matrix_nnz; /* non-zeros of the assembled normal matrix (last linearisation) */
+} dfa_solve_timing;
+int dfa_solver_enable_timing(dfa_solver* s, int enable);
+int dfa_solver_get_timing(dfa_solver* s, dfa_solve_timing* host_out, dfa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,36 @@ def test_knn_bit_exact_and_weights(A, D, k, n):
     assert np.all(host(w)[ref < 0] == 0)
 
 
+@pytest.mark.parametrize("kind", ["clustered", "planar", "far_queries", "duplicates", "line", "lattice"])
+@pytest.mark.parametrize("k", [4, 8])
+def test_knn_grid_path_is_exact_on_awkward_geometry(A, kind, k):
+    # sizes above the grid threshold (D * n >= 2^22); the uniform grid must return exactly the
+    # exhaustive (distance, index)-ordered answer whatever the node distribution
+    rng = np.random.default_rng(hash(kind) % 1000 + k)
+    D, n = 1500, 6000
+    q = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    if kind == "clustered":
+        centres = rng.uniform(-1, 1, (6, 3))
+        nodes = (centres[rng.integers(0, 6, D)] + rng.normal(0, 0.01, (D, 3))).astype(np.float32)
+    elif kind == "planar":
+        nodes = rng.uniform(-1, 1, (D, 3)).astype(np.float32)
+        nodes[:, 2] = 0.25  # zero extent along z
+    elif kind == "far_queries":
+        nodes = rng.uniform(-0.1, 0.1, (D, 3)).astype(np.float32)
+        q = (q * 50).astype(np.float32)  # far outside the node bounding box
+    elif kind == "duplicates":
+        nodes = np.repeat(rng.uniform(-1, 1, (D // 10, 3)), 10, axis=0).astype(np.float32)
+    elif kind == "line":
+        nodes = np.zeros((D, 3), np.float32)
+        nodes[:, 0] = np.linspace(-1, 1, D)
+    else:  # integer lattice: massive exact ties
+        g = np.stack(np.meshgrid(*[np.arange(12.0)] * 3, indexing="ij"), -1).reshape(-1, 3)
+        nodes = g[:D].astype(np.float32)
+        q = rng.integers(0, 12, (n, 3)).astype(np.float32) + np.float32(0.5)
+    idx, _ = A.knn(dev(nodes), dev(np.full(len(nodes), 0.3, np.float32)), dev(q), k)
+    assert np.array_equal(host(idx), O.knn(nodes, q, k, threads=8))
+
+
 def test_knn_exact_ties_keep_lower_index(A):
     # integer lattice: many exactly equal distances
     g = np.stack(np.meshgrid(*[np.arange(6.0)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
