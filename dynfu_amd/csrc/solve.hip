@@ -340,11 +340,23 @@ __device__ __forceinline__ double block_sum(float v, float* red) {
     return tot;
 }
 
+// float flavour (fewer registers; used by the register-resident kernel)
+template <int NWAVES>
+__device__ __forceinline__ float block_sum_f(float v, float* red) {
+    const float w = wave_total(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NWAVES; ++i) tot += red[i];
+    return tot;
+}
+
 // S = matrix entries per row kept in registers for the whole solve (values as fp32, columns as
 // packed u16): the matrix is constant over the PCG iterations, so the only per-iteration
 // memory traffic left is the LDS gather of the direction vector.  Rows longer than S read the
 // excess from global memory (L2).  S = 0 streams the whole matrix from L2 every iteration.
-template <int NT, int RPT, int S>
+template <int NT, int RPT, int S, bool FALLBACK_ONLY = false>
 __global__ __launch_bounds__(NT) void pcg_kernel(SolveView s, SolveState* __restrict__ st, int max_iter,
                                                    float pcg_tol) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -352,6 +364,7 @@ __global__ __launch_bounds__(NT) void pcg_kernel(SolveView s, SolveState* __rest
     float* red0 = (float*)(smem + sizeof(float4) * (size_t)s.Dpad);  // 2 x 16 wave partials
     float* red1 = red0 + 16;
     if (st->done) return;
+    if (FALLBACK_ONLY && !st->pcg_fallback) return;  // the register-resident kernel handled it
     const int tid = threadIdx.x;
     const int D   = s.D;
 
@@ -532,6 +545,244 @@ __global__ __launch_bounds__(NT) void pcg_kernel(SolveView s, SolveState* __rest
 }
 
 // ------------------------------------------------------------------------------------------
+// PCG with the WHOLE matrix in registers (D <= 2 * NT rows).
+//
+// The matrix is constant over the PCG iterations, and a single CU can stream at most 64 B/clk
+// through its vector memory path: re-reading a padded ELL image every iteration costs more than
+// everything else in the loop together (measured: 6.1 k of 10.5 k cycles per iteration).  Here a
+// thread keeps its rows' entries in registers for the whole solve — E values and E/2 words of
+// packed 16-bit columns — so the only per-iteration memory traffic left is the LDS gather of p
+// (one ds_read_b128 per non-zero).
+//
+// Register arrays need compile-time indices, so row lengths must be (nearly) uniform across the
+// lanes of a wave or the padding eats the gain.  The prologue therefore counting-sorts the rows
+// by length in LDS and gives thread t the t-th LONGEST row ("A", slots 0.. upwards) and the t-th
+// SHORTEST row ("B", slots E-1.. downwards): lengths vary slowly along a wave, nA + nB is about
+// the true row-pair length, and both loop bounds are wave-uniform (no divergence, no selects).
+// Entries of B that do not fit (rare) are streamed from L2 each iteration.
+template <int NT, int E>
+__global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState* __restrict__ st, int max_iter,
+                                                        float pcg_tol) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int D     = s.D;
+    float4* p_s     = (float4*)smem;  // D x 16 B
+    float* red0     = (float*)(smem + sizeof(float4) * (size_t)s.Dpad);
+    float* red1     = red0 + 16;
+    int* hist       = (int*)(red1 + 16);  // 258 bins
+    int* perm       = hist + 260;         // D row ids, longest row first
+    if (st->done) return;
+    const int tid = threadIdx.x;
+
+    // ---- rows sorted by length (descending), counting sort in LDS
+    for (int i = tid; i < 260; i += NT) hist[i] = 0;
+    __syncthreads();
+    int my_cnt[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = tid + NT * h;
+        my_cnt[h]     = row < D ? min(s.ell_cnt[row], 256) : -1;
+        if (my_cnt[h] >= 0) atomicAdd(&hist[256 - my_cnt[h]], 1);  // bin 0 = longest
+    }
+    __syncthreads();
+    if (tid < 64) {  // exclusive scan of 257 bins by one wave (5 bins per lane)
+        int loc[5], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int b = tid * 5 + j;
+            loc[j]      = b < 257 ? hist[b] : 0;
+            sum += loc[j];
+        }
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (tid >= o) incl += t;
+        }
+        int off = incl - sum;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int b = tid * 5 + j;
+            if (b < 257) hist[b] = off;
+            off += loc[j];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        if (my_cnt[h] >= 0) perm[atomicAdd(&hist[256 - my_cnt[h]], 1)] = tid + NT * h;
+    __syncthreads();
+
+    // ---- this thread's pair: rank t (long, "A") and rank D-1-t (short, "B")
+    const int ia = tid, ib = D - 1 - tid;
+    const int rowA = (ia < D && ia <= ib) ? perm[ia] : -1;
+    const int rowB = (ib >= 0 && ib > ia) ? perm[ib] : -1;
+    const int cntA = rowA >= 0 ? min(s.ell_cnt[rowA], 256) : 0;
+    const int cntB = rowB >= 0 ? min(s.ell_cnt[rowB], 256) : 0;
+    int nA = min(cntA, E), nAfull = cntA, nBfull = cntB;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        nA     = max(nA, __shfl_xor(nA, o, 64));
+        nAfull = max(nAfull, __shfl_xor(nAfull, o, 64));
+        nBfull = max(nBfull, __shfl_xor(nBfull, o, 64));
+    }
+    nA             = (nA + 1) & ~1;  // even: a packed column word never mixes A and B slots
+    const int capB = E - nA;         // wave-uniform
+    const int regB = min(cntB, capB);
+    int nB         = regB;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nB = max(nB, __shfl_xor(nB, o, 64));
+    nB = min((nB + 1) & ~1, capB);
+    const int rA = rowA >= 0 ? rowA : 0, rB = rowB >= 0 ? rowB : 0;
+    // a pair that does not fit E slots: leave the system to the streaming kernel launched next
+    const int unfit = __syncthreads_or(cntA > E || cntB > capB);
+    if (tid == 0) st->pcg_fallback = unfit;
+    if (unfit) return;
+
+    // values and columns -> registers for the whole solve (slot q: entry q of A for q < nA,
+    // entry E-1-q of B otherwise); two 16-bit columns per register
+    float mval[E];
+    uint32_t mcol[E / 2];
+#pragma unroll
+    for (int q2 = 0; q2 < E / 2; ++q2) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q     = 2 * q2 + h;
+            const bool isA  = q < nA;
+            const int ent   = isA ? q : E - 1 - q;
+            const int r     = isA ? rA : rB;
+            const bool live = isA ? (q < cntA) : (E - 1 - q < regB);
+            float v         = s.ell_vals[(size_t)ent * D + r];  // unconditional load, masked after
+            int col         = s.ell_cols[(size_t)ent * D + r];
+            if (!live) v = 0.f, col = 0;
+            mval[q] = v;
+            packed |= (uint32_t)col << (16 * h);
+        }
+        mcol[q2] = packed;
+        if ((q2 & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the loads in flight
+    }
+
+    float xA[3], rA_[3], pA[3], xB[3], rB_[3], pB[3];
+    float minvA = 0.f, minvB = 0.f, rz_loc = 0.f;
+    if (rowA >= 0) {
+        const float d = s.diag[rowA];
+        minvA         = d > FLT_EPSILON ? 1.0f / d : 1.0f;
+    }
+    if (rowB >= 0) {
+        const float d = s.diag[rowB];
+        minvB         = d > FLT_EPSILON ? 1.0f / d : 1.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        xA[c] = xB[c] = 0.f;
+        rA_[c] = rowA >= 0 ? s.g[3 * rowA + c] : 0.f;
+        rB_[c] = rowB >= 0 ? s.g[3 * rowB + c] : 0.f;
+        pA[c]  = minvA * rA_[c];
+        pB[c]  = minvB * rB_[c];
+        rz_loc = fmaf(rA_[c], pA[c], fmaf(rB_[c], pB[c], rz_loc));
+    }
+    if (rowA >= 0) p_s[rowA] = make_float4(pA[0], pA[1], pA[2], 0.f);
+    if (rowB >= 0) p_s[rowB] = make_float4(pB[0], pB[1], pB[2], 0.f);
+    float rz           = block_sum_f<NT / 64>(rz_loc, red1);
+    const float rz0    = rz;
+    const float floor_ = 1e-12f;
+    const float tol2   = pcg_tol * pcg_tol > floor_ ? pcg_tol * pcg_tol : floor_;
+    int it             = 0;
+    const bool skip    = st->grad_first > 0.0 && (double)rz0 <= 1e-12 * st->grad_first;
+    const char* pbase   = (const char*)p_s;
+#ifdef DFA_PCG_PROFILE
+    long long pc_[6] = {0, 0, 0, 0, 0, 0};
+    long long last_  = clock64();
+#endif
+    if (!skip) {
+        while (it < max_iter) {
+            if (!(rz > 0.f)) break;
+            PROF_MARK(5);
+            float aA[3] = {0.f, 0.f, 0.f}, aB[3] = {0.f, 0.f, 0.f};
+            // 4 slots per step: 4 independent gathers in flight, then their FMAs.  The empty asm makes
+            // the packed column words opaque per iteration, otherwise the compiler hoists the
+            // unpacking out of the PCG loop and doubles the registers the columns occupy.
+#pragma unroll
+            for (int q0 = 0; q0 < E; q0 += 4) {
+                const bool in01 = q0 < nA || q0 >= E - nB, in23 = q0 + 2 < nA || q0 + 2 >= E - nB;  // wave-uniform
+                if (in01 || in23) {
+                    uint32_t c01 = mcol[q0 / 2], c23 = mcol[q0 / 2 + 1];
+                    asm volatile("" : "+v"(c01), "+v"(c23));
+                    const float4 g0 = *(const float4*)(pbase + ((c01 & 0xffffu) << 4));
+                    const float4 g1 = *(const float4*)(pbase + ((c01 >> 16) << 4));
+                    const float4 g2 = *(const float4*)(pbase + ((c23 & 0xffffu) << 4));
+                    const float4 g3 = *(const float4*)(pbase + ((c23 >> 16) << 4));
+                    asm volatile("" ::"v"(g0.w), "v"(g1.w), "v"(g2.w), "v"(g3.w));  // keep ds_read_b128
+                    const float v0 = mval[q0], v1 = mval[q0 + 1], v2 = mval[q0 + 2], v3 = mval[q0 + 3];
+                    if (q0 < nA) {  // slots outside both ranges hold value 0
+                        aA[0] = fmaf(v0, g0.x, aA[0]), aA[1] = fmaf(v0, g0.y, aA[1]), aA[2] = fmaf(v0, g0.z, aA[2]);
+                        aA[0] = fmaf(v1, g1.x, aA[0]), aA[1] = fmaf(v1, g1.y, aA[1]), aA[2] = fmaf(v1, g1.z, aA[2]);
+                    } else {
+                        aB[0] = fmaf(v0, g0.x, aB[0]), aB[1] = fmaf(v0, g0.y, aB[1]), aB[2] = fmaf(v0, g0.z, aB[2]);
+                        aB[0] = fmaf(v1, g1.x, aB[0]), aB[1] = fmaf(v1, g1.y, aB[1]), aB[2] = fmaf(v1, g1.z, aB[2]);
+                    }
+                    if (q0 + 2 < nA) {
+                        aA[0] = fmaf(v2, g2.x, aA[0]), aA[1] = fmaf(v2, g2.y, aA[1]), aA[2] = fmaf(v2, g2.z, aA[2]);
+                        aA[0] = fmaf(v3, g3.x, aA[0]), aA[1] = fmaf(v3, g3.y, aA[1]), aA[2] = fmaf(v3, g3.z, aA[2]);
+                    } else {
+                        aB[0] = fmaf(v2, g2.x, aB[0]), aB[1] = fmaf(v2, g2.y, aB[1]), aB[2] = fmaf(v2, g2.z, aB[2]);
+                        aB[0] = fmaf(v3, g3.x, aB[0]), aB[1] = fmaf(v3, g3.y, aB[1]), aB[2] = fmaf(v3, g3.z, aB[2]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float pap_loc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pap_loc = fmaf(pA[c], aA[c], fmaf(pB[c], aB[c], pap_loc));
+            PROF_MARK(0);
+            const float pAp = block_sum_f<NT / 64>(pap_loc, red0);
+            PROF_MARK(1);
+            if (!(pAp > 0.f)) break;
+            const float alpha = rz / pAp;
+            float rzn_loc     = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                xA[c]   = fmaf(alpha, pA[c], xA[c]);
+                xB[c]   = fmaf(alpha, pB[c], xB[c]);
+                rA_[c]  = fmaf(-alpha, aA[c], rA_[c]);
+                rB_[c]  = fmaf(-alpha, aB[c], rB_[c]);
+                rzn_loc = fmaf(rA_[c], minvA * rA_[c], fmaf(rB_[c], minvB * rB_[c], rzn_loc));
+            }
+            PROF_MARK(2);
+            const float rz_new = block_sum_f<NT / 64>(rzn_loc, red1);
+            PROF_MARK(3);
+            ++it;
+            if (rz_new <= tol2 * rz0) break;
+            const float beta = rz_new / rz;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                pA[c] = fmaf(beta, pA[c], minvA * rA_[c]);
+                pB[c] = fmaf(beta, pB[c], minvB * rB_[c]);
+            }
+            if (rowA >= 0) p_s[rowA] = make_float4(pA[0], pA[1], pA[2], 0.f);
+            if (rowB >= 0) p_s[rowB] = make_float4(pB[0], pB[1], pB[2], 0.f);
+            rz = rz_new;
+            __syncthreads();
+            PROF_MARK(4);
+        }
+    }
+#ifdef DFA_PCG_PROFILE
+    if (tid == 0)
+        for (int i = 0; i < 6; ++i) st->prof[i] += pc_[i];
+#endif
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (rowA >= 0) s.t[3 * rowA + c] += xA[c];
+        if (rowB >= 0) s.t[3 * rowB + c] += xB[c];
+    }
+    if (tid == 0) {
+        if (st->grad_first == 0.0) st->grad_first = (double)rz0;
+        st->pcg_iters += it;
+        st->gn_iters += 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // write-back: dg_se3_i <- DQ(0,0,0,t_i) * dg_se3_i  (opt_solver.cpp:270-285, node.cpp:19-23)
 __global__ __launch_bounds__(256) void writeback_kernel(SolveView s) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -608,6 +859,29 @@ hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float 
     // per SIMD) and the cheaper the barriers; the LDS gather rate is reached from 4 waves per CU.
     static const int variant = getenv("DFA_PCG_VARIANT") ? atoi(getenv("DFA_PCG_VARIANT")) : -1;
     const int D = s.D;
+    if (variant < 0 && D <= 2048) {
+        constexpr int NT = 1024, E = 32;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)pcg_paired_kernel<NT, E>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        const size_t sh = sizeof(float4) * (size_t)s.Dpad + 32 * sizeof(float) + sizeof(int) * (260 + (size_t)s.Dpad);
+        pcg_paired_kernel<NT, E><<<1, NT, sh, st>>>(s, state, max_iter, pcg_tol);
+        // rows too long for the register slots (sets state->pcg_fallback): streaming kernel, which
+        // returns at once otherwise
+        static bool attr2 = false;
+        if (!attr2) {
+            hipError_t e = hipFuncSetAttribute((const void*)pcg_kernel<1024, 2, 0, true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+            if (e != hipSuccess) return e;
+            attr2 = true;
+        }
+        pcg_kernel<1024, 2, 0, true><<<1, 1024, shmem, st>>>(s, state, max_iter, pcg_tol);
+        return hipGetLastError();
+    }
     if (D <= 512) PCG_LAUNCH(512, 1, 32);
     else if (D <= 1024) PCG_LAUNCH(1024, 1, 32);
     else if (D <= 2048) {

@@ -17,6 +17,7 @@ struct SolveState {
     int pcg_iters;
     int max_row_nnz;
     int overflow;       // a row of the normal matrix did not fit the plan's ELL capacity
+    int pcg_fallback;   // set by the register-resident PCG when a row pair exceeds its slots
     long long prof[8];  // DFA_PCG_PROFILE builds: shader cycles per PCG phase (thread 0)
 };
 
