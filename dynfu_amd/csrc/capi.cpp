@@ -267,11 +267,10 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
     A(rw, R * k);
     A(rtau, R);
     A(rb, R * 3);
-    A(re, R * 3);
+    A(re, R * (2 * (size_t)k + 4));
     A(reg_idx, D * k);
-    A(node_cnt, D);
+    A(blk_hist, D * dfa::SOLVE_TG_BLOCKS);
     A(node_ptr, D + 1);
-    A(cursor, D);
     A(node_list, R * k);
     A(ell_cols, D * s->ell_cap);
     A(ell_vals, D * s->ell_cap);
@@ -396,6 +395,9 @@ int dfa_solver_get_stats(dfa_solver* s, dfa_solve_stats* host_out, dfa_stream_t 
     if (getenv("DFA_PCG_PROFILE_PRINT"))
         fprintf(stderr, "pcg phase cycles: spmv %lld  red_pAp %lld  update %lld  red_rz %lld  p_update+barrier %lld  loop %lld  (iters %d)\n",
                 h.prof[0], h.prof[1], h.prof[2], h.prof[3], h.prof[4], h.prof[5], h.pcg_iters);
+    if (getenv("DFA_PCG_PROFILE_PRINT"))
+        fprintf(stderr, "assemble block 7 cycles: init %lld  list+hash %lld  reduce+barrier %lld  compact %lld\n",
+                h.prof[6] / 1000000, h.prof[6] % 1000000, h.prof[7] / 1000000, h.prof[7] % 1000000);
     if (h.overflow)
         return fail(DFA_ERR_CAPACITY, "normal-matrix row wider than the plan's ELL capacity (%d > %d)", h.max_row_nnz,
                     s->ell_cap);

@@ -66,19 +66,33 @@ __global__ __launch_bounds__(256) void build_data_rhs_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------
-// transpose graph node -> (row, slot): count / scan / fill
+// transpose graph node -> (row, slot).  A counting sort of the R*k slot entries by node id with
+// workgroup-private histograms in LDS: TG_BLOCKS workgroups each own a contiguous chunk of the
+// entries, count into LDS (no global atomics: 1 M device-scope atomics on 2 k counters were
+// the whole cost of the first version), publish their histogram, a single workgroup turns the
+// [block][node] table into node offsets + per-block bases, and the fill pass replays the
+// chunk with an LDS cursor per node.  Deterministic up to the order inside one chunk.
 
-__global__ __launch_bounds__(256) void count_kernel(const int32_t* __restrict__ ridx, size_t total,
-                                                    int32_t* __restrict__ node_cnt) {
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const int n = ridx[e];
-    if (n >= 0) atomicAdd(&node_cnt[n], 1);
+constexpr int TG_BLOCKS = 256;
+
+__global__ __launch_bounds__(1024) void tg_count_kernel(const int32_t* __restrict__ ridx, size_t total, int D,
+                                                        int32_t* __restrict__ blk_hist /* [TG_BLOCKS][D] */) {
+    extern __shared__ int32_t hist[];
+    for (int i = threadIdx.x; i < D; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const size_t chunk = (total + TG_BLOCKS - 1) / TG_BLOCKS;
+    const size_t beg = chunk * blockIdx.x, end = min(beg + chunk, total);
+    for (size_t e = beg + threadIdx.x; e < end; e += blockDim.x) {
+        const int n = ridx[e];
+        if (n >= 0) atomicAdd(&hist[n], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += blockDim.x) blk_hist[(size_t)blockIdx.x * D + i] = hist[i];
 }
 
-// single workgroup exclusive scan of node_cnt[0..D) -> node_ptr[0..D]; also zeroes the cursors
-__global__ __launch_bounds__(1024) void scan_kernel(const int32_t* __restrict__ node_cnt, int D,
-                                                    int32_t* __restrict__ node_ptr, int32_t* __restrict__ cursor) {
+// one workgroup: node totals -> exclusive scan -> node_ptr; blk_hist becomes per-block bases
+__global__ __launch_bounds__(1024) void tg_scan_kernel(int32_t* __restrict__ blk_hist, int D,
+                                                       int32_t* __restrict__ node_ptr) {
     __shared__ int32_t wave_tot[16];
     __shared__ int32_t carry;
     if (threadIdx.x == 0) carry = 0;
@@ -86,8 +100,10 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int32_t* __restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int base = 0; base < D; base += 1024) {
         const int i = base + threadIdx.x;
-        const int v = i < D ? node_cnt[i] : 0;
-        int incl    = v;
+        int v       = 0;
+        if (i < D)
+            for (int b = 0; b < TG_BLOCKS; ++b) v += blk_hist[(size_t)b * D + i];
+        int incl = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int t = __shfl_up(incl, o, 64);
@@ -99,8 +115,13 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int32_t* __restrict__ 
         for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
         const int c = carry;
         if (i < D) {
-            node_ptr[i] = c + wave_off + incl - v;
-            cursor[i]   = 0;
+            int run     = c + wave_off + incl - v;
+            node_ptr[i] = run;
+            for (int b = 0; b < TG_BLOCKS; ++b) {
+                const int h                = blk_hist[(size_t)b * D + i];
+                blk_hist[(size_t)b * D + i] = run;
+                run += h;
+            }
         }
         __syncthreads();
         if (threadIdx.x == 1023) carry = c + wave_off + incl;
@@ -109,13 +130,18 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int32_t* __restrict__ 
     if (threadIdx.x == 0) node_ptr[D] = carry;
 }
 
-__global__ __launch_bounds__(256) void fill_kernel(const int32_t* __restrict__ ridx, size_t total,
-                                                   const int32_t* __restrict__ node_ptr,
-                                                   int32_t* __restrict__ cursor, uint32_t* __restrict__ node_list) {
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const int n = ridx[e];
-    if (n >= 0) node_list[node_ptr[n] + atomicAdd(&cursor[n], 1)] = (uint32_t)e;
+__global__ __launch_bounds__(1024) void tg_fill_kernel(const int32_t* __restrict__ ridx, size_t total, int D,
+                                                       const int32_t* __restrict__ blk_base,
+                                                       uint32_t* __restrict__ node_list) {
+    extern __shared__ int32_t cursor[];
+    for (int i = threadIdx.x; i < D; i += blockDim.x) cursor[i] = blk_base[(size_t)blockIdx.x * D + i];
+    __syncthreads();
+    const size_t chunk = (total + TG_BLOCKS - 1) / TG_BLOCKS;
+    const size_t beg = chunk * blockIdx.x, end = min(beg + chunk, total);
+    for (size_t e = beg + threadIdx.x; e < end; e += blockDim.x) {
+        const int n = ridx[e];
+        if (n >= 0) node_list[atomicAdd(&cursor[n], 1)] = (uint32_t)e;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -200,8 +226,18 @@ __global__ __launch_bounds__(256) void residual_kernel(SolveView s, double* __re
             }
         }
         const float ex = s.rb[3 * r] - sx, ey = s.rb[3 * r + 1] - sy, ez = s.rb[3 * r + 2] - sz;
-        s.re[3 * r] = ex, s.re[3 * r + 1] = ey, s.re[3 * r + 2] = ez;
-        c = (double)s.rtau[r] * ((double)ex * ex + (double)ey * ey + (double)ez * ez);
+        const float tau = s.rtau[r];
+        // packed row record for the assembly gather: k node ids, k weights, (e, tau) — one
+        // contiguous (2k+4)-word block per row instead of three separate cache lines
+        float* rec = s.re + r * (size_t)(2 * s.k + 4);
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (j < s.k) {
+                rec[j]       = __int_as_float(s.ridx[r * s.k + j]);
+                rec[s.k + j] = s.rw[r * s.k + j];
+            }
+        rec[2 * s.k] = ex, rec[2 * s.k + 1] = ey, rec[2 * s.k + 2] = ez, rec[2 * s.k + 3] = tau;
+        c = (double)tau * ((double)ex * ex + (double)ey * ey + (double)ez * ez);
     }
     c = wave_sum_all(c);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
@@ -235,92 +271,148 @@ __global__ __launch_bounds__(256) void control_kernel(SolveState* __restrict__ s
 }
 
 // ------------------------------------------------------------------------------------------
-// assembly: one wave per node.  LDS hash (HASH entries) keyed by column -> ELL row.
+// assembly: one 256-thread workgroup per node.  Its ~128 k rows (transpose graph) are spread
+// over the 4 waves, every row contributes k (column, tau w_a w_b) pairs to an LDS hash keyed by
+// column; wave 0 then compacts the hash into the node's ELL row.  Each row is one packed record
+// (k ids, k weights, e, tau) read with 16-byte loads from a single cache line.
 
 constexpr int HASH      = 512;
 constexpr int HASH_MASK = HASH - 1;
 
+// one row record = (2k+4) consecutive words written by residual_kernel
+template <int K>
+__device__ __forceinline__ float4 load_record(const SolveView& s, size_t r, int (&idx)[K], float (&w)[K]) {
+    const float* rec = s.re + r * (size_t)(2 * s.k + 4);
+    if (s.k == K && (K % 4) == 0) {
+        const float4* v = (const float4*)rec;  // (2K+4)*4 bytes is a multiple of 16
+#pragma unroll
+        for (int q = 0; q < K / 4; ++q) {
+            const float4 i4 = v[q], w4 = v[K / 4 + q];
+            idx[4 * q] = __float_as_int(i4.x), idx[4 * q + 1] = __float_as_int(i4.y);
+            idx[4 * q + 2] = __float_as_int(i4.z), idx[4 * q + 3] = __float_as_int(i4.w);
+            w[4 * q] = w4.x, w[4 * q + 1] = w4.y, w[4 * q + 2] = w4.z, w[4 * q + 3] = w4.w;
+        }
+        return v[K / 2];
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        idx[j] = j < s.k ? __float_as_int(rec[j]) : -1;
+        w[j]   = j < s.k ? rec[s.k + j] : 0.f;
+    }
+    return make_float4(rec[2 * s.k], rec[2 * s.k + 1], rec[2 * s.k + 2], rec[2 * s.k + 3]);
+}
+
 template <int K>
 __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* __restrict__ st) {
-    __shared__ int hkey[4][HASH];
-    __shared__ float hval[4][HASH];
+    __shared__ int key[HASH];
+    __shared__ float val[HASH];
+    __shared__ float gpart[4][3];
+    __shared__ int wave_cnt[4];
+    __shared__ int ovf;
     if (st->done) return;
+    const int a    = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int a    = blockIdx.x * 4 + wave;
-    if (a >= s.D) return;
-    int* key   = hkey[wave];
-    float* val = hval[wave];
-    for (int i = lane; i < HASH; i += 64) key[i] = -1, val[i] = 0.f;
-    // wave-private LDS region: a wave-level fence is enough, lanes of a wave run in lockstep
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+#ifdef DFA_PCG_PROFILE
+    long long t0_ = clock64(), t1_, t2_, t3_, t4_;
+#endif
+    for (int i = threadIdx.x; i < HASH; i += 256) key[i] = -1, val[i] = 0.f;
+    if (threadIdx.x == 0) ovf = 0;
+    __syncthreads();
+#ifdef DFA_PCG_PROFILE
+    t1_ = clock64();
+#endif
 
     const int beg = s.node_ptr[a], end = s.node_ptr[a + 1];
     float gx = 0.f, gy = 0.f, gz = 0.f;
-    bool overflow = false;
-    for (int p = beg + lane; p < end; p += 64) {
+    for (int p = beg + (int)threadIdx.x; p < end; p += 256) {
         const uint32_t e = s.node_list[p];
         const size_t r   = e / (uint32_t)s.k;
-        const float tau  = s.rtau[r];
-        const float wa   = s.rw[e];
-        const float tw   = tau * wa;
-        gx += tw * s.re[3 * r], gy += tw * s.re[3 * r + 1], gz += tw * s.re[3 * r + 2];
-        if (tau != 0.f) {
+        const int slot   = (int)(e - (uint32_t)r * (uint32_t)s.k);
+        int idx[K];
+        float w[K];
+        const float4 et = load_record<K>(s, r, idx, w);  // (e.x, e.y, e.z, tau)
+        float wa = 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) wa = (j == slot) ? w[j] : wa;
+        const float tw = et.w * wa;
+        gx += tw * et.x, gy += tw * et.y, gz += tw * et.z;
+        if (et.w != 0.f) {
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                if (j < s.k) {
-                    const int b = s.ridx[r * s.k + j];
-                    if (b >= 0) {
-                        const float v = tw * s.rw[r * s.k + j];
-                        uint32_t h    = ((uint32_t)b * 2654435761u) >> (32 - 9);
-                        int probes    = 0;
-                        for (;; h = (h + 1) & HASH_MASK) {
-                            const int cur = atomicCAS(&key[h], -1, b);
-                            if (cur == -1 || cur == b) {
-                                atomicAdd(&val[h], v);
-                                break;
-                            }
-                            if (++probes >= HASH) {
-                                overflow = true;
-                                break;
-                            }
+                const int b = idx[j];
+                if (b >= 0) {
+                    const float v = tw * w[j];
+                    uint32_t h    = ((uint32_t)b * 2654435761u) >> (32 - 9);
+                    int probes    = 0;
+                    for (;; h = (h + 1) & HASH_MASK) {
+                        const int cur = atomicCAS(&key[h], -1, b);
+                        if (cur == -1 || cur == b) {
+                            atomicAdd(&val[h], v);
+                            break;
+                        }
+                        if (++probes >= HASH) {
+                            ovf = 1;
+                            break;
                         }
                     }
                 }
             }
         }
     }
-    gx = wave_sum_all(gx), gy = wave_sum_all(gy), gz = wave_sum_all(gz);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    // compact the hash into the ELL row (slot-major: entry s of row a at [s*D + a])
-    int cnt = 0;
+#ifdef DFA_PCG_PROFILE
+    t2_ = clock64();
+#endif
+    gx = wave_total(gx), gy = wave_total(gy), gz = wave_total(gz);
+    if (lane == 0) gpart[wave][0] = gx, gpart[wave][1] = gy, gpart[wave][2] = gz;
+    __syncthreads();
+#ifdef DFA_PCG_PROFILE
+    t3_ = clock64();
+#endif
+    // compact the hash into the ELL row (slot-major: entry q of row a at [q*D + a]); each wave owns
+    // HASH/4 consecutive hash slots, wave offsets come from a 4-entry LDS prefix
+    constexpr int PER_WAVE = HASH / 4;
+    int wcnt               = 0;
+    for (int base = 0; base < PER_WAVE; base += 64)
+        wcnt += __popcll(__ballot(key[wave * PER_WAVE + base + lane] >= 0));
+    if (lane == 0) wave_cnt[wave] = wcnt;
+    __syncthreads();
+    int pos0 = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        pos0 += w < wave ? wave_cnt[w] : 0;
+        total += wave_cnt[w];
+    }
     float diag = 0.f;
-    for (int base = 0; base < HASH; base += 64) {
-        const int kk       = key[base + lane];
-        const float vv     = val[base + lane];
-        const bool valid   = kk >= 0;
-        const uint64_t m   = __ballot(valid);
-        const int pos      = cnt + __popcll(m & ((1ull << lane) - 1ull));
+    for (int base = 0; base < PER_WAVE; base += 64) {
+        const int kk     = key[wave * PER_WAVE + base + lane];
+        const float vv   = val[wave * PER_WAVE + base + lane];
+        const bool valid = kk >= 0;
+        const uint64_t m = __ballot(valid);
+        const int pos    = pos0 + __popcll(m & ((1ull << lane) - 1ull));
         if (valid) {
             if (pos < s.ell_cap) {
                 s.ell_cols[(size_t)pos * s.D + a] = kk;
                 s.ell_vals[(size_t)pos * s.D + a] = vv;
             }
-            if (kk == a) diag = vv;
+            if (kk == a) s.diag[a] = vv, diag = 1.f;
         }
-        cnt += __popcll(m);
+        pos0 += __popcll(m);
     }
-    diag = wave_sum_all(diag);
-    if (lane == 0) {
-        s.ell_cnt[a] = min(cnt, s.ell_cap);
-        s.diag[a]    = diag;
-        s.g[3 * a] = gx, s.g[3 * a + 1] = gy, s.g[3 * a + 2] = gz;
-        atomicMax(&st->max_row_nnz, cnt);
-        if (cnt > s.ell_cap) st->overflow = 1;
+    const bool has_diag = __syncthreads_or(diag != 0.f);
+    if (threadIdx.x == 0) {
+        s.ell_cnt[a] = min(total, s.ell_cap);
+        if (!has_diag) s.diag[a] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s.g[3 * a + c] = (gpart[0][c] + gpart[1][c]) + (gpart[2][c] + gpart[3][c]);
+        // 2048 device-scope atomics on one word cost ~11 ns each: only the (few) blocks that raise
+        // the running maximum issue one
+        if (total > *(volatile int*)&st->max_row_nnz) atomicMax(&st->max_row_nnz, total);
+        if (total > s.ell_cap || ovf) st->overflow = 1;
+#ifdef DFA_PCG_PROFILE
+        t4_ = clock64();
+        if (a == 7) st->prof[6] = (t1_ - t0_) * 1000000 + (t2_ - t1_), st->prof[7] = (t3_ - t2_) * 1000000 + (t4_ - t3_);
+#endif
     }
-    if (__ballot(overflow) && lane == 0) st->overflow = 1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -808,10 +900,11 @@ hipError_t solve_build_graph(const SolveView& s, hipStream_t st) {
     hipError_t e;
     build_reg_rows_kernel<<<(D * k + 255) / 256, 256, 0, st>>>(s.reg_idx, D, k, N, s.ridx, s.rw, s.rb);
     if (N > 0) build_data_rhs_kernel<<<(3 * N + 255) / 256, 256, 0, st>>>(s.canon, s.live, N, s.rb);
-    if ((e = hipMemsetAsync(s.node_cnt, 0, sizeof(int32_t) * (size_t)D, st)) != hipSuccess) return e;
-    count_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(s.ridx, total, s.node_cnt);
-    scan_kernel<<<1, 1024, 0, st>>>(s.node_cnt, D, s.node_ptr, s.cursor);
-    fill_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(s.ridx, total, s.node_ptr, s.cursor, s.node_list);
+    (void)e;
+    const size_t lds = sizeof(int32_t) * (size_t)D;
+    tg_count_kernel<<<TG_BLOCKS, 1024, lds, st>>>(s.ridx, total, D, s.blk_hist);
+    tg_scan_kernel<<<1, 1024, 0, st>>>(s.blk_hist, D, s.node_ptr);
+    tg_fill_kernel<<<TG_BLOCKS, 1024, lds, st>>>(s.ridx, total, D, s.blk_hist, s.node_list);
     return hipGetLastError();
 }
 
@@ -836,7 +929,7 @@ hipError_t solve_residual(const SolveView& s, SolveState* state, double* cost_pa
 }
 
 hipError_t solve_assemble(const SolveView& s, SolveState* state, hipStream_t st) {
-    KDISPATCH(assemble_kernel, s.k, <<<(s.D + 3) / 4, 256, 0, st>>>(s, state));
+    KDISPATCH(assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state));
     return hipGetLastError();
 }
 

@@ -35,12 +35,11 @@ struct SolveView {
     float* rw;      // R x k   slot weight
     float* rtau;    // R       robust weight (Tukey) / w_reg^2
     float* rb;      // R x 3   target  (live - canonical | 0)
-    float* re;      // R x 3   e = b - sum w t at the current linearisation
+    float* re;      // R x (2k+4) packed row records: k node ids, k weights, e = b - sum w t, tau
     int32_t* reg_idx;  // D x k
     // transpose graph
-    int32_t* node_cnt;    // D
+    int32_t* blk_hist;    // TG_BLOCKS x D  workgroup-private histograms / bases of the counting sort
     int32_t* node_ptr;    // D + 1
-    int32_t* cursor;      // D
     uint32_t* node_list;  // R x k   flat (row*k + slot) indices grouped by node
     // normal equations, ELL slot-major: entry q of row a at [q*D + a]
     int32_t* ell_cols;
@@ -54,6 +53,7 @@ struct SolveView {
     float* node_dq_out;  // D x 8
 };
 
+constexpr int SOLVE_TG_BLOCKS = 256;
 hipError_t solve_build_graph(const SolveView& s, hipStream_t st);
 hipError_t solve_weights(const SolveView& s, float tukey_offset, float psi_data, float w_reg_sq, float psi_reg,
                          hipStream_t st);
