@@ -83,6 +83,7 @@ struct dfa_solver {
     dfa::SolveView v;          // pointers into `blocks`
     dfa::SolveState* state;    // device
     double* cost_partials;     // device
+    unsigned int* ticket;      // device: arrival counter of the linearise kernel (self re-arming)
     std::vector<void*> blocks;  // every hipMalloc of this plan
     GridScratch grid;           // node grid of the current problem
     bool has_problem;
@@ -287,6 +288,9 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
     }
     if (rc == DFA_OK) rc = plan_alloc(s, &s->state, 1);
     if (rc == DFA_OK) rc = plan_alloc(s, &s->cost_partials, (R + 255) / 256 + 1);
+    if (rc == DFA_OK) rc = plan_alloc(s, &s->ticket, 64);
+    if (rc == DFA_OK && hipMemset(s->ticket, 0, 64 * sizeof(unsigned int)) != hipSuccess)
+        rc = fail(DFA_ERR_HIP, "hipMemset (ticket)");
     if (rc != DFA_OK) {
         dfa_solver_destroy(s);
         return rc;
@@ -352,11 +356,14 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
     s->ev_used = 0;
     s->ev_pcg.clear();
     s->ev_asm.clear();
+    HIP_TRY(hipMemsetAsync(s->ticket, 0, 64 * sizeof(unsigned int), st));
     for (int outer = 0; outer < p->num_iter; ++outer) {
-        // preNonlinearSolve (opt_solver.cpp:135-140)
-        HIP_TRY(dfa::solve_weights(v, p->tukey_offset, p->psi_data, w_reg_sq, p->psi_reg, st));
+        // preNonlinearSolve (opt_solver.cpp:135-140): the Huber weights are only observable after
+        // the solve, so they are evaluated for the last outer iteration alone
+        if (outer == p->num_iter - 1) HIP_TRY(dfa::solve_huber(v, p->psi_reg, st));
         for (int gn = 0; gn < p->nonlinear_iter; ++gn) {
-            HIP_TRY(dfa::solve_residual(v, s->state, s->cost_partials, gn == 0 ? 0 : 1, p->gn_tol, st));
+            HIP_TRY(dfa::solve_linearise(v, s->state, s->cost_partials, s->ticket, gn == 0, gn == 0 ? 0 : 1,
+                                         p->gn_tol, p->tukey_offset, p->psi_data, w_reg_sq, st));
             int ev = s->timing ? timing_begin(s, st) : -1;
             HIP_TRY(dfa::solve_assemble(v, s->state, st));
             timing_end(s, ev, st);
@@ -367,8 +374,11 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
             if (ev >= 0) s->ev_pcg.push_back(ev);
         }
     }
-    if (p->num_iter == 0) HIP_TRY(dfa::solve_weights(v, p->tukey_offset, p->psi_data, w_reg_sq, p->psi_reg, st));
-    HIP_TRY(dfa::solve_residual(v, s->state, s->cost_partials, 2, 0.f, st));
+    // final cost at the solved t; weights re-evaluated only if no iteration ever did
+    const bool no_weights = p->num_iter == 0 || p->nonlinear_iter == 0;
+    if (p->num_iter == 0) HIP_TRY(dfa::solve_huber(v, p->psi_reg, st));
+    HIP_TRY(dfa::solve_linearise(v, s->state, s->cost_partials, s->ticket, no_weights ? 1 : 0, 2, 0.f,
+                                 p->tukey_offset, p->psi_data, w_reg_sq, st));
     // postSingleSolve -> copyResultToCPUFromFloat3 (opt_solver.cpp:133,270-285), composed once
     HIP_TRY(dfa::solve_writeback(v, st));
     return DFA_OK;

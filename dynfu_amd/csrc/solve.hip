@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void build_data_rhs_kernel(const float* __rest
 // [block][node] table into node offsets + per-block bases, and the fill pass replays the
 // chunk with an LDS cursor per node.  Deterministic up to the order inside one chunk.
 
-constexpr int TG_BLOCKS = 256;
+constexpr int TG_BLOCKS = SOLVE_TG_BLOCKS;
 
 __global__ __launch_bounds__(1024) void tg_count_kernel(const int32_t* __restrict__ ridx, size_t total, int D,
                                                         int32_t* __restrict__ blk_hist /* [TG_BLOCKS][D] */) {
@@ -145,21 +145,25 @@ __global__ __launch_bounds__(1024) void tg_fill_kernel(const int32_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
-// per outer iteration: Tukey biweights (opt_solver.cpp:204-231) from the current warp
-//   warp(c) = calcDQB(c)(c) with node transforms DQ(t_i) * dg_se3_i   (:270-285, node.cpp:19-23)
+// linearisation, one launch per Gauss-Newton iteration:
+//   [outer-iteration start only] robust weights: Tukey biweight of the current warp error for
+//       the data rows (opt_solver.cpp:204-231; warp(c) = calcDQB(c)(c) with node transforms
+//       DQ(t_i) * dg_se3_i, :270-285 + node.cpp:19-23), w_reg^2 for the regularisation rows (:30);
+//   residual  e_r = b_r - sum_j w_rj t_{n_rj}  -> tail (e, tau) of the row's packed record;
+//   cost      sum tau |e|^2: one partial per workgroup, the LAST workgroup to arrive (agent-scope
+//       release/acquire around a ticket counter) adds the partials in index order (deterministic)
+//       and runs the Gauss-Newton control logic — no separate control launch.
 
 template <int K>
-__global__ __launch_bounds__(256) void tukey_kernel(SolveView s, float tukey_offset, float psi_data) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= s.N) return;
-    const f3 c = mk3(s.canon[3 * (size_t)v], s.canon[3 * (size_t)v + 1], s.canon[3 * (size_t)v + 2]);
+__device__ __forceinline__ float tukey_weight(const SolveView& s, size_t v, float tukey_offset, float psi_data) {
+    const f3 c = mk3(s.canon[3 * v], s.canon[3 * v + 1], s.canon[3 * v + 2]);
     DQ sum     = dq_identity();
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         if (j < s.k) {
-            const int n = s.ridx[(size_t)v * s.k + j];
+            const int n = s.ridx[v * s.k + j];
             if (n >= 0) {
-                const float w = s.rw[(size_t)v * s.k + j];
+                const float w = s.rw[v * s.k + j];
                 const DQ cur  = dq_mul(dq_from_translation(s.t[3 * n], s.t[3 * n + 1], s.t[3 * n + 2]),
                                        dq_load(s.node_dq + 8 * (size_t)n));
                 sum           = dq_mul(sum, dq_scale(cur, w));
@@ -167,53 +171,42 @@ __global__ __launch_bounds__(256) void tukey_kernel(SolveView s, float tukey_off
         }
     }
     const f3 warped = dq_transform(dq_normalize(sum), c);
-    const float ex = s.live[3 * (size_t)v] - warped.x, ey = s.live[3 * (size_t)v + 1] - warped.y,
-                ez = s.live[3 * (size_t)v + 2] - warped.z;
+    const float ex = s.live[3 * v] - warped.x, ey = s.live[3 * v + 1] - warped.y, ez = s.live[3 * v + 2] - warped.z;
     // calcTukeyBiweight (:204-212)
     const float d = sqrtf(ex * ex + ey * ey + ez * ez) / tukey_offset;
-    float tau     = 0.f;
     if (d < psi_data) {
         const double q = 1.0 - ((double)d * (double)d) / ((double)psi_data * (double)psi_data);
-        tau            = (float)(q * q);
+        return (float)(q * q);
     }
-    s.rtau[v] = tau;
+    return 0.f;
 }
 
-// reg rows' tau = w_reg^2 (opt_solver.cpp:30) and Huber weights (opt_solver.cpp:233-268,
-// computed for interface parity; energy.t:70 never uses them)
-__global__ __launch_bounds__(256) void reg_weights_kernel(SolveView s, float w_reg_sq, float psi_reg) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < s.D * s.k) s.rtau[(size_t)s.N + e] = w_reg_sq;
-    if (e < s.D) {
-        const int i   = e;
-        const DQ dq_i = dq_mul(dq_from_translation(s.t[3 * i], s.t[3 * i + 1], s.t[3 * i + 2]),
-                               dq_load(s.node_dq + 8 * (size_t)i));
-        float h = 0.f;
-        for (int j = 0; j < s.k; ++j) {
-            const int m = s.reg_idx[(size_t)i * s.k + j];
-            if (m < 0) break;
-            const f3 pm   = mk3(s.node_pos[3 * m], s.node_pos[3 * m + 1], s.node_pos[3 * m + 2]);
-            const DQ dq_m = dq_mul(dq_from_translation(s.t[3 * m], s.t[3 * m + 1], s.t[3 * m + 2]),
-                                   dq_load(s.node_dq + 8 * (size_t)m));
-            const f3 a = dq_transform(dq_i, pm), b = dq_transform(dq_m, pm);
-            const float ex = a.x - b.x, ey = a.y - b.y, ez = a.z - b.z;
-            const float err = sqrtf(ex * ex + ey * ey + ez * ez);
-            h               = fabsf(err) <= psi_reg ? 1.f : psi_reg / fabsf(err);  // last neighbour wins (:263)
-        }
-        s.huber[i] = h;
-    }
-}
+struct LineariseArgs {
+    int update_weights;  // first linearisation of an outer iteration
+    int mode;            // 0 first of outer, 1 later GN iteration, 2 final cost only
+    float gn_tol, tukey_offset, psi_data, w_reg_sq;
+};
 
-// ------------------------------------------------------------------------------------------
-// per linearisation: e_r = b_r - sum_j w_rj t_{n_rj},  cost = sum tau |e|^2
+constexpr int LIN_SHARDS     = 32;    // ticket counters: one device-scope atomic costs ~11 ns when
+constexpr int LIN_MAX_BLOCKS = 1024;  // serialised on one word, so arrivals are sharded 2-level
 
 template <int K>
-__global__ __launch_bounds__(256) void residual_kernel(SolveView s, double* __restrict__ cost_partials) {
+__global__ __launch_bounds__(256) void linearise_kernel(SolveView s, SolveState* __restrict__ st,
+                                                        double* __restrict__ cost_partials,
+                                                        unsigned int* __restrict__ ticket /*[LIN_SHARDS+1]*/,
+                                                        LineariseArgs a) {
     __shared__ double wsum[4];
+    __shared__ int is_last;
     const size_t R = (size_t)s.N + (size_t)s.D * s.k;
-    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     double c       = 0.0;
-    if (r < R) {
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (size_t)gridDim.x * blockDim.x) {
+        float tau;
+        if (a.update_weights) {
+            tau       = r < (size_t)s.N ? tukey_weight<K>(s, r, a.tukey_offset, a.psi_data) : a.w_reg_sq;
+            s.rtau[r] = tau;
+        } else {
+            tau = s.rtau[r];
+        }
         float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
@@ -226,34 +219,43 @@ __global__ __launch_bounds__(256) void residual_kernel(SolveView s, double* __re
             }
         }
         const float ex = s.rb[3 * r] - sx, ey = s.rb[3 * r + 1] - sy, ez = s.rb[3 * r + 2] - sz;
-        const float tau = s.rtau[r];
-        // packed row record for the assembly gather: k node ids, k weights, (e, tau) — one
-        // contiguous (2k+4)-word block per row instead of three separate cache lines
-        float* rec = s.re + r * (size_t)(2 * s.k + 4);
-#pragma unroll
-        for (int j = 0; j < K; ++j)
-            if (j < s.k) {
-                rec[j]       = __int_as_float(s.ridx[r * s.k + j]);
-                rec[s.k + j] = s.rw[r * s.k + j];
-            }
-        rec[2 * s.k] = ex, rec[2 * s.k + 1] = ey, rec[2 * s.k + 2] = ez, rec[2 * s.k + 3] = tau;
-        c = (double)tau * ((double)ex * ex + (double)ey * ey + (double)ez * ez);
+        // tail of the packed row record (head = k ids + k weights, written once per frame)
+        *(float4*)(s.re + r * (size_t)(2 * s.k + 4) + 2 * s.k) = make_float4(ex, ey, ez, tau);
+        c += (double)tau * ((double)ex * ex + (double)ey * ey + (double)ez * ez);
     }
     c = wave_sum_all(c);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) cost_partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-}
+    if (threadIdx.x == 0) {
+        // publish the partial write-through (sc1) — no release fence, which would write back the
+        // whole L2's dirty record tails — then arrive: shard counter first, top counter for the
+        // last arriver of each shard
+        __hip_atomic_store(&cost_partials[blockIdx.x], (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int shard   = blockIdx.x % LIN_SHARDS;
+        const unsigned int members = (gridDim.x - shard + LIN_SHARDS - 1) / LIN_SHARDS;
+        const unsigned int nshards = min((unsigned int)LIN_SHARDS, gridDim.x);
+        int last                   = 0;
+        if (__hip_atomic_fetch_add(&ticket[shard], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+            __hip_atomic_store(&ticket[shard], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+            if (__hip_atomic_fetch_add(&ticket[LIN_SHARDS], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                nshards - 1) {
+                __hip_atomic_store(&ticket[LIN_SHARDS], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1;
+            }
+        }
+        is_last = last;
+    }
+    __syncthreads();
+    if (!is_last) return;
 
-// one thread-block: sums the partials in a fixed order (deterministic), Gauss-Newton control
-__global__ __launch_bounds__(256) void control_kernel(SolveState* __restrict__ st,
-                                                      const double* __restrict__ cost_partials, int nparts,
-                                                      int mode /*0 first of outer, 1 later GN, 2 final*/,
-                                                      float gn_tol) {
+    // last workgroup: ordered sum of the partials + Gauss-Newton control
     __shared__ double sm[256];
-    double c = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += 256) c += cost_partials[i];
-    sm[threadIdx.x] = c;
+    double acc = 0.0;
+    for (unsigned int i = threadIdx.x; i < gridDim.x; i += 256)
+        acc += __hip_atomic_load(&cost_partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sm[threadIdx.x] = acc;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
@@ -262,12 +264,49 @@ __global__ __launch_bounds__(256) void control_kernel(SolveState* __restrict__ s
     if (threadIdx.x == 0) {
         const double cost = sm[0];
         if (!st->have_initial) st->initial_cost = cost, st->have_initial = 1;
-        if (mode == 0) st->done = 0;
+        if (a.mode == 0) st->done = 0;
         // Gauss-Newton early-out: relative cost decrease of the previous step below gn_tol
-        if (mode == 1 && !st->done && gn_tol > 0.f && (st->cost - cost) <= (double)gn_tol * st->cost) st->done = 1;
+        if (a.mode == 1 && !st->done && a.gn_tol > 0.f && (st->cost - cost) <= (double)a.gn_tol * st->cost)
+            st->done = 1;
         st->cost       = cost;
         st->final_cost = cost;
     }
+}
+
+// Huber weights (opt_solver.cpp:233-268): computed for interface parity, energy.t:70 never uses them
+__global__ __launch_bounds__(256) void huber_kernel(SolveView s, float psi_reg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.D) return;
+    const DQ dq_i = dq_mul(dq_from_translation(s.t[3 * i], s.t[3 * i + 1], s.t[3 * i + 2]),
+                           dq_load(s.node_dq + 8 * (size_t)i));
+    float h = 0.f;
+    for (int j = 0; j < s.k; ++j) {
+        const int m = s.reg_idx[(size_t)i * s.k + j];
+        if (m < 0) break;
+        const f3 pm   = mk3(s.node_pos[3 * m], s.node_pos[3 * m + 1], s.node_pos[3 * m + 2]);
+        const DQ dq_m = dq_mul(dq_from_translation(s.t[3 * m], s.t[3 * m + 1], s.t[3 * m + 2]),
+                               dq_load(s.node_dq + 8 * (size_t)m));
+        const f3 pa = dq_transform(dq_i, pm), pb = dq_transform(dq_m, pm);
+        const float ex = pa.x - pb.x, ey = pa.y - pb.y, ez = pa.z - pb.z;
+        const float err = sqrtf(ex * ex + ey * ey + ez * ez);
+        h               = fabsf(err) <= psi_reg ? 1.f : psi_reg / fabsf(err);  // last neighbour wins (:263)
+    }
+    s.huber[i] = h;
+}
+
+// head of the packed row records: k node ids + k weights (constant over a frame)
+template <int K>
+__global__ __launch_bounds__(256) void pack_records_kernel(SolveView s) {
+    const size_t R = (size_t)s.N + (size_t)s.D * s.k;
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float* rec = s.re + r * (size_t)(2 * s.k + 4);
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if (j < s.k) {
+            rec[j]       = __int_as_float(s.ridx[r * s.k + j]);
+            rec[s.k + j] = s.rw[r * s.k + j];
+        }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -905,26 +944,27 @@ hipError_t solve_build_graph(const SolveView& s, hipStream_t st) {
     tg_count_kernel<<<TG_BLOCKS, 1024, lds, st>>>(s.ridx, total, D, s.blk_hist);
     tg_scan_kernel<<<1, 1024, 0, st>>>(s.blk_hist, D, s.node_ptr);
     tg_fill_kernel<<<TG_BLOCKS, 1024, lds, st>>>(s.ridx, total, D, s.blk_hist, s.node_list);
-    return hipGetLastError();
-}
-
-hipError_t solve_weights(const SolveView& s, float tukey_offset, float psi_data, float w_reg_sq, float psi_reg,
-                         hipStream_t st) {
-    if (s.N > 0) KDISPATCH(tukey_kernel, s.k, <<<(s.N + 255) / 256, 256, 0, st>>>(s, tukey_offset, psi_data));
-    reg_weights_kernel<<<(s.D * s.k + 255) / 256, 256, 0, st>>>(s, w_reg_sq, psi_reg);
+    KDISPATCH(pack_records_kernel, k, <<<(unsigned)((R + 255) / 256), 256, 0, st>>>(s));
     return hipGetLastError();
 }
 
 int solve_residual_blocks(const SolveView& s) {
-    const size_t R = (size_t)s.N + (size_t)s.D * s.k;
-    return (int)((R + 255) / 256);
+    const size_t R  = (size_t)s.N + (size_t)s.D * s.k;
+    const size_t nb = (R + 255) / 256;
+    return (int)(nb < (size_t)LIN_MAX_BLOCKS ? nb : (size_t)LIN_MAX_BLOCKS);
 }
 
-hipError_t solve_residual(const SolveView& s, SolveState* state, double* cost_partials, int mode, float gn_tol,
-                          hipStream_t st) {
+hipError_t solve_linearise(const SolveView& s, SolveState* state, double* cost_partials, unsigned int* ticket,
+                           int update_weights, int mode, float gn_tol, float tukey_offset, float psi_data,
+                           float w_reg_sq, hipStream_t st) {
     const int nb = solve_residual_blocks(s);
-    KDISPATCH(residual_kernel, s.k, <<<nb, 256, 0, st>>>(s, cost_partials));
-    control_kernel<<<1, 256, 0, st>>>(state, cost_partials, nb, mode, gn_tol);
+    LineariseArgs a{update_weights, mode, gn_tol, tukey_offset, psi_data, w_reg_sq};
+    KDISPATCH(linearise_kernel, s.k, <<<nb, 256, 0, st>>>(s, state, cost_partials, ticket, a));
+    return hipGetLastError();
+}
+
+hipError_t solve_huber(const SolveView& s, float psi_reg, hipStream_t st) {
+    huber_kernel<<<(s.D + 255) / 256, 256, 0, st>>>(s, psi_reg);
     return hipGetLastError();
 }
 

@@ -53,13 +53,14 @@ struct SolveView {
     float* node_dq_out;  // D x 8
 };
 
-constexpr int SOLVE_TG_BLOCKS = 256;
+constexpr int SOLVE_TG_BLOCKS = 64;
 hipError_t solve_build_graph(const SolveView& s, hipStream_t st);
-hipError_t solve_weights(const SolveView& s, float tukey_offset, float psi_data, float w_reg_sq, float psi_reg,
-                         hipStream_t st);
 int solve_residual_blocks(const SolveView& s);
-hipError_t solve_residual(const SolveView& s, SolveState* state, double* cost_partials, int mode, float gn_tol,
-                          hipStream_t st);
+// robust weights (optional) + residuals + cost + Gauss-Newton control, one launch
+hipError_t solve_linearise(const SolveView& s, SolveState* state, double* cost_partials, unsigned int* ticket,
+                           int update_weights, int mode, float gn_tol, float tukey_offset, float psi_data,
+                           float w_reg_sq, hipStream_t st);
+hipError_t solve_huber(const SolveView& s, float psi_reg, hipStream_t st);
 hipError_t solve_assemble(const SolveView& s, SolveState* state, hipStream_t st);
 int solve_pcg_max_nodes();
 hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, hipStream_t st);
