@@ -69,5 +69,64 @@ def build(force=False, verbose=False):
     return LIB
 
 
+HOST = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(HERE, "libdynfu_amd_host.so")
+HOST_SOURCES = ["device.cpp", "tsdf_volume.cpp", "warp_field.cpp", "opt_solver.cpp"]
+
+
+def build_host(force=False, verbose=False):
+    """C++ host adaptors (kfusion::cuda::TsdfVolume, Warpfield, CombinedSolver, ...) above the C ABI
+    -> dynfu_amd/libdynfu_amd_host.so.  Plain C++ (no device code), linked against
+    libdynfu_amd.so and the HIP runtime."""
+    lib = build(force=force, verbose=verbose)
+    inc = os.path.join(HOST, "include")
+    srcs = [os.path.join(HOST, "src", f) for f in HOST_SOURCES]
+    deps = srcs + [lib, os.path.abspath(__file__)]
+    for root, _, files in os.walk(inc):
+        deps += [os.path.join(root, f) for f in files]
+    if force or _stale(HOST_LIB, deps):
+        cmd = [hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + inc] + srcs + \
+              ["-L" + HERE, "-ldynfu_amd", "-Wl,-rpath,$ORIGIN", "-o", HOST_LIB]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("host library build failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
+    return HOST_LIB
+
+
+def build_cpp_tests(force=False, verbose=False):
+    """tests/cpp/*.cpp -> tests/cpp/build/<name> (git-ignored; travels to the GPU box)."""
+    host = build_host(force=force, verbose=verbose)
+    root = os.path.dirname(HERE)
+    tdir = os.path.join(root, "tests", "cpp")
+    out = os.path.join(tdir, "build")
+    os.makedirs(out, exist_ok=True)
+    inc = os.path.join(HOST, "include")
+    oracle_dir = os.path.join(root, "oracle")
+    built = {}
+    for name, needs in (("test_host_dq", []), ("test_host_solver", ["host"]), ("test_host_tsdf", ["host", "oracle"])):
+        src = os.path.join(tdir, name + ".cpp")
+        exe = os.path.join(out, name)
+        deps = [src, os.path.join(tdir, "minitest.hpp"), host]
+        if force or _stale(exe, deps):
+            cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-I" + inc, src, "-o", exe]
+            if "host" in needs:
+                cmd += ["-L" + HERE, "-ldynfu_amd_host", "-ldynfu_amd", "-Wl,-rpath," + HERE,
+                        "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
+            if "oracle" in needs:
+                cmd += ["-L" + oracle_dir, "-loracle", "-Wl,-rpath," + oracle_dir]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("C++ test build failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
+        built[name] = exe
+    return built
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--host" in sys.argv:
+        print(build_host(force="--force" in sys.argv, verbose=True))
+        print(build_cpp_tests(force="--force" in sys.argv, verbose=True))

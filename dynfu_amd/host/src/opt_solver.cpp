@@ -1,0 +1,93 @@
+// opt_solver.cpp — CombinedSolver on the dynfu_amd solver plan
+// (reference: src/dynfu/utils/opt_solver.cpp; the Opt GN/PCG it drives is replaced by
+// dfa_solver_solve).
+#include <dynfu/utils/opt_solver.hpp>
+
+#include <dfa_host/device.hpp>
+
+#include "../../../include/dynfu_amd.h"
+
+struct CombinedSolver::Impl {
+    dfa_solver* plan = nullptr;
+    dfa::DeviceArray<float> node_pos, node_dq, node_w, canon, live, canon_n, live_n;
+    int D = 0, N = 0;
+    ~Impl() { dfa_solver_destroy(plan); }
+};
+
+CombinedSolver::CombinedSolver(Warpfield warpfield, CombinedSolverParameters params, float tukeyOffset_,
+                               float psi_data_, float lambda_, float psi_reg_)
+    : m_warpfield(warpfield), m_params(params), tukeyOffset(tukeyOffset_), psi_data(psi_data_), lambda(lambda_),
+      psi_reg(psi_reg_), impl(std::make_shared<Impl>()) {}
+CombinedSolver::~CombinedSolver() = default;
+
+// opt_solver.cpp:15-54 (+ resetGPUMemory :149-202): stage AoS -> SoA, upload, build the graphs
+void CombinedSolver::initializeProblemInstance(const std::shared_ptr<dynfu::Frame> canonicalFrame,
+                                               const std::shared_ptr<dynfu::Frame> liveFrame, dfa::Affine3f /*affine*/) {
+    auto nodes = m_warpfield.getNodes();
+    auto& cv = canonicalFrame->getVertices();
+    auto& cn = canonicalFrame->getNormals();
+    auto& lv = liveFrame->getVertices();
+    auto& ln = liveFrame->getNormals();
+    const int D = (int)nodes.size(), N = (int)cv.size();
+    if ((int)lv.size() != N) throw dfa::Error(DFA_ERR_INVALID, "canonical / live vertex counts differ");
+    std::vector<float> pos(3 * (size_t)D), w(D), dq(8 * (size_t)D), c(3 * (size_t)N), l(3 * (size_t)N),
+        cnv(3 * (size_t)N), lnv(3 * (size_t)N);
+    for (int i = 0; i < D; ++i) {
+        const dfa::PointXYZ g = nodes[i]->getPosition();
+        pos[3 * i] = g.x, pos[3 * i + 1] = g.y, pos[3 * i + 2] = g.z;
+        w[i] = nodes[i]->getRadialBasisWeight();
+        const auto& q = *nodes[i]->getTransformation();
+        const auto r = q.getReal(), d = q.getDual();
+        float* o = &dq[8 * (size_t)i];
+        o[0] = r.a, o[1] = r.b, o[2] = r.c, o[3] = r.d, o[4] = d.a, o[5] = d.b, o[6] = d.c, o[7] = d.d;
+    }
+    for (int i = 0; i < N; ++i) {
+        c[3 * i] = cv[i].x, c[3 * i + 1] = cv[i].y, c[3 * i + 2] = cv[i].z;
+        l[3 * i] = lv[i].x, l[3 * i + 1] = lv[i].y, l[3 * i + 2] = lv[i].z;
+        if (i < (int)cn.size()) cnv[3 * i] = cn[i].normal_x, cnv[3 * i + 1] = cn[i].normal_y, cnv[3 * i + 2] = cn[i].normal_z;
+        if (i < (int)ln.size()) lnv[3 * i] = ln[i].normal_x, lnv[3 * i + 1] = ln[i].normal_y, lnv[3 * i + 2] = ln[i].normal_z;
+    }
+    Impl& I = *impl;
+    I.D = D, I.N = N;
+    I.node_pos.upload(pos), I.node_w.upload(w), I.node_dq.upload(dq);
+    I.canon.upload(c), I.live.upload(l), I.canon_n.upload(cnv), I.live_n.upload(lnv);
+    if (I.plan) dfa_solver_destroy(I.plan), I.plan = nullptr;
+    dfa::check(dfa_solver_create(D, N, m_warpfield.getKnn(), &I.plan), "CombinedSolver: dfa_solver_create");
+    dfa::check(dfa_solver_set_problem(I.plan, I.node_pos.ptr(), I.node_dq.ptr(), I.node_w.ptr(), D, I.canon.ptr(),
+                                      I.canon_n.ptr(), I.live.ptr(), I.live_n.ptr(), N, nullptr),
+               "CombinedSolver::initializeProblemInstance");
+}
+
+// CombinedSolverBase::solveAll with the hooks of opt_solver.cpp:107-147; results are written back
+// to the shared Nodes ONCE (copyResultToCPUFromFloat3 :270-285 + Node::updateTransformation)
+void CombinedSolver::solveAll() {
+    Impl& I = *impl;
+    if (!I.plan) throw dfa::Error(DFA_ERR_INVALID, "solveAll before initializeProblemInstance");
+    dfa_solve_params p;
+    p.num_iter       = m_params.numIter;
+    p.nonlinear_iter = m_params.nonLinearIter;
+    p.linear_iter    = m_params.linearIter;
+    p.tukey_offset   = tukeyOffset;
+    p.psi_data       = psi_data;
+    p.lambda         = lambda;
+    p.psi_reg        = psi_reg;
+    p.pcg_tol        = 0.f;
+    p.gn_tol         = 0.f;
+    dfa::check(dfa_solver_solve(I.plan, &p, nullptr), "CombinedSolver::solveAll");
+    dfa_solve_stats st;
+    dfa::check(dfa_solver_get_stats(I.plan, &st, nullptr), "CombinedSolver::solveAll (stats)");
+    initial_cost_ = st.initial_cost, final_cost_ = st.final_cost;
+    std::vector<float> t(3 * (size_t)I.D);
+    dfa::DeviceMemory tmp;  // borrowed view: copy out of the plan
+    if (I.D) {
+        dfa::device_synchronize();
+        // plan-owned device array -> host
+        extern void dfa_host_copy_from_device(void*, const void*, size_t);
+        dfa_host_copy_from_device(t.data(), dfa_solver_translations(I.plan), t.size() * sizeof(float));
+    }
+    auto nodes = m_warpfield.getNodes();
+    for (int i = 0; i < I.D; ++i) {
+        auto dq = std::make_shared<DualQuaternion<float>>(0.f, 0.f, 0.f, t[3 * i], t[3 * i + 1], t[3 * i + 2]);
+        nodes[i]->updateTransformation(dq);
+    }
+}

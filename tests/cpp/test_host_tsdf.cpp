@@ -1,0 +1,111 @@
+// test_host_tsdf.cpp — kfusion::cuda::TsdfVolume adaptor (create / clear / integrate / raycast /
+// setters with the trunc-dist clamp) against the CPU oracle, bit-exact.  The reference has no
+// TSDF tests; the call sequence is KinFu's (src/kfusion/kinfu.cpp:47-60,206-225).
+#include <cstring>
+
+#include <kfusion/cuda/tsdf_volume.hpp>
+
+#include "../../oracle/oracle.h"
+#include "minitest.hpp"
+
+using namespace kfusion;
+
+namespace {
+std::vector<unsigned short> make_depth(int W, int H) {
+    std::vector<unsigned short> d((size_t)W * H);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const float u = (x - W / 2) / (float)W, v = (y - H / 2) / (float)H;
+            const float r2 = u * u + v * v;
+            d[(size_t)y * W + x] = r2 < 0.09f ? (unsigned short)(1200 + 900 * r2 * 10) : 2400;  // bump in front of a wall
+            if (x < 3 || y < 3 || x >= W - 3 || y >= H - 3) d[(size_t)y * W + x] = 0;
+        }
+    return d;
+}
+}  // namespace
+
+TEST(TsdfVolumeTest, SettersFollowTheReferenceDefaultsAndClamp) {
+    cuda::TsdfVolume vol(Vec3i::all(64));
+    ASSERT_EQ(vol.getMaxWeight(), 128);                            // tsdf_volume.cpp:21
+    ASSERT_NEAR(vol.getTruncDist(), 2.1f * 3.f / 64, 1e-7);        // 0.03 clamped to 2.1 voxels (:57-61)
+    vol.setTruncDist(0.2f);
+    ASSERT_NEAR(vol.getTruncDist(), 0.2f, 1e-7);
+    vol.setSize(Vec3f::all(1.f));
+    ASSERT_NEAR(vol.getVoxelSize()[0], 1.f / 64, 1e-9);
+    vol.setPose(Affine3f().translate(Vec3f(1, 2, 3)));
+    vol.applyAffine(Affine3f().translate(Vec3f(1, 0, 0)));
+    ASSERT_NEAR(vol.getPose().translation()[0], 2.f, 1e-7);
+}
+
+TEST(TsdfVolumeTest, IntegrateAndRaycastMatchTheOracleBitExactly) {
+    const int W = 160, H = 120, DIM = 64;
+    const Intr intr(131.25f, 131.25f, W / 2 - 0.5f, H / 2 - 0.5f);
+    cuda::TsdfVolume vol(Vec3i::all(DIM));
+    vol.setTruncDist(0.04f), vol.setMaxWeight(64), vol.setSize(Vec3f::all(3.f));
+    vol.setPose(Affine3f().translate(Vec3f(-1.5f, -1.5f, 0.5f)));  // kinfu.cpp:22
+    vol.setRaycastStepFactor(0.75f), vol.setGradientDeltaFactor(0.5f);
+
+    std::vector<unsigned short> depth = make_depth(W, H);
+    cuda::Depth d_depth;
+    d_depth.upload(depth, W);
+    cuda::Dists dists;
+    cuda::computeDists(d_depth, dists, intr);
+    const Affine3f camera;  // identity
+    vol.clear();
+    vol.integrate(dists, camera, intr);
+    vol.integrate(dists, camera, intr);
+
+    // oracle
+    std::vector<unsigned short> o_dists((size_t)W * H);
+    orc_compute_dists(depth.data(), W * 2, o_dists.data(), W * 2, W, H, intr.fx, intr.fy, intr.cx, intr.cy);
+    std::vector<unsigned short> h_dists;
+    int cols;
+    dists.download(h_dists, cols);
+    ASSERT_TRUE(h_dists == o_dists);
+    std::vector<uint32_t> o_vol((size_t)DIM * DIM * DIM, 0u), h_vol(o_vol.size());
+    const Vec3f vs = vol.getVoxelSize();
+    float vol2cam[12];
+    (camera.inv() * vol.getPose()).to12(vol2cam);
+    for (int rep = 0; rep < 2; ++rep)
+        orc_tsdf_integrate(o_dists.data(), W * 2, W, H, o_vol.data(), DIM, DIM, DIM, vs.v, vol.getTruncDist(), 64, vol2cam,
+                           intr.fx, intr.fy, intr.cx, intr.cy, 4);
+    vol.data().download(h_vol.data(), h_vol.size() * 4);
+    ASSERT_TRUE(h_vol == o_vol);
+
+    // fused clear + integrate == clear(); integrate()
+    cuda::TsdfVolume vol2(Vec3i::all(DIM));
+    vol2.setTruncDist(0.04f), vol2.setMaxWeight(64), vol2.setPose(vol.getPose());
+    vol2.clearAndIntegrate(dists, camera, intr);
+    vol.clear();
+    vol.integrate(dists, camera, intr);
+    std::vector<uint32_t> h2(h_vol.size());
+    vol2.data().download(h2.data(), h2.size() * 4);
+    vol.data().download(h_vol.data(), h_vol.size() * 4);
+    ASSERT_TRUE(h2 == h_vol);
+
+    // raycast (points) vs oracle, raw bits
+    cuda::Cloud points(H, W);
+    cuda::Normals normals(H, W);
+    vol.raycast(camera, intr, points, normals);
+    std::vector<Point> hp;
+    std::vector<Normal> hn;
+    points.download(hp, cols), normals.download(hn, cols);
+    float cam2vol[12], rinv[9];
+    Affine3f c2v = vol.getPose().inv() * camera;
+    c2v.to12(cam2vol), c2v.inverse_rotation(rinv);
+    std::vector<float> op((size_t)W * H * 4), on(op.size());
+    orc_tsdf_raycast_points(h_vol.data(), DIM, DIM, DIM, vs.v, vol.getTruncDist(), cam2vol, rinv, intr.fx, intr.fy, intr.cx,
+                            intr.cy, 0.75f, 0.5f, op.data(), W * 16, on.data(), W * 16, W, H, 4);
+    ASSERT_TRUE(std::memcmp(hp.data(), op.data(), op.size() * 4) == 0);
+    ASSERT_TRUE(std::memcmp(hn.data(), on.data(), on.size() * 4) == 0);
+    size_t hits = 0;
+    for (auto& p : hp) hits += p.x == p.x;
+    ASSERT_TRUE(hits > (size_t)W * H / 2);
+
+    // swap() hands the blob over (tsdf_volume.cpp:71)
+    cuda::CudaData other;
+    vol.swap(other);
+    ASSERT_TRUE(vol.data().empty() && other.sizeBytes() == (size_t)DIM * DIM * DIM * 4);
+}
+
+int main(int argc, char** argv) { return mt::run_all(argc, argv); }

@@ -1,0 +1,50 @@
+"""The C++ host adaptors (dynfu_amd/host: kfusion::cuda::TsdfVolume, DualQuaternion, Node, Warpfield,
+CombinedSolver with the reference's interfaces) driven by C++ test programs that mirror the
+reference's gtest files (tests/cpp/*.cpp)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exes():
+    from dynfu_amd import build as B
+    import oracle
+    oracle.build()
+    return B.build_cpp_tests()
+
+
+def _run(exe):
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_host_dual_quaternion_known_answers(exes):
+    out = _run(exes["test_host_dq"])
+    assert "23 tests, 0 failed" in out
+
+
+def test_host_library_exports_the_adaptor_classes(exes):
+    lib = os.path.join(ROOT, "dynfu_amd", "libdynfu_amd_host.so")
+    syms = subprocess.run(["nm", "-DC", lib], capture_output=True, text=True).stdout
+    for name in ("kfusion::cuda::TsdfVolume::integrate", "kfusion::cuda::TsdfVolume::raycast",
+                 "kfusion::cuda::TsdfVolume::clear", "kfusion::cuda::computeDists", "Warpfield::calcDQB",
+                 "Warpfield::warpToLive", "Warpfield::findNeighborsIndex", "CombinedSolver::initializeProblemInstance",
+                 "CombinedSolver::solveAll"):
+        assert name in syms, name
+
+
+@pytest.mark.gpu
+def test_host_combined_solver_runs_reference_opttests(exes):
+    out = _run(exes["test_host_solver"])
+    assert "8 tests, 0 failed" in out
+
+
+@pytest.mark.gpu
+def test_host_tsdf_volume_matches_oracle(exes):
+    out = _run(exes["test_host_tsdf"])
+    assert "2 tests, 0 failed" in out
