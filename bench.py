@@ -122,7 +122,9 @@ def cpu_baseline(cfg_name, frames):
     import oracle as O
     from dynfu_amd import synth
     cfg = synth.CONFIGS[cfg_name]
-    threads = os.cpu_count() or 1
+    # OpenMP over at most 16 threads: the restatement's parallel regions are short (one per PCG
+    # iteration), on a many-core host more threads only add fork/join cost
+    threads = min(os.cpu_count() or 1, int(os.environ.get("DFA_CPU_THREADS", "16")))
     fx, fy, cx, cy = synth.intrinsics(cfg)
     voxel, trunc, vol2cam, _, _ = synth.volume_params(cfg)
     dim, k = cfg["dim"], cfg["k"]
@@ -148,64 +150,54 @@ def cpu_baseline(cfg_name, frames):
         O.warp_to_live(c["node_pos"], dq, c["node_w"], k, c["verts"], c["normals"], threads=threads)
         pcg += st["pcg_iters"]
     dt = time.perf_counter() - t0
-    return dict(value=frames / dt, unit="frames/s", cores=threads, kind="port",
+    return dict(value=round(frames / dt, 4), unit="frames/s", cores=threads, kind="port",
                 sample="%d full frames of config %s (compute_dists, clear, integrate %d^3, k-NN graph, %d GN x PCG "
                        "(%d PCG iterations in total), write-back, warpToLive) by the C restatement in oracle/, "
-                       "OpenMP over %d threads, fp32; %.1f s" % (frames, cfg_name, dim, cfg["gn_iters"], pcg, threads,
-                                                                 dt))
+                       "OpenMP over %d of the host's %d cores, fp32; %.1f s" % (frames, cfg_name, dim, cfg["gn_iters"],
+                                                                                pcg, threads, os.cpu_count() or 1, dt))
 
 
 def main():
     args = parse()
     import torch
-    import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    from dynfu_amd import replicas
+    rank, local, world = replicas.env_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
-    n_gpus = max(args.gpus, world) if world > 1 else 1
+    replicas.init(backend="nccl", device=device)  # RCCL; only barriers + one MAX all-reduce use it
+    n_gpus = world
+    if args.gpus != world and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run for N > 1" % (args.gpus, world),
+              file=sys.stderr)
 
     seq = Sequence(args.config, device)
     cfg = seq.cfg
     K, Wm = args.steps, args.warmup
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for f in range(Wm):
         seq.frame(f, args.serial)
-    barrier()
     fuse_events = []
     seq.solver.enable_timing(True)
-    pcg_ms = asm_ms = 0.0
-    pcg_launches = pcg_iters = 0
-    t0 = time.perf_counter()
-    for f in range(K):
-        seq.frame(Wm + f, args.serial, fuse_events)
-    barrier()
-    dt = time.perf_counter() - t0
+
+    def timed():
+        for f in range(K):
+            seq.frame(Wm + f, args.serial, fuse_events)
+
+    # barrier + synchronize on both sides, MAX over ranks
+    dt_max = replicas.timed_region(timed, device)
     # per-kernel numbers of the LAST timed frame's solve + all timed fuse launches
     tm = seq.solver.timing()
     st = seq.solver.stats()
     seq.solver.enable_timing(False)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt_max = float(tmax.item())
 
     # ---- parity spot check of the last frame (outside the timed region)
     t_err = float((seq.solver.translations() - seq.t_true[(Wm + K - 1) % seq.n_frames]).abs().max())
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        replicas.shutdown()
         return
 
     # ---- roofline of the kernels measured live with HIP events on their launch streams
@@ -251,8 +243,7 @@ def main():
         torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_frames)
     print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    replicas.shutdown()
 
 
 if __name__ == "__main__":
