@@ -30,6 +30,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+# HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 for wide reads + WRITE_SIZE, corrected as
+# MI355X_MICROARCH.md prescribes) — profiles/r01_pmc_tsdf.md.  Collected offline: PMC needs its own runs.
+PMC_TRAFFIC_BYTES = {("C2", "fused_integrate"): 0.5439e9}
 
 
 def parse():
@@ -214,15 +217,19 @@ def main():
     pcg_gbs = pcg_bytes / (pcg_total_ms * 1e-3) / 1e9 if pcg_total_ms > 0 else float("nan")
     fuse_entry = dict(kernel="integrate_kernel<FUSED_CLEAR,4> (clear+integrate %d^3)" % dim, bound="hbm",
                       achieved=round(fuse_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(fuse_gbs / HBM_PEAK_GBS, 4),
-                      traffic=None, avg_launch_ms=round(fuse_ms, 4), launches_per_frame=1,
-                      algorithmic_bytes_per_launch=fuse_bytes)
+                      traffic=PMC_TRAFFIC_BYTES.get((args.config, "fused_integrate")),
+                      traffic_source="profiles/r01_pmc_tsdf.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                      avg_launch_ms=round(fuse_ms, 4), launches_per_frame=1, algorithmic_bytes_per_launch=fuse_bytes)
     pcg_entry = dict(kernel="pcg_kernel (single-workgroup block-Jacobi PCG)", bound="hbm",
                      achieved=round(pcg_gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(pcg_gbs / HBM_PEAK_GBS, 6),
                      traffic=None, avg_launch_ms=round(pcg_total_ms / max(1, tm["pcg_launches"]), 4),
                      launches_per_frame=tm["pcg_launches"], pcg_iterations_per_frame=its, matrix_nnz=nnz,
                      algorithmic_bytes_per_frame=pcg_bytes,
-                     note="cache-resident and latency-bound: one workgroup, %d barriers-separated iterations; "
-                          "HBM fraction shown for completeness" % its)
+                     lds_gather=dict(bytes_per_frame=16.0 * nnz * its, achieved_gbs=round(16.0 * nnz * its / (pcg_total_ms * 1e-3) / 1e9, 1) if pcg_total_ms > 0 else None,
+                                     peak_gbs=614.4, note="single-CU LDS peak 256 B/clk x 2.4 GHz"),
+                     note="register/LDS-resident and synchronisation-bound by design: ONE workgroup, %d "
+                          "barrier-separated iterations; its ceiling is the single-CU LDS gather rate, the HBM "
+                          "fraction is shown because the contract asks for it" % its)
     dominant, other = (pcg_entry, fuse_entry) if pcg_total_ms > fuse_ms else (fuse_entry, pcg_entry)
 
     out = dict(metric="frames/sec (warp-solve + TSDF fuse), 512^3 vol / 2k nodes / VGA depth",
