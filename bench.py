@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4", "T0", "T1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the bounded CPU sample")
+    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded CPU sample")
     ap.add_argument("--serial", action="store_true", help="run fuse and solve on one stream (A/B of the overlap)")
     return ap.parse_args()
 

@@ -278,6 +278,9 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
     A(ell_cnt, D);
     A(diag, D);
     A(g, D * 3);
+    A(pk_perm, D);
+    A(pk_vals, D * s->ell_cap);
+    A(pk_cols, D * s->ell_cap);
     A(t, D * 3);
     A(huber, D);
     A(node_dq_out, D * 8);

@@ -471,6 +471,18 @@ __device__ __forceinline__ double block_sum(float v, float* red) {
     return tot;
 }
 
+// DFA_PCG_PROFILE builds accumulate shader cycles per PCG phase (thread 0) into SolveState::prof
+#ifdef DFA_PCG_PROFILE
+#define PROF_MARK(i)                      \
+    do {                                  \
+        const long long now_ = clock64(); \
+        pc_[i] += now_ - last_;           \
+        last_ = now_;                     \
+    } while (0)
+#else
+#define PROF_MARK(i)
+#endif
+
 // float flavour (fewer registers; used by the register-resident kernel)
 template <int NWAVES>
 __device__ __forceinline__ float block_sum_f(float v, float* red) {
@@ -483,128 +495,131 @@ __device__ __forceinline__ float block_sum_f(float v, float* red) {
     return tot;
 }
 
-// S = matrix entries per row kept in registers for the whole solve (values as fp32, columns as
-// packed u16): the matrix is constant over the PCG iterations, so the only per-iteration
-// memory traffic left is the LDS gather of the direction vector.  Rows longer than S read the
-// excess from global memory (L2).  S = 0 streams the whole matrix from L2 every iteration.
-template <int NT, int RPT, int S, bool FALLBACK_ONLY = false>
+// Streaming PCG for systems too large for the register-resident kernel (D > 2048 or rows wider than
+// its slots): one persistent workgroup, RPT rows per thread, the matrix re-read from L2 every
+// iteration.  A single CU moves 64 B/clk through its vector memory path, so the bytes per iteration
+// are what matters: the prologue counting-sorts the rows by length (wave-uniform loop bounds with
+// almost no padding) and repacks the ELL image rank-major with 16-bit columns — 6 B per non-zero,
+// fully coalesced — into the plan's workspace.
+template <int NT, int RPT, bool FALLBACK_ONLY>
 __global__ __launch_bounds__(NT) void pcg_kernel(SolveView s, SolveState* __restrict__ st, int max_iter,
                                                    float pcg_tol) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* p_s = (float4*)smem;                                // D entries
+    float4* p_s = (float4*)smem;                                      // D entries
     float* red0 = (float*)(smem + sizeof(float4) * (size_t)s.Dpad);  // 2 x 16 wave partials
     float* red1 = red0 + 16;
+    int* hist   = (int*)(red1 + 16);                                  // 260 bins
     if (st->done) return;
     if (FALLBACK_ONLY && !st->pcg_fallback) return;  // the register-resident kernel handled it
     const int tid = threadIdx.x;
     const int D   = s.D;
 
-    float x[RPT][3], r[RPT][3], p[RPT][3], minv[RPT];
-    float mval[RPT][S > 0 ? S : 1];
-    uint32_t mcol[RPT][S > 0 ? (S + 1) / 2 : 1];
-    int rcnt[RPT];
-    int wmax = 0;  // longest row among this wave's rows (wave-uniform loop bound)
+    // ---- rows sorted by length (descending): rank -> row in s.pk_perm
+    for (int i = tid; i < 260; i += NT) hist[i] = 0;
+    __syncthreads();
+    int my_cnt[RPT];
+#pragma unroll
+    for (int h = 0; h < RPT; ++h) {
+        const int row = tid + NT * h;
+        my_cnt[h]     = row < D ? min(s.ell_cnt[row], 256) : -1;
+        if (my_cnt[h] >= 0) atomicAdd(&hist[256 - my_cnt[h]], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        int loc[5], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int b = tid * 5 + j;
+            loc[j]      = b < 257 ? hist[b] : 0;
+            sum += loc[j];
+        }
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (tid >= o) incl += t;
+        }
+        int off = incl - sum;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int b = tid * 5 + j;
+            if (b < 257) hist[b] = off;
+            off += loc[j];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < RPT; ++h)
+        if (my_cnt[h] >= 0) s.pk_perm[atomicAdd(&hist[256 - my_cnt[h]], 1)] = tid + NT * h;
+    __syncthreads();  // workgroup-scope visibility of pk_perm
+
+    // ---- my rows = ranks tid + NT*i; repack them rank-major (coalesced from now on)
+    int row[RPT], rcnt[RPT], wmax[RPT];
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-        const int row = tid + NT * i;
-        rcnt[i]       = row < D ? s.ell_cnt[row] : 0;
-        if (S > 0) {
-#pragma unroll
-            for (int q = 0; q < S; ++q) {
-                const int rowc = row < D ? row : 0;
-                float v        = s.ell_vals[(size_t)q * D + rowc];
-                int col        = s.ell_cols[(size_t)q * D + rowc];
-                if (!(q < rcnt[i])) v = 0.f, col = 0;
-                mval[i][q] = v;
-                if (q & 1) mcol[i][q >> 1] |= (uint32_t)col << 16;
-                else mcol[i][q >> 1] = (uint32_t)col;
-            }
+        const int rank = tid + NT * i;
+        row[i]         = rank < D ? s.pk_perm[rank] : -1;
+        rcnt[i]        = row[i] >= 0 ? min(s.ell_cnt[row[i]], 256) : 0;
+        for (int q = 0; q < rcnt[i]; ++q) {
+            s.pk_vals[(size_t)q * D + rank] = s.ell_vals[(size_t)q * D + row[i]];
+            s.pk_cols[(size_t)q * D + rank] = (uint16_t)s.ell_cols[(size_t)q * D + row[i]];
         }
-        wmax = max(wmax, rcnt[i]);
-    }
+        int m = rcnt[i];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
+        for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+        wmax[i] = m;  // wave-uniform
+    }
+    __syncthreads();
+
+    float x[RPT][3], r[RPT][3], p[RPT][3], minv[RPT];
     float rz_loc = 0.f;
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-        const int row = tid + NT * i;
-        if (row < D) {
-            const float d = s.diag[row];
+        if (row[i] >= 0) {
+            const float d = s.diag[row[i]];
             minv[i]       = d > FLT_EPSILON ? 1.0f / d : 1.0f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 x[i][c] = 0.f;
-                r[i][c] = s.g[3 * row + c];
+                r[i][c] = s.g[3 * row[i] + c];
                 p[i][c] = minv[i] * r[i][c];
-                rz_loc = fmaf(r[i][c], p[i][c], rz_loc);
+                rz_loc  = fmaf(r[i][c], p[i][c], rz_loc);
             }
-            p_s[row] = make_float4(p[i][0], p[i][1], p[i][2], 0.f);
+            p_s[row[i]] = make_float4(p[i][0], p[i][1], p[i][2], 0.f);
         } else {
             minv[i] = 0.f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) x[i][c] = r[i][c] = p[i][c] = 0.f;
         }
     }
-    double rz        = block_sum<NT / 64>(rz_loc, red1);  // the barrier inside also publishes p_s
-    const double rz0 = rz;
+    double rz           = block_sum<NT / 64>(rz_loc, red1);  // the barrier inside also publishes p_s
+    const double rz0    = rz;
     const double floor_ = 1e-12;  // squared-residual-ratio floor of float arithmetic
     const double tol2   = (double)pcg_tol * (double)pcg_tol > floor_ ? (double)pcg_tol * (double)pcg_tol : floor_;
     int it              = 0;
     const bool skip     = st->grad_first > 0.0 && rz0 <= floor_ * st->grad_first;
-#ifdef DFA_PCG_PROFILE
-    long long pc_[6] = {0, 0, 0, 0, 0, 0};
-#define PROF_MARK(i)                      \
-    do {                                  \
-        const long long now_ = clock64(); \
-        pc_[i] += now_ - last_;           \
-        last_ = now_;                     \
-    } while (0)
-    long long last_ = clock64();
-#else
-#define PROF_MARK(i)
-#endif
     if (!skip) {
         while (it < max_iter) {
             if (!(rz > 0.0)) break;
-            PROF_MARK(5);
-            // Ap for own rows
             float ap[RPT][3];
             float pap_loc = 0.f;
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
-                const int row = tid + NT * i;
+                const int rank  = tid + NT * i;
+                const int rankc = rank < D ? rank : 0;
                 float ax = 0.f, ay = 0.f, az = 0.f;
-                if (S > 0) {
-                    // chunks of 8 gathers; the scheduling barrier keeps the compiler from hoisting
-                    // all S ds_read_b128 (4 VGPRs each) ahead of the FMAs
-#pragma unroll
-                    for (int q0 = 0; q0 < S; q0 += 8) {
-                        if (q0 < wmax) {  // wave-uniform; padded entries have value 0 and column 0
-#pragma unroll
-                            for (int q = q0; q < q0 + 8 && q < S; ++q) {
-                                const uint32_t cw = mcol[i][q >> 1];
-                                const int col     = (q & 1) ? (int)(cw >> 16) : (int)(cw & 0xffffu);
-                                const float4 pc   = p_s[col];
-                                const float v     = mval[i][q];
-                                ax = fmaf(v, pc.x, ax), ay = fmaf(v, pc.y, ay), az = fmaf(v, pc.z, az);
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                // entries beyond the register slots stream from L2, 8 (coalesced, slot-major) loads
-                // in flight per lane; wmax is wave-uniform so the loop has no divergence
-                for (int q0 = S; q0 < wmax; q0 += 8) {
+                // 8 (coalesced, rank-major) loads in flight per lane; wmax is wave-uniform.  Loads are
+                // unconditional (slots up to the ELL capacity are valid memory) and masked AFTER the
+                // load: a load under a per-element condition makes hipcc branch around it and wait
+                // vmcnt(0) each time — 16 serial L2 round trips per chunk.
+                for (int q0 = 0; q0 < wmax[i]; q0 += 8) {
                     int colv[8];
                     float valv[8];
-                    // unconditional loads (slots up to the ELL capacity are valid memory), masked
-                    // AFTER the load: a load under a per-element condition makes hipcc branch around
-                    // it and wait vmcnt(0) each time — 16 serial L2 round trips per chunk
-                    const int rowc = row < D ? row : 0;
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        colv[u] = s.ell_cols[(size_t)(q0 + u) * D + rowc];
-                        valv[u] = s.ell_vals[(size_t)(q0 + u) * D + rowc];
+                        const int q = min(q0 + u, 255);
+                        colv[u]     = s.pk_cols[(size_t)q * D + rankc];
+                        valv[u]     = s.pk_vals[(size_t)q * D + rankc];
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
@@ -621,9 +636,7 @@ __global__ __launch_bounds__(NT) void pcg_kernel(SolveView s, SolveState* __rest
                 ap[i][0] = ax, ap[i][1] = ay, ap[i][2] = az;
                 pap_loc = fmaf(p[i][0], ax, fmaf(p[i][1], ay, fmaf(p[i][2], az, pap_loc)));
             }
-            PROF_MARK(0);
             const double pAp = block_sum<NT / 64>(pap_loc, red0);
-            PROF_MARK(1);
             if (!(pAp > 0.0)) break;
             const float alpha = (float)(rz / pAp);
             float rzn_loc     = 0.f;
@@ -636,36 +649,27 @@ __global__ __launch_bounds__(NT) void pcg_kernel(SolveView s, SolveState* __rest
                     rzn_loc = fmaf(r[i][c], minv[i] * r[i][c], rzn_loc);
                 }
             }
-            PROF_MARK(2);
             const double rz_new = block_sum<NT / 64>(rzn_loc, red1);
-            PROF_MARK(3);
             ++it;
             if (rz_new <= tol2 * rz0) break;
             const float beta = (float)(rz_new / rz);
             // every thread has read p_s for this iteration (two barriers passed since the SpMV)
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
-                const int row = tid + NT * i;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) p[i][c] = fmaf(beta, p[i][c], minv[i] * r[i][c]);
-                if (row < D) p_s[row] = make_float4(p[i][0], p[i][1], p[i][2], 0.f);
+                if (row[i] >= 0) p_s[row[i]] = make_float4(p[i][0], p[i][1], p[i][2], 0.f);
             }
             rz = rz_new;
             __syncthreads();
-            PROF_MARK(4);
         }
     }
-#ifdef DFA_PCG_PROFILE
-    if (tid == 0)
-        for (int i = 0; i < 6; ++i) st->prof[i] += pc_[i];
-#endif
     // t += delta
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-        const int row = tid + NT * i;
-        if (row < D) {
+        if (row[i] >= 0) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) s.t[3 * row + c] += x[i][c];
+            for (int c = 0; c < 3; ++c) s.t[3 * row[i] + c] += x[i][c];
         }
     }
     if (tid == 0) {
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(NT) void pcg_kernel(SolveView s, SolveState* __rest
 // SHORTEST row ("B", slots E-1.. downwards): lengths vary slowly along a wave, nA + nB is about
 // the true row-pair length, and both loop bounds are wave-uniform (no divergence, no selects).
 // Entries of B that do not fit (rare) are streamed from L2 each iteration.
-template <int NT, int E>
+template <int NT, int P, int E>
 __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState* __restrict__ st, int max_iter,
                                                         float pcg_tol) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -703,13 +707,14 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
     int* perm       = hist + 260;         // D row ids, longest row first
     if (st->done) return;
     const int tid = threadIdx.x;
+    constexpr int R = 2 * P;  // rows per thread
 
     // ---- rows sorted by length (descending), counting sort in LDS
     for (int i = tid; i < 260; i += NT) hist[i] = 0;
     __syncthreads();
-    int my_cnt[2];
+    int my_cnt[R];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < R; ++h) {
         const int row = tid + NT * h;
         my_cnt[h]     = row < D ? min(s.ell_cnt[row], 256) : -1;
         if (my_cnt[h] >= 0) atomicAdd(&hist[256 - my_cnt[h]], 1);  // bin 0 = longest
@@ -739,81 +744,86 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
     }
     __syncthreads();
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < R; ++h)
         if (my_cnt[h] >= 0) perm[atomicAdd(&hist[256 - my_cnt[h]], 1)] = tid + NT * h;
     __syncthreads();
 
-    // ---- this thread's pair: rank t (long, "A") and rank D-1-t (short, "B")
-    const int ia = tid, ib = D - 1 - tid;
-    const int rowA = (ia < D && ia <= ib) ? perm[ia] : -1;
-    const int rowB = (ib >= 0 && ib > ia) ? perm[ib] : -1;
-    const int cntA = rowA >= 0 ? min(s.ell_cnt[rowA], 256) : 0;
-    const int cntB = rowB >= 0 ? min(s.ell_cnt[rowB], 256) : 0;
-    int nA = min(cntA, E), nAfull = cntA, nBfull = cntB;
+    // ---- this thread's pairs: pair j = rank j*NT + t (long, "A") and rank D-1-j*NT-t (short, "B")
+    int rowA[P], rowB[P], nA[P], nB[P];
+    float mval[P][E];
+    uint32_t mcol[P][E / 2];
+    bool unfit_any = false;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        nA     = max(nA, __shfl_xor(nA, o, 64));
-        nAfull = max(nAfull, __shfl_xor(nAfull, o, 64));
-        nBfull = max(nBfull, __shfl_xor(nBfull, o, 64));
+    for (int j = 0; j < P; ++j) {
+        const int ia = j * NT + tid, ib = D - 1 - j * NT - tid;
+        rowA[j]      = (ia < D && ia <= ib) ? perm[ia] : -1;
+        rowB[j]      = (ib >= 0 && ib > ia) ? perm[ib] : -1;
+        const int cntA = rowA[j] >= 0 ? min(s.ell_cnt[rowA[j]], 256) : 0;
+        const int cntB = rowB[j] >= 0 ? min(s.ell_cnt[rowB[j]], 256) : 0;
+        int na         = min(cntA, E);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) na = max(na, __shfl_xor(na, o, 64));
+        na             = (na + 1) & ~1;  // even: a packed column word never mixes A and B slots
+        const int capB = E - na;         // wave-uniform
+        const int regB = min(cntB, capB);
+        int nb         = regB;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nb = max(nb, __shfl_xor(nb, o, 64));
+        nA[j] = na, nB[j] = min((nb + 1) & ~1, capB);
+        unfit_any |= cntA > E || cntB > capB;
+        const int rA = rowA[j] >= 0 ? rowA[j] : 0, rB = rowB[j] >= 0 ? rowB[j] : 0;
+        // values and columns -> registers for the whole solve (slot q: entry q of A for q < nA, entry
+        // E-1-q of B otherwise); two 16-bit columns per register
+#pragma unroll
+        for (int q2 = 0; q2 < E / 2; ++q2) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int q     = 2 * q2 + h;
+                const bool isA  = q < na;
+                const int ent   = isA ? q : E - 1 - q;
+                const int r     = isA ? rA : rB;
+                const bool live = isA ? (q < cntA) : (E - 1 - q < regB);
+                float v         = s.ell_vals[(size_t)ent * D + r];  // unconditional load, masked after
+                int col         = s.ell_cols[(size_t)ent * D + r];
+                if (!live) v = 0.f, col = 0;
+                mval[j][q] = v;
+                packed |= (uint32_t)col << (16 * h);
+            }
+            mcol[j][q2] = packed;
+            if ((q2 & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the loads in flight
+        }
     }
-    nA             = (nA + 1) & ~1;  // even: a packed column word never mixes A and B slots
-    const int capB = E - nA;         // wave-uniform
-    const int regB = min(cntB, capB);
-    int nB         = regB;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nB = max(nB, __shfl_xor(nB, o, 64));
-    nB = min((nB + 1) & ~1, capB);
-    const int rA = rowA >= 0 ? rowA : 0, rB = rowB >= 0 ? rowB : 0;
     // a pair that does not fit E slots: leave the system to the streaming kernel launched next
-    const int unfit = __syncthreads_or(cntA > E || cntB > capB);
+    const int unfit = __syncthreads_or(unfit_any);
     if (tid == 0) st->pcg_fallback = unfit;
     if (unfit) return;
 
-    // values and columns -> registers for the whole solve (slot q: entry q of A for q < nA,
-    // entry E-1-q of B otherwise); two 16-bit columns per register
-    float mval[E];
-    uint32_t mcol[E / 2];
+    float xA[P][3], rA_[P][3], pA[P][3], xB[P][3], rB_[P][3], pB[P][3], minvA[P], minvB[P];
+    float rz_loc = 0.f;
 #pragma unroll
-    for (int q2 = 0; q2 < E / 2; ++q2) {
-        uint32_t packed = 0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int q     = 2 * q2 + h;
-            const bool isA  = q < nA;
-            const int ent   = isA ? q : E - 1 - q;
-            const int r     = isA ? rA : rB;
-            const bool live = isA ? (q < cntA) : (E - 1 - q < regB);
-            float v         = s.ell_vals[(size_t)ent * D + r];  // unconditional load, masked after
-            int col         = s.ell_cols[(size_t)ent * D + r];
-            if (!live) v = 0.f, col = 0;
-            mval[q] = v;
-            packed |= (uint32_t)col << (16 * h);
+    for (int j = 0; j < P; ++j) {
+        minvA[j] = minvB[j] = 0.f;
+        if (rowA[j] >= 0) {
+            const float d = s.diag[rowA[j]];
+            minvA[j]      = d > FLT_EPSILON ? 1.0f / d : 1.0f;
         }
-        mcol[q2] = packed;
-        if ((q2 & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the loads in flight
-    }
-
-    float xA[3], rA_[3], pA[3], xB[3], rB_[3], pB[3];
-    float minvA = 0.f, minvB = 0.f, rz_loc = 0.f;
-    if (rowA >= 0) {
-        const float d = s.diag[rowA];
-        minvA         = d > FLT_EPSILON ? 1.0f / d : 1.0f;
-    }
-    if (rowB >= 0) {
-        const float d = s.diag[rowB];
-        minvB         = d > FLT_EPSILON ? 1.0f / d : 1.0f;
-    }
+        if (rowB[j] >= 0) {
+            const float d = s.diag[rowB[j]];
+            minvB[j]      = d > FLT_EPSILON ? 1.0f / d : 1.0f;
+        }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        xA[c] = xB[c] = 0.f;
-        rA_[c] = rowA >= 0 ? s.g[3 * rowA + c] : 0.f;
-        rB_[c] = rowB >= 0 ? s.g[3 * rowB + c] : 0.f;
-        pA[c]  = minvA * rA_[c];
-        pB[c]  = minvB * rB_[c];
-        rz_loc = fmaf(rA_[c], pA[c], fmaf(rB_[c], pB[c], rz_loc));
+        for (int c = 0; c < 3; ++c) {
+            xA[j][c] = xB[j][c] = 0.f;
+            rA_[j][c] = rowA[j] >= 0 ? s.g[3 * rowA[j] + c] : 0.f;
+            rB_[j][c] = rowB[j] >= 0 ? s.g[3 * rowB[j] + c] : 0.f;
+            pA[j][c]  = minvA[j] * rA_[j][c];
+            pB[j][c]  = minvB[j] * rB_[j][c];
+            rz_loc    = fmaf(rA_[j][c], pA[j][c], fmaf(rB_[j][c], pB[j][c], rz_loc));
+        }
+        if (rowA[j] >= 0) p_s[rowA[j]] = make_float4(pA[j][0], pA[j][1], pA[j][2], 0.f);
+        if (rowB[j] >= 0) p_s[rowB[j]] = make_float4(pB[j][0], pB[j][1], pB[j][2], 0.f);
     }
-    if (rowA >= 0) p_s[rowA] = make_float4(pA[0], pA[1], pA[2], 0.f);
-    if (rowB >= 0) p_s[rowB] = make_float4(pB[0], pB[1], pB[2], 0.f);
     float rz           = block_sum_f<NT / 64>(rz_loc, red1);
     const float rz0    = rz;
     const float floor_ = 1e-12f;
@@ -829,42 +839,56 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
         while (it < max_iter) {
             if (!(rz > 0.f)) break;
             PROF_MARK(5);
-            float aA[3] = {0.f, 0.f, 0.f}, aB[3] = {0.f, 0.f, 0.f};
-            // 4 slots per step: 4 independent gathers in flight, then their FMAs.  The empty asm makes
-            // the packed column words opaque per iteration, otherwise the compiler hoists the
-            // unpacking out of the PCG loop and doubles the registers the columns occupy.
-#pragma unroll
-            for (int q0 = 0; q0 < E; q0 += 4) {
-                const bool in01 = q0 < nA || q0 >= E - nB, in23 = q0 + 2 < nA || q0 + 2 >= E - nB;  // wave-uniform
-                if (in01 || in23) {
-                    uint32_t c01 = mcol[q0 / 2], c23 = mcol[q0 / 2 + 1];
-                    asm volatile("" : "+v"(c01), "+v"(c23));
-                    const float4 g0 = *(const float4*)(pbase + ((c01 & 0xffffu) << 4));
-                    const float4 g1 = *(const float4*)(pbase + ((c01 >> 16) << 4));
-                    const float4 g2 = *(const float4*)(pbase + ((c23 & 0xffffu) << 4));
-                    const float4 g3 = *(const float4*)(pbase + ((c23 >> 16) << 4));
-                    asm volatile("" ::"v"(g0.w), "v"(g1.w), "v"(g2.w), "v"(g3.w));  // keep ds_read_b128
-                    const float v0 = mval[q0], v1 = mval[q0 + 1], v2 = mval[q0 + 2], v3 = mval[q0 + 3];
-                    if (q0 < nA) {  // slots outside both ranges hold value 0
-                        aA[0] = fmaf(v0, g0.x, aA[0]), aA[1] = fmaf(v0, g0.y, aA[1]), aA[2] = fmaf(v0, g0.z, aA[2]);
-                        aA[0] = fmaf(v1, g1.x, aA[0]), aA[1] = fmaf(v1, g1.y, aA[1]), aA[2] = fmaf(v1, g1.z, aA[2]);
-                    } else {
-                        aB[0] = fmaf(v0, g0.x, aB[0]), aB[1] = fmaf(v0, g0.y, aB[1]), aB[2] = fmaf(v0, g0.z, aB[2]);
-                        aB[0] = fmaf(v1, g1.x, aB[0]), aB[1] = fmaf(v1, g1.y, aB[1]), aB[2] = fmaf(v1, g1.z, aB[2]);
-                    }
-                    if (q0 + 2 < nA) {
-                        aA[0] = fmaf(v2, g2.x, aA[0]), aA[1] = fmaf(v2, g2.y, aA[1]), aA[2] = fmaf(v2, g2.z, aA[2]);
-                        aA[0] = fmaf(v3, g3.x, aA[0]), aA[1] = fmaf(v3, g3.y, aA[1]), aA[2] = fmaf(v3, g3.z, aA[2]);
-                    } else {
-                        aB[0] = fmaf(v2, g2.x, aB[0]), aB[1] = fmaf(v2, g2.y, aB[1]), aB[2] = fmaf(v2, g2.z, aB[2]);
-                        aB[0] = fmaf(v3, g3.x, aB[0]), aB[1] = fmaf(v3, g3.y, aB[1]), aB[2] = fmaf(v3, g3.z, aB[2]);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            float aA[P][3], aB[P][3];
             float pap_loc = 0.f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) pap_loc = fmaf(pA[c], aA[c], fmaf(pB[c], aB[c], pap_loc));
+            for (int j = 0; j < P; ++j) {
+                aA[j][0] = aA[j][1] = aA[j][2] = aB[j][0] = aB[j][1] = aB[j][2] = 0.f;
+                // 4 slots per step: 4 independent gathers in flight, then their FMAs.  The empty asm
+                // makes the packed column words opaque per iteration, otherwise the compiler hoists the
+                // unpacking out of the PCG loop and doubles the registers the columns occupy.
+#pragma unroll
+                for (int q0 = 0; q0 < E; q0 += 4) {
+                    const bool in01 = q0 < nA[j] || q0 >= E - nB[j];          // wave-uniform
+                    const bool in23 = q0 + 2 < nA[j] || q0 + 2 >= E - nB[j];  // wave-uniform
+                    if (in01 || in23) {
+                        uint32_t c01 = mcol[j][q0 / 2], c23 = mcol[j][q0 / 2 + 1];
+                        asm volatile("" : "+v"(c01), "+v"(c23));
+                        const float4 g0 = *(const float4*)(pbase + ((c01 & 0xffffu) << 4));
+                        const float4 g1 = *(const float4*)(pbase + ((c01 >> 16) << 4));
+                        const float4 g2 = *(const float4*)(pbase + ((c23 & 0xffffu) << 4));
+                        const float4 g3 = *(const float4*)(pbase + ((c23 >> 16) << 4));
+                        asm volatile("" ::"v"(g0.w), "v"(g1.w), "v"(g2.w), "v"(g3.w));  // keep ds_read_b128
+                        const float v0 = mval[j][q0], v1 = mval[j][q0 + 1], v2 = mval[j][q0 + 2],
+                                    v3 = mval[j][q0 + 3];
+                        if (q0 < nA[j]) {  // slots outside both ranges hold value 0
+                            aA[j][0] = fmaf(v0, g0.x, aA[j][0]), aA[j][1] = fmaf(v0, g0.y, aA[j][1]);
+                            aA[j][2] = fmaf(v0, g0.z, aA[j][2]);
+                            aA[j][0] = fmaf(v1, g1.x, aA[j][0]), aA[j][1] = fmaf(v1, g1.y, aA[j][1]);
+                            aA[j][2] = fmaf(v1, g1.z, aA[j][2]);
+                        } else {
+                            aB[j][0] = fmaf(v0, g0.x, aB[j][0]), aB[j][1] = fmaf(v0, g0.y, aB[j][1]);
+                            aB[j][2] = fmaf(v0, g0.z, aB[j][2]);
+                            aB[j][0] = fmaf(v1, g1.x, aB[j][0]), aB[j][1] = fmaf(v1, g1.y, aB[j][1]);
+                            aB[j][2] = fmaf(v1, g1.z, aB[j][2]);
+                        }
+                        if (q0 + 2 < nA[j]) {
+                            aA[j][0] = fmaf(v2, g2.x, aA[j][0]), aA[j][1] = fmaf(v2, g2.y, aA[j][1]);
+                            aA[j][2] = fmaf(v2, g2.z, aA[j][2]);
+                            aA[j][0] = fmaf(v3, g3.x, aA[j][0]), aA[j][1] = fmaf(v3, g3.y, aA[j][1]);
+                            aA[j][2] = fmaf(v3, g3.z, aA[j][2]);
+                        } else {
+                            aB[j][0] = fmaf(v2, g2.x, aB[j][0]), aB[j][1] = fmaf(v2, g2.y, aB[j][1]);
+                            aB[j][2] = fmaf(v2, g2.z, aB[j][2]);
+                            aB[j][0] = fmaf(v3, g3.x, aB[j][0]), aB[j][1] = fmaf(v3, g3.y, aB[j][1]);
+                            aB[j][2] = fmaf(v3, g3.z, aB[j][2]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) pap_loc = fmaf(pA[j][c], aA[j][c], fmaf(pB[j][c], aB[j][c], pap_loc));
+            }
             PROF_MARK(0);
             const float pAp = block_sum_f<NT / 64>(pap_loc, red0);
             PROF_MARK(1);
@@ -872,13 +896,15 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
             const float alpha = rz / pAp;
             float rzn_loc     = 0.f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                xA[c]   = fmaf(alpha, pA[c], xA[c]);
-                xB[c]   = fmaf(alpha, pB[c], xB[c]);
-                rA_[c]  = fmaf(-alpha, aA[c], rA_[c]);
-                rB_[c]  = fmaf(-alpha, aB[c], rB_[c]);
-                rzn_loc = fmaf(rA_[c], minvA * rA_[c], fmaf(rB_[c], minvB * rB_[c], rzn_loc));
-            }
+            for (int j = 0; j < P; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    xA[j][c]  = fmaf(alpha, pA[j][c], xA[j][c]);
+                    xB[j][c]  = fmaf(alpha, pB[j][c], xB[j][c]);
+                    rA_[j][c] = fmaf(-alpha, aA[j][c], rA_[j][c]);
+                    rB_[j][c] = fmaf(-alpha, aB[j][c], rB_[j][c]);
+                    rzn_loc = fmaf(rA_[j][c], minvA[j] * rA_[j][c], fmaf(rB_[j][c], minvB[j] * rB_[j][c], rzn_loc));
+                }
             PROF_MARK(2);
             const float rz_new = block_sum_f<NT / 64>(rzn_loc, red1);
             PROF_MARK(3);
@@ -886,12 +912,15 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
             if (rz_new <= tol2 * rz0) break;
             const float beta = rz_new / rz;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                pA[c] = fmaf(beta, pA[c], minvA * rA_[c]);
-                pB[c] = fmaf(beta, pB[c], minvB * rB_[c]);
+            for (int j = 0; j < P; ++j) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    pA[j][c] = fmaf(beta, pA[j][c], minvA[j] * rA_[j][c]);
+                    pB[j][c] = fmaf(beta, pB[j][c], minvB[j] * rB_[j][c]);
+                }
+                if (rowA[j] >= 0) p_s[rowA[j]] = make_float4(pA[j][0], pA[j][1], pA[j][2], 0.f);
+                if (rowB[j] >= 0) p_s[rowB[j]] = make_float4(pB[j][0], pB[j][1], pB[j][2], 0.f);
             }
-            if (rowA >= 0) p_s[rowA] = make_float4(pA[0], pA[1], pA[2], 0.f);
-            if (rowB >= 0) p_s[rowB] = make_float4(pB[0], pB[1], pB[2], 0.f);
             rz = rz_new;
             __syncthreads();
             PROF_MARK(4);
@@ -902,10 +931,12 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
         for (int i = 0; i < 6; ++i) st->prof[i] += pc_[i];
 #endif
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        if (rowA >= 0) s.t[3 * rowA + c] += xA[c];
-        if (rowB >= 0) s.t[3 * rowB + c] += xB[c];
-    }
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (rowA[j] >= 0) s.t[3 * rowA[j] + c] += xA[j][c];
+            if (rowB[j] >= 0) s.t[3 * rowB[j] + c] += xB[j][c];
+        }
     if (tid == 0) {
         if (st->grad_first == 0.0) st->grad_first = (double)rz0;
         st->pcg_iters += it;
@@ -975,59 +1006,61 @@ hipError_t solve_assemble(const SolveView& s, SolveState* state, hipStream_t st)
 
 int solve_pcg_max_nodes() { return 1024 * 8; }
 
-hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, hipStream_t st) {
-    const size_t shmem = sizeof(float4) * (size_t)s.Dpad + 32 * sizeof(float);
-#define PCG_LAUNCH(NT, R, SS)                                                                                      \
-    do {                                                                                                           \
-        static bool attr_set = false;                                                                              \
-        if (!attr_set) {                                                                                           \
-            hipError_t e = hipFuncSetAttribute((const void*)pcg_kernel<NT, R, SS>,                                 \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);    \
-            if (e != hipSuccess) return e;                                                                         \
-            attr_set = true;                                                                                       \
-        }                                                                                                          \
-        pcg_kernel<NT, R, SS><<<1, NT, shmem, st>>>(s, state, max_iter, pcg_tol);                                  \
-    } while (0)
-    // Geometry: the fewer waves, the more registers per lane for matrix rows (512 VGPRs / waves
-    // per SIMD) and the cheaper the barriers; the LDS gather rate is reached from 4 waves per CU.
-    static const int variant = getenv("DFA_PCG_VARIANT") ? atoi(getenv("DFA_PCG_VARIANT")) : -1;
-    const int D = s.D;
-    if (variant < 0 && D <= 2048) {
-        constexpr int NT = 1024, E = 32;
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)pcg_paired_kernel<NT, E>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
-        const size_t sh = sizeof(float4) * (size_t)s.Dpad + 32 * sizeof(float) + sizeof(int) * (260 + (size_t)s.Dpad);
-        pcg_paired_kernel<NT, E><<<1, NT, sh, st>>>(s, state, max_iter, pcg_tol);
-        // rows too long for the register slots (sets state->pcg_fallback): streaming kernel, which
-        // returns at once otherwise
-        static bool attr2 = false;
-        if (!attr2) {
-            hipError_t e = hipFuncSetAttribute((const void*)pcg_kernel<1024, 2, 0, true>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-            if (e != hipSuccess) return e;
-            attr2 = true;
-        }
-        pcg_kernel<1024, 2, 0, true><<<1, 1024, shmem, st>>>(s, state, max_iter, pcg_tol);
-        return hipGetLastError();
-    }
-    if (D <= 512) PCG_LAUNCH(512, 1, 32);
-    else if (D <= 1024) PCG_LAUNCH(1024, 1, 32);
-    else if (D <= 2048) {
-        if (variant == 0) PCG_LAUNCH(1024, 2, 0);
-        else if (variant == 2) PCG_LAUNCH(512, 4, 16);
-        else if (variant == 3) PCG_LAUNCH(1024, 2, 8);
-        else if (variant == 4) PCG_LAUNCH(512, 4, 8);
-        else PCG_LAUNCH(1024, 2, 0);
-    } else if (D <= 4096) PCG_LAUNCH(1024, 4, 0);
-    else if (D <= 8192) PCG_LAUNCH(1024, 8, 0);
-    else return hipErrorInvalidValue;
-#undef PCG_LAUNCH
+template <class Kernel>
+static hipError_t allow_big_lds(Kernel* k, bool& done) {
+    if (done) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    done         = e == hipSuccess;
+    return e;
+}
+
+// streaming kernel (matrix re-read from L2 every iteration): 1024 threads, RPT rows per thread
+template <int RPT, bool FALLBACK_ONLY>
+static hipError_t launch_streaming_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol,
+                                       hipStream_t st) {
+    static bool attr = false;
+    hipError_t e     = allow_big_lds(pcg_kernel<1024, RPT, FALLBACK_ONLY>, attr);
+    if (e != hipSuccess) return e;
+    const size_t shmem = sizeof(float4) * (size_t)s.Dpad + 32 * sizeof(float) + 260 * sizeof(int);
+    pcg_kernel<1024, RPT, FALLBACK_ONLY><<<1, 1024, shmem, st>>>(s, state, max_iter, pcg_tol);
     return hipGetLastError();
+}
+
+// register-resident kernel: NT threads own 2*P*NT rows, P pairs of E matrix slots per thread
+template <int NT, int P, int E>
+static hipError_t launch_paired_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol,
+                                    hipStream_t st) {
+    static bool attr = false;
+    hipError_t e     = allow_big_lds(pcg_paired_kernel<NT, P, E>, attr);
+    if (e != hipSuccess) return e;
+    const size_t sh = sizeof(float4) * (size_t)s.Dpad + 32 * sizeof(float) + sizeof(int) * (260 + (size_t)s.Dpad);
+    pcg_paired_kernel<NT, P, E><<<1, NT, sh, st>>>(s, state, max_iter, pcg_tol);
+    return hipGetLastError();
+}
+
+hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, hipStream_t st) {
+    // DFA_PCG_VARIANT=0 forces the streaming kernel (A/B baseline)
+    static const bool force_streaming = getenv("DFA_PCG_VARIANT") && atoi(getenv("DFA_PCG_VARIANT")) == 0;
+    const int D = s.D;
+    hipError_t e;
+    if (D <= 2048 && !force_streaming) {
+        // Register-resident matrix.  512 threads leave 256 VGPRs per lane (64 slots per row pair: k = 8
+        // rows fit), 1024 threads 128 VGPRs (32 slots: k = 4).  A pair that does not fit sets
+        // state->pcg_fallback and the streaming kernel launched right behind takes over; otherwise that
+        // launch returns at once.
+        static const int v2 = getenv("DFA_PCG_VARIANT") ? atoi(getenv("DFA_PCG_VARIANT")) : -1;
+        if (D <= 1024) e = launch_paired_pcg<512, 1, 64>(s, state, max_iter, pcg_tol, st);
+        else if (v2 == 2) e = launch_paired_pcg<512, 2, 32>(s, state, max_iter, pcg_tol, st);
+        else e = launch_paired_pcg<1024, 1, 32>(s, state, max_iter, pcg_tol, st);
+        if (e != hipSuccess) return e;
+        if (D <= 1024) return launch_streaming_pcg<1, true>(s, state, max_iter, pcg_tol, st);
+        return launch_streaming_pcg<2, true>(s, state, max_iter, pcg_tol, st);
+    }
+    if (D <= 1024) return launch_streaming_pcg<1, false>(s, state, max_iter, pcg_tol, st);
+    if (D <= 2048) return launch_streaming_pcg<2, false>(s, state, max_iter, pcg_tol, st);
+    if (D <= 4096) return launch_streaming_pcg<4, false>(s, state, max_iter, pcg_tol, st);
+    if (D <= 8192) return launch_streaming_pcg<8, false>(s, state, max_iter, pcg_tol, st);
+    return hipErrorInvalidValue;
 }
 
 hipError_t solve_writeback(const SolveView& s, hipStream_t st) {

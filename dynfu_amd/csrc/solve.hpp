@@ -47,6 +47,10 @@ struct SolveView {
     int32_t* ell_cnt;  // D
     float* diag;       // D
     float* g;          // D x 3   -J^T r
+    // workspace of the streaming PCG: rows sorted by length, rank-major repacked matrix
+    int32_t* pk_perm;   // D
+    float* pk_vals;     // ell_cap x D
+    uint16_t* pk_cols;  // ell_cap x D
     // unknown and outputs
     float* t;            // D x 3
     float* huber;        // D

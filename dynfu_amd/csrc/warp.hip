@@ -222,6 +222,87 @@ __device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32
     }
 }
 
+// ---- wave-cooperative grid search: ONE WAVE PER QUERY -----------------------------------------
+// For a few thousand queries (the node -> node regularisation graph) one lane per query leaves
+// most of the chip idle and every lane walks ~100 cells serially.  Here the 64 lanes of a wave
+// split the cells of each shell, keep private sorted lists, stop when at least K candidates lie
+// strictly inside the shell bound, and merge their lists with K rounds of a 64-bit wave minimum
+// on (distance bits << 32 | index) keys — the same (distance, index) order as the other paths.
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long t = __shfl_xor(v, o, 64);
+        v                          = t < v ? t : v;
+    }
+    return v;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__ node_pos,
+                                                       const float* __restrict__ node_w, int D,
+                                                       const float* __restrict__ query, int n_query, int k,
+                                                       int32_t* __restrict__ idx, float* __restrict__ weights,
+                                                       KnnGridView grid) {
+    const int v    = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (v >= n_query) return;
+    const KnnGridDesc g = *grid.desc;
+    const f3 q = mk3(query[3 * (size_t)v], query[3 * (size_t)v + 1], query[3 * (size_t)v + 2]);
+    KnnList<K> best;
+    best.init();
+    int cx, cy, cz;
+    cell_of(g, q, cx, cy, cz);
+    const int rmax = max(g.dim[0], max(g.dim[1], g.dim[2]));
+    for (int r = 0; r < rmax; ++r) {
+        const int side = 2 * r + 1, ncell = side * side * side;
+        for (int c = lane; c < ncell; c += 64) {
+            const int dx = c % side - r, dy = (c / side) % side - r, dz = c / (side * side) - r;
+            if (max(abs(dx), max(abs(dy), abs(dz))) != r) continue;  // interior: earlier shells
+            const int x = cx + dx, y = cy + dy, z = cz + dz;
+            if (x < 0 || y < 0 || z < 0 || x >= g.dim[0] || y >= g.dim[1] || z >= g.dim[2]) continue;
+            const int cell = x + g.dim[0] * (y + g.dim[1] * z);
+            const int beg = grid.cell_start[cell], end = grid.cell_start[cell + 1];
+            for (int j = beg; j < end; ++j) {
+                const float4 n = grid.sorted[j];
+                best.push(dist2(q, n.x, n.y, n.z), __float_as_int(n.w));
+            }
+        }
+        // unvisited nodes are >= r*cs away: done once K candidates are strictly closer (margin as in
+        // knn_grid_query)
+        const float bound = (float)r * g.cs, b2 = bound * bound * 0.9999f;
+        int inside = 0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) inside += best.d[j] < b2 ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) inside += __shfl_xor(inside, o, 64);
+        if (inside >= K) break;
+    }
+    // merge: K rounds of wave-min over each lane's current head
+    int pos = 0;
+    for (int j = 0; j < K; ++j) {
+        float hd = __builtin_inff();
+        int hi   = 0x7fffffff;
+#pragma unroll
+        for (int t = 0; t < K; ++t)
+            if (t == pos) hd = best.d[t], hi = best.i[t];
+        const unsigned long long key = ((unsigned long long)__float_as_uint(hd) << 32) | (unsigned int)hi;
+        const unsigned long long win = wave_min_u64(key);
+        if (key == win && hi != 0x7fffffff) ++pos;
+        if (lane == 0 && j < k) {
+            const int n            = (int)(win & 0xffffffffu);
+            const int node         = n == 0x7fffffff ? -1 : n;
+            idx[(size_t)v * k + j] = node;
+            if (weights) {
+                float w = 0.f;
+                if (node >= 0)
+                    w = transformation_weight(mk3(node_pos[3 * node], node_pos[3 * node + 1], node_pos[3 * node + 2]),
+                                              node_w[node], q);
+                weights[(size_t)v * k + j] = w;
+            }
+        }
+    }
+}
+
 template <int K, bool GRID>
 __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ node_pos,
                                                   const float* __restrict__ node_w, int D,
@@ -337,6 +418,13 @@ hipError_t launch_knn(const float* node_pos, const float* node_w, int D, const f
     dim3 block(256), gridDim((n_query + 255) / 256);
     const bool use_grid = grid != nullptr;
     KnnGridView g       = use_grid ? *grid : KnnGridView{};
+    if (use_grid && n_query <= 32768) {  // few queries: one wave per query
+        dim3 wgrid((n_query + 3) / 4);
+        if (k <= 4) knn_wave_kernel<4><<<wgrid, block, 0, s>>>(node_pos, node_w, D, query, n_query, k, idx, weights, g);
+        else if (k <= 8) knn_wave_kernel<8><<<wgrid, block, 0, s>>>(node_pos, node_w, D, query, n_query, k, idx, weights, g);
+        else knn_wave_kernel<16><<<wgrid, block, 0, s>>>(node_pos, node_w, D, query, n_query, k, idx, weights, g);
+        return hipGetLastError();
+    }
     KGDISPATCH(knn_kernel, k, use_grid, <<<gridDim, block, 0, s>>>(node_pos, node_w, D, query, n_query, k, idx, weights, g));
     return hipGetLastError();
 }
