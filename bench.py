@@ -72,7 +72,7 @@ class Sequence:
         self.verts, self.normals = dev(c["verts"]), dev(c["normals"])
         # live vertices of every frame: canon + sum_j w_j t*_j(frame)   (device-side, once)
         idx, w = A.knn(self.nodes, self.node_w, self.verts, self.k)
-        t_true = torch.from_numpy(np.stack([synth.true_translations(c["node_pos"], f)
+        t_true = torch.from_numpy(np.stack([synth.true_translations(c["node_pos"], f, cfg["k"])
                                             for f in range(self.n_frames)])).to(device)
         idx_l = idx.long().clamp(min=0)
         self.live = torch.stack([(self.verts.double() + (w.double()[..., None] * t_true[f].double()[idx_l]).sum(1))
@@ -138,7 +138,7 @@ def cpu_baseline(cfg_name, frames):
     w = np.zeros(idx.shape, np.float32)
     d2 = ((c["verts"][:, None, :].astype(np.float64) - c["node_pos"][idx].astype(np.float64)) ** 2).sum(-1)
     w = np.exp(-d2 / (2 * float(c["node_w"][0]) ** 2)).astype(np.float32)
-    lives = [synth.live_vertices(c["verts"], idx, w, synth.true_translations(c["node_pos"], f)) for f in range(frames)]
+    lives = [synth.live_vertices(c["verts"], idx, w, synth.true_translations(c["node_pos"], f, cfg["k"])) for f in range(frames)]
     O.tsdf_integrate(vol[:8], O.compute_dists(depths[0], fx, fy, cx, cy), voxel, trunc, 64, vol2cam, fx, fy, cx, cy,
                      threads=threads)  # warm the thread pool
     t0 = time.perf_counter()

@@ -337,7 +337,7 @@ int dfa_solver_set_problem(dfa_solver* s, const float* node_pos, const float* no
     HIP_TRY(dfa::launch_knn(node_pos, node_w, D, node_pos, D, s->k, v.reg_idx, nullptr, grid, st));
     HIP_TRY(dfa::solve_build_graph(v, st));
     // resetGPUMemory (:149-202): unknowns start at zero
-    HIP_TRY(hipMemsetAsync(v.t, 0, sizeof(float) * 3 * (size_t)D, st));
+    HIP_TRY(dfa::solve_reset(v, s->state, s->ticket, 64, st));
     s->has_problem = true;
     return DFA_OK;
 }
@@ -350,8 +350,7 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
     REQUIRE(p->lambda >= 0.f, "lambda must be non-negative");
     const dfa::SolveView& v = s->v;
     hipStream_t st          = S(stream);
-    HIP_TRY(hipMemsetAsync(s->state, 0, sizeof(dfa::SolveState), st));
-    HIP_TRY(hipMemsetAsync(v.t, 0, sizeof(float) * 3 * (size_t)v.D, st));
+    HIP_TRY(dfa::solve_reset(v, s->state, s->ticket, 64, st));
     // w_reg = sqrt(lambda / (D * KNN))  (opt_solver.cpp:30); rows carry tau = w_reg^2
     const double w_reg    = std::sqrt((double)p->lambda / ((double)v.D * (double)v.k));
     const float w_reg_f   = (float)w_reg;
@@ -359,7 +358,6 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
     s->ev_used = 0;
     s->ev_pcg.clear();
     s->ev_asm.clear();
-    HIP_TRY(hipMemsetAsync(s->ticket, 0, 64 * sizeof(unsigned int), st));
     for (int outer = 0; outer < p->num_iter; ++outer) {
         // preNonlinearSolve (opt_solver.cpp:135-140): the Huber weights are only observable after
         // the solve, so they are evaluated for the last outer iteration alone

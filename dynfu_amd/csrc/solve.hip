@@ -273,6 +273,18 @@ __global__ __launch_bounds__(256) void linearise_kernel(SolveView s, SolveState*
     }
 }
 
+// start of a solve: unknowns, state block and arrival tickets zeroed by ONE launch
+__global__ __launch_bounds__(256) void reset_kernel(float* __restrict__ t, int n3, SolveState* __restrict__ st,
+                                                    unsigned int* __restrict__ ticket, int nticket) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n3) t[i] = 0.f;
+    if (blockIdx.x == 0) {
+        unsigned int* w = (unsigned int*)st;
+        for (int j = threadIdx.x; j < (int)(sizeof(SolveState) / 4); j += blockDim.x) w[j] = 0u;
+        for (int j = threadIdx.x; j < nticket; j += blockDim.x) ticket[j] = 0u;
+    }
+}
+
 // Huber weights (opt_solver.cpp:233-268): computed for interface parity, energy.t:70 never uses them
 __global__ __launch_bounds__(256) void huber_kernel(SolveView s, float psi_reg) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -991,6 +1003,11 @@ hipError_t solve_linearise(const SolveView& s, SolveState* state, double* cost_p
     const int nb = solve_residual_blocks(s);
     LineariseArgs a{update_weights, mode, gn_tol, tukey_offset, psi_data, w_reg_sq};
     KDISPATCH(linearise_kernel, s.k, <<<nb, 256, 0, st>>>(s, state, cost_partials, ticket, a));
+    return hipGetLastError();
+}
+
+hipError_t solve_reset(const SolveView& s, SolveState* state, unsigned int* ticket, int nticket, hipStream_t st) {
+    reset_kernel<<<(3 * s.D + 255) / 256, 256, 0, st>>>(s.t, 3 * s.D, state, ticket, nticket);
     return hipGetLastError();
 }
 

@@ -65,6 +65,7 @@ hipError_t solve_linearise(const SolveView& s, SolveState* state, double* cost_p
                            int update_weights, int mode, float gn_tol, float tukey_offset, float psi_data,
                            float w_reg_sq, hipStream_t st);
 hipError_t solve_huber(const SolveView& s, float psi_reg, hipStream_t st);
+hipError_t solve_reset(const SolveView& s, SolveState* state, unsigned int* ticket, int nticket, hipStream_t st);
 hipError_t solve_assemble(const SolveView& s, SolveState* state, hipStream_t st);
 int solve_pcg_max_nodes();
 hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, hipStream_t st);

@@ -118,11 +118,15 @@ def canonical(cfg):
     return dict(verts=verts, normals=normals, node_pos=node_pos, node_w=node_w, node_dq=node_dq)
 
 
-def true_translations(node_pos, frame):
-    """ground-truth node translations of frame `frame` (metres)"""
+def true_translations(node_pos, frame, k=4):
+    """ground-truth node translations of frame `frame` (metres).  The reference model sums the
+    UN-normalised RBF weights of the k neighbours (energy.t:50-53), so a vertex moves by about
+    (sum of weights ~ 0.93 k) x |t|: the amplitude is 1 cm at k = 4 and scaled by 4/k above, which
+    keeps the displacement inside the Tukey cut-off (4.652 x 0.01 m) for most vertices."""
     ph = 2 * math.pi * frame / N_FRAMES
     p = node_pos.astype(np.float64)
-    t = 0.01 * np.stack([np.sin(7 * p[:, 0] + ph), np.cos(5 * p[:, 1] + ph), np.sin(3 * p[:, 2] + ph)], -1)
+    amp = 0.01 * min(1.0, 4.0 / k)
+    t = amp * np.stack([np.sin(7 * p[:, 0] + ph), np.cos(5 * p[:, 1] + ph), np.sin(3 * p[:, 2] + ph)], -1)
     return t.astype(np.float32)
 
 

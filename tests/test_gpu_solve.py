@@ -73,7 +73,7 @@ def _problem(name, frame=3, n_verts=None):
     for v in range(len(verts)):
         for j in range(k):
             w[v, j] = O.transformation_weight(c["node_pos"][idx[v, j]], float(c["node_w"][idx[v, j]]), verts[v])
-    t_true = synth.true_translations(c["node_pos"], frame)
+    t_true = synth.true_translations(c["node_pos"], frame, cfg["k"])
     live = synth.live_vertices(verts, idx, w, t_true)
     return cfg, c, verts, live, t_true
 
@@ -139,6 +139,57 @@ def test_early_exit_tolerances_reach_same_solution(A):
     assert out[1][1]["pcg_iters"] < 2 * 3 * 256 and out[0][1]["pcg_iters"] < 2 * 3 * 256
 
 
+@pytest.mark.parametrize("name", ["C1", "C3"])
+def test_large_configs_recover_the_ground_truth_field(A, name):
+    """BASELINE configs C1 (512 nodes, k = 8) and C3 (4096 nodes, k = 8, 524288 vertices): the
+    register-resident (C1) and the streaming (C3) PCG kernels recover the synthetic node
+    translations; the graph equals the exhaustive-search graph on a sample of the vertices."""
+    import torch
+    cfg = synth.CONFIGS[name]
+    c = synth.canonical(cfg)
+    k, D = cfg["k"], cfg["D"]
+    nodes, node_w, node_dq, verts = (dev(c[n]) for n in ("node_pos", "node_w", "node_dq", "verts"))
+    idx, w = A.knn(nodes, node_w, verts, k)
+    sample = np.arange(0, len(c["verts"]), 997)
+    assert np.array_equal(host(idx)[sample], O.knn(c["node_pos"], c["verts"][sample], k, threads=8))
+    t_true = synth.true_translations(c["node_pos"], 5, cfg["k"])
+    live = dev(synth.live_vertices(c["verts"], host(idx), host(w), t_true))
+    s = A.Solver(D, len(c["verts"]), k)
+    s.set_problem(nodes, node_dq, node_w, verts, live)
+    s.solve(_params(A, num_iter=3, nonlinear_iter=1, lambda_=1.0, pcg_tol=1e-6))
+    st = s.stats()
+    assert st["final_cost"] < 1e-4 * st["initial_cost"]
+    warped, _ = A.warp_to_live(nodes, s.node_dq(), node_w, k, verts)
+    assert float((warped - live).abs().max()) < 2e-4
+    assert st["max_row_nnz"] <= 256
+    s.close()
+
+
+def test_degenerate_problems(A):
+    """no vertices (regulariser only), a single node, fewer nodes than k, k = 1"""
+    import torch
+    z = lambda *sh: torch.zeros(sh, device="cuda")
+    ident = lambda D: torch.tensor([[1.0, 0, 0, 0, 0, 0, 0, 0]] * D, device="cuda")
+    nodes = torch.rand((16, 3), device="cuda")
+    s = A.Solver(16, 0, 4)
+    s.set_problem(nodes, ident(16), torch.full((16,), 0.3, device="cuda"), z(0, 3), z(0, 3))
+    s.solve(_params(A, num_iter=2, nonlinear_iter=2, lambda_=10.0))
+    assert float(s.translations().abs().max()) == 0.0  # nothing pulls the nodes
+    s.close()
+    for D, k in ((1, 4), (3, 8), (5, 1)):
+        nodes = torch.rand((D, 3), device="cuda")
+        verts = torch.rand((50, 3), device="cuda")
+        live = verts + 0.01
+        s = A.Solver(D, 50, k)
+        s.set_problem(nodes, ident(D), torch.full((D,), 2.0, device="cuda"), verts, live)
+        s.solve(_params(A, num_iter=2, nonlinear_iter=2, lambda_=0.0))
+        st = s.stats()
+        assert np.isfinite(st["final_cost"]) and st["final_cost"] <= st["initial_cost"] * (1 + 1e-6)
+        g = host(s.data_graph())
+        assert g.shape == (50, k) and (g[:, : min(k, D)] >= 0).all() and (g[:, min(k, D):] == -1).all()
+        s.close()
+
+
 def test_plan_capacity_and_argument_errors(A):
     import torch
     s = A.Solver(16, 100, 4)
@@ -164,7 +215,7 @@ def test_config_c2_full_size_properties(A):
     k, D = cfg["k"], cfg["D"]
     nodes, node_w, node_dq, verts = (dev(c[n]) for n in ("node_pos", "node_w", "node_dq", "verts"))
     idx, w = A.knn(nodes, node_w, verts, k)
-    t_true = synth.true_translations(c["node_pos"], 11)
+    t_true = synth.true_translations(c["node_pos"], 11, cfg["k"])
     live_np = synth.live_vertices(c["verts"], host(idx), host(w), t_true)
     live = dev(live_np)
     s = A.Solver(D, len(c["verts"]), k)

@@ -218,6 +218,37 @@ def test_full_size_properties_512(A):
     assert np.array_equal(host(a, np.uint32), ref)
 
 
+def test_full_size_properties_1024(A):
+    """BASELINE config C4 (1024^3, 4 GiB volume, 720p depth): fused == clear + integrate, a second
+    sweep doubles the weights of exactly the touched voxels, and the per-z-slab XOR/sum checksum of
+    the volume is independent of the z chunking."""
+    import torch
+    cfg, intr, voxel, trunc, vol2cam, _, _, depth = _scene("C4")
+    dim = cfg["dim"]
+    dists = torch.empty((cfg["height"], cfg["width"]), dtype=torch.uint16, device="cuda")
+    A.compute_dists(dev(depth), dists, *intr)
+    a = torch.empty((dim, dim, dim), dtype=torch.int32, device="cuda")
+    A.tsdf_clear_integrate(a, dists, voxel, trunc, 64, vol2cam, *intr)
+    b = torch.full((dim, dim, dim), 0x7F7F7F7F, dtype=torch.int32, device="cuda")
+    A.tsdf_clear(b)
+    A.tsdf_integrate(b, dists, voxel, trunc, 64, vol2cam, *intr)
+    assert torch.equal(a, b)
+    checksum = lambda v: (v.view(dim, -1).long().sum(1))
+    ca = checksum(a)
+    touched = int(((a >> 16) == 1).sum())
+    assert 0.02 * dim ** 3 < touched < 0.9 * dim ** 3
+    del b
+    A.tsdf_integrate(a, dists, voxel, trunc, 64, vol2cam, *intr)
+    assert int(((a >> 16) == 2).sum()) == touched and int(((a >> 16) == 1).sum()) == 0
+    os.environ["DFA_TSDF_ZCHUNK"] = "200"
+    try:
+        c = torch.empty_like(a)
+        A.tsdf_clear_integrate(c, dists, voxel, trunc, 64, vol2cam, *intr)
+    finally:
+        del os.environ["DFA_TSDF_ZCHUNK"]
+    assert torch.equal(checksum(c), ca)
+
+
 def test_argument_errors_are_loud(A):
     import torch
     v = torch.zeros((8, 8, 8), dtype=torch.int32, device="cuda")

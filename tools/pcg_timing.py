@@ -12,7 +12,7 @@ dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 nodes, node_w, node_dq, verts = (dev(c[n]) for n in ("node_pos", "node_w", "node_dq", "verts"))
 k = cfg["k"]
 idx, w = A.knn(nodes, node_w, verts, k)
-t_true = synth.true_translations(c["node_pos"], 7)
+t_true = synth.true_translations(c["node_pos"], 7, cfg["k"])
 live = dev(synth.live_vertices(c["verts"], idx.cpu().numpy(), w.cpu().numpy(), t_true))
 s = A.Solver(cfg["D"], len(c["verts"]), k)
 s.set_problem(nodes, node_dq, node_w, verts, live)
