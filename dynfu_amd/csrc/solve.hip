@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
 #endif
 
     const int beg = s.node_ptr[a], end = s.node_ptr[a + 1];
-    float gx = 0.f, gy = 0.f, gz = 0.f;
+    float gx = 0.f, gy = 0.f, gz = 0.f, dsum = 0.f;
     for (int p = beg + (int)threadIdx.x; p < end; p += 256) {
         const uint32_t e = s.node_list[p];
         const size_t r   = e / (uint32_t)s.k;
@@ -388,25 +388,52 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
         const float tw = et.w * wa;
         gx += tw * et.x, gy += tw * et.y, gz += tw * et.z;
         if (et.w != 0.f) {
+            // first probe of all k columns read together (keys never change once set): the common
+            // case "column already present" costs one LDS read + one fire-and-forget ds_add instead
+            // of a returning CAS per column
+            uint32_t h0[K];
+            int k0[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                h0[j] = ((uint32_t)idx[j] * 2654435761u) >> (32 - 9);
+                k0[j] = key[h0[j]];
+            }
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const int b = idx[j];
-                if (b >= 0) {
-                    const float v = tw * w[j];
-                    uint32_t h    = ((uint32_t)b * 2654435761u) >> (32 - 9);
-                    int probes    = 0;
-                    for (;; h = (h + 1) & HASH_MASK) {
-                        const int cur = atomicCAS(&key[h], -1, b);
-                        if (cur == -1 || cur == b) {
-                            atomicAdd(&val[h], v);
-                            break;
-                        }
-                        if (++probes >= HASH) {
-                            ovf = 1;
-                            break;
-                        }
-                    }
+                if (b < 0) continue;
+                const float v = tw * w[j];
+                if (b == a) {  // the diagonal is hit by every row: kept in a register
+                    dsum += v;
+                    continue;
                 }
+                uint32_t h = h0[j];
+                int cur    = k0[j];
+                for (int probes = 0;; ++probes) {
+                    if (cur == -1) cur = atomicCAS(&key[h], -1, b), cur = cur == -1 ? b : cur;
+                    if (cur == b) {
+                        atomicAdd(&val[h], v);
+                        break;
+                    }
+                    if (probes >= HASH) {
+                        ovf = 1;
+                        break;
+                    }
+                    h   = (h + 1) & HASH_MASK;
+                    cur = key[h];
+                }
+            }
+        }
+    }
+    // the diagonal: one add per wave into its (pre-inserted) slot
+    dsum = wave_total(dsum);
+    if (lane == 0 && dsum != 0.f) {
+        uint32_t h = ((uint32_t)a * 2654435761u) >> (32 - 9);
+        for (int probes = 0; probes < HASH; ++probes, h = (h + 1) & HASH_MASK) {
+            const int cur = atomicCAS(&key[h], -1, a);
+            if (cur == -1 || cur == a) {
+                atomicAdd(&val[h], dsum);
+                break;
             }
         }
     }
@@ -419,7 +446,8 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
 #ifdef DFA_PCG_PROFILE
     t3_ = clock64();
 #endif
-    // compact the hash into the ELL row (slot-major: entry q of row a at [q*D + a]); each wave owns
+    // compact the hash into the ELL row (slot-major: entry q of row a at [q*D + a]: a slot of all rows is
+    // one contiguous 4*D-byte segment, which the sorted-row PCG prologues re-read from L1/L2); each wave owns
     // HASH/4 consecutive hash slots, wave offsets come from a 4-entry LDS prefix
     constexpr int PER_WAVE = HASH / 4;
     int wcnt               = 0;
