@@ -10,6 +10,7 @@ _LIB = None
 SYMBOLS = [
     "dfa_last_error", "dfa_version", "dfa_compute_dists", "dfa_tsdf_clear", "dfa_tsdf_integrate",
     "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_knn", "dfa_warp_to_live",
+    "dfa_correspond",
     "dfa_solver_create", "dfa_solver_destroy", "dfa_solver_set_problem", "dfa_solver_solve",
     "dfa_solver_translations", "dfa_solver_node_dq", "dfa_solver_tukey_weights", "dfa_solver_huber_weights",
     "dfa_solver_data_graph", "dfa_solver_reg_graph", "dfa_solver_get_stats", "dfa_solver_enable_timing",
@@ -68,6 +69,7 @@ def load():
     L.dfa_tsdf_raycast_depth.argtypes = ray
     L.dfa_knn.argtypes = [vp, vp, i, vp, i, i, vp, vp, vp]
     L.dfa_warp_to_live.argtypes = [vp, vp, vp, i, i, vp, vp, i, vp, vp, vp]
+    L.dfa_correspond.argtypes = [vp, vp, i, vp, i, vp, vp, vp, vp]
     L.dfa_solver_create.argtypes = [i, i, i, C.POINTER(vp)]
     L.dfa_solver_destroy.argtypes = [vp]
     L.dfa_solver_destroy.restype = None
@@ -224,6 +226,20 @@ def warp_to_live(node_pos, node_dq, node_w, k, verts, normals=None):
                                    _dev(verts, torch.float32, "verts"), _dev(normals, torch.float32, "normals"),
                                    verts.shape[0], _dev(out_v), _dev(out_n), _stream()))
     return out_v, out_n
+
+
+def correspond(canon_v, canon_n, live_v, want_index=True):
+    """DynFusion::findCorrespondingFrame: (vertices, normals, index) of the nearest canonical vertex
+    of every live vertex."""
+    torch = _torch()
+    n_live = live_v.shape[0]
+    out_v = torch.empty((n_live, 3), dtype=torch.float32, device=live_v.device)
+    out_n = torch.empty_like(out_v) if canon_n is not None else None
+    idx = torch.empty((n_live,), dtype=torch.int32, device=live_v.device) if want_index else None
+    _check(load().dfa_correspond(_dev(canon_v, torch.float32, "canon_v"), _dev(canon_n, torch.float32, "canon_n"),
+                                 canon_v.shape[0], _dev(live_v, torch.float32, "live_v"), n_live, _dev(out_v),
+                                 _dev(out_n), _dev(idx), _stream()))
+    return out_v, out_n, idx
 
 
 # ------------------------------------------------------------------------------ solver seam

@@ -241,6 +241,22 @@ int dfa_warp_to_live(const float* node_pos, const float* node_dq, const float* n
     return DFA_OK;
 }
 
+int dfa_correspond(const float* canon_vertices, const float* canon_normals, int n_canon, const float* live_vertices,
+                   int n_live, float* out_vertices, float* out_normals, int32_t* out_index, dfa_stream_t stream) {
+    REQUIRE(canon_vertices && n_canon > 0, "no canonical vertices");
+    REQUIRE(n_live >= 0 && (n_live == 0 || live_vertices), "bad live vertices");
+    REQUIRE(!out_normals || canon_normals, "normals requested without canonical normals");
+    const dfa::KnnGridView* grid = nullptr;
+    if (want_grid(n_canon, n_live)) {
+        HIP_TRY(g_thread_grid.reserve(n_canon));
+        HIP_TRY(dfa::knn_grid_build(g_thread_grid.v, canon_vertices, n_canon, S(stream)));
+        grid = &g_thread_grid.v;
+    }
+    HIP_TRY(dfa::launch_correspond(canon_vertices, canon_normals, n_canon, live_vertices, n_live, out_vertices,
+                                   out_normals, out_index, grid, S(stream)));
+    return DFA_OK;
+}
+
 // ------------------------------------------------------------------------------- solver seam
 
 int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {

@@ -389,6 +389,38 @@ __global__ __launch_bounds__(256) void warp_to_live_kernel(const float* __restri
     }
 }
 
+// DynFusion::findCorrespondingFrame (dyn_fusion.cpp:212-242): for every LIVE vertex the nearest
+// vertex of the (warped) canonical cloud, by the same exact (distance, index) order as the k-NN
+// above with k = 1; the canonical vertex and normal at that index are gathered into a cloud that
+// is index-aligned with the live one.  The reference rebuilds a nanoflann KD-tree over the N
+// canonical points every frame on the host (:221-224) and queries it once per live vertex.
+template <bool GRID>
+__global__ __launch_bounds__(256) void correspond_kernel(const float* __restrict__ canon_v,
+                                                         const float* __restrict__ canon_n, int n_canon,
+                                                         const float* __restrict__ live_v, int n_live,
+                                                         float* __restrict__ out_v, float* __restrict__ out_n,
+                                                         int32_t* __restrict__ out_idx, KnnGridView grid) {
+    __shared__ float4 tile[GRID ? 1 : KNN_TILE];
+    const int v       = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = v < n_live;
+    f3 q              = mk3(0.f, 0.f, 0.f);
+    if (active) q = mk3(live_v[3 * (size_t)v], live_v[3 * (size_t)v + 1], live_v[3 * (size_t)v + 2]);
+    KnnList<1> best;
+    if (GRID) {
+        if (!active) return;
+        knn_grid_query<1>(*grid.desc, grid.cell_start, grid.sorted, q, best);
+    } else {
+        knn_scan<1>(canon_v, n_canon, q, best, tile);
+        if (!active) return;
+    }
+    const int n = best.index(0);  // -1 only if every distance is NaN
+    if (out_idx) out_idx[v] = n;
+    const size_t src = 3 * (size_t)max(n, 0), dst = 3 * (size_t)v;
+    if (out_v) out_v[dst] = canon_v[src], out_v[dst + 1] = canon_v[src + 1], out_v[dst + 2] = canon_v[src + 2];
+    if (out_n && canon_n)
+        out_n[dst] = canon_n[src], out_n[dst + 1] = canon_n[src + 1], out_n[dst + 2] = canon_n[src + 2];
+}
+
 // ------------------------------------------------------------------------------ launchers
 
 hipError_t knn_grid_build(const KnnGridView& g, const float* node_pos, int D, hipStream_t s) {
@@ -438,6 +470,16 @@ hipError_t launch_warp_to_live(const float* node_pos, const float* node_dq, cons
     KnnGridView g       = use_grid ? *grid : KnnGridView{};
     KGDISPATCH(warp_to_live_kernel, k, use_grid,
                <<<gridDim, block, 0, s>>>(node_pos, node_dq, node_w, D, k, verts, normals, N, out_verts, out_normals, g));
+    return hipGetLastError();
+}
+
+hipError_t launch_correspond(const float* canon_v, const float* canon_n, int n_canon, const float* live_v,
+                             int n_live, float* out_v, float* out_n, int32_t* out_idx, const KnnGridView* grid,
+                             hipStream_t s) {
+    if (n_live == 0) return hipSuccess;
+    dim3 block(256), gridDim((n_live + 255) / 256);
+    if (grid) correspond_kernel<true><<<gridDim, block, 0, s>>>(canon_v, canon_n, n_canon, live_v, n_live, out_v, out_n, out_idx, *grid);
+    else correspond_kernel<false><<<gridDim, block, 0, s>>>(canon_v, canon_n, n_canon, live_v, n_live, out_v, out_n, out_idx, KnnGridView{});
     return hipGetLastError();
 }
 

@@ -107,6 +107,16 @@ int dfa_warp_to_live(const float* node_pos, const float* node_dq, const float* n
                      const float* vertices, const float* normals, int N, float* out_vertices, float* out_normals,
                      dfa_stream_t stream);
 
+/* DynFusion::findCorrespondingFrame (src/dynfu/dyn_fusion.cpp:212-242): for each of the
+ * n_live live vertices the nearest of the n_canon (warped) canonical vertices — exact 1-NN,
+ * ties to the lower index — and the canonical vertex / normal at that index gathered into
+ * clouds index-aligned with the live one (the "corresponding canonical frame" handed to
+ * CombinedSolver::initializeProblemInstance, dyn_fusion.cpp:206).  Replaces the per-frame
+ * nanoflann KD-tree over the canonical cloud (:221-224) by a device-built uniform grid.
+ * canon_normals / out_normals / out_vertices / out_index may each be NULL (skipped). */
+int dfa_correspond(const float* canon_vertices, const float* canon_normals, int n_canon, const float* live_vertices,
+                   int n_live, float* out_vertices, float* out_normals, int32_t* out_index, dfa_stream_t stream);
+
 /* ===================================================================================== */
 /* Solver seam — replaces class CombinedSolver (include/dynfu/utils/opt_solver.hpp:19-110, */
 /* src/dynfu/utils/opt_solver.cpp) and the Opt GN/PCG it drives with energy.t            */

@@ -252,6 +252,15 @@ def knn(nodes, query, k, threads=1):
     return idx
 
 
+def correspond(canon_v, canon_n, live_v, threads=1):
+    """DynFusion::findCorrespondingFrame (src/dynfu/dyn_fusion.cpp:212-242): nearest canonical vertex
+    of every live vertex (exact 1-NN, orc_knn) and the gathered vertex / normal clouds."""
+    canon_v = _f32(canon_v)
+    idx = knn(canon_v, live_v, 1, threads)[:, 0]
+    out_n = _f32(canon_n)[idx] if canon_n is not None else None
+    return canon_v[idx], out_n, idx
+
+
 def ref_knn(nodes, query, k):
     """k-NN by the reference's vendored nanoflann. Returns (idx, dist_sqr)."""
     R = ref_lib()

@@ -111,3 +111,47 @@ def test_warp_empty_and_errors(A):
     assert ov.shape == (0, 3)
     with pytest.raises(A.DynfuAmdError):
         A.knn(nodes, w, torch.zeros((3, 3), device="cuda"), 17)
+
+
+# ------------------------------------------------------------------ correspondence (dyn_fusion.cpp:212-242)
+def _surface_clouds(n_canon, n_live, seed):
+    """canonical = points on the synthetic sphere cap, live = a displaced, differently sampled set"""
+    rng = np.random.default_rng(seed)
+    def cap(n):
+        d = rng.normal(size=(n, 3))
+        d[:, 2] = -np.abs(d[:, 2])
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        return (synth.SPHERE_C + 0.5 * d).astype(np.float32), d.astype(np.float32)
+    cv, cn = cap(n_canon)
+    lv, _ = cap(n_live)
+    lv += rng.normal(0, 0.004, lv.shape).astype(np.float32)
+    return cv, cn, lv
+
+
+@pytest.mark.parametrize("n_canon,n_live", [(65536, 65536), (3000, 10000), (17, 1000), (1, 5), (40000, 129)])
+def test_correspond_bit_exact(A, n_canon, n_live):
+    cv, cn, lv = _surface_clouds(n_canon, n_live, n_canon + n_live)
+    lv[: min(n_live, n_canon) // 2] = cv[: min(n_live, n_canon) // 2]  # exact hits
+    ov, on, idx = A.correspond(dev(cv), dev(cn), dev(lv))
+    rv, rn, ridx = O.correspond(cv, cn, lv, threads=8)
+    assert np.array_equal(host(idx), ridx)
+    assert np.array_equal(host(ov), rv) and np.array_equal(host(on), rn)
+    # the reference's own KD-tree (nanoflann, oracle/_ref) agrees wherever the nearest point is unique
+    ref = O.ref_knn(cv, lv[:20000], 1)
+    if ref is not None:
+        d = ((lv[:20000].astype(np.float64) - cv[ref[0][:, 0]].astype(np.float64)) ** 2).sum(1)
+        dm = ((lv[:20000].astype(np.float64) - rv[:20000].astype(np.float64)) ** 2).sum(1)
+        assert np.all((ref[0][:, 0] == ridx[:20000]) | (np.abs(d - dm) <= 1e-12))
+
+
+def test_correspond_duplicates_optional_outputs_and_errors(A):
+    import torch
+    cv = np.tile(np.array([[0, 0, 1], [0.5, 0, 1], [0, 0, 1]], np.float32), (50, 1))  # every point 50 (or 100) times
+    lv = np.array([[0, 0, 1.01], [0.4, 0, 1], [9, 9, 9]], np.float32)
+    ov, on, idx = A.correspond(dev(cv), None, dev(lv))
+    assert on is None and host(idx).tolist() == [0, 1, 1]  # ties -> lowest index
+    assert np.array_equal(host(ov), cv[[0, 1, 1]])
+    ov, on, idx = A.correspond(dev(cv), dev(cv), torch.zeros((0, 3), device="cuda"))
+    assert ov.shape == (0, 3) and idx.shape == (0,)
+    with pytest.raises(A.DynfuAmdError):
+        A.correspond(torch.zeros((0, 3), device="cuda"), None, dev(lv))
