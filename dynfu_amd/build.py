@@ -71,7 +71,7 @@ def build(force=False, verbose=False):
 
 HOST = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(HERE, "libdynfu_amd_host.so")
-HOST_SOURCES = ["device.cpp", "tsdf_volume.cpp", "warp_field.cpp", "opt_solver.cpp"]
+HOST_SOURCES = ["device.cpp", "tsdf_volume.cpp", "warp_field.cpp", "opt_solver.cpp", "dyn_fusion.cpp"]
 
 
 def build_host(force=False, verbose=False):
@@ -105,7 +105,8 @@ def build_cpp_tests(force=False, verbose=False):
     inc = os.path.join(HOST, "include")
     oracle_dir = os.path.join(root, "oracle")
     built = {}
-    for name, needs in (("test_host_dq", []), ("test_host_solver", ["host"]), ("test_host_tsdf", ["host", "oracle"])):
+    for name, needs in (("test_host_dq", []), ("test_host_solver", ["host"]), ("test_host_tsdf", ["host", "oracle"]),
+                        ("test_host_dynfusion", ["host"])):
         src = os.path.join(tdir, name + ".cpp")
         exe = os.path.join(out, name)
         deps = [src, os.path.join(tdir, "minitest.hpp"), host]

@@ -67,6 +67,35 @@ struct GridScratch {
     }
 };
 
+// scratch of the 128^3 point grid of dfa_correspond; grows on demand, never shrinks
+struct PointGridScratch {
+    dfa::PointGridView v{};
+    int cap_points = 0;
+    void release() {
+        (void)hipFree(v.g.desc), (void)hipFree(v.g.cell_count), (void)hipFree(v.g.cell_start);
+        (void)hipFree(v.g.node_cell), (void)hipFree(v.g.sorted), (void)hipFree(v.chunk_sums);
+        (void)hipFree(v.bbox_partials);
+        v          = dfa::PointGridView{};
+        cap_points = 0;
+    }
+    hipError_t reserve(int n) {
+        if (n <= cap_points) return hipSuccess;
+        release();
+        hipError_t e;
+        const size_t cells = dfa::PGRID_MAX_CELLS;
+        if ((e = hipMalloc((void**)&v.g.desc, sizeof(dfa::KnnGridDesc))) != hipSuccess) return e;
+        if ((e = hipMalloc((void**)&v.g.cell_count, sizeof(int32_t) * cells)) != hipSuccess) return e;
+        if ((e = hipMalloc((void**)&v.g.cell_start, sizeof(int32_t) * (cells + 1))) != hipSuccess) return e;
+        if ((e = hipMalloc((void**)&v.g.node_cell, sizeof(int32_t) * (size_t)n)) != hipSuccess) return e;
+        if ((e = hipMalloc((void**)&v.g.sorted, sizeof(float4) * (size_t)n)) != hipSuccess) return e;
+        if ((e = hipMalloc((void**)&v.chunk_sums, sizeof(int32_t) * (cells / dfa::PGRID_CHUNK))) != hipSuccess) return e;
+        if ((e = hipMalloc((void**)&v.bbox_partials, sizeof(float) * 6 * dfa::PGRID_BBOX_BLOCKS)) != hipSuccess) return e;
+        cap_points = n;
+        return hipSuccess;
+    }
+};
+thread_local PointGridScratch g_thread_point_grid;
+
 // The standalone entry points (dfa_knn, dfa_warp_to_live) have no plan to keep scratch in:
 // one grid per host thread, reused across calls (stream-ordered use; grows synchronously).
 thread_local GridScratch g_thread_grid;
@@ -247,7 +276,11 @@ int dfa_correspond(const float* canon_vertices, const float* canon_normals, int 
     REQUIRE(n_live >= 0 && (n_live == 0 || live_vertices), "bad live vertices");
     REQUIRE(!out_normals || canon_normals, "normals requested without canonical normals");
     const dfa::KnnGridView* grid = nullptr;
-    if (want_grid(n_canon, n_live)) {
+    if (n_canon >= 16384 && want_grid(n_canon, n_live)) {  // large cloud: 128^3 point grid
+        HIP_TRY(g_thread_point_grid.reserve(n_canon));
+        HIP_TRY(dfa::point_grid_build(g_thread_point_grid.v, canon_vertices, n_canon, S(stream)));
+        grid = &g_thread_point_grid.v.g;
+    } else if (want_grid(n_canon, n_live)) {
         HIP_TRY(g_thread_grid.reserve(n_canon));
         HIP_TRY(dfa::knn_grid_build(g_thread_grid.v, canon_vertices, n_canon, S(stream)));
         grid = &g_thread_grid.v;

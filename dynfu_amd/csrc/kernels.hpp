@@ -40,6 +40,17 @@ struct KnnGridView {
     int32_t* node_cell;   // D
     float4* sorted;       // D   (x, y, z, node index bits), grouped by cell
 };
+// The same structure at up to 128^3 cells for large point sets (dfa_correspond's canonical cloud)
+constexpr int PGRID_MAX_DIM     = 128;
+constexpr int PGRID_MAX_CELLS   = PGRID_MAX_DIM * PGRID_MAX_DIM * PGRID_MAX_DIM;
+constexpr int PGRID_CHUNK       = 8192;  // cells per scan workgroup -> 256 chunks
+constexpr int PGRID_BBOX_BLOCKS = 512;
+struct PointGridView {
+    KnnGridView g;           // cell_count: PGRID_MAX_CELLS, cell_start: PGRID_MAX_CELLS + 1
+    int32_t* chunk_sums;     // PGRID_MAX_CELLS / PGRID_CHUNK
+    float* bbox_partials;    // PGRID_BBOX_BLOCKS x 6
+};
+hipError_t point_grid_build(const PointGridView& pg, const float* pts, int n, hipStream_t s);
 hipError_t knn_grid_build(const KnnGridView& g, const float* node_pos, int D, hipStream_t s);
 // grid == nullptr: exhaustive scan
 hipError_t launch_knn(const float* node_pos, const float* node_w, int D, const float* query, int n_query, int k,

@@ -187,13 +187,137 @@ __global__ __launch_bounds__(256) void grid_fill_kernel(const float* __restrict_
                                  __int_as_float(i));
 }
 
+// ---- large point sets (the canonical cloud of dfa_correspond): up to 128^3 cells ----------------
+// Same data structure, built by multi-workgroup kernels: bounding box by per-block partials, the
+// exclusive scan of the cell counts in chunks of PGRID_CHUNK cells (chunk sums, then a scan kernel
+// that first adds up the sums of the chunks before it).
+__global__ __launch_bounds__(256) void pgrid_bbox_kernel(const float* __restrict__ pts, int n,
+                                                         float* __restrict__ partials /* gridDim.x x 6 */) {
+    __shared__ float sh[6][4];
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        for (int c = 0; c < 3; ++c) {
+            const float v = pts[3 * (size_t)i + c];
+            mn[c] = fminf(mn[c], v), mx[c] = fmaxf(mx[c], v);
+        }
+    for (int c = 0; c < 3; ++c) {
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o, 64));
+            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) sh[c][threadIdx.x >> 6] = mn[c], sh[3 + c][threadIdx.x >> 6] = mx[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int c = threadIdx.x;
+        float a     = sh[c][0];
+        for (int w = 1; w < 4; ++w) a = c < 3 ? fminf(a, sh[c][w]) : fmaxf(a, sh[c][w]);
+        partials[6 * blockIdx.x + c] = a;
+    }
+}
+
+__global__ __launch_bounds__(64) void pgrid_finalize_kernel(const float* __restrict__ partials, int nblocks, int n,
+                                                            KnnGridDesc* __restrict__ desc) {
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int b = threadIdx.x; b < nblocks; b += 64)
+        for (int c = 0; c < 3; ++c) mn[c] = fminf(mn[c], partials[6 * b + c]), mx[c] = fmaxf(mx[c], partials[6 * b + 3 + c]);
+    for (int c = 0; c < 3; ++c)
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o, 64));
+            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o, 64));
+        }
+    if (threadIdx.x == 0) {
+        float ext[3];
+        for (int c = 0; c < 3; ++c) desc->bmin[c] = mn[c], ext[c] = fmaxf(mx[c] - mn[c], 0.f);
+        const float emax = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
+        // points of a surface: the volume rule over-estimates the spacing, so aim below it and let the
+        // 128-cells-per-axis cap decide for thin clouds
+        float cs = 0.7f * cbrtf((ext[0] * ext[1] * ext[2]) / (float)n);
+        cs       = fmaxf(cs, emax / (float)PGRID_MAX_DIM);
+        if (!(cs > 0.f)) cs = 1.f;
+        desc->cs = cs, desc->inv_cs = 1.f / cs;
+        for (int c = 0; c < 3; ++c) desc->dim[c] = min(max((int)(ext[c] * desc->inv_cs) + 1, 1), PGRID_MAX_DIM);
+    }
+}
+
+__device__ __forceinline__ int pgrid_cells(const KnnGridDesc& g) { return g.dim[0] * g.dim[1] * g.dim[2]; }
+
+__global__ __launch_bounds__(256) void pgrid_clear_kernel(const KnnGridDesc* __restrict__ desc,
+                                                          int32_t* __restrict__ cell_count) {
+    const int nc = pgrid_cells(*desc);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += gridDim.x * blockDim.x) cell_count[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void pgrid_sum_kernel(const KnnGridDesc* __restrict__ desc,
+                                                        const int32_t* __restrict__ cell_count,
+                                                        int32_t* __restrict__ chunk_sums) {
+    __shared__ int sh[4];
+    const int nc = pgrid_cells(*desc), base = blockIdx.x * PGRID_CHUNK;
+    int sum = 0;
+    for (int i = base + threadIdx.x; i < min(base + PGRID_CHUNK, nc); i += 256) sum += cell_count[i];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void pgrid_scan_kernel(const KnnGridDesc* __restrict__ desc,
+                                                         int32_t* __restrict__ cell_count /* in: counts, out: cursors */,
+                                                         int32_t* __restrict__ cell_start,
+                                                         const int32_t* __restrict__ chunk_sums) {
+    __shared__ int sh[4], sh2[4];
+    const int nc = pgrid_cells(*desc), base = blockIdx.x * PGRID_CHUNK;
+    if (base >= nc) return;
+    // offset of this chunk = sum of the chunk sums before it (at most PGRID_MAX_CELLS / PGRID_CHUNK = 256)
+    int before = (int)threadIdx.x < (int)blockIdx.x ? chunk_sums[threadIdx.x] : 0;
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = before;
+    constexpr int PER = PGRID_CHUNK / 256;
+    const int first   = base + threadIdx.x * PER;
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) loc[j] = first + j < nc ? cell_count[first + j] : 0, sum += loc[j];
+    int incl       = sum;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) sh2[wave] = incl;
+    __syncthreads();
+    int off = sh[0] + sh[1] + sh[2] + sh[3] + incl - sum;
+    for (int w = 0; w < wave; ++w) off += sh2[w];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        if (first + j < nc) {
+            cell_start[first + j] = off;
+            cell_count[first + j] = off;
+            off += loc[j];
+            if (first + j == nc - 1) cell_start[nc] = off;
+        }
+    }
+}
+
 // exact k-NN through the grid: Chebyshev shells r = 0, 1, 2, ... around the query's cell
-template <int K>
+// TIGHT: the stop bound also counts the query's distance to the nearest wall of its own cell (the
+// visited block of cells extends r cells beyond that wall), which lets a 1-NN search stop inside
+// shell 0 / 1 of a fine grid.  Same result either way — the bound only decides when to stop.
+template <int K, bool TIGHT = false>
 __device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32_t* __restrict__ cell_start,
                                                const float4* __restrict__ sorted, f3 q, KnnList<K>& best) {
     best.init();
     int cx, cy, cz;
     cell_of(g, q, cx, cy, cz);
+    float margin = 0.f;  // in cells; 0 for queries outside the grid (clamped above)
+    if (TIGHT) {
+        const float ux = (q.x - g.bmin[0]) * g.inv_cs - (float)cx, uy = (q.y - g.bmin[1]) * g.inv_cs - (float)cy,
+                    uz = (q.z - g.bmin[2]) * g.inv_cs - (float)cz;
+        const float m = fminf(fminf(fminf(ux, 1.f - ux), fminf(uy, 1.f - uy)), fminf(uz, 1.f - uz));
+        margin        = m > 0.f ? m : 0.f;  // negative (outside) or NaN -> 0
+    }
     const int rmax = max(g.dim[0], max(g.dim[1], g.dim[2]));
     for (int r = 0; r < rmax; ++r) {
         const int z0 = max(cz - r, 0), z1 = min(cz + r, g.dim[2] - 1);
@@ -217,7 +341,9 @@ __device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32
         // every node not visited yet is at least r*cs away (from the query's projection onto
         // the grid, hence from the query); stop when the k-th candidate is strictly closer,
         // with a relative margin that absorbs the rounding of the cell assignment
-        const float bound = (float)r * g.cs;
+        // (TIGHT: the cell coordinate of a point is rounded with an error ~1e-5 cells at 128 cells per
+        // axis; 1e-3 cells are taken off the bound before the relative margin)
+        const float bound = TIGHT ? fmaxf((float)r + margin - 1e-3f, 0.f) * g.cs : (float)r * g.cs;
         if (best.d[K - 1] < bound * bound * 0.9999f) break;
     }
 }
@@ -408,7 +534,7 @@ __global__ __launch_bounds__(256) void correspond_kernel(const float* __restrict
     KnnList<1> best;
     if (GRID) {
         if (!active) return;
-        knn_grid_query<1>(*grid.desc, grid.cell_start, grid.sorted, q, best);
+        knn_grid_query<1, true>(*grid.desc, grid.cell_start, grid.sorted, q, best);
     } else {
         knn_scan<1>(canon_v, n_canon, q, best, tile);
         if (!active) return;
@@ -422,6 +548,20 @@ __global__ __launch_bounds__(256) void correspond_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------ launchers
+
+hipError_t point_grid_build(const PointGridView& pg, const float* pts, int n, hipStream_t s) {
+    const KnnGridView& g = pg.g;
+    const int nb         = (n + 255) / 256;
+    const int bbox_blocks = nb < PGRID_BBOX_BLOCKS ? nb : PGRID_BBOX_BLOCKS;
+    pgrid_bbox_kernel<<<bbox_blocks, 256, 0, s>>>(pts, n, pg.bbox_partials);
+    pgrid_finalize_kernel<<<1, 64, 0, s>>>(pg.bbox_partials, bbox_blocks, n, g.desc);
+    pgrid_clear_kernel<<<1024, 256, 0, s>>>(g.desc, g.cell_count);
+    grid_count_kernel<<<nb, 256, 0, s>>>(pts, n, g.desc, g.cell_count, g.node_cell);
+    pgrid_sum_kernel<<<PGRID_MAX_CELLS / PGRID_CHUNK, 256, 0, s>>>(g.desc, g.cell_count, pg.chunk_sums);
+    pgrid_scan_kernel<<<PGRID_MAX_CELLS / PGRID_CHUNK, 256, 0, s>>>(g.desc, g.cell_count, g.cell_start, pg.chunk_sums);
+    grid_fill_kernel<<<nb, 256, 0, s>>>(pts, n, g.node_cell, g.cell_count, g.sorted);
+    return hipGetLastError();
+}
 
 hipError_t knn_grid_build(const KnnGridView& g, const float* node_pos, int D, hipStream_t s) {
     grid_setup_kernel<<<1, 1024, 0, s>>>(node_pos, D, g.desc, g.cell_count);

@@ -155,3 +155,29 @@ def test_correspond_duplicates_optional_outputs_and_errors(A):
     assert ov.shape == (0, 3) and idx.shape == (0,)
     with pytest.raises(A.DynfuAmdError):
         A.correspond(torch.zeros((0, 3), device="cuda"), None, dev(lv))
+
+
+@pytest.mark.parametrize("kind", ["planar", "coincident", "clustered_far", "lattice", "line", "volume"])
+def test_correspond_point_grid_is_exact_on_awkward_geometry(A, kind):
+    rng = np.random.default_rng(11)
+    n = 30000
+    if kind == "planar":
+        cv = np.c_[rng.uniform(-1, 1, (n, 2)), np.full(n, 1.25)]
+    elif kind == "coincident":
+        cv = np.tile([[0.25, -0.5, 2.0]], (n, 1))
+    elif kind == "clustered_far":
+        cv = np.r_[rng.normal(0, 0.01, (n - 10, 3)), rng.uniform(50, 60, (10, 3))]
+    elif kind == "lattice":  # many exactly equidistant candidates
+        g = np.arange(31) * 0.125
+        cv = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    elif kind == "line":
+        cv = np.c_[np.linspace(-3, 3, n), np.zeros(n), np.zeros(n)]
+    else:
+        cv = rng.uniform(-1, 1, (n, 3))
+    cv = cv.astype(np.float32)
+    lo, hi = cv.min(0), cv.max(0)
+    lv = np.r_[rng.uniform(lo - 0.3, hi + 0.3, (3000, 3)), cv[::50] + 0.0625,  # lattice: cell centres
+               rng.uniform(-100, 100, (200, 3))].astype(np.float32)
+    _, _, idx = A.correspond(dev(cv), None, dev(lv))
+    _, _, ridx = O.correspond(cv, None, lv, threads=8)
+    assert np.array_equal(host(idx), ridx)

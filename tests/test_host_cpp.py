@@ -34,7 +34,8 @@ def test_host_library_exports_the_adaptor_classes(exes):
     for name in ("kfusion::cuda::TsdfVolume::integrate", "kfusion::cuda::TsdfVolume::raycast",
                  "kfusion::cuda::TsdfVolume::clear", "kfusion::cuda::computeDists", "Warpfield::calcDQB",
                  "Warpfield::warpToLive", "Warpfield::findNeighborsIndex", "CombinedSolver::initializeProblemInstance",
-                 "CombinedSolver::solveAll"):
+                 "CombinedSolver::solveAll", "DynFusion::warpCanonicalToLiveOpt", "DynFusion::findCorrespondingFrame",
+                 "DynFusion::init", "DynFusion::fuse"):
         assert name in syms, name
 
 
@@ -48,3 +49,9 @@ def test_host_combined_solver_runs_reference_opttests(exes):
 def test_host_tsdf_volume_matches_oracle(exes):
     out = _run(exes["test_host_tsdf"])
     assert "2 tests, 0 failed" in out
+
+
+@pytest.mark.gpu
+def test_host_dynfusion_sequence(exes):
+    out = _run(exes["test_host_dynfusion"])
+    assert "3 tests, 0 failed" in out

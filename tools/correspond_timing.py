@@ -19,7 +19,11 @@ dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 nodes, nw = dev(c["node_pos"]), dev(c["node_w"])
 verts, normals = dev(c["verts"]), dev(c["normals"])
 idx, w = A.knn(nodes, nw, verts, cfg["k"])
-t_true = synth.true_translations(c["node_pos"], 3, cfg["k"])
+# frame-to-frame motion: the canonical cloud has already been warped by the previous frame's field
+# (dyn_fusion.cpp:196), so the live surface is one frame's increment away from it
+t_true = synth.true_translations(c["node_pos"], 3, cfg["k"]) - synth.true_translations(c["node_pos"], 2, cfg["k"])
+if len(sys.argv) > 3:  # "full": the whole displacement of frame 3 (several cells of the grid)
+    t_true = synth.true_translations(c["node_pos"], 3, cfg["k"])
 live = dev(synth.live_vertices(c["verts"], idx.cpu().numpy(), w.cpu().numpy(), t_true))
 # live cloud in a different order than the canonical one (marching cubes gives no alignment)
 perm = torch.randperm(live.shape[0], device="cuda")
