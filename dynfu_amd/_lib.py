@@ -10,7 +10,7 @@ _LIB = None
 SYMBOLS = [
     "dfa_last_error", "dfa_version", "dfa_compute_dists", "dfa_tsdf_clear", "dfa_tsdf_integrate",
     "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_knn", "dfa_warp_to_live",
-    "dfa_correspond",
+    "dfa_correspond", "dfa_marching_cubes", "dfa_mc_default_tables",
     "dfa_solver_create", "dfa_solver_destroy", "dfa_solver_set_problem", "dfa_solver_solve",
     "dfa_solver_translations", "dfa_solver_node_dq", "dfa_solver_tukey_weights", "dfa_solver_huber_weights",
     "dfa_solver_data_graph", "dfa_solver_reg_graph", "dfa_solver_get_stats", "dfa_solver_enable_timing",
@@ -69,6 +69,8 @@ def load():
     L.dfa_tsdf_raycast_depth.argtypes = ray
     L.dfa_knn.argtypes = [vp, vp, i, vp, i, i, vp, vp, vp]
     L.dfa_warp_to_live.argtypes = [vp, vp, vp, i, i, vp, vp, i, vp, vp, vp]
+    L.dfa_marching_cubes.argtypes = [vp, i, i, i, vp, vp, vp, vp, i, vp, vp]
+    L.dfa_mc_default_tables.argtypes = [vp, vp]
     L.dfa_correspond.argtypes = [vp, vp, i, vp, i, vp, vp, vp, vp]
     L.dfa_solver_create.argtypes = [i, i, i, C.POINTER(vp)]
     L.dfa_solver_destroy.argtypes = [vp]
@@ -199,6 +201,29 @@ def tsdf_raycast_depth(vol, voxel_size, trunc, cam2vol, Rinv, fx, fy, cx, cy, st
                                          delta_factor, _dev(depth, torch.uint16, "depth"), depth.stride(0) * 2,
                                          _dev(normals, torch.float32, "normals"), normals.stride(0) * 4, cols, rows,
                                          _stream()))
+
+
+# ----------------------------------------------------------------------- marching-cubes seam
+def mc_default_tables():
+    """(tri_table 256x16, num_verts_table 256) int32 numpy arrays of dfa_mc_default_tables."""
+    import numpy as np
+    tri, nv = np.zeros((256, 16), np.int32), np.zeros(256, np.int32)
+    _check(load().dfa_mc_default_tables(tri.ctypes.data_as(C.c_void_p), nv.ctypes.data_as(C.c_void_p)))
+    return tri, nv
+
+
+def marching_cubes(vol, cell_size, tri_table, num_verts_table, max_vertices):
+    """cuda::MarchingCubes::run.  tri_table / num_verts_table: int32 CUDA tensors (256x16, 256).
+    Returns (points (max_vertices, 4) float32 CUDA tensor, total int32 CUDA tensor of 1 element);
+    only the first min(total, max_vertices) points are written."""
+    torch = _torch()
+    X, Y, Z = _vol_dims(vol)
+    pts = torch.empty((max(max_vertices, 1), 4), dtype=torch.float32, device=vol.device)
+    total = torch.zeros((1,), dtype=torch.int32, device=vol.device)
+    _check(load().dfa_marching_cubes(_dev(vol), X, Y, Z, _farr(cell_size, 3), _dev(tri_table, torch.int32, "tri_table"),
+                                     _dev(num_verts_table, torch.int32, "num_verts_table"),
+                                     _dev(pts) if max_vertices > 0 else None, max_vertices, _dev(total), _stream()))
+    return pts, total
 
 
 def _flat(m):

@@ -96,6 +96,25 @@ struct PointGridScratch {
 };
 thread_local PointGridScratch g_thread_point_grid;
 
+// scratch of dfa_marching_cubes (segment offsets + scan partials); grows on demand
+struct McScratch {
+    int32_t* seg_off    = nullptr;
+    int32_t* chunk_sums = nullptr;
+    long cap_segs       = 0;
+    hipError_t reserve(long nsegs) {
+        if (nsegs <= cap_segs) return hipSuccess;
+        (void)hipFree(seg_off), (void)hipFree(chunk_sums);
+        seg_off = chunk_sums = nullptr, cap_segs = 0;
+        hipError_t e;
+        if ((e = hipMalloc((void**)&seg_off, sizeof(int32_t) * (size_t)(nsegs + 1))) != hipSuccess) return e;
+        if ((e = hipMalloc((void**)&chunk_sums, sizeof(int32_t) * (size_t)dfa::mc_scan_chunks(nsegs))) != hipSuccess)
+            return e;
+        cap_segs = nsegs;
+        return hipSuccess;
+    }
+};
+thread_local McScratch g_thread_mc;
+
 // The standalone entry points (dfa_knn, dfa_warp_to_live) have no plan to keep scratch in:
 // one grid per host thread, reused across calls (stream-ordered use; grows synchronously).
 thread_local GridScratch g_thread_grid;
@@ -232,6 +251,30 @@ int dfa_tsdf_raycast_depth(const uint32_t* volume, int X, int Y, int Z, const fl
     HIP_TRY(dfa::launch_raycast_depth(volume, X, Y, Z, voxel_size, trunc_dist, cam2vol, Rinv, fx, fy, cx, cy,
                                       step_factor, delta_factor, depth, depth_step, normals, normals_step, cols, rows,
                                       S(stream)));
+    return DFA_OK;
+}
+
+// ------------------------------------------------------------------------ marching-cubes seam
+
+int dfa_marching_cubes(const uint32_t* volume, int X, int Y, int Z, const float cell_size[3],
+                       const int32_t* tri_table, const int32_t* num_verts_table, float* out_points, int max_vertices,
+                       int32_t* total_vertices, dfa_stream_t stream) {
+    REQUIRE(volume_args_ok(volume, X, Y, Z), "bad volume");
+    REQUIRE(cell_size && tri_table && num_verts_table, "null parameter block / case tables");
+    REQUIRE(max_vertices >= 0 && (max_vertices == 0 || out_points), "bad output buffer");
+    REQUIRE((long)X * Y * Z / 64 < (1L << 31), "volume too large");
+    const bool vec4  = (X % 4 == 0) && (((uintptr_t)volume & 15) == 0);
+    const long nsegs = dfa::mc_segments(X, Y, Z, vec4);
+    HIP_TRY(g_thread_mc.reserve(nsegs));
+    HIP_TRY(dfa::launch_marching_cubes(volume, X, Y, Z, cell_size, tri_table, num_verts_table, out_points,
+                                       max_vertices, total_vertices, g_thread_mc.seg_off, g_thread_mc.chunk_sums,
+                                       S(stream)));
+    return DFA_OK;
+}
+
+int dfa_mc_default_tables(int32_t* tri_table, int32_t* num_verts_table) {
+    REQUIRE(tri_table && num_verts_table, "null table");
+    dfa::mc_default_tables(tri_table, num_verts_table);
     return DFA_OK;
 }
 

@@ -63,4 +63,13 @@ hipError_t launch_correspond(const float* canon_v, const float* canon_n, int n_c
                              int n_live, float* out_v, float* out_n, int32_t* out_idx, const KnnGridView* grid,
                              hipStream_t s);
 
+// mc.hip
+long mc_segments(int X, int Y, int Z, bool vec4);  // entries of seg_off (+1)
+long mc_scan_chunks(long nsegs);                   // entries of chunk_sums
+hipError_t launch_marching_cubes(const uint32_t* vol, int X, int Y, int Z, const float cell_size[3],
+                                 const int32_t* tri_table, const int32_t* num_verts_table, float* out_points,
+                                 int max_vertices, int32_t* total_vertices, int32_t* seg_off, int32_t* chunk_sums,
+                                 hipStream_t s);
+void mc_default_tables(int32_t tri_table[256 * 16], int32_t num_verts_table[256]);
+
 }  // namespace dfa

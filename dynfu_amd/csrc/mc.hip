@@ -1,0 +1,349 @@
+// mc.hip — marching cubes over the packed TSDF volume for gfx950.
+//
+// Reference semantics: src/kfusion/cuda/marching_cubes.cu (computeCubeIndex :35-73, OccupiedVoxels
+// :75-141, computeOffsetsAndTotalVertices :165-181, TrianglesGenerator :183-257) and the host
+// driver src/kfusion/marching_cubes.cpp:20-61.  The reference hard-codes a 128^3 volume
+// (include/kfusion/internal.hpp:74, marching_cubes.cu:147,283-285); here the dimensions are
+// arguments.
+//
+// MI355X design.  The reference compacts the occupied voxels with one global atomicAdd per warp
+// and z slice (the voxel order of its output therefore changes from run to run), scans with
+// thrust and synchronises with the host three times.  Here the output order is DEFINED — ascending
+// linear voxel index — and nothing leaves the device:
+//   1. count sweep: HBM-bound streaming read of the volume.  A lane owns 4 consecutive x voxels
+//      (one 16-byte load per row), a wave one 256-voxel row segment, a thread marches along z and
+//      keeps the two rows of slice z in registers while it loads slice z + 1; the x + 1 neighbour
+//      comes from the next lane by a wave shuffle.  Output: vertices per segment.
+//   2. exclusive scan of the segment counts (chunked, two small kernels).
+//   3. emit: one wave per segment, segments without vertices leave after reading two integers
+//      (97 % of them for a surface); the others recompute their cubes, place every voxel by a wave
+//      prefix sum and write float4 points {x, y, z, 1} (store_point :255-257).
+// The case tables are arguments (device pointers), as in kfusion::device::bindTextures (:14-19).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "device_math.hpp"
+#include "kernels.hpp"
+
+namespace dfa {
+
+namespace {
+
+struct McArgs {
+    const uint32_t* vol;
+    int X, Y, Z;
+    int nseg;    // row segments per row: ceil(X / (64 * VX))
+    int zchunk;  // count sweep: slices per workgroup
+    float csx, csy, csz;
+    const int32_t* tri;
+    const int32_t* nverts;
+};
+
+// the VX voxels a lane owns in one row plus the voxel after them; zeros (weight 0 -> "no cube",
+// marching_cubes.cu:38-60) wherever the row or the voxel does not exist
+template <int VX>
+struct Row {
+    uint32_t v[VX + 1];
+};
+
+template <int VX>
+__device__ __forceinline__ Row<VX> load_row(const McArgs& a, int x0, int y, int z) {
+    Row<VX> r;
+#pragma unroll
+    for (int i = 0; i <= VX; ++i) r.v[i] = 0u;
+    const bool row_ok = y < a.Y && z < a.Z;
+    const uint32_t* p = a.vol + (size_t)a.X * ((size_t)y + (size_t)a.Y * (size_t)z);
+    if (row_ok && x0 < a.X) {
+        if (VX == 4) {
+            const uint4 q = *reinterpret_cast<const uint4*>(p + x0);
+            r.v[0] = q.x, r.v[1] = q.y, r.v[2] = q.z, r.v[3] = q.w;
+        } else {
+            r.v[0] = p[x0];
+        }
+    }
+    // the neighbour's first voxel; the last lane of the wave reads it from memory
+    const uint32_t next = __shfl_down(r.v[0], 1, 64);
+    if ((threadIdx.x & 63) == 63) {
+        if (row_ok && x0 + VX < a.X) r.v[VX] = p[x0 + VX];
+    } else {
+        r.v[VX] = next;
+    }
+    return r;
+}
+
+// bit c of `neg`: f < 0 (isoValue = 0, internal.hpp:72); returns false if any weight is 0
+__device__ __forceinline__ int cube_case(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t c4, uint32_t c5,
+                                         uint32_t c6, uint32_t c7) {
+    const uint32_t c[8] = {c0, c1, c2, c3, c4, c5, c6, c7};
+    bool valid          = true;
+    int ci              = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        valid = valid && (c[k] >> 16) != 0u;
+        ci |= (int)(half_bits_to_float(c[k] & 0xffffu) < 0.f) << k;  // :63-71
+    }
+    return valid ? ci : 0;
+}
+
+// cube i (0..VX-1) of the lane from the four rows (y,z) (y+1,z) (y,z+1) (y+1,z+1); corner order :37-60
+template <int VX>
+__device__ __forceinline__ int lane_cube(const Row<VX>& a0, const Row<VX>& a1, const Row<VX>& b0, const Row<VX>& b1,
+                                         int i) {
+    return cube_case(a0.v[i], a0.v[i + 1], a1.v[i + 1], a1.v[i], b0.v[i], b0.v[i + 1], b1.v[i + 1], b1.v[i]);
+}
+
+__device__ __forceinline__ int wave_sum_int(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------- 1. count
+template <int VX>
+__global__ __launch_bounds__(256) void mc_count_kernel(const McArgs a, int32_t* __restrict__ seg_count) {
+    __shared__ uint8_t nv_lds[256];
+    {
+        const int t  = threadIdx.y * 64 + threadIdx.x;
+        const int nv = a.nverts[t];
+        nv_lds[t]    = (t == 0 || t == 255) ? 0 : (uint8_t)min(max(nv, 0), 15);  // :99
+    }
+    __syncthreads();
+    const int seg = blockIdx.x, x0 = (seg * 64 + threadIdx.x) * VX;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (y >= a.Y) return;  // whole wave
+    const int z0 = blockIdx.z * a.zchunk, z1 = min(z0 + a.zchunk, a.Z - 1);
+    if (z0 >= z1) return;
+    Row<VX> a0 = load_row<VX>(a, x0, y, z0), a1 = load_row<VX>(a, x0, y + 1, z0);
+    for (int z = z0; z < z1; ++z) {
+        const Row<VX> b0 = load_row<VX>(a, x0, y, z + 1), b1 = load_row<VX>(a, x0, y + 1, z + 1);
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < VX; ++i) n += nv_lds[lane_cube<VX>(a0, a1, b0, b1, i)];
+        n = wave_sum_int(n);
+        if (threadIdx.x == 0 && n) seg_count[((size_t)z * a.Y + y) * a.nseg + seg] = n;
+        a0 = b0, a1 = b1;
+    }
+}
+
+// ------------------------------------------------------------------------------- 2. scan
+constexpr int SCAN_CHUNK = 8192;  // entries per workgroup
+
+__global__ __launch_bounds__(256) void scan_sum_kernel(const int32_t* __restrict__ in, long n,
+                                                       int32_t* __restrict__ chunk_sums) {
+    __shared__ int sh[4];
+    const long base = (long)blockIdx.x * SCAN_CHUNK;
+    int sum         = 0;
+    for (long i = base + threadIdx.x; i < min(base + SCAN_CHUNK, n); i += 256) sum += in[i];
+    sum = wave_sum_int(sum);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// out[i] = sum of in[0..i), out[n] = total; in and out may alias
+__global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* in, long n, int32_t* out,
+                                                         const int32_t* __restrict__ chunk_sums) {
+    __shared__ int sh[4], sh2[4];
+    const long base = (long)blockIdx.x * SCAN_CHUNK;
+    int before      = 0;
+    for (int c = threadIdx.x; c < (int)blockIdx.x; c += 256) before += chunk_sums[c];
+    before = wave_sum_int(before);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = before;
+    constexpr int PER = SCAN_CHUNK / 256;
+    const long first  = base + (long)threadIdx.x * PER;
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) loc[j] = first + j < n ? in[first + j] : 0, sum += loc[j];
+    int incl       = sum;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) sh2[wave] = incl;
+    __syncthreads();
+    int off = sh[0] + sh[1] + sh[2] + sh[3] + incl - sum;
+    for (int w = 0; w < wave; ++w) off += sh2[w];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        if (first + j < n) {
+            out[first + j] = off;
+            off += loc[j];
+            if (first + j == n - 1) out[n] = off;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- 3. emit
+// vertex_interp (:193-199) for one axis-aligned edge; only the coordinate along the edge moves but
+// the reference interpolates all three, and p0 + t * 0 may round differently from p0 only for
+// non-finite t — kept literal.
+__device__ __forceinline__ f3 vertex_interp(f3 p0, f3 p1, float f0, float f1) {
+    const float t = (0.f - f0) / (f1 - f0 + 1e-15f);
+    return mk3(p0.x + t * (p1.x - p0.x), p0.y + t * (p1.y - p0.y), p0.z + t * (p1.z - p0.z));
+}
+
+template <int VX>
+__global__ __launch_bounds__(256) void mc_emit_kernel(const McArgs a, const int32_t* __restrict__ seg_off,
+                                                      float4* __restrict__ out, int max_vertices, long nsegs_total) {
+    const long s = (long)blockIdx.x * 4 + threadIdx.y;  // segment = wave
+    if (s >= nsegs_total) return;
+    const int begin = seg_off[s], end = seg_off[s + 1];
+    if (begin == end || begin >= max_vertices) return;  // whole wave
+    const int seg = (int)(s % a.nseg);
+    const long yz = s / a.nseg;
+    const int y = (int)(yz % a.Y), z = (int)(yz / a.Y);
+    const int x0 = (seg * 64 + threadIdx.x) * VX;
+    const Row<VX> a0 = load_row<VX>(a, x0, y, z), a1 = load_row<VX>(a, x0, y + 1, z);
+    const Row<VX> b0 = load_row<VX>(a, x0, y, z + 1), b1 = load_row<VX>(a, x0, y + 1, z + 1);
+    int ci[VX], nv[VX], mine = 0;
+#pragma unroll
+    for (int i = 0; i < VX; ++i) {
+        ci[i] = lane_cube<VX>(a0, a1, b0, b1, i);
+        nv[i] = (ci[i] == 0 || ci[i] == 255) ? 0 : min(max(a.nverts[ci[i]], 0), 15);
+        mine += nv[i];
+    }
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if ((int)threadIdx.x >= o) incl += t;
+    }
+    int index = begin + incl - mine;
+#pragma unroll
+    for (int i = 0; i < VX; ++i) {
+        if (nv[i] == 0) continue;
+        const int x = x0 + i;
+        const uint32_t c[8] = {a0.v[i], a0.v[i + 1], a1.v[i + 1], a1.v[i], b0.v[i], b0.v[i + 1], b1.v[i + 1], b1.v[i]};
+        float f[8];
+        f3 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            f[k]         = half_bits_to_float(c[k] & 0xffffu);
+            const int dx = (k == 1 || k == 2 || k == 5 || k == 6), dy = (k == 2 || k == 3 || k == 6 || k == 7),
+                      dz = k >> 2;
+            // getNodeCoo :183-191: (i + 0.5) * cell_size
+            v[k] = mk3(((float)(x + dx) + 0.5f) * a.csx, ((float)(y + dy) + 0.5f) * a.csy, ((float)(z + dz) + 0.5f) * a.csz);
+        }
+        for (int j = 0; j < nv[i]; ++j) {
+            const int e = a.tri[ci[i] * 16 + j] & 15;
+            // edge e joins corners (e0, e1): :233-244
+            const int e0 = e < 8 ? e : e - 8;
+            const int e1 = e < 4 ? ((e + 1) & 3) : e < 8 ? 4 + ((e + 1) & 3) : e - 4;
+            f3 p0 = v[0], p1 = v[0];
+            float f0 = f[0], f1 = f[0];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {  // register select instead of dynamic indexing
+                if (k == e0) p0 = v[k], f0 = f[k];
+                if (k == e1) p1 = v[k], f1 = f[k];
+            }
+            const f3 p = vertex_interp(p0, p1, f0, f1);
+            if (index + j < max_vertices) out[index + j] = make_float4(p.x, p.y, p.z, 1.0f);
+        }
+        index += nv[i];
+    }
+}
+
+__global__ void mc_total_kernel(const int32_t* __restrict__ seg_off, long nsegs_total, int32_t* __restrict__ total) {
+    *total = seg_off[nsegs_total];
+}
+
+}  // namespace
+
+long mc_segments(int X, int Y, int Z, bool vec4) {
+    const int vx = vec4 ? 4 : 1;
+    return (long)((X + 64 * vx - 1) / (64 * vx)) * Y * Z;
+}
+long mc_scan_chunks(long nsegs) { return (nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK; }
+
+hipError_t launch_marching_cubes(const uint32_t* vol, int X, int Y, int Z, const float cell_size[3],
+                                 const int32_t* tri_table, const int32_t* num_verts_table, float* out_points,
+                                 int max_vertices, int32_t* total_vertices, int32_t* seg_off, int32_t* chunk_sums,
+                                 hipStream_t s) {
+    const bool vec4 = (X % 4 == 0) && (((uintptr_t)vol & 15) == 0);
+    const int vx    = vec4 ? 4 : 1;
+    McArgs a;
+    a.vol = vol, a.X = X, a.Y = Y, a.Z = Z;
+    a.nseg = (X + 64 * vx - 1) / (64 * vx);
+    a.csx = cell_size[0], a.csy = cell_size[1], a.csz = cell_size[2];
+    a.tri = tri_table, a.nverts = num_verts_table;
+    const long nsegs = (long)a.nseg * Y * Z;
+    // z chunks: >= 2048 workgroups when the volume allows, chunks of at least 16 slices
+    const long columns = (long)a.nseg * ((Y + 3) / 4);
+    int zchunk         = Z;
+    while (columns * ((Z + zchunk - 1) / zchunk) < 2048 && zchunk > 16) zchunk = (zchunk + 1) / 2;
+    a.zchunk = zchunk;
+    hipError_t e = hipMemsetAsync(seg_off, 0, sizeof(int32_t) * (size_t)(nsegs + 1), s);
+    if (e != hipSuccess) return e;
+    dim3 block(64, 4), grid(a.nseg, (Y + 3) / 4, (Z + zchunk - 1) / zchunk);
+    if (vec4) mc_count_kernel<4><<<grid, block, 0, s>>>(a, seg_off);
+    else mc_count_kernel<1><<<grid, block, 0, s>>>(a, seg_off);
+    const int chunks = (int)mc_scan_chunks(nsegs);
+    scan_sum_kernel<<<chunks, 256, 0, s>>>(seg_off, nsegs, chunk_sums);
+    scan_apply_kernel<<<chunks, 256, 0, s>>>(seg_off, nsegs, seg_off, chunk_sums);
+    if (out_points && max_vertices > 0) {
+        const unsigned eblocks = (unsigned)((nsegs + 3) / 4);
+        if (vec4) mc_emit_kernel<4><<<eblocks, block, 0, s>>>(a, seg_off, (float4*)out_points, max_vertices, nsegs);
+        else mc_emit_kernel<1><<<eblocks, block, 0, s>>>(a, seg_off, (float4*)out_points, max_vertices, nsegs);
+    }
+    if (total_vertices) mc_total_kernel<<<1, 1, 0, s>>>(seg_off, nsegs, total_vertices);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------- default case tables
+// A marching-cubes case table derived from first principles (host code, runs once): for every
+// sign configuration the crossed edges are joined face by face — two crossings of a face by one
+// segment, four crossings (the ambiguous face) by the two segments that cut off the INSIDE
+// corners, a rule that depends on the face's own corners only and therefore matches across
+// neighbouring cubes — the segments close into loops, and every loop is fan-triangulated from its
+// lowest edge id.  Corner / edge numbering and winding as the reference's kernels expect
+// (corners marching_cubes.cu:37-60, edges :233-244, case 1 = {0, 8, 3}).  It is NOT the
+// hand-made table the reference compiles in (src/kfusion/marching_cubes.cpp:86-343): pass that one
+// to dfa_marching_cubes for output identical to the reference's; this one is for callers that
+// have none.  At most 5 triangles per case, as the 16-wide rows require.
+void mc_default_tables(int32_t tri_table[256 * 16], int32_t num_verts_table[256]) {
+    static const int corner_of_edge[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6},
+                                              {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+    // corner cycles of the six faces, counter-clockwise seen from outside the cube
+    static const int face[6][4] = {{0, 3, 2, 1}, {4, 5, 6, 7}, {0, 1, 5, 4}, {3, 7, 6, 2}, {0, 4, 7, 3}, {1, 2, 6, 5}};
+    int edge_id[8][8];
+    for (auto& r : edge_id)
+        for (int& v : r) v = -1;
+    for (int e = 0; e < 12; ++e)
+        edge_id[corner_of_edge[e][0]][corner_of_edge[e][1]] = edge_id[corner_of_edge[e][1]][corner_of_edge[e][0]] = e;
+    for (int cs = 0; cs < 256; ++cs) {
+        int next[12];
+        for (int& v : next) v = -1;
+        for (const auto& fc : face) {
+            int ce[4], leaving[4], n = 0;  // crossings met on the ccw walk: edge, 1 if the walk leaves the inside
+            for (int j = 0; j < 4; ++j) {
+                const int p = fc[j], q = fc[(j + 1) & 3];
+                const int ip = (cs >> p) & 1, iq = (cs >> q) & 1;
+                if (ip != iq) ce[n] = edge_id[p][q], leaving[n] = ip, ++n;
+            }
+            // segments run from an "enter" crossing to the following "leave" crossing, so that each
+            // one cuts off the inside corners between them
+            for (int j = 0; j < n; ++j)
+                if (!leaving[j]) next[ce[j]] = ce[(j + 1) % n];
+        }
+        int32_t* row = tri_table + cs * 16;
+        for (int j = 0; j < 16; ++j) row[j] = -1;
+        int nv = 0;
+        bool used[12] = {false};
+        for (int start = 0; start < 12; ++start) {
+            if (next[start] < 0 || used[start]) continue;
+            int loop[12], len = 0;
+            for (int e = start; !used[e]; e = next[e]) used[e] = true, loop[len++] = e;
+            // reverse the walk (winding of case 1 = {0, 8, 3}); `start` is the loop's lowest edge id
+            int rl[12];
+            rl[0] = loop[0];
+            for (int j = 1; j < len; ++j) rl[j] = loop[len - j];
+            for (int j = 1; j + 1 < len; ++j) row[nv++] = rl[0], row[nv++] = rl[j], row[nv++] = rl[j + 1];
+        }
+        num_verts_table[cs] = nv;
+    }
+}
+
+}  // namespace dfa

@@ -87,6 +87,33 @@ int dfa_tsdf_raycast_depth(const uint32_t* volume, int X, int Y, int Z, const fl
                            int normals_step, int cols, int rows, dfa_stream_t stream);
 
 /* ===================================================================================== */
+/* Marching-cubes seam — replaces kfusion::device::{bindTextures, getOccupiedVoxels,        */
+/* computeOffsetsAndTotalVertices, generateTriangles} (include/kfusion/internal.hpp:121-150, */
+/* src/kfusion/cuda/marching_cubes.cu), driven by cuda::MarchingCubes::run                  */
+/* (src/kfusion/marching_cubes.cpp:20-61)                                                   */
+
+/* One call = the whole extraction, nothing synchronises with the host.
+ * volume: packed TSDF as above, any dims >= 2 (the reference is fixed to 128^3).
+ * cell_size: edge lengths of a cell (the reference passes volume_size / 128 = the voxel size,
+ *   marching_cubes.cu:283-285).
+ * tri_table (256 x 16 edge ids, -1 padded) and num_verts_table (256): DEVICE pointers, the
+ *   buffers the reference binds as textures (marching_cubes.cu:14-19).
+ * out_points: max_vertices float4 {x, y, z, 1} (store_point :255-257), three per triangle, in
+ *   ascending linear voxel order z*X*Y + y*X + x (the reference's order is atomics-dependent);
+ *   may be NULL with max_vertices = 0 to count only.
+ * total_vertices (device, optional): vertices the volume produces; when it exceeds max_vertices
+ *   only the first max_vertices were written. */
+int dfa_marching_cubes(const uint32_t* volume, int X, int Y, int Z, const float cell_size[3],
+                       const int32_t* tri_table, const int32_t* num_verts_table, float* out_points, int max_vertices,
+                       int32_t* total_vertices, dfa_stream_t stream);
+
+/* A valid case table pair for callers that do not have the reference's (HOST buffers, 256 x 16
+ * and 256 ints): derived from the face-by-face rule described in csrc/mc.hip.  Same corner / edge
+ * numbering and winding as the reference's table (src/kfusion/marching_cubes.cpp:86-343) but not
+ * the same triangulation of every case — pass the reference's arrays for identical meshes. */
+int dfa_mc_default_tables(int32_t* tri_table, int32_t* num_verts_table);
+
+/* ===================================================================================== */
 /* Warp-field seam — replaces the per-vertex CPU loops of class Warpfield                */
 /* (src/dynfu/warp_field.cpp:99-171, src/dynfu/utils/node.cpp:29-36)                     */
 

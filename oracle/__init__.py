@@ -20,7 +20,9 @@ def build(force=False):
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc", ".cpp"))]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     ref_so = os.path.join(_HERE, "_ref", "libref_knn.so")
-    if stale or (not os.path.exists(ref_so) and os.path.exists("/root/reference/include/nanoflann/nanoflann.hpp")):
+    ref_mc = os.path.join(_HERE, "_ref", "mc_tables.bin")
+    have_ref = os.path.exists("/root/reference/include/nanoflann/nanoflann.hpp")
+    if stale or (have_ref and not (os.path.exists(ref_so) and os.path.exists(ref_mc))):
         subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
     return so
 
@@ -46,6 +48,18 @@ def ref_lib():
         _REF.ref_knn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _REF.ref_knn.restype = None
     return _REF
+
+
+def ref_mc_tables():
+    """The reference's marching-cubes case tables (oracle/_ref/mc_tables.bin, extracted from the
+    reference checkout at build time); None if not built.  Returns (tri 256x16, num_verts 256) int32."""
+    p = os.path.join(_HERE, "_ref", "mc_tables.bin")
+    if not os.path.exists(p):
+        build()
+    if not os.path.exists(p):
+        return None
+    a = np.fromfile(p, dtype="<i4")
+    return np.ascontiguousarray(a[:4096].reshape(256, 16)), np.ascontiguousarray(a[4096:])
 
 
 class SolveParams(C.Structure):
@@ -103,6 +117,8 @@ def _declare(L):
     for n in ("roll", "pitch", "yaw"):
         getattr(L, "orc_dq_" + n).argtypes = [vp]
         getattr(L, "orc_dq_" + n).restype = f
+    L.orc_marching_cubes.argtypes = [vp, i, i, i, vp, vp, vp, vp, C.c_long, vp]
+    L.orc_marching_cubes.restype = C.c_long
     L.orc_knn.argtypes = [vp, i, vp, i, i, vp, i]
     L.orc_transformation_weight.argtypes = [vp, f, vp]
     L.orc_transformation_weight.restype = f
@@ -245,6 +261,21 @@ def dq_yaw(a):
 
 
 # ------------------------------------------------------------------ warp field -----
+def marching_cubes(vol, cell_size, tri_table, num_verts_table, max_vertices=None):
+    """orc_marching_cubes: (points float32 (n,4), total vertices, occupied voxels).  vol: uint32 (Z,Y,X)."""
+    vol = np.ascontiguousarray(vol, np.uint32)
+    Z, Y, X = vol.shape
+    tri = np.ascontiguousarray(tri_table, np.int32)
+    nv = np.ascontiguousarray(num_verts_table, np.int32)
+    cs = _f32(cell_size)
+    occ = C.c_long(0)
+    if max_vertices is None:  # count first
+        max_vertices = lib().orc_marching_cubes(_p(vol), X, Y, Z, _p(cs), _p(tri), _p(nv), None, 0, C.byref(occ))
+    out = np.zeros((max(max_vertices, 1), 4), np.float32)
+    total = lib().orc_marching_cubes(_p(vol), X, Y, Z, _p(cs), _p(tri), _p(nv), _p(out), max_vertices, C.byref(occ))
+    return out[:min(total, max_vertices)], total, occ.value
+
+
 def knn(nodes, query, k, threads=1):
     nodes, query = _f32(nodes), _f32(query)
     idx = np.empty((len(query), k), np.int32)

@@ -69,6 +69,13 @@ void orc_tsdf_raycast_depth(const uint32_t* vol, int X, int Y, int Z, const floa
                             float step_factor, float delta_factor, uint16_t* depth, int depth_step, float* normals,
                             int normals_step, int cols, int rows, int threads);
 
+/* ------------------------------------------------------- marching cubes -- */
+/* src/kfusion/cuda/marching_cubes.cu (see mc_oracle.c); PARITY UNPINNED.  Case tables are
+ * arguments (256 x 16 edge ids, -1 padded; 256 vertex counts).  Returns the total vertex count;
+ * writes at most max_vertices float4 points in ascending linear voxel order. */
+long orc_marching_cubes(const uint32_t* vol, int X, int Y, int Z, const float cell_size[3], const int32_t* tri_table,
+                        const int32_t* num_verts_table, float* out_points, long max_vertices, long* occupied);
+
 /* ------------------------------------------------------- dual quaternion -- */
 /* DualQuaternion<float> (include/dynfu/utils/dual_quaternion.hpp). Storage:
  * 8 floats = real (w,x,y,z) then dual (w,x,y,z); Hamilton product as
