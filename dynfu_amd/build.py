@@ -71,7 +71,8 @@ def build(force=False, verbose=False):
 
 HOST = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(HERE, "libdynfu_amd_host.so")
-HOST_SOURCES = ["device.cpp", "tsdf_volume.cpp", "warp_field.cpp", "opt_solver.cpp", "dyn_fusion.cpp"]
+HOST_SOURCES = ["device.cpp", "tsdf_volume.cpp", "warp_field.cpp", "opt_solver.cpp", "dyn_fusion.cpp",
+                "marching_cubes.cpp"]
 
 
 def build_host(force=False, verbose=False):

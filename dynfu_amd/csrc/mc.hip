@@ -15,12 +15,15 @@
 //      keeps the two rows of slice z in registers while it loads slice z + 1; the x + 1 neighbour
 //      comes from the next lane by a wave shuffle.  Output: vertices per segment.
 //   2. exclusive scan of the segment counts (chunked, two small kernels).
-//   3. emit: one wave per segment, segments without vertices leave after reading two integers
-//      (97 % of them for a surface); the others recompute their cubes, place every voxel by a wave
-//      prefix sum and write float4 points {x, y, z, 1} (store_point :255-257).
+//   3. emit: persistent waves look for segments with vertices (3 % of them for a surface), stage
+//      such a segment's four rows in LDS, and then every lane produces one VERTEX at a time (its
+//      cube found by a binary search over the cube offsets): 64 consecutive float4 points
+//      {x, y, z, 1} (store_point :255-257) per wave store.
 // The case tables are arguments (device pointers), as in kfusion::device::bindTextures (:14-19).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "device_math.hpp"
@@ -72,6 +75,40 @@ __device__ __forceinline__ Row<VX> load_row(const McArgs& a, int x0, int y, int 
     return r;
 }
 
+// NR consecutive rows y .. y + NR - 1 of slice z.  The voxel after the wave's last one is fetched for
+// all NR rows by ONE load instruction (lane r reads row r's) and handed to lane 63 by a readlane —
+// the sweep is bound by vector-memory instruction issue, not by bytes.
+template <int VX, int NR>
+__device__ __forceinline__ void load_rows(const McArgs& a, int x0, int y, int z, Row<VX> (&out)[NR]) {
+    const int lane = threadIdx.x & 63;
+    const bool z_ok = z < a.Z;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        Row<VX>& o = out[r];
+#pragma unroll
+        for (int i = 0; i <= VX; ++i) o.v[i] = 0u;
+        const uint32_t* p = a.vol + (size_t)a.X * ((size_t)(y + r) + (size_t)a.Y * (size_t)z);
+        if (z_ok && y + r < a.Y && x0 < a.X) {
+            if (VX == 4) {
+                const uint4 q = *reinterpret_cast<const uint4*>(p + x0);
+                o.v[0] = q.x, o.v[1] = q.y, o.v[2] = q.z, o.v[3] = q.w;
+            } else {
+                o.v[0] = p[x0];
+            }
+        }
+    }
+    const int xend = (x0 - lane * VX) + 64 * VX;  // first voxel of the next segment
+    uint32_t extra = 0u;
+    if (lane < NR && z_ok && y + lane < a.Y && xend < a.X)
+        extra = a.vol[(size_t)xend + (size_t)a.X * ((size_t)(y + lane) + (size_t)a.Y * (size_t)z)];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const uint32_t next = __shfl_down(out[r].v[0], 1, 64);
+        const uint32_t last = __shfl(extra, r, 64);
+        out[r].v[VX]        = lane == 63 ? last : next;
+    }
+}
+
 // bit c of `neg`: f < 0 (isoValue = 0, internal.hpp:72); returns false if any weight is 0
 __device__ __forceinline__ int cube_case(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t c4, uint32_t c5,
                                          uint32_t c6, uint32_t c7) {
@@ -100,29 +137,46 @@ __device__ __forceinline__ int wave_sum_int(int v) {
 }
 
 // ------------------------------------------------------------------------------- 1. count
+// wave total of per-lane triangle counts in [0, 31]: five ballots + scalar popcounts, no
+// cross-lane dependency chain in the z loop
+__device__ __forceinline__ int wave_sum_5bit(int n) {
+    int s = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) s += __popcll(__ballot((n >> b) & 1)) << b;
+    return s;
+}
+
+constexpr int MC_ROWS = 2;  // rows of cubes per wave: 3 row loads per slice serve 2 rows (y+1 shared)
+
 template <int VX>
 __global__ __launch_bounds__(256) void mc_count_kernel(const McArgs a, int32_t* __restrict__ seg_count) {
-    __shared__ uint8_t nv_lds[256];
+    __shared__ uint8_t ntri_lds[256];  // triangles per case
     {
         const int t  = threadIdx.y * 64 + threadIdx.x;
         const int nv = a.nverts[t];
-        nv_lds[t]    = (t == 0 || t == 255) ? 0 : (uint8_t)min(max(nv, 0), 15);  // :99
+        ntri_lds[t]  = (t == 0 || t == 255) ? 0 : (uint8_t)(min(max(nv, 0), 15) / 3);  // :99
     }
     __syncthreads();
     const int seg = blockIdx.x, x0 = (seg * 64 + threadIdx.x) * VX;
-    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int y = (blockIdx.y * 4 + threadIdx.y) * MC_ROWS;
     if (y >= a.Y) return;  // whole wave
     const int z0 = blockIdx.z * a.zchunk, z1 = min(z0 + a.zchunk, a.Z - 1);
     if (z0 >= z1) return;
-    Row<VX> a0 = load_row<VX>(a, x0, y, z0), a1 = load_row<VX>(a, x0, y + 1, z0);
+    Row<VX> lo[MC_ROWS + 1];
+    load_rows<VX, MC_ROWS + 1>(a, x0, y, z0, lo);
     for (int z = z0; z < z1; ++z) {
-        const Row<VX> b0 = load_row<VX>(a, x0, y, z + 1), b1 = load_row<VX>(a, x0, y + 1, z + 1);
-        int n = 0;
+        Row<VX> hi[MC_ROWS + 1];
+        load_rows<VX, MC_ROWS + 1>(a, x0, y, z + 1, hi);
 #pragma unroll
-        for (int i = 0; i < VX; ++i) n += nv_lds[lane_cube<VX>(a0, a1, b0, b1, i)];
-        n = wave_sum_int(n);
-        if (threadIdx.x == 0 && n) seg_count[((size_t)z * a.Y + y) * a.nseg + seg] = n;
-        a0 = b0, a1 = b1;
+        for (int r = 0; r < MC_ROWS; ++r) {
+            int n = 0;
+#pragma unroll
+            for (int i = 0; i < VX; ++i) n += ntri_lds[lane_cube<VX>(lo[r], lo[r + 1], hi[r], hi[r + 1], i)];
+            n = wave_sum_5bit(n);  // VX * 5 <= 20 triangles per lane
+            if (threadIdx.x == 0 && n && y + r < a.Y) seg_count[((size_t)z * a.Y + y + r) * a.nseg + seg] = 3 * n;
+        }
+#pragma unroll
+        for (int r = 0; r <= MC_ROWS; ++r) lo[r] = hi[r];
     }
 }
 
@@ -143,7 +197,8 @@ __global__ __launch_bounds__(256) void scan_sum_kernel(const int32_t* __restrict
 
 // out[i] = sum of in[0..i), out[n] = total; in and out may alias
 __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* in, long n, int32_t* out,
-                                                         const int32_t* __restrict__ chunk_sums) {
+                                                         const int32_t* __restrict__ chunk_sums,
+                                                         int32_t* __restrict__ total) {
     __shared__ int sh[4], sh2[4];
     const long base = (long)blockIdx.x * SCAN_CHUNK;
     int before      = 0;
@@ -171,7 +226,10 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* in, long
         if (first + j < n) {
             out[first + j] = off;
             off += loc[j];
-            if (first + j == n - 1) out[n] = off;
+            if (first + j == n - 1) {
+                out[n] = off;
+                if (total) *total = off;
+            }
         }
     }
 }
@@ -185,69 +243,122 @@ __device__ __forceinline__ f3 vertex_interp(f3 p0, f3 p1, float f0, float f1) {
     return mk3(p0.x + t * (p1.x - p0.x), p0.y + t * (p1.y - p0.y), p0.z + t * (p1.z - p0.z));
 }
 
+// per-wave staging of one segment in LDS: the half-float tsdf of the four rows (64 * VX + 1 voxels
+// each) and, per cube, its case and the offset of its first vertex inside the segment
 template <int VX>
-__global__ __launch_bounds__(256) void mc_emit_kernel(const McArgs a, const int32_t* __restrict__ seg_off,
-                                                      float4* __restrict__ out, int max_vertices, long nsegs_total) {
-    const long s = (long)blockIdx.x * 4 + threadIdx.y;  // segment = wave
-    if (s >= nsegs_total) return;
-    const int begin = seg_off[s], end = seg_off[s + 1];
-    if (begin == end || begin >= max_vertices) return;  // whole wave
+struct SegStage {
+    static constexpr int W = 64 * VX + 1;
+    uint16_t f[4][W + 3];
+    uint16_t start[64 * VX];
+    uint8_t ci[64 * VX];
+};
+
+// one segment, the whole wave cooperating (wave-uniform arguments).  Lanes first own cubes (case
+// and vertex count, wave prefix sum), then own VERTICES: vertex t of the segment finds its cube by
+// a binary search over the cube offsets, its edge in the case table, and interpolates — 64
+// consecutive float4 stores per wave instead of lanes looping over their own cubes' vertices.
+template <int VX>
+__device__ __forceinline__ void emit_segment(const McArgs& a, const uint8_t* __restrict__ tri_lds,
+                                             const uint8_t* __restrict__ nv_lds, SegStage<VX>& st, long s, int begin,
+                                             int count, float4* __restrict__ out, int max_vertices) {
     const int seg = (int)(s % a.nseg);
     const long yz = s / a.nseg;
     const int y = (int)(yz % a.Y), z = (int)(yz / a.Y);
-    const int x0 = (seg * 64 + threadIdx.x) * VX;
-    const Row<VX> a0 = load_row<VX>(a, x0, y, z), a1 = load_row<VX>(a, x0, y + 1, z);
-    const Row<VX> b0 = load_row<VX>(a, x0, y, z + 1), b1 = load_row<VX>(a, x0, y + 1, z + 1);
-    int ci[VX], nv[VX], mine = 0;
+    const int lane = threadIdx.x & 63;
+    const int x0   = (seg * 64 + lane) * VX;
+    Row<VX> r[4];  // (y,z) (y+1,z) (y,z+1) (y+1,z+1)
+    r[0] = load_row<VX>(a, x0, y, z), r[1] = load_row<VX>(a, x0, y + 1, z);
+    r[2] = load_row<VX>(a, x0, y, z + 1), r[3] = load_row<VX>(a, x0, y + 1, z + 1);
+    int ci[VX], mine = 0;
 #pragma unroll
     for (int i = 0; i < VX; ++i) {
-        ci[i] = lane_cube<VX>(a0, a1, b0, b1, i);
-        nv[i] = (ci[i] == 0 || ci[i] == 255) ? 0 : min(max(a.nverts[ci[i]], 0), 15);
-        mine += nv[i];
+        ci[i] = lane_cube<VX>(r[0], r[1], r[2], r[3], i);
+        mine += nv_lds[ci[i]];
     }
     int incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const int t = __shfl_up(incl, o, 64);
-        if ((int)threadIdx.x >= o) incl += t;
+        if (lane >= o) incl += t;
     }
-    int index = begin + incl - mine;
+    int off = incl - mine;
 #pragma unroll
     for (int i = 0; i < VX; ++i) {
-        if (nv[i] == 0) continue;
-        const int x = x0 + i;
-        const uint32_t c[8] = {a0.v[i], a0.v[i + 1], a1.v[i + 1], a1.v[i], b0.v[i], b0.v[i + 1], b1.v[i + 1], b1.v[i]};
-        float f[8];
-        f3 v[8];
+        st.ci[lane * VX + i]    = (uint8_t)ci[i];
+        st.start[lane * VX + i] = (uint16_t)off;
+        off += nv_lds[ci[i]];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            f[k]         = half_bits_to_float(c[k] & 0xffffu);
-            const int dx = (k == 1 || k == 2 || k == 5 || k == 6), dy = (k == 2 || k == 3 || k == 6 || k == 7),
-                      dz = k >> 2;
-            // getNodeCoo :183-191: (i + 0.5) * cell_size
-            v[k] = mk3(((float)(x + dx) + 0.5f) * a.csx, ((float)(y + dy) + 0.5f) * a.csy, ((float)(z + dz) + 0.5f) * a.csz);
-        }
-        for (int j = 0; j < nv[i]; ++j) {
-            const int e = a.tri[ci[i] * 16 + j] & 15;
-            // edge e joins corners (e0, e1): :233-244
-            const int e0 = e < 8 ? e : e - 8;
-            const int e1 = e < 4 ? ((e + 1) & 3) : e < 8 ? 4 + ((e + 1) & 3) : e - 4;
-            f3 p0 = v[0], p1 = v[0];
-            float f0 = f[0], f1 = f[0];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {  // register select instead of dynamic indexing
-                if (k == e0) p0 = v[k], f0 = f[k];
-                if (k == e1) p1 = v[k], f1 = f[k];
-            }
-            const f3 p = vertex_interp(p0, p1, f0, f1);
-            if (index + j < max_vertices) out[index + j] = make_float4(p.x, p.y, p.z, 1.0f);
-        }
-        index += nv[i];
+        for (int q = 0; q < 4; ++q) st.f[q][lane * VX + i] = (uint16_t)(r[q].v[i] & 0xffffu);
     }
+    if (lane == 63) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) st.f[q][64 * VX] = (uint16_t)(r[q].v[VX] & 0xffffu);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int t = lane; t < count; t += 64) {
+        // last cube whose first vertex is at or before t (cubes without vertices share the offset of
+        // the next cube that has some, so the last one is the owner)
+        int lo = 0, hi = 64 * VX;  // answer in [lo, hi)
+#pragma unroll
+        for (int step = 0; step < (VX == 4 ? 8 : 6); ++step) {
+            const int mid = (lo + hi) >> 1;
+            if ((int)st.start[mid] <= t) lo = mid;
+            else hi = mid;
+        }
+        const int c  = lo;
+        const int cs = st.ci[c];
+        const int e  = tri_lds[cs * 16 + (t - (int)st.start[c])];
+        // edge e joins corners (e0, e1): :233-244; corner k sits at (dx, dy, dz) = bits of 0x66, 0xCC, k >> 2
+        const int e0 = e < 8 ? e : e - 8;
+        const int e1 = e < 4 ? ((e + 1) & 3) : e < 8 ? 4 + ((e + 1) & 3) : e - 4;
+        const int dx0 = (0x66 >> e0) & 1, dy0 = (0xCC >> e0) & 1, dz0 = e0 >> 2;
+        const int dx1 = (0x66 >> e1) & 1, dy1 = (0xCC >> e1) & 1, dz1 = e1 >> 2;
+        const int x   = seg * 64 * VX + c;
+        const float f0 = half_bits_to_float(st.f[dy0 + 2 * dz0][c + dx0]);
+        const float f1 = half_bits_to_float(st.f[dy1 + 2 * dz1][c + dx1]);
+        // getNodeCoo :183-191: (i + 0.5) * cell_size
+        const f3 p0 = mk3(((float)(x + dx0) + 0.5f) * a.csx, ((float)(y + dy0) + 0.5f) * a.csy, ((float)(z + dz0) + 0.5f) * a.csz);
+        const f3 p1 = mk3(((float)(x + dx1) + 0.5f) * a.csx, ((float)(y + dy1) + 0.5f) * a.csy, ((float)(z + dz1) + 0.5f) * a.csz);
+        const f3 p  = vertex_interp(p0, p1, f0, f1);
+        if (begin + t < max_vertices) out[begin + t] = make_float4(p.x, p.y, p.z, 1.0f);
+    }
+    __builtin_amdgcn_wave_barrier();  // the next segment overwrites the staging area
 }
 
-__global__ void mc_total_kernel(const int32_t* __restrict__ seg_off, long nsegs_total, int32_t* __restrict__ total) {
-    *total = seg_off[nsegs_total];
+// Persistent waves.  97 % of the segments of a surface volume are empty, and the others cluster in
+// space, so wave w looks at the segments w, w + W, w + 2W, ... (W = waves of the grid): lane l reads
+// the offsets of segment w + (64 i + l) W, a ballot finds the ones with vertices and the wave emits
+// them one after the other — neighbouring segments land on different waves.
+template <int VX>
+__global__ __launch_bounds__(256) void mc_emit_kernel(const McArgs a, const int32_t* __restrict__ seg_off,
+                                                      float4* __restrict__ out, int max_vertices, long nsegs_total) {
+    // case tables in LDS: a vertex costs one dependent table read, and lanes emit up to 4 x 15 of them
+    __shared__ uint8_t tri_lds[256 * 16], nv_lds[256];
+    __shared__ SegStage<VX> stage[4];
+    {
+        const int t = threadIdx.y * 64 + threadIdx.x;
+        for (int j = 0; j < 16; ++j) tri_lds[t * 16 + j] = (uint8_t)(a.tri[t * 16 + j] & 15);
+        nv_lds[t] = (t == 0 || t == 255) ? 0 : (uint8_t)(3 * (min(max(a.nverts[t], 0), 15) / 3));
+    }
+    __syncthreads();
+    const long nwaves = (long)gridDim.x * 4;
+    const long w      = (long)blockIdx.x * 4 + threadIdx.y;
+    const int lane    = threadIdx.x;
+    for (long base = w; base < nsegs_total; base += 64 * nwaves) {
+        const long s = base + (long)lane * nwaves;
+        int begin = 0, end = 0;
+        if (s < nsegs_total) begin = seg_off[s], end = seg_off[s + 1];
+        unsigned long long todo = __ballot(end > begin && begin < max_vertices);
+        while (todo) {
+            const int l = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int b = __shfl(begin, l, 64);
+            emit_segment<VX>(a, tri_lds, nv_lds, stage[threadIdx.y], base + (long)l * nwaves, b, __shfl(end, l, 64) - b, out,
+                             max_vertices);
+        }
+    }
 }
 
 }  // namespace
@@ -271,24 +382,27 @@ hipError_t launch_marching_cubes(const uint32_t* vol, int X, int Y, int Z, const
     a.tri = tri_table, a.nverts = num_verts_table;
     const long nsegs = (long)a.nseg * Y * Z;
     // z chunks: >= 2048 workgroups when the volume allows, chunks of at least 16 slices
-    const long columns = (long)a.nseg * ((Y + 3) / 4);
+    const long columns = (long)a.nseg * ((Y + 4 * MC_ROWS - 1) / (4 * MC_ROWS));
     int zchunk         = Z;
     while (columns * ((Z + zchunk - 1) / zchunk) < 2048 && zchunk > 16) zchunk = (zchunk + 1) / 2;
     a.zchunk = zchunk;
+    // only segments with vertices are written by the count sweep (an unconditional 4-byte store per
+    // wave and slice costs 25 %: the sweep is bound by vector-memory instruction issue)
     hipError_t e = hipMemsetAsync(seg_off, 0, sizeof(int32_t) * (size_t)(nsegs + 1), s);
     if (e != hipSuccess) return e;
-    dim3 block(64, 4), grid(a.nseg, (Y + 3) / 4, (Z + zchunk - 1) / zchunk);
+    dim3 block(64, 4), grid(a.nseg, (Y + 4 * MC_ROWS - 1) / (4 * MC_ROWS), (Z + zchunk - 1) / zchunk);
     if (vec4) mc_count_kernel<4><<<grid, block, 0, s>>>(a, seg_off);
     else mc_count_kernel<1><<<grid, block, 0, s>>>(a, seg_off);
     const int chunks = (int)mc_scan_chunks(nsegs);
     scan_sum_kernel<<<chunks, 256, 0, s>>>(seg_off, nsegs, chunk_sums);
-    scan_apply_kernel<<<chunks, 256, 0, s>>>(seg_off, nsegs, seg_off, chunk_sums);
+    scan_apply_kernel<<<chunks, 256, 0, s>>>(seg_off, nsegs, seg_off, chunk_sums, total_vertices);
     if (out_points && max_vertices > 0) {
-        const unsigned eblocks = (unsigned)((nsegs + 3) / 4);
+        long want = 8192;
+        if (const char* e = getenv("DFA_MC_EMIT_BLOCKS")) want = std::max(1L, atol(e));
+        const unsigned eblocks = (unsigned)std::min<long>((nsegs + 3) / 4, want);
         if (vec4) mc_emit_kernel<4><<<eblocks, block, 0, s>>>(a, seg_off, (float4*)out_points, max_vertices, nsegs);
         else mc_emit_kernel<1><<<eblocks, block, 0, s>>>(a, seg_off, (float4*)out_points, max_vertices, nsegs);
     }
-    if (total_vertices) mc_total_kernel<<<1, 1, 0, s>>>(seg_off, nsegs, total_vertices);
     return hipGetLastError();
 }
 

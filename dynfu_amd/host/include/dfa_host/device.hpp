@@ -15,6 +15,8 @@ class DeviceMemory {  // kfusion::cuda::DeviceMemory ("CudaData")
 public:
     DeviceMemory() : size_(0) {}
     explicit DeviceMemory(size_t bytes) { create(bytes); }
+    // non-owning wrapper of user memory (device_memory.cpp:54-56)
+    DeviceMemory(void* ptr, size_t bytes) : data_(ptr, [](void*) {}), size_(bytes) {}
     void create(size_t bytes);  // no-op when the size is unchanged (device_memory.cpp:90-104)
     void release() {
         data_.reset();
@@ -47,6 +49,7 @@ class DeviceArray : public DeviceMemory {
 public:
     DeviceArray() {}
     explicit DeviceArray(size_t n) : DeviceMemory(n * sizeof(T)) {}
+    DeviceArray(T* ptr, size_t n) : DeviceMemory(ptr, n * sizeof(T)) {}  // non-owning (device_array.hpp)
     void create(size_t n) { DeviceMemory::create(n * sizeof(T)); }
     void upload(const std::vector<T>& v) {
         create(v.size());

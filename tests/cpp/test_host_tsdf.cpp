@@ -3,8 +3,10 @@
 // TSDF tests; the call sequence is KinFu's (src/kfusion/kinfu.cpp:47-60,206-225).
 #include <cstring>
 
+#include <kfusion/cuda/marching_cubes.hpp>
 #include <kfusion/cuda/tsdf_volume.hpp>
 
+#include "../../include/dynfu_amd.h"
 #include "../../oracle/oracle.h"
 #include "minitest.hpp"
 
@@ -106,6 +108,54 @@ TEST(TsdfVolumeTest, IntegrateAndRaycastMatchTheOracleBitExactly) {
     cuda::CudaData other;
     vol.swap(other);
     ASSERT_TRUE(vol.data().empty() && other.sizeBytes() == (size_t)DIM * DIM * DIM * 4);
+}
+
+// cuda::MarchingCubes::run as DynFusion::operator() calls it (dyn_fusion.cpp:73-75,119-121): mesh of an
+// integrated depth frame, bit-exact against the oracle given the same case tables
+TEST(MarchingCubesTest, RunMatchesTheOracleBitExactly) {
+    const int W = 160, H = 120, DIM = 64;
+    const Intr intr(131.25f, 131.25f, W / 2 - 0.5f, H / 2 - 0.5f);
+    cuda::TsdfVolume vol(Vec3i::all(DIM));
+    vol.setTruncDist(0.04f), vol.setMaxWeight(64), vol.setSize(Vec3f::all(3.f));
+    vol.setPose(Affine3f().translate(Vec3f(-1.5f, -1.5f, 0.5f)));
+    cuda::Depth d_depth;
+    d_depth.upload(make_depth(W, H), W);
+    cuda::Dists dists;
+    cuda::computeDists(d_depth, dists, intr);
+    vol.clearAndIntegrate(dists, Affine3f(), intr);
+
+    cuda::MarchingCubes mc;
+    dfa::DeviceArray<cuda::MarchingCubes::PointType> buffer;
+    auto triangles = mc.run(vol, buffer);
+    ASSERT_EQ(buffer.size(), (size_t)cuda::MarchingCubes::DEFAULT_TRIANGLES_BUFFER_SIZE);  // marching_cubes.cpp:23-25
+    ASSERT_TRUE(triangles.size() > 3000 && triangles.size() % 3 == 0);
+    ASSERT_EQ((int)triangles.size(), mc.totalVertices());
+
+    std::vector<uint32_t> h_vol((size_t)DIM * DIM * DIM);
+    vol.data().download(h_vol.data(), h_vol.size() * 4);
+    std::vector<int32_t> tri(256 * 16), nv(256);
+    ASSERT_EQ(dfa_mc_default_tables(tri.data(), nv.data()), 0);
+    const Vec3f vs = vol.getVoxelSize();
+    std::vector<float> ref(4 * triangles.size());
+    long occupied = 0;
+    const long total = orc_marching_cubes(h_vol.data(), DIM, DIM, DIM, vs.v, tri.data(), nv.data(), ref.data(),
+                                          (long)triangles.size(), &occupied);
+    ASSERT_EQ(total, (long)triangles.size());
+    std::vector<cuda::MarchingCubes::PointType> got;
+    triangles.download(got);
+    ASSERT_TRUE(std::memcmp(got.data(), ref.data(), ref.size() * 4) == 0);
+
+    // a buffer that is too small gets the first points only
+    dfa::DeviceArray<cuda::MarchingCubes::PointType> small(300);
+    auto part = mc.run(vol, small);
+    ASSERT_EQ(part.size(), (size_t)300);
+    ASSERT_EQ(mc.totalVertices(), (int)total);
+    part.download(got);
+    ASSERT_TRUE(std::memcmp(got.data(), ref.data(), 300 * 16) == 0);
+
+    // an empty volume gives an empty array (marching_cubes.cpp:42-46)
+    vol.clear();
+    ASSERT_TRUE(mc.run(vol, buffer).empty());
 }
 
 int main(int argc, char** argv) { return mt::run_all(argc, argv); }
