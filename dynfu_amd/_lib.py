@@ -11,11 +11,34 @@ SYMBOLS = [
     "dfa_last_error", "dfa_version", "dfa_compute_dists", "dfa_tsdf_clear", "dfa_tsdf_integrate",
     "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_knn", "dfa_warp_to_live",
     "dfa_correspond", "dfa_marching_cubes", "dfa_mc_default_tables",
+    "dfa_compute_points_normals", "dfa_solver6_create", "dfa_solver6_destroy", "dfa_solver6_set_problem",
+    "dfa_solver6_solve", "dfa_solver6_node_dq", "dfa_solver6_warp", "dfa_solver6_get_stats",
     "dfa_solver_create", "dfa_solver_destroy", "dfa_solver_set_problem", "dfa_solver_solve",
     "dfa_solver_translations", "dfa_solver_node_dq", "dfa_solver_tukey_weights", "dfa_solver_huber_weights",
     "dfa_solver_data_graph", "dfa_solver_reg_graph", "dfa_solver_get_stats", "dfa_solver_enable_timing",
     "dfa_solver_get_timing",
 ]
+
+
+class Solve6Params(C.Structure):
+    """dfa_solve6_params (north-star solve)"""
+    _fields_ = [("num_iter", C.c_int), ("gn_iter", C.c_int), ("linear_iter", C.c_int), ("tukey_offset", C.c_float),
+                ("psi_data", C.c_float), ("lambda_", C.c_float), ("psi_reg", C.c_float), ("dist_thresh", C.c_float),
+                ("cos_thresh", C.c_float), ("damping", C.c_float), ("pcg_tol", C.c_float)]
+
+    DEFAULTS = dict(num_iter=2, gn_iter=3, linear_iter=100, tukey_offset=4.652, psi_data=0.01, lambda_=200.0,
+                    psi_reg=1e-4, dist_thresh=0.1, cos_thresh=0.5, damping=1e-4, pcg_tol=1e-6)
+
+    def __init__(self, **kw):
+        d = dict(self.DEFAULTS)
+        d.update(kw)
+        super().__init__(*[d[n] for n, _ in self._fields_])
+
+
+class _Solve6Stats(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("gn_iters", C.c_int), ("pcg_iters", C.c_int),
+                ("valid_first", C.c_longlong), ("valid_last", C.c_longlong), ("max_row_blocks", C.c_int),
+                ("overflow", C.c_int)]
 
 
 class DynfuAmdError(RuntimeError):
@@ -69,6 +92,16 @@ def load():
     L.dfa_tsdf_raycast_depth.argtypes = ray
     L.dfa_knn.argtypes = [vp, vp, i, vp, i, i, vp, vp, vp]
     L.dfa_warp_to_live.argtypes = [vp, vp, vp, i, i, vp, vp, i, vp, vp, vp]
+    L.dfa_compute_points_normals.argtypes = [vp, i, i, i, f, f, f, f, vp, i, vp, i, vp]
+    L.dfa_solver6_create.argtypes = [i, i, i, C.POINTER(vp)]
+    L.dfa_solver6_destroy.argtypes = [vp]
+    L.dfa_solver6_destroy.restype = None
+    L.dfa_solver6_set_problem.argtypes = [vp, vp, vp, vp, i, vp, vp, i, vp]
+    L.dfa_solver6_solve.argtypes = [vp, vp, i, vp, i, i, i, f, f, f, f, C.POINTER(Solve6Params), vp]
+    L.dfa_solver6_node_dq.argtypes = [vp]
+    L.dfa_solver6_node_dq.restype = vp
+    L.dfa_solver6_warp.argtypes = [vp, vp, vp, vp]
+    L.dfa_solver6_get_stats.argtypes = [vp, C.POINTER(_Solve6Stats), vp]
     L.dfa_marching_cubes.argtypes = [vp, i, i, i, vp, vp, vp, vp, i, vp, vp]
     L.dfa_mc_default_tables.argtypes = [vp, vp]
     L.dfa_correspond.argtypes = [vp, vp, i, vp, i, vp, vp, vp, vp]
@@ -348,3 +381,69 @@ class Solver:
         _check(load().dfa_solver_get_stats(self._h, C.byref(st), _stream()))
         return dict(initial_cost=st.initial_cost, final_cost=st.final_cost, gn_iters=st.gn_iters,
                     pcg_iters=st.pcg_iters, max_row_nnz=st.max_row_nnz)
+
+
+# ------------------------------------------------------------------------ north-star solver seam
+def compute_points_normals(depth, fx, fy, cx, cy):
+    """kfusion::cuda::computePointNormals: (points, normals) float32 (H, W, 4) CUDA tensors"""
+    torch = _torch()
+    rows, cols = depth.shape
+    pts = torch.empty((rows, cols, 4), dtype=torch.float32, device=depth.device)
+    nrm = torch.empty_like(pts)
+    _check(load().dfa_compute_points_normals(_dev(depth, torch.uint16, "depth"), depth.stride(0) * 2, cols, rows, fx, fy,
+                                             cx, cy, _dev(pts), cols * 16, _dev(nrm), cols * 16, _stream()))
+    return pts, nrm
+
+
+class Solver6:
+    """dfa_solver6 plan: the north-star 6-DoF solve."""
+
+    def __init__(self, max_D, max_N, k):
+        _torch()
+        self._h = C.c_void_p()
+        self.k, self.max_D, self.max_N = k, max_D, max_N
+        _check(load().dfa_solver6_create(max_D, max_N, k, C.byref(self._h)))
+        self._keep = None
+        self.D = self.N = 0
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            load().dfa_solver6_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def set_problem(self, node_pos, node_dq, node_w, canon, canon_normals=None):
+        f32 = _torch().float32
+        self.D, self.N = node_pos.shape[0], canon.shape[0]
+        self._keep = (node_pos, node_dq, node_w, canon, canon_normals)  # borrowed by the plan
+        _check(load().dfa_solver6_set_problem(self._h, _dev(node_pos, f32, "node_pos"), _dev(node_dq, f32, "node_dq"),
+                                              _dev(node_w, f32, "node_w"), self.D, _dev(canon, f32, "canon"),
+                                              _dev(canon_normals, f32, "canon_normals"), self.N, _stream()))
+
+    def solve(self, vmap, nmap, fx, fy, cx, cy, params):
+        f32 = _torch().float32
+        rows, cols = vmap.shape[:2]
+        _check(load().dfa_solver6_solve(self._h, _dev(vmap, f32, "vmap"), vmap.stride(0) * 4, _dev(nmap, f32, "nmap"),
+                                        nmap.stride(0) * 4, cols, rows, fx, fy, cx, cy, C.byref(params), _stream()))
+
+    def node_dq(self):
+        torch = _torch()
+        ptr = load().dfa_solver6_node_dq(self._h)
+
+        class _Holder:
+            __cuda_array_interface__ = dict(shape=(self.D, 8), typestr="<f4", data=(int(ptr), False), version=2)
+
+        return torch.as_tensor(_Holder(), device="cuda").clone()
+
+    def warp(self, want_normals=True):
+        torch = _torch()
+        out_v = torch.empty((self.N, 3), dtype=torch.float32, device="cuda")
+        out_n = torch.empty_like(out_v) if want_normals and self._keep[4] is not None else None
+        _check(load().dfa_solver6_warp(self._h, _dev(out_v), _dev(out_n), _stream()))
+        return out_v, out_n
+
+    def stats(self):
+        st = _Solve6Stats()
+        _check(load().dfa_solver6_get_stats(self._h, C.byref(st), _stream()))
+        return {n: getattr(st, n) for n, _ in _Solve6Stats._fields_}

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libdynfu_amd.so")
-SOURCES = ["tsdf.hip", "warp.hip", "solve.hip", "mc.hip", "capi.cpp"]
+SOURCES = ["tsdf.hip", "warp.hip", "solve.hip", "solve6.hip", "mc.hip", "capi.cpp"]
 ARCH = "gfx950"
 EXTRA = os.environ.get("DFA_EXTRA_CXXFLAGS", "").split()
 FLAGS = EXTRA + ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function",

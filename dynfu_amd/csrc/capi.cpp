@@ -13,6 +13,7 @@
 #include "../../include/dynfu_amd.h"
 #include "kernels.hpp"
 #include "solve.hpp"
+#include "solve6.hpp"
 
 namespace {
 
@@ -140,6 +141,30 @@ struct dfa_solver {
     std::vector<int> ev_pcg, ev_asm; // indices of the begin events of each bracketed launch
     size_t ev_used;
 };
+
+struct dfa_solver6 {
+    int max_D, max_N, k;
+    dfa::Solve6View v;
+    dfa::Solve6State* state;
+    float* raw_w;       // N x k un-normalised weights of the k-NN pass
+    int32_t* raw_reg;   // D x (k + 1)
+    const float* node_dq;  // borrowed: transforms at set_problem time
+    std::vector<void*> blocks;
+    GridScratch grid;
+    bool has_problem;
+};
+
+namespace {
+template <class T>
+int plan6_alloc(dfa_solver6* s, T** out, size_t count) {
+    void* p      = nullptr;
+    hipError_t e = hipMalloc(&p, sizeof(T) * (count ? count : 1));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc (solver6 plan)");
+    s->blocks.push_back(p);
+    *out = (T*)p;
+    return DFA_OK;
+}
+}  // namespace
 
 namespace {
 // returns the index of a fresh event pair's begin event, recorded on st
@@ -537,6 +562,159 @@ int dfa_solver_get_timing(dfa_solver* s, dfa_solve_timing* out, dfa_stream_t str
         out->matrix_nnz = nnz;
     }
     return DFA_OK;
+}
+
+// -------------------------------------------------------------------- north-star solver seam
+
+int dfa_compute_points_normals(const uint16_t* depth, int depth_step, int cols, int rows, float fx, float fy, float cx,
+                               float cy, float* points, int points_step, float* normals, int normals_step,
+                               dfa_stream_t stream) {
+    REQUIRE(depth && points && normals && cols > 0 && rows > 0, "bad images");
+    REQUIRE(depth_step >= cols * 2 && points_step >= cols * 16 && normals_step >= cols * 16, "row step smaller than a row");
+    REQUIRE(fx != 0.f && fy != 0.f, "zero focal length");
+    HIP_TRY(dfa::launch_points_normals(depth, depth_step, cols, rows, fx, fy, cx, cy, points, points_step, normals,
+                                       normals_step, S(stream)));
+    return DFA_OK;
+}
+
+int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
+    REQUIRE(out, "null out");
+    *out = nullptr;
+    REQUIRE(max_D > 0 && max_N >= 0, "bad sizes");
+    REQUIRE(k >= 1 && k <= 8, "k out of range 1..8");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DFA_ERR_NO_GPU, "no HIP device");
+    dfa_solver6* s = new (std::nothrow) dfa_solver6();
+    REQUIRE(s, "out of host memory");
+    s->max_D = max_D, s->max_N = max_N, s->k = k, s->has_problem = false, s->node_dq = nullptr;
+    std::memset(&s->v, 0, sizeof(s->v));
+    s->v.cap = 64;
+    const size_t N = (size_t)max_N, D = (size_t)max_D, cap = (size_t)s->v.cap;
+    int rc = DFA_OK;
+#define A(field, count) \
+    if (rc == DFA_OK) rc = plan6_alloc(s, &s->v.field, (count))
+    A(idx, N * k);
+    A(wn, N * k);
+    A(reg_idx, D * k);
+    A(blk_hist, D * dfa::SOLVE_TG_BLOCKS);
+    A(node_ptr, D + 1);
+    A(node_list, N * k);
+    A(rnode_ptr, D + 1);
+    A(rnode_list, D * k);
+    A(dq, D * 8);
+    A(ghat, D * 3);
+    A(avec, N * k * 6);
+    A(res, N);
+    A(rho, N);
+    A(wrow, N);
+    A(rres, D * k * 3);
+    A(rvec, D * k * 18);
+    A(rhub, D * k);
+    A(bcols, D * cap);
+    A(bcnt, D);
+    A(bvals, D * cap * 36);
+    A(minv, D * 36);
+    A(g, D * 6);
+    A(x, D * 6);
+    A(z, D * 6);
+    A(q, D * 6);
+    A(r[0], D * 6);
+    A(r[1], D * 6);
+    A(p[0], D * 6);
+    A(p[1], D * 6);
+    A(pq_part, (size_t)dfa::s6_matvec_blocks(max_D));
+    A(rz_part[0], (size_t)dfa::s6_update_blocks(max_D));
+    A(rz_part[1], (size_t)dfa::s6_update_blocks(max_D));
+#undef A
+    if (rc == DFA_OK) rc = plan6_alloc(s, &s->raw_w, N * k);
+    if (rc == DFA_OK) rc = plan6_alloc(s, &s->raw_reg, D * (k + 1));
+    if (rc == DFA_OK) rc = plan6_alloc(s, &s->state, 1);
+    if (rc == DFA_OK) {
+        hipError_t e = s->grid.reserve(max_D);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMalloc (node grid)");
+    }
+    if (rc != DFA_OK) {
+        dfa_solver6_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return DFA_OK;
+}
+
+void dfa_solver6_destroy(dfa_solver6* s) {
+    if (!s) return;
+    for (void* p : s->blocks) (void)hipFree(p);
+    s->grid.release();
+    delete s;
+}
+
+int dfa_solver6_set_problem(dfa_solver6* s, const float* node_pos, const float* node_dq, const float* node_w, int D,
+                            const float* canon_vertices, const float* canon_normals, int N, dfa_stream_t stream) {
+    REQUIRE(s, "null plan");
+    REQUIRE(node_pos && node_dq && node_w && D > 0, "no nodes");
+    REQUIRE(N >= 0 && (N == 0 || canon_vertices), "bad vertex arrays");
+    if (D > s->max_D || N > s->max_N) return fail(DFA_ERR_CAPACITY, "problem larger than the plan");
+    dfa::Solve6View& v = s->v;
+    v.N = N, v.D = D, v.k = s->k;
+    v.node_pos = node_pos, v.node_w = node_w, v.canon = canon_vertices, v.canon_n = canon_normals;
+    s->node_dq = node_dq;
+    const dfa::KnnGridView* grid = nullptr;
+    if (want_grid(D, N)) {
+        HIP_TRY(dfa::knn_grid_build(s->grid.v, node_pos, D, S(stream)));
+        grid = &s->grid.v;
+    }
+    HIP_TRY(dfa::launch_knn(node_pos, node_w, D, canon_vertices, N, s->k, v.idx, s->raw_w, grid, S(stream)));
+    const int kreg = s->k + 1;
+    HIP_TRY(dfa::launch_knn(node_pos, node_w, D, node_pos, D, kreg, s->raw_reg, nullptr, grid, S(stream)));
+    HIP_TRY(dfa::s6_build_graph(v, s->raw_w, s->raw_reg, kreg, S(stream)));
+    s->has_problem = true;
+    return DFA_OK;
+}
+
+int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_step, const float* live_normal_map,
+                      int normal_step, int cols, int rows, float fx, float fy, float cx, float cy,
+                      const dfa_solve6_params* prm, dfa_stream_t stream) {
+    REQUIRE(s && s->has_problem, "no problem set");
+    REQUIRE(prm, "null params");
+    REQUIRE(live_vertex_map && live_normal_map && cols > 0 && rows > 0, "bad live maps");
+    REQUIRE(vertex_step >= cols * 16 && normal_step >= cols * 16, "row step smaller than a row");
+    REQUIRE(prm->num_iter >= 0 && prm->gn_iter >= 0 && prm->linear_iter >= 0, "negative iteration count");
+    REQUIRE(prm->tukey_offset > 0.f && prm->psi_data > 0.f && prm->psi_reg > 0.f, "non-positive robust parameter");
+    REQUIRE(prm->damping >= 0.f && prm->lambda >= 0.f, "negative damping / lambda");
+    dfa::Solve6Params p{prm->num_iter, prm->gn_iter, prm->linear_iter, prm->tukey_offset, prm->psi_data, prm->lambda,
+                        prm->psi_reg, prm->dist_thresh, prm->cos_thresh, prm->damping, prm->pcg_tol};
+    dfa::Solve6Image img{live_vertex_map, live_normal_map, vertex_step, normal_step, cols, rows, fx, fy, cx, cy};
+    hipStream_t st = S(stream);
+    HIP_TRY(dfa::s6_begin(s->v, s->state, s->node_dq, st));
+    for (int outer = 0; outer < p.num_iter; ++outer)
+        for (int gn = 0; gn < p.gn_iter; ++gn) {
+            HIP_TRY(dfa::s6_linearise(s->v, s->state, img, p, gn == 0, st));
+            HIP_TRY(dfa::s6_assemble(s->v, s->state, p, st));
+            HIP_TRY(dfa::s6_pcg(s->v, s->state, p, st));
+            HIP_TRY(dfa::s6_update(s->v, s->state, st));
+        }
+    return DFA_OK;
+}
+
+const float* dfa_solver6_node_dq(const dfa_solver6* s) { return s ? s->v.dq : nullptr; }
+
+int dfa_solver6_warp(dfa_solver6* s, float* out_vertices, float* out_normals, dfa_stream_t stream) {
+    REQUIRE(s && s->has_problem, "no problem set");
+    REQUIRE(out_vertices, "null output");
+    HIP_TRY(dfa::s6_warp(s->v, s->v.dq, out_vertices, out_normals, S(stream)));
+    return DFA_OK;
+}
+
+int dfa_solver6_get_stats(dfa_solver6* s, dfa_solve6_stats* out, dfa_stream_t stream) {
+    REQUIRE(s && out, "null argument");
+    dfa::Solve6State h;
+    HIP_TRY(hipMemcpyAsync(&h, s->state, sizeof(h), hipMemcpyDeviceToHost, S(stream)));
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    out->initial_cost = h.initial_cost, out->final_cost = h.final_cost;
+    out->gn_iters = h.gn_iters, out->pcg_iters = h.pcg_iters;
+    out->valid_first = (long long)h.valid_first, out->valid_last = (long long)h.valid_last;
+    out->max_row_blocks = h.max_row_blocks, out->overflow = h.overflow;
+    return h.overflow ? fail(DFA_ERR_CAPACITY, "a block row of the normal matrix exceeded the plan's capacity") : DFA_OK;
 }
 
 }  // extern "C"

@@ -1004,6 +1004,16 @@ __global__ __launch_bounds__(256) void writeback_kernel(SolveView s) {
         else kernel<16> __VA_ARGS__;                   \
     } while (0)
 
+// node -> (row, slot) lists of any R x k index array (shared with solve6.hip)
+hipError_t solve_transpose_graph(const int32_t* ridx, size_t total, int D, int32_t* blk_hist, int32_t* node_ptr,
+                                 uint32_t* node_list, hipStream_t st) {
+    const size_t lds = sizeof(int32_t) * (size_t)D;
+    tg_count_kernel<<<TG_BLOCKS, 1024, lds, st>>>(ridx, total, D, blk_hist);
+    tg_scan_kernel<<<1, 1024, 0, st>>>(blk_hist, D, node_ptr);
+    tg_fill_kernel<<<TG_BLOCKS, 1024, lds, st>>>(ridx, total, D, blk_hist, node_list);
+    return hipGetLastError();
+}
+
 hipError_t solve_build_graph(const SolveView& s, hipStream_t st) {
     const int D = s.D, N = s.N, k = s.k;
     const size_t R = (size_t)N + (size_t)D * k, total = R * k;

@@ -59,6 +59,10 @@ struct SolveView {
 
 constexpr int SOLVE_TG_BLOCKS = 64;
 hipError_t solve_build_graph(const SolveView& s, hipStream_t st);
+// counting-sort transposition of an (rows x k) node-index array: blk_hist = SOLVE_TG_BLOCKS x D scratch,
+// node_ptr = D + 1, node_list = flat (row * k + slot) indices grouped by node (entries < 0 skipped)
+hipError_t solve_transpose_graph(const int32_t* ridx, size_t total, int D, int32_t* blk_hist, int32_t* node_ptr,
+                                 uint32_t* node_list, hipStream_t st);
 int solve_residual_blocks(const SolveView& s);
 // robust weights (optional) + residuals + cost + Gauss-Newton control, one launch
 hipError_t solve_linearise(const SolveView& s, SolveState* state, double* cost_partials, unsigned int* ticket,

@@ -1,0 +1,761 @@
+// solve6.hip — the NORTH-STAR solve on gfx950: 6-DoF twist per deformation node, dual-quaternion
+// blend of the k nearest nodes with normalised weights, projective point-to-plane data term
+// against the live vertex / normal maps, ARAP-style edge regulariser, Gauss-Newton with a
+// block-Jacobi (6x6) preconditioned CG on the block-sparse normal equations.
+//
+// Not in the reference's code: BASELINE.json:north_star / SURVEY.md App. B.2 ask for it, DESIGN.md
+// §4.5 fixes the formulas, oracle/solve6_oracle.c states them on the CPU in double precision.  The
+// reference pieces this follows where they apply: the point-to-plane row [s x n, n | n.(d - s)] and
+// the nearest-pixel projective lookup of the rigid ICP (src/kfusion/cuda/proj_icp.cu:72-98,343-350),
+// the RBF weight (src/dynfu/utils/node.cpp:29-36), the Tukey / Huber weights
+// (src/dynfu/utils/opt_solver.cpp:204-268), w_reg^2 = lambda / (D k) (opt_solver.cpp:30).
+//
+// Per Gauss-Newton iteration (all launches on one stream, nothing returns to the host):
+//   s6_nodes      g^_i = T_i(g_i), clears the cost accumulators
+//   s6_linearise  one lane per vertex: blend, project, gate, residual, Tukey weight, and the row's
+//                 k 6-vectors n . dp/dxi_j through two per-vertex linear functionals (8 MACs per
+//                 column instead of three quaternion products)
+//   s6_reg        one lane per regularisation edge
+//   s6_assemble   one workgroup per node: gathers the rows that touch the node through the
+//                 transposed graph, reduces their 6x6 outer products into an LDS hash keyed by the
+//                 column node (diagonal block in registers), writes a block-ELL row, the inverse of
+//                 the damped diagonal block and the gradient.  No global atomics on the matrix.
+//   s6_pcg_*      two launches per PCG iteration (kernel boundaries are the grid barriers: 3 us each,
+//                 a hand-rolled grid barrier is >= 4 us on this part): matvec with p = z + beta p
+//                 folded into the gather, one WAVE per block row (lane = (slot mod 10, row of the
+//                 6x6 block): 1.4 KB contiguous per wave load); then x, r, z = M^-1 r.  Scalars are
+//                 re-summed from per-workgroup partials by every workgroup (deterministic).
+//   s6_update     T_i <- twist about g^_i applied on the left
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "dq_device.hpp"
+#include "kernels.hpp"
+#include "solve.hpp"
+#include "solve6.hpp"
+
+namespace dfa {
+
+namespace {
+
+__device__ __forceinline__ Quat qconj(Quat a) { return Quat{a.w, -a.x, -a.y, -a.z}; }
+__device__ __forceinline__ float qdot(Quat a, Quat b) { return a.w * b.w + a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ Quat pureq(f3 v) { return Quat{0.f, v.x, v.y, v.z}; }
+__device__ __forceinline__ f3 qvec(Quat a) { return mk3(a.x, a.y, a.z); }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// e_c^ (x) q for the basis vectors e_x, e_y, e_z
+__device__ __forceinline__ Quat basis_mul(int c, Quat q) {
+    return c == 0 ? Quat{-q.x, q.w, -q.z, q.y} : c == 1 ? Quat{-q.y, q.z, q.w, -q.x} : Quat{-q.z, -q.y, q.x, q.w};
+}
+// rotation + translation of a unit dual quaternion
+__device__ __forceinline__ f3 dq_point(DQ q, f3 c) {
+    const f3 rc = qvec(qmul(qmul(q.r, pureq(c)), qconj(q.r)));
+    const f3 t  = qvec(qmul(q.d, qconj(q.r)));
+    return mk3(rc.x + 2.f * t.x, rc.y + 2.f * t.y, rc.z + 2.f * t.z);
+}
+
+// ------------------------------------------------------------------------------------ graphs
+__global__ __launch_bounds__(256) void s6_normalise_kernel(const float* __restrict__ raw_w, int N, int k,
+                                                           float* __restrict__ wn) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    float sum = 0.f;
+    for (int j = 0; j < k; ++j) sum += raw_w[(size_t)v * k + j];
+    for (int j = 0; j < k; ++j) wn[(size_t)v * k + j] = sum > 0.f ? raw_w[(size_t)v * k + j] / sum : 0.f;
+}
+
+// k nearest OTHER nodes from a (k + 1)-NN list of the nodes among themselves
+__global__ __launch_bounds__(256) void s6_reg_graph_kernel(const int32_t* __restrict__ raw, int D, int kreg, int k,
+                                                           int32_t* __restrict__ reg_idx) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= D) return;
+    int o = 0;
+    for (int j = 0; j < kreg && o < k; ++j) {
+        const int m = raw[(size_t)n * kreg + j];
+        if (m >= 0 && m != n) reg_idx[(size_t)n * k + o++] = m;
+    }
+    for (; o < k; ++o) reg_idx[(size_t)n * k + o] = -1;
+}
+
+// ------------------------------------------------------------------------------------ blend
+template <int K>
+struct Blend {
+    Quat a, b;   // un-normalised blended real / dual parts
+    float m;     // |a|^2
+    float s[K];  // hemisphere sign of each neighbour (0 = unused slot)
+};
+
+template <int K>
+__device__ __forceinline__ void blend(const float* __restrict__ dq, const int32_t* idx, const float* wn, int k,
+                                      Blend<K>& B) {
+    B.a = Quat{0.f, 0.f, 0.f, 0.f}, B.b = B.a;
+    Quat r0   = Quat{1.f, 0.f, 0.f, 0.f};
+    bool have = false;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        B.s[j] = 0.f;
+        if (j >= k || idx[j] < 0 || wn[j] == 0.f) continue;
+        const DQ q = dq_load(dq + 8 * (size_t)idx[j]);
+        if (!have) r0 = q.r, have = true;
+        const float sg = qdot(q.r, r0) < 0.f ? -1.f : 1.f;
+        B.s[j]         = sg;
+        const float w  = wn[j] * sg;
+        B.a = qadd(B.a, qscale(q.r, w)), B.b = qadd(B.b, qscale(q.d, w));
+    }
+    B.m = qdot(B.a, B.a);
+}
+
+template <int K>
+__device__ __forceinline__ f3 blend_point(const Blend<K>& B, f3 c) {
+    const Quat ac = qconj(B.a);
+    const f3 u    = qvec(qmul(qmul(B.a, pureq(c)), ac));
+    const f3 t    = qvec(qmul(B.b, ac));
+    const float im = 1.f / B.m;
+    return mk3((u.x + 2.f * t.x) * im, (u.y + 2.f * t.y) * im, (u.z + 2.f * t.z) * im);
+}
+template <int K>
+__device__ __forceinline__ f3 blend_normal(const Blend<K>& B, f3 n) {
+    const f3 u     = qvec(qmul(qmul(B.a, pureq(n)), qconj(B.a)));
+    const float im = 1.f / B.m;
+    return mk3(u.x * im, u.y * im, u.z * im);
+}
+
+// ------------------------------------------------------------------------------- per iteration
+__global__ __launch_bounds__(256) void s6_nodes_kernel(Solve6View s, Solve6State* st) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0) st->cost = 0.0, st->valid = 0ull;
+    if (n >= s.D) return;
+    const f3 g = dq_point(dq_load(s.dq + 8 * (size_t)n), mk3(s.node_pos[3 * n], s.node_pos[3 * n + 1], s.node_pos[3 * n + 2]));
+    s.ghat[3 * n] = g.x, s.ghat[3 * n + 1] = g.y, s.ghat[3 * n + 2] = g.z;
+}
+
+__device__ __forceinline__ float tukey6(float err, float offset, float c) {  // opt_solver.cpp:204-231
+    const float e = err / offset;
+    if (e < c) {
+        const float t = 1.f - (e * e) / (c * c);
+        return t * t;
+    }
+    return 0.f;
+}
+
+__device__ __forceinline__ void block_add_cost(double cost, unsigned int nvalid, Solve6State* st) {
+    __shared__ double sc[8];
+    __shared__ unsigned int sn[8];
+    cost   = wave_sum_all(cost);
+    nvalid = (unsigned int)wave_sum_all((double)nvalid);
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) sc[wave] = cost, sn[wave] = nvalid;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double c = 0;
+        unsigned int n = 0;
+        for (int w = 0; w < nw; ++w) c += sc[w], n += sn[w];
+        if (c != 0.0) atomicAdd(&st->cost, c);
+        if (n) atomicAdd(&st->valid, (unsigned long long)n);
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void s6_linearise_kernel(Solve6View s, Solve6State* st, Solve6Image img,
+                                                           Solve6Params prm, int update_w) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    double cost = 0.0;
+    unsigned int nvalid = 0;
+    if (v < s.N) {
+        const int k = s.k;
+        int32_t idx[K];
+        float wn[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            idx[j] = j < k ? s.idx[(size_t)v * k + j] : -1;
+            wn[j]  = j < k ? s.wn[(size_t)v * k + j] : 0.f;
+        }
+        float* av = s.avec + (size_t)v * k * 6;
+        float w_eff = 0.f, rr = 0.f;
+        bool ok     = false;
+        Blend<K> B;
+        blend<K>(s.dq, idx, wn, k, B);
+        const f3 c = mk3(s.canon[3 * (size_t)v], s.canon[3 * (size_t)v + 1], s.canon[3 * (size_t)v + 2]);
+        f3 p = c, nl = mk3(0.f, 0.f, 0.f);
+        if (B.m > 0.f) {
+            p = blend_point<K>(B, c);
+            if (p.z > 0.f) {
+                // nearest pixel (proj_icp.cu:80-86 uses __float2int_rn)
+                const int u = (int)rintf(img.fx * (p.x / p.z) + img.cx), w = (int)rintf(img.fy * (p.y / p.z) + img.cy);
+                if (u >= 0 && w >= 0 && u < img.cols && w < img.rows) {
+                    const float4 L  = *reinterpret_cast<const float4*>((const char*)img.vmap + (size_t)w * img.vstep + 16 * (size_t)u);
+                    const float4 Ln = *reinterpret_cast<const float4*>((const char*)img.nmap + (size_t)w * img.nstep + 16 * (size_t)u);
+                    if (L.x == L.x && Ln.x == Ln.x) {
+                        const f3 dl      = mk3(p.x - L.x, p.y - L.y, p.z - L.z);
+                        const float dist = sqrtf(dot3(dl, dl));
+                        nl               = mk3(Ln.x, Ln.y, Ln.z);
+                        bool gate        = dist <= prm.dist_thresh;
+                        if (gate && s.canon_n) {
+                            const f3 n0 = mk3(s.canon_n[3 * (size_t)v], s.canon_n[3 * (size_t)v + 1], s.canon_n[3 * (size_t)v + 2]);
+                            gate        = dot3(blend_normal<K>(B, n0), nl) >= prm.cos_thresh;
+                        }
+                        if (gate) ok = true, rr = dot3(nl, dl);
+                    }
+                }
+            }
+        }
+        if (ok) {
+            if (update_w) s.rho[v] = tukey6(fabsf(rr), prm.tukey_offset, prm.psi_data);
+            w_eff = s.rho[v];
+            // n . dp = lW . W + lD . Wd  for the twist's (W, Wd) = (omega^ r, omega^ d + v0^ r), times w~ s / m
+            const Quat ac = qconj(B.a), nq = pureq(nl);
+            const Quat T = qmul(ac, nq);                                  // a* n^
+            const Quat U = qmul(qmul(pureq(c), ac), nq);                  // (c^ a*) n^
+            const Quat S = qscale(qmul(qconj(B.b), nq), -1.f);            // -b* n^
+            const float np = dot3(nl, p);
+            const Quat lD = Quat{-T.w, T.x, T.y, T.z};
+            const Quat lW = Quat{-(U.w + S.w) - np * B.a.w, (U.x + S.x) - np * B.a.x, (U.y + S.y) - np * B.a.y,
+                                 (U.z + S.z) - np * B.a.z};
+            const float im = 1.f / B.m;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                if (j >= k) continue;
+                float o[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (B.s[j] != 0.f) {
+                    const int n  = idx[j];
+                    const DQ q   = dq_load(s.dq + 8 * (size_t)n);
+                    const f3 gh  = mk3(s.ghat[3 * n], s.ghat[3 * n + 1], s.ghat[3 * n + 2]);
+                    const float f = wn[j] * B.s[j] * im;
+#pragma unroll
+                    for (int col = 0; col < 3; ++col) {
+                        // rotation about g^: origin form v0 = g^ x e_col
+                        const f3 e  = mk3(col == 0 ? 1.f : 0.f, col == 1 ? 1.f : 0.f, col == 2 ? 1.f : 0.f);
+                        const f3 v0 = cross(gh, e);
+                        const Quat W  = basis_mul(col, q.r);
+                        const Quat Wd = qadd(basis_mul(col, q.d), qmul(pureq(v0), q.r));
+                        o[col]     = f * (qdot(lW, W) + qdot(lD, Wd));
+                        o[3 + col] = f * qdot(lD, W);  // translation e_col: (W, Wd) = (0, e_col^ r)
+                    }
+                }
+#pragma unroll
+                for (int col = 0; col < 6; ++col) av[j * 6 + col] = o[col];
+            }
+            cost   = (double)w_eff * (double)rr * (double)rr;
+            nvalid = w_eff > 0.f;
+        }
+        s.res[v]  = rr;
+        s.wrow[v] = ok ? w_eff : 0.f;
+    }
+    block_add_cost(cost, nvalid, st);
+}
+
+__global__ __launch_bounds__(256) void s6_reg_kernel(Solve6View s, Solve6State* st, float wreg2, float psi_reg,
+                                                     int update_w) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    double cost = 0.0;
+    if (e < s.D * s.k) {
+        const int n = e / s.k, m = s.reg_idx[e];
+        float* er = s.rres + 3 * (size_t)e;
+        float* vc = s.rvec + 18 * (size_t)e;
+        float ev[3] = {0.f, 0.f, 0.f}, vec[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) vec[i] = 0.f;
+        if (m >= 0) {
+            const f3 y   = dq_point(dq_load(s.dq + 8 * (size_t)n), mk3(s.node_pos[3 * m], s.node_pos[3 * m + 1], s.node_pos[3 * m + 2]));
+            const f3 ghm = mk3(s.ghat[3 * m], s.ghat[3 * m + 1], s.ghat[3 * m + 2]);
+            const f3 ghn = mk3(s.ghat[3 * n], s.ghat[3 * n + 1], s.ghat[3 * n + 2]);
+            ev[0] = y.x - ghm.x, ev[1] = y.y - ghm.y, ev[2] = y.z - ghm.z;
+            const float en = sqrtf(ev[0] * ev[0] + ev[1] * ev[1] + ev[2] * ev[2]);
+            if (update_w) s.rhub[e] = en <= psi_reg ? 1.f : psi_reg / en;  // opt_solver.cpp:233-268
+            const float l0 = y.x - ghn.x, l1 = y.y - ghn.y, l2 = y.z - ghn.z;
+            // rows of [ -[l]x | I ]
+            vec[0] = 0.f, vec[1] = l2, vec[2] = -l1, vec[3] = 1.f;
+            vec[6] = -l2, vec[7] = 0.f, vec[8] = l0, vec[10] = 1.f;
+            vec[12] = l1, vec[13] = -l0, vec[14] = 0.f, vec[17] = 1.f;
+            cost = (double)wreg2 * (double)s.rhub[e] * (double)en * (double)en;
+        }
+        er[0] = ev[0], er[1] = ev[1], er[2] = ev[2];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) vc[i] = vec[i];
+    }
+    block_add_cost(cost, 0u, st);
+}
+
+// --------------------------------------------------------------------------------- assembly
+constexpr int S6_HASH = 128;
+
+__device__ __forceinline__ int hash_slot(int* keys, int b) {
+    unsigned h = ((unsigned)b * 2654435761u) >> 25;  // 7 bits
+    for (int probe = 0; probe < S6_HASH; ++probe) {
+        const int seen = atomicCAS(&keys[h], -1, b);
+        if (seen == -1 || seen == b) return (int)h;
+        h = (h + 1) & (S6_HASH - 1);
+    }
+    return -1;
+}
+
+// inverse of a symmetric positive definite 6x6 (Cholesky); identity-scaled fallback if it fails
+__device__ void inv6(const float* M, float* out) {
+    float L[36];
+    bool ok = true;
+    for (int i = 0; i < 36; ++i) L[i] = 0.f;
+    for (int i = 0; i < 6 && ok; ++i)
+        for (int j = 0; j <= i; ++j) {
+            float sm = M[6 * i + j];
+            for (int q = 0; q < j; ++q) sm -= L[6 * i + q] * L[6 * j + q];
+            if (i == j) {
+                if (!(sm > 0.f)) {
+                    ok = false;
+                    break;
+                }
+                L[6 * i + i] = sqrtf(sm);
+            } else {
+                L[6 * i + j] = sm / L[6 * j + j];
+            }
+        }
+    if (!ok) {
+        for (int i = 0; i < 36; ++i) out[i] = 0.f;
+        return;  // z = 0 for this node (as the oracle does)
+    }
+    // columns of the inverse: solve L L^T x = e_c
+    for (int c = 0; c < 6; ++c) {
+        float y[6], x[6];
+        for (int i = 0; i < 6; ++i) {
+            float sm = i == c ? 1.f : 0.f;
+            for (int q = 0; q < i; ++q) sm -= L[6 * i + q] * y[q];
+            y[i] = sm / L[6 * i + i];
+        }
+        for (int i = 5; i >= 0; --i) {
+            float sm = y[i];
+            for (int q = i + 1; q < 6; ++q) sm -= L[6 * q + i] * x[q];
+            x[i] = sm / L[6 * i + i];
+        }
+        for (int i = 0; i < 6; ++i) out[6 * i + c] = x[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void s6_assemble_kernel(Solve6View s, Solve6State* st, float wreg2, float damping) {
+    __shared__ int keys[S6_HASH];
+    __shared__ float acc[S6_HASH][36];
+    __shared__ float red[4][42];
+    __shared__ float diag[42];
+    __shared__ int rank_of[S6_HASH];
+    __shared__ int cnt_sh;
+    const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
+    if (a == 0 && tid == 0) {  // bookkeeping of the linearisation that just finished
+        if (!st->have_first) st->initial_cost = st->cost, st->valid_first = st->valid, st->have_first = 1;
+        st->final_cost = st->cost, st->valid_last = st->valid;
+        st->gn_iters += 1;
+    }
+    for (int i = tid; i < S6_HASH; i += 256) keys[i] = -1;
+    for (int i = tid; i < S6_HASH * 36; i += 256) (&acc[0][0])[i] = 0.f;
+    __syncthreads();
+    float dg[36], gg[6];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) dg[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) gg[i] = 0.f;
+    bool lost = false;
+
+    // data rows that touch node a
+    const int beg = s.node_ptr[a], end = s.node_ptr[a + 1];
+    for (int e = beg + tid; e < end; e += 256) {
+        const unsigned entry = s.node_list[e];
+        const unsigned v     = entry / (unsigned)k;
+        const float w        = s.wrow[v];
+        if (w == 0.f) continue;
+        float as[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) as[c] = s.avec[(size_t)entry * 6 + c];
+        const float wr = w * s.res[v];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) gg[c] -= as[c] * wr;
+        for (int j = 0; j < k; ++j) {
+            const int b = s.idx[(size_t)v * k + j];
+            if (b < 0) continue;
+            float aj[6];
+#pragma unroll
+            for (int d = 0; d < 6; ++d) aj[d] = s.avec[((size_t)v * k + j) * 6 + d];
+            if (b == a) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) dg[c * 6 + d] += w * as[c] * aj[d];
+            } else {
+                const int h = hash_slot(keys, b);
+                if (h < 0) {
+                    lost = true;
+                    continue;
+                }
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const float wa = w * as[c];
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) atomicAdd(&acc[h][c * 6 + d], wa * aj[d]);
+                }
+            }
+        }
+    }
+    // regularisation edges leaving a (a -> m): rows c of e = T_a g_m - g^_m, vectors (an_c at a, -e_{3+c} at m)
+    if (tid < k) {
+        const int e = a * k + tid, m = s.reg_idx[e];
+        if (m >= 0) {
+            const float wt = wreg2 * s.rhub[e];
+            const int h    = hash_slot(keys, m);
+            if (h < 0) lost = true;
+            for (int c = 0; c < 3; ++c) {
+                const float* an = s.rvec + 18 * (size_t)e + 6 * c;
+                const float ec  = s.rres[3 * (size_t)e + c];
+                for (int q = 0; q < 6; ++q) {
+                    gg[q] -= wt * an[q] * ec;
+                    for (int q2 = 0; q2 < 6; ++q2) dg[q * 6 + q2] += wt * an[q] * an[q2];
+                    if (h >= 0) atomicAdd(&acc[h][q * 6 + 3 + c], -wt * an[q]);
+                }
+            }
+        }
+    }
+    // regularisation edges arriving at a (n -> a)
+    for (int e = s.rnode_ptr[a] + tid; e < s.rnode_ptr[a + 1]; e += 256) {
+        const unsigned entry = s.rnode_list[e];
+        const int n          = (int)(entry / (unsigned)k);
+        const float wt       = wreg2 * s.rhub[entry];
+        const int h          = hash_slot(keys, n);
+        if (h < 0) lost = true;
+        for (int c = 0; c < 3; ++c) {
+            const float* an = s.rvec + 18 * (size_t)entry + 6 * c;
+            const float ec  = s.rres[3 * (size_t)entry + c];
+            gg[3 + c] += wt * ec;
+            dg[(3 + c) * 6 + 3 + c] += wt;
+            if (h >= 0)
+                for (int q = 0; q < 6; ++q) atomicAdd(&acc[h][(3 + c) * 6 + q], -wt * an[q]);
+        }
+    }
+    // workgroup totals of the register accumulators
+#pragma unroll
+    for (int i = 0; i < 36; ++i) dg[i] = wave_sum_all(dg[i]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) gg[i] = wave_sum_all(gg[i]);
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 36; ++i) red[tid >> 6][i] = dg[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) red[tid >> 6][36 + i] = gg[i];
+    }
+    __syncthreads();
+    if (tid < 42) {
+        float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        if (tid < 36 && tid % 7 == 0) v += damping;
+        diag[tid] = v;
+    }
+    // rank of every used hash slot by its column id -> deterministic block order
+    if (tid < S6_HASH) {
+        int r = -1;
+        const int mine = keys[tid];
+        if (mine >= 0) {
+            r = 0;
+            for (int h = 0; h < S6_HASH; ++h) r += keys[h] >= 0 && keys[h] < mine;
+        }
+        rank_of[tid] = r;
+    }
+    if (tid == 0) cnt_sh = 0;
+    __syncthreads();
+    if (tid < S6_HASH && rank_of[tid] >= 0) atomicAdd(&cnt_sh, 1);
+    __syncthreads();
+    const int nblk = cnt_sh + 1;  // + diagonal
+    int32_t* cols  = s.bcols + (size_t)a * s.cap;
+    float* vals    = s.bvals + (size_t)a * s.cap * 36;
+    if (tid < 36) vals[tid] = diag[tid];
+    if (tid == 0) cols[0] = a;
+    if (tid < 6) s.g[6 * (size_t)a + tid] = diag[36 + tid];
+    for (int h = tid >> 1; h < S6_HASH; h += 128) {  // two lanes per slot: 18 values each
+        const int r = rank_of[h];
+        if (r < 0 || r + 1 >= s.cap) continue;
+        const int half = tid & 1;
+        if (half == 0) cols[r + 1] = keys[h];
+        for (int i = 0; i < 18; ++i) vals[(size_t)(r + 1) * 36 + half * 18 + i] = acc[h][half * 18 + i];
+    }
+    if (tid == 0) {
+        s.bcnt[a] = nblk < s.cap ? nblk : s.cap;
+        atomicMax(&st->max_row_blocks, nblk);
+        inv6(diag, s.minv + 36 * (size_t)a);
+    }
+    if (lost || (tid == 0 && nblk > s.cap)) st->overflow = 1;
+}
+
+// -------------------------------------------------------------------------------------- PCG
+__device__ __forceinline__ float sum_partials(const float* __restrict__ part, int n) {
+    float acc = 0.f;
+    for (int i = threadIdx.x & 63; i < n; i += 64) acc += part[i];
+    return wave_sum_all(acc);  // every wave computes the same value in the same order
+}
+
+__global__ __launch_bounds__(256) void s6_pcg_init_kernel(Solve6View s, Solve6State* st) {
+    __shared__ float sh[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (node, component)
+    float rz    = 0.f;
+    if (i == 0) st->pcg_done = 0;
+    if (i < 6 * s.D) {
+        const int n = i / 6, c = i - 6 * n;
+        const float* Mi = s.minv + 36 * (size_t)n + 6 * c;
+        const float* gn = s.g + 6 * (size_t)n;
+        float z = 0.f;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) z += Mi[d] * gn[d];
+        s.x[i] = 0.f, s.r[0][i] = gn[c], s.z[i] = z;
+        rz = gn[c] * z;
+    }
+    rz = wave_sum_all(rz);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = rz;
+    __syncthreads();
+    if (threadIdx.x == 0) s.rz_part[0][blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// q = H p with p = z + beta p_old formed on the fly; one wave per block row
+__global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_matvec_kernel(Solve6View s, Solve6State* st, int it,
+                                                                                float tol2) {
+    __shared__ float stage[S6_NODES_PER_BLOCK][64];
+    __shared__ float pq_sh[S6_NODES_PER_BLOCK];
+    if (st->pcg_done) return;
+    const int nub = s6_update_blocks(s.D);
+    const float rz_cur = sum_partials(s.rz_part[it & 1], nub);
+    float beta = 0.f;
+    if (it == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->rz0 = rz_cur;
+    } else {
+        const float rz_prev = sum_partials(s.rz_part[(it - 1) & 1], nub);
+        beta                = rz_cur / rz_prev;
+    }
+    const float rz0 = it == 0 ? rz_cur : st->rz0;
+    if (!(rz_cur > 0.f) || rz_cur <= tol2 * rz0) {  // converged (or breakdown): same decision in every workgroup
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->pcg_done = 1;
+        return;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int a    = blockIdx.x * S6_NODES_PER_BLOCK + wave;
+    const float* pold = s.p[(it + 1) & 1];
+    float* pnew       = s.p[it & 1];
+    float total = 0.f, pn = 0.f;
+    if (a < s.D) {
+        const int ss = lane / 6, c = lane - 6 * ss;
+        float acc    = 0.f;
+        if (lane < 60) {
+            const int cnt = s.bcnt[a];
+            for (int sl = ss; sl < cnt; sl += 10) {
+                const int col  = s.bcols[(size_t)a * s.cap + sl];
+                const float* H = s.bvals + ((size_t)a * s.cap + sl) * 36 + 6 * c;
+#pragma unroll
+                for (int d = 0; d < 6; ++d) {
+                    float pv = s.z[6 * (size_t)col + d];
+                    if (it > 0) pv += beta * pold[6 * (size_t)col + d];
+                    acc += H[d] * pv;
+                }
+            }
+        }
+        stage[wave][lane] = acc;
+    }
+    __syncthreads();
+    if (a < s.D && lane < 6) {
+#pragma unroll
+        for (int ss = 0; ss < 10; ++ss) total += stage[wave][ss * 6 + lane];
+        pn = s.z[6 * (size_t)a + lane];
+        if (it > 0) pn += beta * pold[6 * (size_t)a + lane];
+        pnew[6 * (size_t)a + lane] = pn;
+        s.q[6 * (size_t)a + lane]  = total;
+    }
+    const float pq = wave_sum_all(lane < 6 ? pn * total : 0.f);
+    if (lane == 0) pq_sh[wave] = pq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < S6_NODES_PER_BLOCK; ++w) t += pq_sh[w];
+        s.pq_part[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void s6_pcg_update_kernel(Solve6View s, Solve6State* st, int it) {
+    __shared__ float sh[4];
+    if (st->pcg_done) return;
+    const float rz_cur = sum_partials(s.rz_part[it & 1], s6_update_blocks(s.D));
+    const float pq     = sum_partials(s.pq_part, s6_matvec_blocks(s.D));
+    if (!(pq > 0.f)) {  // breakdown: stop here, x keeps its value
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->pcg_done = 1;
+        return;
+    }
+    const float alpha = rz_cur / pq;
+    const int i       = blockIdx.x * blockDim.x + threadIdx.x;
+    float rz          = 0.f;
+    const float* p    = s.p[it & 1];
+    const float* rold = s.r[it & 1];  // ping-pong: the six lanes of a node all read the whole old residual
+    float* rnew       = s.r[(it + 1) & 1];
+    if (i < 6 * s.D) {
+        const int n = i / 6, c = i - 6 * n;
+        s.x[i] += alpha * p[i];
+        float rn[6];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) rn[d] = rold[6 * (size_t)n + d] - alpha * s.q[6 * (size_t)n + d];
+        const float* Mi = s.minv + 36 * (size_t)n + 6 * c;
+        float z = 0.f;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) z += Mi[d] * rn[d];
+        rnew[i] = rn[c];
+        s.z[i]  = z;
+        rz      = rn[c] * z;
+    }
+    rz = wave_sum_all(rz);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = rz;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s.rz_part[(it + 1) & 1][blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        if (blockIdx.x == 0) st->pcg_iters += 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------ update
+__global__ __launch_bounds__(256) void s6_update_kernel(Solve6View s) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= s.D) return;
+    const float* tw = s.x + 6 * (size_t)n;
+    const DQ q      = dq_load(s.dq + 8 * (size_t)n);
+    const f3 gh     = mk3(s.ghat[3 * n], s.ghat[3 * n + 1], s.ghat[3 * n + 2]);
+    const float th  = sqrtf(tw[0] * tw[0] + tw[1] * tw[1] + tw[2] * tw[2]);
+    const float sc  = th > 1e-6f ? sinf(0.5f * th) / th : 0.5f;
+    const Quat qo   = Quat{cosf(0.5f * th), sc * tw[0], sc * tw[1], sc * tw[2]};
+    Quat rn         = qmul(qo, q.r);
+    const f3 t0     = qvec(qmul(q.d, qconj(q.r)));
+    const f3 tc     = mk3(2.f * t0.x - gh.x, 2.f * t0.y - gh.y, 2.f * t0.z - gh.z);
+    const f3 tr     = qvec(qmul(qmul(qo, pureq(tc)), qconj(qo)));
+    const f3 t      = mk3(tr.x + gh.x + tw[3], tr.y + gh.y + tw[4], tr.z + gh.z + tw[5]);
+    rn              = qscale(rn, 1.f / sqrtf(qdot(rn, rn)));
+    const Quat dn   = qscale(qmul(pureq(t), rn), 0.5f);
+    dq_store(s.dq + 8 * (size_t)n, DQ{rn, dn});
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void s6_warp_kernel(Solve6View s, const float* __restrict__ dq,
+                                                      float* __restrict__ out_v, float* __restrict__ out_n) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= s.N) return;
+    int32_t idx[K];
+    float wn[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        idx[j] = j < s.k ? s.idx[(size_t)v * s.k + j] : -1;
+        wn[j]  = j < s.k ? s.wn[(size_t)v * s.k + j] : 0.f;
+    }
+    Blend<K> B;
+    blend<K>(dq, idx, wn, s.k, B);
+    const f3 c = mk3(s.canon[3 * (size_t)v], s.canon[3 * (size_t)v + 1], s.canon[3 * (size_t)v + 2]);
+    const f3 p = B.m > 0.f ? blend_point<K>(B, c) : c;
+    out_v[3 * (size_t)v] = p.x, out_v[3 * (size_t)v + 1] = p.y, out_v[3 * (size_t)v + 2] = p.z;
+    if (out_n && s.canon_n) {
+        const f3 n0 = mk3(s.canon_n[3 * (size_t)v], s.canon_n[3 * (size_t)v + 1], s.canon_n[3 * (size_t)v + 2]);
+        const f3 n  = B.m > 0.f ? blend_normal<K>(B, n0) : n0;
+        out_n[3 * (size_t)v] = n.x, out_n[3 * (size_t)v + 1] = n.y, out_n[3 * (size_t)v + 2] = n.z;
+    }
+}
+
+__global__ __launch_bounds__(256) void s6_begin_kernel(Solve6View s, Solve6State* st, const float* __restrict__ node_dq) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        st->cost = 0.0, st->initial_cost = 0.0, st->final_cost = 0.0;
+        st->valid = st->valid_first = st->valid_last = 0ull;
+        st->have_first = 0, st->gn_iters = 0, st->pcg_iters = 0, st->overflow = 0, st->max_row_blocks = 0;
+        st->pcg_done = 0, st->rz0 = 0.f;
+    }
+    if (i < 8 * s.D) s.dq[i] = node_dq[i];
+    if (i < s.N) s.rho[i] = 0.f;
+    if (i < s.D * s.k) s.rhub[i] = 1.f;
+}
+
+// kfusion::device::computePointNormals (src/kfusion/cuda/imgproc.cu:187-215)
+__global__ __launch_bounds__(256) void points_normals_kernel(const uint16_t* __restrict__ depth, int depth_step, int cols,
+                                                             int rows, float finvx, float finvy, float cx, float cy,
+                                                             float* __restrict__ points, int points_step,
+                                                             float* __restrict__ normals, int normals_step) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= cols || y >= rows) return;
+    const float qnan = __builtin_nanf("");
+    float4 P = make_float4(qnan, qnan, qnan, qnan), Nn = P;  // :195-196
+    if (x < cols - 1 && y < rows - 1) {                      // :198
+        const uint16_t* d0 = (const uint16_t*)((const char*)depth + (size_t)y * depth_step);
+        const uint16_t* d1 = (const uint16_t*)((const char*)depth + (size_t)(y + 1) * depth_step);
+        const float z00 = d0[x] * 0.001f, z01 = d0[x + 1] * 0.001f, z10 = d1[x] * 0.001f;
+        if (z00 * z01 * z10 != 0.f) {  // :206
+            // Reprojector device.hpp:50-54: x = z * (u - cx) * finv.x
+            const f3 v00 = mk3(z00 * ((float)x - cx) * finvx, z00 * ((float)y - cy) * finvy, z00);
+            const f3 v01 = mk3(z01 * ((float)(x + 1) - cx) * finvx, z01 * ((float)y - cy) * finvy, z01);
+            const f3 v10 = mk3(z10 * ((float)x - cx) * finvx, z10 * ((float)(y + 1) - cy) * finvy, z10);
+            const f3 n   = normalized(cross(v01 - v00, v10 - v00));
+            Nn = make_float4(-n.x, -n.y, -n.z, 0.f);  // :212
+            P  = make_float4(v00.x, v00.y, v00.z, 0.f);
+        }
+    }
+    *reinterpret_cast<float4*>((char*)points + (size_t)y * points_step + 16 * (size_t)x)   = P;
+    *reinterpret_cast<float4*>((char*)normals + (size_t)y * normals_step + 16 * (size_t)x) = Nn;
+}
+
+}  // namespace
+
+#define K6DISPATCH(kernel, k, ...)            \
+    do {                                      \
+        if ((k) <= 4) kernel<4> __VA_ARGS__;  \
+        else kernel<8> __VA_ARGS__;           \
+    } while (0)
+
+hipError_t s6_build_graph(const Solve6View& s, const float* raw_w, const int32_t* raw_reg, int kreg, hipStream_t st) {
+    if (s.N > 0) s6_normalise_kernel<<<(s.N + 255) / 256, 256, 0, st>>>(raw_w, s.N, s.k, s.wn);
+    s6_reg_graph_kernel<<<(s.D + 255) / 256, 256, 0, st>>>(raw_reg, s.D, kreg, s.k, s.reg_idx);
+    hipError_t e = solve_transpose_graph(s.idx, (size_t)s.N * s.k, s.D, s.blk_hist, s.node_ptr, s.node_list, st);
+    if (e != hipSuccess) return e;
+    return solve_transpose_graph(s.reg_idx, (size_t)s.D * s.k, s.D, s.blk_hist, s.rnode_ptr, s.rnode_list, st);
+}
+
+hipError_t s6_begin(const Solve6View& s, Solve6State* state, const float* node_dq, hipStream_t st) {
+    const int n = std::max(std::max(8 * s.D, s.N), s.D * s.k);
+    s6_begin_kernel<<<(n + 255) / 256, 256, 0, st>>>(s, state, node_dq);
+    return hipGetLastError();
+}
+
+hipError_t s6_linearise(const Solve6View& s, Solve6State* state, const Solve6Image& img, const Solve6Params& p,
+                        int update_weights, hipStream_t st) {
+    s6_nodes_kernel<<<(s.D + 255) / 256, 256, 0, st>>>(s, state);
+    if (s.N > 0) K6DISPATCH(s6_linearise_kernel, s.k, <<<(s.N + 255) / 256, 256, 0, st>>>(s, state, img, p, update_weights));
+    const float wreg2 = p.lambda / ((float)s.D * (float)s.k);
+    s6_reg_kernel<<<(s.D * s.k + 255) / 256, 256, 0, st>>>(s, state, wreg2, p.psi_reg, update_weights);
+    return hipGetLastError();
+}
+
+hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Params& p, hipStream_t st) {
+    const float wreg2 = p.lambda / ((float)s.D * (float)s.k);
+    s6_assemble_kernel<<<s.D, 256, 0, st>>>(s, state, wreg2, p.damping);
+    return hipGetLastError();
+}
+
+hipError_t s6_pcg(const Solve6View& s, Solve6State* state, const Solve6Params& p, hipStream_t st) {
+    const int ub = s6_update_blocks(s.D), mb = s6_matvec_blocks(s.D);
+    s6_pcg_init_kernel<<<ub, 256, 0, st>>>(s, state);
+    const float tol2 = p.pcg_tol * p.pcg_tol;
+    for (int it = 0; it < p.linear_iter; ++it) {
+        s6_pcg_matvec_kernel<<<mb, 64 * S6_NODES_PER_BLOCK, 0, st>>>(s, state, it, tol2);
+        s6_pcg_update_kernel<<<ub, 256, 0, st>>>(s, state, it);
+    }
+    return hipGetLastError();
+}
+
+hipError_t s6_update(const Solve6View& s, Solve6State*, hipStream_t st) {
+    s6_update_kernel<<<(s.D + 255) / 256, 256, 0, st>>>(s);
+    return hipGetLastError();
+}
+
+hipError_t s6_warp(const Solve6View& s, const float* dq, float* out_v, float* out_n, hipStream_t st) {
+    if (s.N == 0) return hipSuccess;
+    K6DISPATCH(s6_warp_kernel, s.k, <<<(s.N + 255) / 256, 256, 0, st>>>(s, dq, out_v, out_n));
+    return hipGetLastError();
+}
+
+hipError_t launch_points_normals(const uint16_t* depth, int depth_step, int cols, int rows, float fx, float fy, float cx,
+                                 float cy, float* points, int points_step, float* normals, int normals_step,
+                                 hipStream_t st) {
+    dim3 grid((cols + 31) / 32, (rows + 7) / 8);
+    points_normals_kernel<<<grid, 256, 0, st>>>(depth, depth_step, cols, rows, 1.f / fx, 1.f / fy, cx, cy, points,
+                                                points_step, normals, normals_step);
+    return hipGetLastError();
+}
+
+}  // namespace dfa

@@ -1,0 +1,92 @@
+// solve6.hpp — device-side view of a north-star (6-DoF) solver plan and the launchers of
+// solve6.hip (internal).  Formulas: DESIGN.md §4.5; CPU statement: oracle/solve6_oracle.c.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dfa {
+
+struct Solve6Params {
+    int num_iter, gn_iter, linear_iter;
+    float tukey_offset, psi_data, lambda, psi_reg, dist_thresh, cos_thresh, damping, pcg_tol;
+};
+
+// Device-resident scalars of one solve
+struct Solve6State {
+    double cost;         // accumulator of the linearisation in flight
+    double initial_cost;
+    double final_cost;
+    unsigned long long valid, valid_first, valid_last;
+    int have_first;
+    int gn_iters, pcg_iters;
+    int overflow;        // a block row did not fit the plan's capacity / hash table
+    int max_row_blocks;
+    int pcg_done;        // sticky flag of the PCG in flight
+    float rz0;           // r.z of its first iteration
+};
+
+struct Solve6Image {  // live vertex / normal maps (borrowed): float4 pixels, NaN where undefined
+    const float* vmap;
+    const float* nmap;
+    int vstep, nstep;  // bytes per row
+    int cols, rows;
+    float fx, fy, cx, cy;
+};
+
+struct Solve6View {
+    int N, D, k, cap;  // cap = 6x6 blocks per block row (slot 0 = diagonal)
+    // problem (borrowed)
+    const float* node_pos;  // D x 3
+    const float* node_w;    // D
+    const float* canon;     // N x 3
+    const float* canon_n;   // N x 3 or null
+    // graphs
+    int32_t* idx;       // N x k  nearest nodes
+    float* wn;          // N x k  normalised radial basis weights
+    int32_t* reg_idx;   // D x k  nearest OTHER nodes
+    int32_t* blk_hist;  // transposition scratch
+    int32_t* node_ptr;  // D + 1
+    uint32_t* node_list;   // (vertex * k + slot) grouped by node
+    int32_t* rnode_ptr;    // D + 1
+    uint32_t* rnode_list;  // (node * k + slot) of the regularisation edges ARRIVING at a node
+    // state of the iteration
+    float* dq;    // D x 8  current node transforms
+    float* ghat;  // D x 3  current node positions T_i(g_i)
+    // linearisation
+    float* avec;  // N x k x 6   n . dp/dxi per slot
+    float* res;   // N           n . (p - l)
+    float* rho;   // N           Tukey weight (frozen between re-weightings)
+    float* wrow;  // N           rho where the association is valid, else 0
+    float* rres;  // D x k x 3   regularisation residuals
+    float* rvec;  // D x k x 18  d e / d xi_n  (3 rows x 6)
+    float* rhub;  // D x k       Huber weights (frozen)
+    // normal equations, block ELL
+    int32_t* bcols;  // D x cap
+    int32_t* bcnt;   // D
+    float* bvals;    // D x cap x 36
+    float* minv;     // D x 36  inverse of the (damped) diagonal block
+    float* g;        // D x 6   -J^T W r
+    // PCG
+    float *x, *z, *q, *r[2], *p[2];  // D x 6 (r, p ping-pong between iterations)
+    float* pq_part;               // per matvec workgroup
+    float* rz_part[2];            // per update workgroup
+};
+
+constexpr int S6_NODES_PER_BLOCK = 8;  // matvec: one wave per node, 512 threads
+__host__ __device__ inline int s6_matvec_blocks(int D) { return (D + S6_NODES_PER_BLOCK - 1) / S6_NODES_PER_BLOCK; }
+__host__ __device__ inline int s6_update_blocks(int D) { return (6 * D + 255) / 256; }
+
+hipError_t s6_build_graph(const Solve6View& s, const float* raw_w /* N x k */, const int32_t* raw_reg /* D x (k+1) */,
+                          int kreg, hipStream_t st);
+hipError_t s6_begin(const Solve6View& s, Solve6State* state, const float* node_dq, hipStream_t st);
+hipError_t s6_linearise(const Solve6View& s, Solve6State* state, const Solve6Image& img, const Solve6Params& p,
+                        int update_weights, hipStream_t st);
+hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Params& p, hipStream_t st);
+hipError_t s6_pcg(const Solve6View& s, Solve6State* state, const Solve6Params& p, hipStream_t st);
+hipError_t s6_update(const Solve6View& s, Solve6State* state, hipStream_t st);
+hipError_t s6_warp(const Solve6View& s, const float* dq, float* out_v, float* out_n, hipStream_t st);
+hipError_t launch_points_normals(const uint16_t* depth, int depth_step, int cols, int rows, float fx, float fy, float cx,
+                                 float cy, float* points, int points_step, float* normals, int normals_step,
+                                 hipStream_t st);
+
+}  // namespace dfa

@@ -219,6 +219,62 @@ typedef struct {
 int dfa_solver_enable_timing(dfa_solver* s, int enable);
 int dfa_solver_get_timing(dfa_solver* s, dfa_solve_timing* host_out, dfa_stream_t stream);
 
+/* ===================================================================================== */
+/* North-star solver — the 6-DoF mode BASELINE.json:north_star asks for; NOT in the          */
+/* reference's code (its energy.t solves translations only).  Formulas: DESIGN.md §4.5.     */
+/* Unknown per node: a twist (omega, v) about the node's current position; model: dual-      */
+/* quaternion blend of the k nearest nodes with normalised RBF weights; data term: projective */
+/* point-to-plane against the live vertex / normal maps (row shape of                       */
+/* src/kfusion/cuda/proj_icp.cu:343-350), Tukey-weighted; regulariser: T_n g_m - T_m g_m over */
+/* the k nearest other nodes, Huber-weighted, w_reg^2 = lambda/(D k) (opt_solver.cpp:30);     */
+/* solver: Gauss-Newton with block-Jacobi (6x6) PCG.                                        */
+
+/* kfusion::cuda::computePointNormals (src/kfusion/imgproc.cpp:27-36, cuda/imgproc.cu:187-226):
+ * float4 vertex and normal maps of a depth image, quiet NaN where undefined. */
+int dfa_compute_points_normals(const uint16_t* depth, int depth_step, int cols, int rows, float fx, float fy, float cx,
+                               float cy, float* points, int points_step, float* normals, int normals_step,
+                               dfa_stream_t stream);
+
+typedef struct dfa_solver6 dfa_solver6;
+
+typedef struct dfa_solve6_params {
+    int num_iter;       /* outer iterations: Tukey / Huber weights recomputed (numIter)        */
+    int gn_iter;        /* Gauss-Newton iterations per outer iteration (nonLinearIter)         */
+    int linear_iter;    /* PCG iterations per Gauss-Newton iteration, at most (linearIter)     */
+    float tukey_offset; /* dyn_fusion.cpp:13 */
+    float psi_data;     /* dyn_fusion.cpp:18 */
+    float lambda;       /* dyn_fusion.cpp:16 */
+    float psi_reg;      /* dyn_fusion.cpp:20 */
+    float dist_thresh;  /* association gate |p - l| (metres)                                   */
+    float cos_thresh;   /* association gate n_warped . n_live                                  */
+    float damping;      /* added to the diagonal of the normal matrix                          */
+    float pcg_tol;      /* PCG stops when r.z <= pcg_tol^2 (r.z)_0                             */
+} dfa_solve6_params;
+
+typedef struct dfa_solve6_stats {
+    double initial_cost, final_cost; /* energy at the first / last linearisation */
+    int gn_iters, pcg_iters;
+    long long valid_first, valid_last; /* data rows with a valid association and non-zero weight */
+    int max_row_blocks, overflow;
+} dfa_solve6_stats;
+
+int dfa_solver6_create(int max_D, int max_N, int k /* 1..8 */, dfa_solver6** out);
+void dfa_solver6_destroy(dfa_solver6* s);
+/* graphs of the frame: k-NN + normalised weights of the canonical vertices, the k nearest other
+ * nodes of every node.  All arrays are borrowed until the next set_problem. */
+int dfa_solver6_set_problem(dfa_solver6* s, const float* node_pos, const float* node_dq, const float* node_w, int D,
+                            const float* canon_vertices, const float* canon_normals /* may be NULL */, int N,
+                            dfa_stream_t stream);
+/* live maps: float4 pixels in the camera frame (the canonical cloud and the nodes are in the same
+ * frame), NaN where undefined — dfa_compute_points_normals or dfa_tsdf_raycast_points output */
+int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_step, const float* live_normal_map,
+                      int normal_step, int cols, int rows, float fx, float fy, float cx, float cy,
+                      const dfa_solve6_params* params, dfa_stream_t stream);
+const float* dfa_solver6_node_dq(const dfa_solver6* s); /* device, D x 8: solved node transforms */
+/* canonical vertices (and normals) of the plan warped by the solved transforms (DQ blend) */
+int dfa_solver6_warp(dfa_solver6* s, float* out_vertices, float* out_normals, dfa_stream_t stream);
+int dfa_solver6_get_stats(dfa_solver6* s, dfa_solve6_stats* out, dfa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

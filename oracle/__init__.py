@@ -357,3 +357,120 @@ def solve_ref(node_pos, node_dq, node_w, k, canon, live, num_iter=1, nonlinear_i
                         _p(dq_out), C.byref(st))
     return t, dq_out, dict(initial_cost=st.initial_cost, final_cost=st.final_cost, gn_iters=st.gn_iters,
                            pcg_iters=st.pcg_iters)
+
+
+# ------------------------------------------------------------- north-star solve (6-DoF), solve6_oracle.c
+class Solve6Params(C.Structure):
+    _fields_ = [("num_iter", C.c_int), ("gn_iter", C.c_int), ("linear_iter", C.c_int), ("tukey_offset", C.c_float),
+                ("psi_data", C.c_float), ("lambda_", C.c_float), ("psi_reg", C.c_float), ("dist_thresh", C.c_float),
+                ("cos_thresh", C.c_float), ("damping", C.c_float), ("pcg_tol", C.c_float), ("threads", C.c_int)]
+
+
+class Solve6Stats(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("gn_iters", C.c_int), ("pcg_iters", C.c_int),
+                ("valid_first", C.c_long), ("valid_last", C.c_long)]
+
+
+SOLVE6_DEFAULTS = dict(num_iter=2, gn_iter=3, linear_iter=100, tukey_offset=4.652, psi_data=0.01, lambda_=200.0,
+                       psi_reg=1e-4, dist_thresh=0.1, cos_thresh=0.5, damping=1e-4, pcg_tol=1e-6, threads=1)
+
+
+def solve6_params(**kw):
+    d = dict(SOLVE6_DEFAULTS)
+    d.update(kw)
+    return Solve6Params(*[d[n] for n, _ in Solve6Params._fields_])
+
+
+def _declare6(L):
+    vp, i, f = C.c_void_p, C.c_int, C.c_float
+    L.orc6_points_normals.argtypes = [vp, i, i, i, f, f, f, f, vp, i, vp, i]
+    L.orc6_graph.argtypes = [vp, vp, i, i, vp, i, vp, vp, vp, i]
+    L.orc6_warp.argtypes = [vp, i, vp, vp, vp, vp, i, vp, vp]
+    L.orc6_data_jacobian.argtypes = [vp, vp, vp, vp, i, vp, vp, vp]
+    L.orc6_apply_twist.argtypes = [vp, vp, vp, vp]
+    sig = [vp, vp, vp, i, i, vp, vp, i, vp, i, vp, i, i, i, f, f, f, f, C.POINTER(Solve6Params)]
+    L.orc6_solve.argtypes = sig + [vp, C.POINTER(Solve6Stats)]
+    L.orc6_cost.argtypes = sig + [vp]
+    L.orc6_cost.restype = C.c_double
+    L._six = True
+
+
+def lib6():
+    L = lib()
+    if not getattr(L, "_six", False):
+        _declare6(L)
+    return L
+
+
+def points_normals(depth, fx, fy, cx, cy):
+    """computePointNormals (imgproc.cu:187-215): (points, normals) float32 (H, W, 4), NaN where undefined"""
+    depth = np.ascontiguousarray(depth, np.uint16)
+    H, W = depth.shape
+    P, Nm = np.empty((H, W, 4), np.float32), np.empty((H, W, 4), np.float32)
+    lib6().orc6_points_normals(_p(depth), W * 2, W, H, fx, fy, cx, cy, _p(P), W * 16, _p(Nm), W * 16)
+    return P, Nm
+
+
+def graph6(node_pos, node_w, k, canon, threads=1):
+    node_pos, node_w, canon = map(_f32, (node_pos, node_w, canon))
+    N, D = len(canon), len(node_pos)
+    idx, wn = np.empty((N, k), np.int32), np.empty((N, k), np.float32)
+    reg = np.empty((D, k), np.int32)
+    lib6().orc6_graph(_p(node_pos), _p(node_w), D, k, _p(canon), N, _p(idx), _p(wn), _p(reg), threads)
+    return idx, wn, reg
+
+
+def warp6(node_dq, idx, wn, canon, canon_n=None):
+    node_dq, canon = _f32(node_dq), _f32(canon)
+    idx, wn = np.ascontiguousarray(idx, np.int32), _f32(wn)
+    out_p = np.empty_like(canon)
+    cn = _f32(canon_n) if canon_n is not None else None
+    out_n = np.empty_like(canon) if cn is not None else None
+    lib6().orc6_warp(_p(node_dq), idx.shape[1], _p(idx), _p(wn), _p(canon), _p(cn), len(canon), _p(out_p), _p(out_n))
+    return out_p, out_n
+
+
+def data_jacobian6(node_pos, node_dq, idx_v, wn_v, c):
+    """(J (k, 6, 3) = d p / d twist_j, p (3,)) of one vertex"""
+    node_pos, node_dq = _f32(node_pos), _f32(node_dq)
+    idx_v, wn_v, c = np.ascontiguousarray(idx_v, np.int32), _f32(wn_v), _f32(c)
+    k = len(idx_v)
+    J, p = np.zeros((k, 6, 3), np.float64), np.zeros(3, np.float64)
+    lib6().orc6_data_jacobian(_p(node_pos), _p(node_dq), _p(idx_v), _p(wn_v), k, _p(c), _p(J), _p(p))
+    return J, p
+
+
+def apply_twist6(node_pos_i, dq, twist):
+    out = np.zeros(8, np.float32)
+    tw = np.ascontiguousarray(twist, np.float64)
+    lib6().orc6_apply_twist(_p(_f32(node_pos_i)), _p(_f32(dq)), _p(tw), _p(out))
+    return out
+
+
+def _solve6_args(node_pos, node_dq, node_w, k, canon, canon_n, vmap, nmap, intr, prm):
+    node_pos, node_dq, node_w, canon, vmap, nmap = map(_f32, (node_pos, node_dq, node_w, canon, vmap, nmap))
+    cn = _f32(canon_n) if canon_n is not None else None
+    H, W = vmap.shape[:2]
+    fx, fy, cx, cy = intr
+    keep = (node_pos, node_dq, node_w, canon, cn, vmap, nmap)
+    args = [_p(node_pos), _p(node_dq), _p(node_w), len(node_pos), k, _p(canon), _p(cn), len(canon), _p(vmap), W * 16,
+            _p(nmap), W * 16, W, H, fx, fy, cx, cy, C.byref(prm)]
+    return keep, args
+
+
+def solve6(node_pos, node_dq, node_w, k, canon, canon_n, vmap, nmap, intr, **params):
+    """North-star solve.  Returns (node_dq_out D x 8, stats dict)."""
+    prm = solve6_params(**params)
+    keep, args = _solve6_args(node_pos, node_dq, node_w, k, canon, canon_n, vmap, nmap, intr, prm)
+    out = np.zeros((len(keep[0]), 8), np.float32)
+    st = Solve6Stats()
+    lib6().orc6_solve(*args, _p(out), C.byref(st))
+    return out, {n: getattr(st, n) for n, _ in Solve6Stats._fields_}
+
+
+def cost6(node_pos, node_dq, node_w, k, canon, canon_n, vmap, nmap, intr, **params):
+    prm = solve6_params(**params)
+    keep, args = _solve6_args(node_pos, node_dq, node_w, k, canon, canon_n, vmap, nmap, intr, prm)
+    nv = C.c_long(0)
+    c = lib6().orc6_cost(*args, C.byref(nv))
+    return c, nv.value

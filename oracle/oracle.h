@@ -158,6 +158,54 @@ void orc_tukey_weights(const float* node_pos, const float* node_dq, const float*
 void orc_huber_weights(const float* node_pos, const float* node_dq, const float* node_w, int D, int k, float psi_reg,
                        float* huber);
 
+/* ------------------------------------------------- north-star solve (6-DoF) -- */
+/* solve6_oracle.c: NOT in the reference's code (BASELINE.json north_star);
+ * PARITY UNPINNED, formulas in DESIGN.md §4.5. */
+typedef struct {
+    int num_iter;       /* outer iterations: Tukey / Huber re-weighting            */
+    int gn_iter;        /* Gauss-Newton iterations per outer iteration             */
+    int linear_iter;    /* max PCG iterations per GN iteration                     */
+    float tukey_offset; /* data residual scale (opt_solver.cpp:204-212)            */
+    float psi_data;     /* Tukey cut-off                                           */
+    float lambda;       /* regulariser weight: w_reg^2 = lambda / (D k)            */
+    float psi_reg;      /* Huber threshold of the regulariser                      */
+    float dist_thresh;  /* association gate: |p - l| <= dist_thresh  (metres)      */
+    float cos_thresh;   /* association gate: n_warped . n_live >= cos_thresh       */
+    float damping;      /* added to the diagonal of the normal matrix              */
+    float pcg_tol;      /* stop when (r.z) <= pcg_tol^2 (r.z)_0                    */
+    int threads;
+} orc6_params;
+
+typedef struct {
+    double initial_cost; /* energy at the first linearisation                      */
+    double final_cost;   /* energy at the last linearisation                       */
+    int gn_iters, pcg_iters;
+    long valid_first, valid_last; /* data rows with a valid association and non-zero weight */
+} orc6_stats;
+
+/* kfusion::device::computePointNormals (src/kfusion/cuda/imgproc.cu:187-215): float4 vertex and
+ * normal maps of a depth image (NaN where undefined), fp32 as the kernel. */
+void orc6_points_normals(const uint16_t* depth, int depth_step, int cols, int rows, float fx, float fy, float cx,
+                         float cy, float* points, int points_step, float* normals, int normals_step);
+/* k-NN + normalised RBF weights (N x k), and the k nearest other nodes of every node (D x k) */
+void orc6_graph(const float* node_pos, const float* node_w, int D, int k, const float* canon, int N, int32_t* idx,
+                float* wn, int32_t* reg_idx, int threads);
+/* dual-quaternion blend warp of vertices (and normals: rotation only) */
+void orc6_warp(const float* node_dq, int k, const int32_t* idx, const float* wn, const float* canon,
+               const float* canon_n, int N, float* out_p, float* out_n);
+/* d p / d (twist of neighbour j): J[j][component][xyz], and the warped point */
+void orc6_data_jacobian(const float* node_pos, const float* node_dq, const int32_t* idx, const float* wn, int k,
+                        const float c[3], double* J, double p_out[3]);
+/* left twist (omega, v) about the node's current position */
+void orc6_apply_twist(const float node_pos_i[3], const float dq_in[8], const double twist[6], float dq_out[8]);
+void orc6_solve(const float* node_pos, const float* node_dq_in, const float* node_w, int D, int k, const float* canon,
+                const float* canon_n, int N, const float* vmap, int vmap_step, const float* nmap, int nmap_step, int cols,
+                int rows, float fx, float fy, float cx, float cy, const orc6_params* prm, float* node_dq_out,
+                orc6_stats* stats);
+double orc6_cost(const float* node_pos, const float* node_dq, const float* node_w, int D, int k, const float* canon,
+                 const float* canon_n, int N, const float* vmap, int vmap_step, const float* nmap, int nmap_step, int cols,
+                 int rows, float fx, float fy, float cx, float cy, const orc6_params* prm, long* nvalid_out);
+
 #ifdef __cplusplus
 }
 #endif
