@@ -1,0 +1,133 @@
+"""-m gpu parity tests of the north-star (6-DoF) solve: HIP (through the C ABI) vs the
+double-precision oracle oracle/solve6_oracle.c.
+
+The mode is not in the reference (parity unpinned); the oracle is pinned by
+tests/test_oracle_solve6.py (finite differences, dense solve).  Tolerances (fp32 kernels vs fp64
+oracle, same iteration counts): energies within 1e-3 relative, association counts equal up to
+pixel-rounding ties (<= 0.1 % of the rows), warped vertices within 2e-5 m on average and 5e-4 m
+at worst, computePointNormals bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle as O  # noqa: E402
+from dynfu_amd import synth  # noqa: E402
+from gpu_util import bits, dev, host  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def A():
+    import dynfu_amd
+    dynfu_amd.load()
+    return dynfu_amd
+
+
+@pytest.mark.parametrize("shape", [(120, 160), (37, 53), (2, 2), (1, 5)])
+def test_points_normals_bit_exact(A, shape):
+    rng = np.random.default_rng(3)
+    H, W = shape
+    depth = (1500 + 300 * np.sin(np.arange(W) / 9.0)[None, :] + rng.integers(0, 40, shape)).astype(np.uint16)
+    depth[rng.random(shape) < 0.05] = 0
+    fx, fy, cx, cy = 131.25, 128.0, W / 2 - 0.5, H / 2 - 0.5
+    P, Nm = A.compute_points_normals(dev(depth), fx, fy, cx, cy)
+    Pr, Nr = O.points_normals(depth, fx, fy, cx, cy)
+    assert np.array_equal(bits(host(P)), bits(Pr)) and np.array_equal(bits(host(Nm)), bits(Nr))
+
+
+def _scene(name, frame):
+    cfg = synth.CONFIGS[name]
+    c = synth.canonical(cfg)
+    intr = synth.intrinsics(cfg)
+    depth = synth.depth_frame(cfg, frame)
+    return cfg, c, intr, depth
+
+
+def _solve_both(A, cfg, c, intr, depth, node_dq, **kw):
+    k = cfg["k"]
+    P, Nm = A.compute_points_normals(dev(depth), *intr)
+    s = A.Solver6(cfg["D"], len(c["verts"]), k)
+    keep = [dev(c["node_pos"]), dev(node_dq), dev(c["node_w"]), dev(c["verts"]), dev(c["normals"])]
+    s.set_problem(*keep)
+    s.solve(P, Nm, *intr, A.Solve6Params(**kw))
+    st = s.stats()
+    dq = host(s.node_dq())
+    wv, wn_ = s.warp()
+    dq_ref, st_ref = O.solve6(c["node_pos"], node_dq, c["node_w"], k, c["verts"], c["normals"], host(P), host(Nm), intr,
+                              threads=8, **kw)
+    return s, dq, st, host(wv), host(wn_), dq_ref, st_ref
+
+
+@pytest.mark.parametrize("name,frame,k_override", [("T0", 4, None), ("T1", 6, None), ("T1", 9, 4)])
+def test_solve_matches_the_oracle(A, name, frame, k_override):
+    cfg, c, intr, depth = _scene(name, frame)
+    if k_override:
+        cfg = dict(cfg, k=k_override)
+    kw = dict(num_iter=2, gn_iter=3, linear_iter=80, lambda_=200.0)
+    s, dq, st, wv, wn_, dq_ref, st_ref = _solve_both(A, cfg, c, intr, depth, c["node_dq"], **kw)
+    assert st["overflow"] == 0 and st["gn_iters"] == st_ref["gn_iters"] == 6
+    assert st["initial_cost"] == pytest.approx(st_ref["initial_cost"], rel=1e-4)
+    assert st["final_cost"] == pytest.approx(st_ref["final_cost"], rel=1e-3)
+    assert abs(st["valid_first"] - st_ref["valid_first"]) <= 1e-3 * st_ref["valid_first"] + 2
+    assert abs(st["pcg_iters"] - st_ref["pcg_iters"]) <= 0.05 * st_ref["pcg_iters"] + 2
+    idx, wn, _ = O.graph6(c["node_pos"], c["node_w"], cfg["k"], c["verts"])
+    p_ref, n_ref = O.warp6(dq_ref, idx, wn, c["verts"], c["normals"])
+    d = np.linalg.norm(wv - p_ref, axis=1)
+    assert d.mean() < 2e-5 and d.max() < 5e-4
+    assert np.abs(wn_ - n_ref).max() < 2e-3
+    # the device warp is the oracle's DQ blend of the device's own transforms
+    p_same, _ = O.warp6(dq, idx, wn, c["verts"])
+    assert np.abs(wv - p_same).max() < 2e-6
+    assert st["final_cost"] < 0.3 * st["initial_cost"]
+
+
+def test_solve_from_perturbed_transforms_and_without_normals(A):
+    cfg, c, intr, depth = _scene("T0", 3)
+    rng = np.random.default_rng(5)
+    dq0 = c["node_dq"].copy()
+    for i in range(len(dq0)):
+        dq0[i] = O.apply_twist6(c["node_pos"][i], dq0[i], np.r_[rng.normal(0, 0.01, 3), rng.normal(0, 0.002, 3)])
+    kw = dict(num_iter=1, gn_iter=2, linear_iter=100, lambda_=500.0)
+    s, dq, st, wv, wn_, dq_ref, st_ref = _solve_both(A, cfg, c, intr, depth, dq0, **kw)
+    assert st["initial_cost"] == pytest.approx(st_ref["initial_cost"], rel=1e-4)
+    assert np.abs(dq - dq_ref).max() < 2e-3
+    # no canonical normals: the normal gate is skipped
+    P, Nm = A.compute_points_normals(dev(depth), *intr)
+    s2 = A.Solver6(cfg["D"], len(c["verts"]), cfg["k"])
+    keep = [dev(c["node_pos"]), dev(dq0), dev(c["node_w"]), dev(c["verts"])]
+    s2.set_problem(*keep)
+    s2.solve(P, Nm, *intr, A.Solve6Params(**kw))
+    ref, st_ref2 = O.solve6(c["node_pos"], dq0, c["node_w"], cfg["k"], c["verts"], None, host(P), host(Nm), intr, **kw)
+    st2 = s2.stats()
+    assert st2["valid_first"] >= st["valid_first"]
+    assert st2["initial_cost"] == pytest.approx(st_ref2["initial_cost"], rel=1e-4)
+
+
+def test_no_live_data_regulariser_only_and_errors(A):
+    import torch
+    cfg, c, intr, depth = _scene("T0", 0)
+    k = cfg["k"]
+    empty = torch.full((cfg["height"], cfg["width"], 4), float("nan"), device="cuda")
+    rng = np.random.default_rng(8)
+    rough = c["node_dq"].copy()
+    for i in range(len(rough)):
+        rough[i] = O.apply_twist6(c["node_pos"][i], rough[i], np.r_[rng.normal(0, 0.05, 3), rng.normal(0, 0.01, 3)])
+    s = A.Solver6(cfg["D"], len(c["verts"]), k)
+    keep = [dev(c["node_pos"]), dev(rough), dev(c["node_w"]), dev(c["verts"]), dev(c["normals"])]
+    s.set_problem(*keep)
+    kw = dict(num_iter=2, gn_iter=3, linear_iter=200, lambda_=200.0, psi_reg=1.0, damping=1e-6)
+    s.solve(empty, empty, *intr, A.Solve6Params(**kw))
+    st = s.stats()
+    ref, st_ref = O.solve6(c["node_pos"], rough, c["node_w"], k, c["verts"], c["normals"], host(empty), host(empty), intr, **kw)
+    assert st["valid_first"] == 0 and st["initial_cost"] == pytest.approx(st_ref["initial_cost"], rel=1e-4)
+    assert st["final_cost"] < 0.05 * st["initial_cost"]
+    # zero iterations: transforms returned unchanged
+    s.solve(empty, empty, *intr, A.Solve6Params(num_iter=0))
+    assert np.array_equal(host(s.node_dq()), rough)
+    with pytest.raises(A.DynfuAmdError):
+        A.Solver6(16, 100, 9)  # k out of range
+    with pytest.raises(A.DynfuAmdError):
+        s.solve(empty, empty, *intr, A.Solve6Params(psi_data=0.0))
+    small = A.Solver6(8, 10, 4)
+    with pytest.raises(A.DynfuAmdError):
+        small.set_problem(*keep)  # larger than the plan
