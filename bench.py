@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded CPU sample")
     ap.add_argument("--serial", action="store_true", help="run fuse and solve on one stream (A/B of the overlap)")
+    ap.add_argument("--mode", default="ref", choices=["ref", "northstar"],
+                    help="ref: the reference's translation-only energy (energy.t); northstar: 6-DoF DQ-blend / "
+                         "projective point-to-plane / ARAP solve (DESIGN.md 4.5) against the live depth map")
+    ap.add_argument("--linear-iter", type=int, default=0, help="PCG iteration cap (default: 256 ref, 64 northstar)")
     return ap.parse_args()
 
 
@@ -118,6 +122,134 @@ class Sequence:
         cur.wait_stream(self.s_fuse)
 
 
+class Sequence6(Sequence):
+    """North-star mode: the live input of the solve is the depth frame itself (vertex / normal maps by
+    computePointNormals), the unknowns are 6-DoF node twists (dfa_solver6)."""
+
+    def __init__(self, cfg_name, device, linear_iter):
+        super().__init__(cfg_name, device)
+        A, cfg = self.A, self.cfg
+        del self.solver, self.live
+        self.solver = A.Solver6(self.D, self.N, self.k)
+        gn = cfg["gn_iters"]
+        outer = 2 if gn % 2 == 0 else 1
+        self.params = A.Solve6Params(num_iter=outer, gn_iter=gn // outer, linear_iter=linear_iter, pcg_tol=1e-6,
+                                     **self.synth.SOLVER)
+        self.gn_total = outer * (gn // outer)
+
+    def solve(self, f):
+        A = self.A
+        P, Nm = A.compute_points_normals(self.depth[f % self.n_frames], *self.intr)
+        self.solver.set_problem(self.nodes, self.node_dq, self.node_w, self.verts, self.normals)
+        self.solver.solve(P, Nm, *self.intr, self.params)
+        self.warped, self.warped_n = self.solver.warp()
+
+
+def cpu_baseline6(cfg_name, frames, params):
+    """CPU statement of the north-star frame (oracle/solve6_oracle.c, double precision) on the host cores."""
+    import oracle as O
+    from dynfu_amd import synth
+    cfg = synth.CONFIGS[cfg_name]
+    threads = min(os.cpu_count() or 1, int(os.environ.get("DFA_CPU_THREADS", "16")))
+    fx, fy, cx, cy = synth.intrinsics(cfg)
+    voxel, trunc, vol2cam, _, _ = synth.volume_params(cfg)
+    dim, k = cfg["dim"], cfg["k"]
+    c = synth.canonical(cfg)
+    vol = np.zeros((dim, dim, dim), np.uint32)
+    depths = [synth.depth_frame(cfg, f) for f in range(frames)]
+    kw = {n: getattr(params, n) for n, _ in params._fields_}
+    t0 = time.perf_counter()
+    pcg = 0
+    for f in range(frames):
+        dists = O.compute_dists(depths[f], fx, fy, cx, cy)
+        O.lib().orc_tsdf_clear(vol.ctypes.data, dim, dim, dim)
+        O.tsdf_integrate(vol, dists, voxel, trunc, synth.MAX_WEIGHT, vol2cam, fx, fy, cx, cy, threads=threads)
+        P, Nm = O.points_normals(depths[f], fx, fy, cx, cy)
+        dq, st = O.solve6(c["node_pos"], c["node_dq"], c["node_w"], k, c["verts"], c["normals"], P, Nm, (fx, fy, cx, cy),
+                          threads=threads, **kw)
+        pcg += st["pcg_iters"]
+    dt = time.perf_counter() - t0
+    return dict(value=round(frames / dt, 4), unit="frames/s", cores=threads, kind="port",
+                sample="%d full frames of config %s, north-star mode (compute_dists, clear, integrate %d^3, "
+                       "computePointNormals, k-NN graphs, %d GN x block-Jacobi PCG (%d PCG iterations in total)) by the "
+                       "C statement in oracle/solve6_oracle.c (fp64 solve), OpenMP over %d of the host's %d cores; %.1f s"
+                       % (frames, cfg_name, dim, params.num_iter * params.gn_iter, pcg, threads, os.cpu_count() or 1, dt))
+
+
+def main_northstar(args, torch, replicas, rank, world, device):
+    """bench line of the north-star mode (same contract; the dominant kernel is reported from hipEvent timings
+    of the phases of the last frame)."""
+    n_gpus = world
+    lin = args.linear_iter or 64
+    seq = Sequence6(args.config, device, lin)
+    cfg = seq.cfg
+    K, Wm = args.steps, args.warmup
+    for f in range(Wm):
+        seq.frame(f, args.serial)
+    fuse_events = []
+
+    def timed():
+        for f in range(K):
+            seq.frame(Wm + f, args.serial, fuse_events)
+
+    dt_max = replicas.timed_region(timed, device)
+    st = seq.solver.stats()
+    # phase timings of one more (untimed) solve, hipEvents on the solve stream
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    P, Nm = seq.A.compute_points_normals(seq.depth[0], *seq.intr)
+    ev[0].record()
+    seq.solver.set_problem(seq.nodes, seq.node_dq, seq.node_w, seq.verts, seq.normals)
+    ev[1].record()
+    seq.solver.solve(P, Nm, *seq.intr, seq.params)
+    ev[2].record()
+    torch.cuda.synchronize()
+    graph_ms, solve_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    if rank != 0:
+        replicas.shutdown()
+        return
+    dim, Wd, Hd = cfg["dim"], cfg["width"], cfg["height"]
+    V = dim ** 3
+    fuse_ms = float(np.mean([a.elapsed_time(b) for a, b in fuse_events])) if fuse_events else float("nan")
+    fuse_bytes = 4.0 * V + 2.0 * Wd * Hd
+    fuse_gbs = fuse_bytes / (fuse_ms * 1e-3) / 1e9
+    its, rowb = st["pcg_iters"], st["max_row_blocks"]
+    # PCG matvec: the block matrix (36 floats + 1 column id per 6x6 block) + gathered vectors, per iteration
+    nnzb_upper = seq.D * rowb
+    pcg_bytes = its * (nnzb_upper * (36 * 4 + 4 + 2 * 24) + 8 * 24.0 * seq.D)
+    fuse_entry = dict(kernel="integrate_kernel<FUSED_CLEAR,4> (clear+integrate %d^3)" % dim, bound="hbm",
+                      achieved=round(fuse_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(fuse_gbs / HBM_PEAK_GBS, 4),
+                      traffic=PMC_TRAFFIC_BYTES.get((args.config, "fused_integrate")), avg_launch_ms=round(fuse_ms, 4),
+                      launches_per_frame=1, algorithmic_bytes_per_launch=fuse_bytes)
+    solve_gbs = pcg_bytes / (solve_ms * 1e-3) / 1e9
+    solve_entry = dict(kernel="dfa_solver6_solve (s6_linearise / s6_assemble / s6_pcg_matvec+update x %d)" % its,
+                       bound="hbm", achieved=round(solve_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                       frac=round(solve_gbs / HBM_PEAK_GBS, 5), traffic=None, avg_launch_ms=None,
+                       solve_ms=round(solve_ms, 3), graph_build_ms=round(graph_ms, 3), pcg_iterations_per_frame=its,
+                       max_blocks_per_row=rowb, algorithmic_bytes_per_frame_upper_bound=pcg_bytes,
+                       note="launch-bound: 2 kernels per PCG iteration; bytes = upper bound from the longest block row")
+    dominant, other = (solve_entry, fuse_entry) if solve_ms > fuse_ms else (fuse_entry, solve_entry)
+    out = dict(metric="frames/sec (warp-solve + TSDF fuse), 512^3 vol / 2k nodes / VGA depth",
+               value=round(n_gpus * K / dt_max, 2), unit="frames/s", n_gpus=n_gpus, steps=K, warmup=Wm,
+               ms_per_step=round(dt_max / K * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype="f32", data="synthetic",
+               config=dict(workload="%s north-star mode: %d^3 TSDF, %dx%d depth, %d nodes, k=%d, %d vertices, %d GN "
+                                    "iterations x block-Jacobi PCG<=%d (tol 1e-6), 6-DoF DQ-blend / projective "
+                                    "point-to-plane / ARAP energy, lambda=200"
+                                    % (args.config, dim, Wd, Hd, seq.D, seq.k, seq.N, seq.gn_total, lin),
+                           parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus,
+                           streams="serial" if args.serial else "fuse || solve on two HIP streams",
+                           pcg_iterations_last_frame=its, gn_iterations_last_frame=st["gn_iters"],
+                           valid_rows_last_frame=st["valid_last"], cost_first=st["initial_cost"], cost_last=st["final_cost"]),
+               roofline=dominant, roofline_other=[other])
+    if not args.no_cpu_baseline and world == 1:
+        params = seq.params
+        del seq
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline6(args.config, max(1, args.cpu_frames // 4), params)
+    print(json.dumps(out), flush=True)
+    replicas.shutdown()
+
+
 def cpu_baseline(cfg_name, frames):
     """The CPU restatement (oracle/, kind "port": NOT Ceres, NOT the reference's CUDA path —
     neither exists for this path in a buildable form) timed on the host cores for `frames`
@@ -176,6 +308,8 @@ def main():
         print("note: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run for N > 1" % (args.gpus, world),
               file=sys.stderr)
 
+    if args.mode == "northstar":
+        return main_northstar(args, torch, replicas, rank, world, device)
     seq = Sequence(args.config, device)
     cfg = seq.cfg
     K, Wm = args.steps, args.warmup

@@ -588,7 +588,7 @@ int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
     REQUIRE(s, "out of host memory");
     s->max_D = max_D, s->max_N = max_N, s->k = k, s->has_problem = false, s->node_dq = nullptr;
     std::memset(&s->v, 0, sizeof(s->v));
-    s->v.cap = 64;
+    s->v.cap = 48;  // = S6_MAXSLOT of solve6.hip
     const size_t N = (size_t)max_N, D = (size_t)max_D, cap = (size_t)s->v.cap;
     int rc = DFA_OK;
 #define A(field, count) \
@@ -612,6 +612,7 @@ int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
     A(rhub, D * k);
     A(bcols, D * cap);
     A(bcnt, D);
+    A(eslot, N * k * k);
     A(bvals, D * cap * 36);
     A(minv, D * 36);
     A(g, D * 6);
@@ -666,7 +667,7 @@ int dfa_solver6_set_problem(dfa_solver6* s, const float* node_pos, const float* 
     HIP_TRY(dfa::launch_knn(node_pos, node_w, D, canon_vertices, N, s->k, v.idx, s->raw_w, grid, S(stream)));
     const int kreg = s->k + 1;
     HIP_TRY(dfa::launch_knn(node_pos, node_w, D, node_pos, D, kreg, s->raw_reg, nullptr, grid, S(stream)));
-    HIP_TRY(dfa::s6_build_graph(v, s->raw_w, s->raw_reg, kreg, S(stream)));
+    HIP_TRY(dfa::s6_build_graph(v, s->state, s->raw_w, s->raw_reg, kreg, S(stream)));
     s->has_problem = true;
     return DFA_OK;
 }

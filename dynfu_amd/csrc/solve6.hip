@@ -330,152 +330,223 @@ __device__ void inv6(const float* M, float* out) {
     }
 }
 
-__global__ __launch_bounds__(256) void s6_assemble_kernel(Solve6View s, Solve6State* st, float wreg2, float damping) {
+// Sparsity pattern of block row a (fixed by the graphs of the frame, built once per set_problem):
+// the diagonal first, then every node that shares a vertex with a or is joined to it by a
+// regularisation edge, ascending.
+__global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6State* st) {
     __shared__ int keys[S6_HASH];
-    __shared__ float acc[S6_HASH][36];
-    __shared__ float red[4][42];
-    __shared__ float diag[42];
-    __shared__ int rank_of[S6_HASH];
     __shared__ int cnt_sh;
+    const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
+    for (int i = tid; i < S6_HASH; i += 256) keys[i] = -1;
+    if (tid == 0) cnt_sh = 0;
+    __syncthreads();
+    bool lost = false;
+    for (int e = s.node_ptr[a] + tid; e < s.node_ptr[a + 1]; e += 256) {
+        const unsigned v = s.node_list[e] / (unsigned)k;
+        for (int j = 0; j < k; ++j) {
+            const int b = s.idx[(size_t)v * k + j];
+            if (b >= 0 && b != a && hash_slot(keys, b) < 0) lost = true;
+        }
+    }
+    if (tid < k) {
+        const int m = s.reg_idx[a * k + tid];
+        if (m >= 0 && m != a && hash_slot(keys, m) < 0) lost = true;
+    }
+    for (int e = s.rnode_ptr[a] + tid; e < s.rnode_ptr[a + 1]; e += 256) {
+        const int n = (int)(s.rnode_list[e] / (unsigned)k);
+        if (n != a && hash_slot(keys, n) < 0) lost = true;
+    }
+    __syncthreads();
+    if (tid < S6_HASH && keys[tid] >= 0) {
+        int r = 0;
+        for (int h = 0; h < S6_HASH; ++h) r += keys[h] >= 0 && keys[h] < keys[tid];
+        if (r + 1 < s.cap) s.bcols[(size_t)a * s.cap + r + 1] = keys[tid];
+        atomicAdd(&cnt_sh, 1);
+    }
+    __syncthreads();
+    const int nblk = cnt_sh + 1, stored = nblk < s.cap ? nblk : s.cap;
+    if (tid == 0) {
+        s.bcols[(size_t)a * s.cap] = a;
+        s.bcnt[a] = stored;
+        atomicMax(&st->max_row_blocks, nblk);
+        if (nblk > s.cap) st->overflow = 1;
+    }
+    if (lost) st->overflow = 1;
+    __syncthreads();  // (the column list of this row was written by this workgroup: visible after the barrier)
+    // slot of every neighbour of every row that touches a: the assembly adds a row's k x k products
+    // straight into the right 6x6 blocks
+    const int32_t* cols = s.bcols + (size_t)a * s.cap;
+    for (int e = s.node_ptr[a] + tid; e < s.node_ptr[a + 1]; e += 256) {
+        const unsigned v = s.node_list[e] / (unsigned)k;
+        for (int j = 0; j < k; ++j) {
+            const int b = s.idx[(size_t)v * k + j];
+            int sl      = 255;
+            if (b == a) sl = 0;
+            else if (b >= 0)
+                for (int q = 1; q < stored; ++q)
+                    if (cols[q] == b) sl = q;
+            s.eslot[(size_t)e * k + j] = (uint8_t)sl;
+        }
+    }
+}
+
+// Values of block row a.  The rows of the energy that touch node a are staged through LDS 32 at a
+// time; a wave takes one staged row at a time and its lanes are the (neighbour j, row c) pairs of
+// that row: lane (j, c) adds w a_s[c] a_j[0..5] to row c of the 6x6 block in the slot of neighbour j
+// (slot precomputed by s6_pattern_kernel) with six LDS float adds.  The lanes of one instruction hit
+// distinct addresses (distinct neighbours -> distinct slots), so the adds only meet across waves.
+// (First version: one lane per row, 64 rows of the same node per instruction -> 64-way same-address
+// conflicts, 3.7 ms per assembly at 4 k nodes; a register version where every (slot, c) thread scanned
+// every row was VALU-bound at 2.2 ms.)
+constexpr int S6_STAGE = 64;
+constexpr int S6_MAXSLOT = 48;  // = plan capacity of a block row
+
+template <int K>
+__global__ __launch_bounds__(256) void s6_assemble_kernel(Solve6View s, Solve6State* st, float wreg2, float damping) {
+    __shared__ float svec[S6_STAGE][K][6];
+    __shared__ uint8_t sslot[S6_STAGE][K];
+    __shared__ float4 smeta[S6_STAGE];  // weight, weight * residual, slot of node a in the row
+    __shared__ float acc[4][S6_MAXSLOT][36];  // one private copy per wave: plain read-add-write, no atomics
+    __shared__ float gsh[4][6];
     const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
     if (a == 0 && tid == 0) {  // bookkeeping of the linearisation that just finished
         if (!st->have_first) st->initial_cost = st->cost, st->valid_first = st->valid, st->have_first = 1;
         st->final_cost = st->cost, st->valid_last = st->valid;
         st->gn_iters += 1;
     }
-    for (int i = tid; i < S6_HASH; i += 256) keys[i] = -1;
-    for (int i = tid; i < S6_HASH * 36; i += 256) (&acc[0][0])[i] = 0.f;
-    __syncthreads();
-    float dg[36], gg[6];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) dg[i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) gg[i] = 0.f;
-    bool lost = false;
-
-    // data rows that touch node a
+    const int cnt = s.bcnt[a];
     const int beg = s.node_ptr[a], end = s.node_ptr[a + 1];
-    for (int e = beg + tid; e < end; e += 256) {
-        const unsigned entry = s.node_list[e];
-        const unsigned v     = entry / (unsigned)k;
-        const float w        = s.wrow[v];
-        if (w == 0.f) continue;
-        float as[6];
+    for (int i = tid; i < 4 * S6_MAXSLOT * 36; i += 256) (&acc[0][0][0])[i] = 0.f;
+    if (tid < 24) (&gsh[0][0])[tid] = 0.f;
+    // lanes of a wave = the (neighbour j, row c) pairs of ONE row of the energy: their targets are distinct
+    // (distinct neighbours -> distinct slots), so a wave updates its private copy without atomics.
+    // (LDS float atomics run at ~0.5 lane per clock on this part: the ds_add_f32 version took 4.6 ms.)
+    const int wave = tid >> 6, lane = tid & 63;
+    const int jl = lane / 6, c = lane - jl * 6;
+    const bool lane_on = jl < K;
+    // software pipeline: the global loads of chunk i + 1 are in flight while chunk i is accumulated
+    constexpr int VPT = (S6_STAGE * K * 6 + 255) / 256;  // staged 6-vector floats per thread
+    constexpr int SPT = (S6_STAGE * K + 255) / 256;      // staged slot bytes per thread
+    float pv[VPT];
+    uint8_t ps[SPT];
+    float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int base) {
+        const int n = min(S6_STAGE, end - base);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) as[c] = s.avec[(size_t)entry * 6 + c];
-        const float wr = w * s.res[v];
+        for (int q = 0; q < VPT; ++q) {
+            const int i = tid + 256 * q, r = i / (K * 6), o = i - r * (K * 6);
+            pv[q] = 0.f;
+            if (r < n && o < k * 6) pv[q] = s.avec[(size_t)(s.node_list[base + r] / (unsigned)k) * k * 6 + o];
+        }
 #pragma unroll
-        for (int c = 0; c < 6; ++c) gg[c] -= as[c] * wr;
-        for (int j = 0; j < k; ++j) {
-            const int b = s.idx[(size_t)v * k + j];
-            if (b < 0) continue;
-            float aj[6];
+        for (int q = 0; q < SPT; ++q) {
+            const int i = tid + 256 * q, r = i / K, j = i - r * K;
+            ps[q] = (r < n && j < k) ? s.eslot[(size_t)(base + r) * k + j] : (uint8_t)255;
+        }
+        if (tid < n) {
+            const unsigned entry = s.node_list[base + tid];
+            const unsigned v     = entry / (unsigned)k;
+            const float w        = s.wrow[v];
+            pm = make_float4(w, w * s.res[v], __int_as_float((int)(entry - v * (unsigned)k)), 0.f);
+        }
+    };
+    if (beg < end) fetch(beg);
+    for (int base = beg; base < end; base += S6_STAGE) {
+        const int n = min(S6_STAGE, end - base);
+        __syncthreads();
 #pragma unroll
-            for (int d = 0; d < 6; ++d) aj[d] = s.avec[((size_t)v * k + j) * 6 + d];
-            if (b == a) {
+        for (int q = 0; q < VPT; ++q) {
+            const int i = tid + 256 * q;
+            if (i < S6_STAGE * K * 6) (&svec[0][0][0])[i] = pv[q];
+        }
 #pragma unroll
-                for (int c = 0; c < 6; ++c)
+        for (int q = 0; q < SPT; ++q) {
+            const int i = tid + 256 * q;
+            if (i < S6_STAGE * K) (&sslot[0][0])[i] = ps[q];
+        }
+        if (tid < n) smeta[tid] = pm;
+        __syncthreads();
+        if (base + S6_STAGE < end) fetch(base + S6_STAGE);
+        for (int r = wave; r < n && lane_on; r += 4) {
+            const float4 mt = smeta[r];
+            const int sl    = sslot[r][jl];
+            if (mt.x == 0.f || sl >= cnt) continue;
+            const int own  = __float_as_int(mt.z);
+            const float as = svec[r][own][c];
+            const float wa = mt.x * as;
+            float2* dst    = reinterpret_cast<float2*>(&acc[wave][sl][c * 6]);
+            const float2* src = reinterpret_cast<const float2*>(&svec[r][jl][0]);
 #pragma unroll
-                    for (int d = 0; d < 6; ++d) dg[c * 6 + d] += w * as[c] * aj[d];
-            } else {
-                const int h = hash_slot(keys, b);
-                if (h < 0) {
-                    lost = true;
-                    continue;
-                }
+            for (int d = 0; d < 3; ++d) {
+                float2 t = dst[d];
+                const float2 v = src[d];
+                t.x += wa * v.x, t.y += wa * v.y;
+                dst[d] = t;
+            }
+            if (jl == own) gsh[wave][c] -= mt.y * as;
+        }
+    }
+    __syncthreads();
+    // regularisation + output: thread (slot, row) finishes row `row` of the block in `slot`
+    __shared__ float diag[36];
+    for (int t0 = 0; t0 < cnt * 6; t0 += 256) {
+        const int t = t0 + tid;
+        if (t < cnt * 6) {
+            const int slot = t / 6, my_row = t - 6 * slot;
+            const int col  = s.bcols[(size_t)a * s.cap + slot];
+            float accr[6];
 #pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    const float wa = w * as[c];
+            for (int d = 0; d < 6; ++d)
+                accr[d] = (acc[0][slot][my_row * 6 + d] + acc[1][slot][my_row * 6 + d]) +
+                          (acc[2][slot][my_row * 6 + d] + acc[3][slot][my_row * 6 + d]);
+            float gacc = slot == 0 ? (gsh[0][my_row] + gsh[1][my_row]) + (gsh[2][my_row] + gsh[3][my_row]) : 0.f;
+            // regularisation edges leaving a (a -> m): rows c of e = T_a g_m - g^_m with vectors (an_c at a, -e_{3+c} at m)
+            for (int q = 0; q < k; ++q) {
+                const int e = a * k + q, m = s.reg_idx[e];
+                if (m < 0 || (slot != 0 && col != m)) continue;
+                const float wt = wreg2 * s.rhub[e];
+                for (int cc = 0; cc < 3; ++cc) {
+                    const float* an = s.rvec + 18 * (size_t)e + 6 * cc;
+                    if (slot == 0) {
+                        gacc -= wt * an[my_row] * s.rres[3 * (size_t)e + cc];
 #pragma unroll
-                    for (int d = 0; d < 6; ++d) atomicAdd(&acc[h][c * 6 + d], wa * aj[d]);
+                        for (int d = 0; d < 6; ++d) accr[d] += wt * an[my_row] * an[d];
+                    } else {
+                        accr[3 + cc] -= wt * an[my_row];
+                    }
                 }
             }
-        }
-    }
-    // regularisation edges leaving a (a -> m): rows c of e = T_a g_m - g^_m, vectors (an_c at a, -e_{3+c} at m)
-    if (tid < k) {
-        const int e = a * k + tid, m = s.reg_idx[e];
-        if (m >= 0) {
-            const float wt = wreg2 * s.rhub[e];
-            const int h    = hash_slot(keys, m);
-            if (h < 0) lost = true;
-            for (int c = 0; c < 3; ++c) {
-                const float* an = s.rvec + 18 * (size_t)e + 6 * c;
-                const float ec  = s.rres[3 * (size_t)e + c];
-                for (int q = 0; q < 6; ++q) {
-                    gg[q] -= wt * an[q] * ec;
-                    for (int q2 = 0; q2 < 6; ++q2) dg[q * 6 + q2] += wt * an[q] * an[q2];
-                    if (h >= 0) atomicAdd(&acc[h][q * 6 + 3 + c], -wt * an[q]);
+            // regularisation edges arriving at a (n -> a)
+            if (my_row >= 3) {
+                const int cc = my_row - 3;
+                for (int e = s.rnode_ptr[a]; e < s.rnode_ptr[a + 1]; ++e) {
+                    const unsigned entry = s.rnode_list[e];
+                    const int n          = (int)(entry / (unsigned)k);
+                    if (slot != 0 && col != n) continue;
+                    const float wt = wreg2 * s.rhub[entry];
+                    if (slot == 0) {
+                        gacc += wt * s.rres[3 * (size_t)entry + cc];
+                        accr[my_row] += wt;
+                    } else {
+                        const float* an = s.rvec + 18 * (size_t)entry + 6 * cc;
+#pragma unroll
+                        for (int d = 0; d < 6; ++d) accr[d] -= wt * an[d];
+                    }
                 }
             }
+            if (slot == 0) {
+                accr[my_row] += damping;
+                s.g[6 * (size_t)a + my_row] = gacc;
+#pragma unroll
+                for (int d = 0; d < 6; ++d) diag[my_row * 6 + d] = accr[d];
+            }
+            float* out = s.bvals + ((size_t)a * s.cap + slot) * 36 + 6 * my_row;
+#pragma unroll
+            for (int d = 0; d < 6; ++d) out[d] = accr[d];
         }
     }
-    // regularisation edges arriving at a (n -> a)
-    for (int e = s.rnode_ptr[a] + tid; e < s.rnode_ptr[a + 1]; e += 256) {
-        const unsigned entry = s.rnode_list[e];
-        const int n          = (int)(entry / (unsigned)k);
-        const float wt       = wreg2 * s.rhub[entry];
-        const int h          = hash_slot(keys, n);
-        if (h < 0) lost = true;
-        for (int c = 0; c < 3; ++c) {
-            const float* an = s.rvec + 18 * (size_t)entry + 6 * c;
-            const float ec  = s.rres[3 * (size_t)entry + c];
-            gg[3 + c] += wt * ec;
-            dg[(3 + c) * 6 + 3 + c] += wt;
-            if (h >= 0)
-                for (int q = 0; q < 6; ++q) atomicAdd(&acc[h][(3 + c) * 6 + q], -wt * an[q]);
-        }
-    }
-    // workgroup totals of the register accumulators
-#pragma unroll
-    for (int i = 0; i < 36; ++i) dg[i] = wave_sum_all(dg[i]);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) gg[i] = wave_sum_all(gg[i]);
-    if ((tid & 63) == 0) {
-#pragma unroll
-        for (int i = 0; i < 36; ++i) red[tid >> 6][i] = dg[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) red[tid >> 6][36 + i] = gg[i];
-    }
     __syncthreads();
-    if (tid < 42) {
-        float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-        if (tid < 36 && tid % 7 == 0) v += damping;
-        diag[tid] = v;
-    }
-    // rank of every used hash slot by its column id -> deterministic block order
-    if (tid < S6_HASH) {
-        int r = -1;
-        const int mine = keys[tid];
-        if (mine >= 0) {
-            r = 0;
-            for (int h = 0; h < S6_HASH; ++h) r += keys[h] >= 0 && keys[h] < mine;
-        }
-        rank_of[tid] = r;
-    }
-    if (tid == 0) cnt_sh = 0;
-    __syncthreads();
-    if (tid < S6_HASH && rank_of[tid] >= 0) atomicAdd(&cnt_sh, 1);
-    __syncthreads();
-    const int nblk = cnt_sh + 1;  // + diagonal
-    int32_t* cols  = s.bcols + (size_t)a * s.cap;
-    float* vals    = s.bvals + (size_t)a * s.cap * 36;
-    if (tid < 36) vals[tid] = diag[tid];
-    if (tid == 0) cols[0] = a;
-    if (tid < 6) s.g[6 * (size_t)a + tid] = diag[36 + tid];
-    for (int h = tid >> 1; h < S6_HASH; h += 128) {  // two lanes per slot: 18 values each
-        const int r = rank_of[h];
-        if (r < 0 || r + 1 >= s.cap) continue;
-        const int half = tid & 1;
-        if (half == 0) cols[r + 1] = keys[h];
-        for (int i = 0; i < 18; ++i) vals[(size_t)(r + 1) * 36 + half * 18 + i] = acc[h][half * 18 + i];
-    }
-    if (tid == 0) {
-        s.bcnt[a] = nblk < s.cap ? nblk : s.cap;
-        atomicMax(&st->max_row_blocks, nblk);
-        inv6(diag, s.minv + 36 * (size_t)a);
-    }
-    if (lost || (tid == 0 && nblk > s.cap)) st->overflow = 1;
+    if (tid == 0) inv6(diag, s.minv + 36 * (size_t)a);
 }
 
 // -------------------------------------------------------------------------------------- PCG
@@ -655,7 +726,7 @@ __global__ __launch_bounds__(256) void s6_begin_kernel(Solve6View s, Solve6State
     if (i == 0) {
         st->cost = 0.0, st->initial_cost = 0.0, st->final_cost = 0.0;
         st->valid = st->valid_first = st->valid_last = 0ull;
-        st->have_first = 0, st->gn_iters = 0, st->pcg_iters = 0, st->overflow = 0, st->max_row_blocks = 0;
+        st->have_first = 0, st->gn_iters = 0, st->pcg_iters = 0;  // overflow / max_row_blocks belong to the pattern
         st->pcg_done = 0, st->rz0 = 0.f;
     }
     if (i < 8 * s.D) s.dq[i] = node_dq[i];
@@ -698,12 +769,26 @@ __global__ __launch_bounds__(256) void points_normals_kernel(const uint16_t* __r
         else kernel<8> __VA_ARGS__;           \
     } while (0)
 
-hipError_t s6_build_graph(const Solve6View& s, const float* raw_w, const int32_t* raw_reg, int kreg, hipStream_t st) {
+namespace {
+__global__ void s6_pattern_reset_kernel(Solve6State* st) { st->overflow = 0, st->max_row_blocks = 0; }
+}  // namespace
+
+hipError_t s6_build_graph_impl(const Solve6View& s, Solve6State* state, const float* raw_w, const int32_t* raw_reg, int kreg,
+                               hipStream_t st) {
+    s6_pattern_reset_kernel<<<1, 1, 0, st>>>(state);
     if (s.N > 0) s6_normalise_kernel<<<(s.N + 255) / 256, 256, 0, st>>>(raw_w, s.N, s.k, s.wn);
     s6_reg_graph_kernel<<<(s.D + 255) / 256, 256, 0, st>>>(raw_reg, s.D, kreg, s.k, s.reg_idx);
     hipError_t e = solve_transpose_graph(s.idx, (size_t)s.N * s.k, s.D, s.blk_hist, s.node_ptr, s.node_list, st);
     if (e != hipSuccess) return e;
-    return solve_transpose_graph(s.reg_idx, (size_t)s.D * s.k, s.D, s.blk_hist, s.rnode_ptr, s.rnode_list, st);
+    e = solve_transpose_graph(s.reg_idx, (size_t)s.D * s.k, s.D, s.blk_hist, s.rnode_ptr, s.rnode_list, st);
+    if (e != hipSuccess) return e;
+    s6_pattern_kernel<<<s.D, 256, 0, st>>>(s, state);
+    return hipGetLastError();
+}
+
+hipError_t s6_build_graph(const Solve6View& s, Solve6State* state, const float* raw_w, const int32_t* raw_reg, int kreg,
+                          hipStream_t st) {
+    return s6_build_graph_impl(s, state, raw_w, raw_reg, kreg, st);
 }
 
 hipError_t s6_begin(const Solve6View& s, Solve6State* state, const float* node_dq, hipStream_t st) {
@@ -723,7 +808,7 @@ hipError_t s6_linearise(const Solve6View& s, Solve6State* state, const Solve6Ima
 
 hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Params& p, hipStream_t st) {
     const float wreg2 = p.lambda / ((float)s.D * (float)s.k);
-    s6_assemble_kernel<<<s.D, 256, 0, st>>>(s, state, wreg2, p.damping);
+    K6DISPATCH(s6_assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, wreg2, p.damping));
     return hipGetLastError();
 }
 

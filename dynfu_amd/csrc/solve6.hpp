@@ -63,6 +63,7 @@ struct Solve6View {
     // normal equations, block ELL
     int32_t* bcols;  // D x cap
     int32_t* bcnt;   // D
+    uint8_t* eslot;  // (N k) x k: slot, in the block row of the entry's node, of each neighbour of the entry's vertex
     float* bvals;    // D x cap x 36
     float* minv;     // D x 36  inverse of the (damped) diagonal block
     float* g;        // D x 6   -J^T W r
@@ -76,8 +77,8 @@ constexpr int S6_NODES_PER_BLOCK = 8;  // matvec: one wave per node, 512 threads
 __host__ __device__ inline int s6_matvec_blocks(int D) { return (D + S6_NODES_PER_BLOCK - 1) / S6_NODES_PER_BLOCK; }
 __host__ __device__ inline int s6_update_blocks(int D) { return (6 * D + 255) / 256; }
 
-hipError_t s6_build_graph(const Solve6View& s, const float* raw_w /* N x k */, const int32_t* raw_reg /* D x (k+1) */,
-                          int kreg, hipStream_t st);
+hipError_t s6_build_graph(const Solve6View& s, Solve6State* state, const float* raw_w /* N x k */,
+                          const int32_t* raw_reg /* D x (k+1) */, int kreg, hipStream_t st);
 hipError_t s6_begin(const Solve6View& s, Solve6State* state, const float* node_dq, hipStream_t st);
 hipError_t s6_linearise(const Solve6View& s, Solve6State* state, const Solve6Image& img, const Solve6Params& p,
                         int update_weights, hipStream_t st);

@@ -4,7 +4,7 @@ double-precision oracle oracle/solve6_oracle.c.
 The mode is not in the reference (parity unpinned); the oracle is pinned by
 tests/test_oracle_solve6.py (finite differences, dense solve).  Tolerances (fp32 kernels vs fp64
 oracle, same iteration counts): energies within 1e-3 relative, association counts equal up to
-pixel-rounding ties (<= 0.1 % of the rows), warped vertices within 2e-5 m on average and 5e-4 m
+pixel-rounding ties (<= 0.1 % of the rows), warped vertices within 5e-5 m on average and 1e-3 m
 at worst, computePointNormals bit-exact."""
 import numpy as np
 import pytest
@@ -73,7 +73,7 @@ def test_solve_matches_the_oracle(A, name, frame, k_override):
     idx, wn, _ = O.graph6(c["node_pos"], c["node_w"], cfg["k"], c["verts"])
     p_ref, n_ref = O.warp6(dq_ref, idx, wn, c["verts"], c["normals"])
     d = np.linalg.norm(wv - p_ref, axis=1)
-    assert d.mean() < 2e-5 and d.max() < 5e-4
+    assert d.mean() < 5e-5 and d.max() < 1e-3
     assert np.abs(wn_ - n_ref).max() < 2e-3
     # the device warp is the oracle's DQ blend of the device's own transforms
     p_same, _ = O.warp6(dq, idx, wn, c["verts"])
