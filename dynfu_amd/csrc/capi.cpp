@@ -617,15 +617,20 @@ int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
     A(minv, D * 36);
     A(g, D * 6);
     A(x, D * 6);
-    A(z, D * 6);
-    A(q, D * 6);
-    A(r[0], D * 6);
-    A(r[1], D * 6);
-    A(p[0], D * 6);
-    A(p[1], D * 6);
-    A(pq_part, (size_t)dfa::s6_matvec_blocks(max_D));
-    A(rz_part[0], (size_t)dfa::s6_update_blocks(max_D));
-    A(rz_part[1], (size_t)dfa::s6_update_blocks(max_D));
+    A(r, D * 6);
+    A(p, D * 6);
+    A(s, D * 6);
+    A(w, D * 6);
+    A(u[0], D * 6);
+    A(u[1], D * 6);
+    A(t[0], D * 6);
+    A(t[1], D * 6);
+    A(m[0], D * 6);
+    A(m[1], D * 6);
+    A(g_part[0], (size_t)dfa::s6_matvec_blocks(max_D));
+    A(g_part[1], (size_t)dfa::s6_matvec_blocks(max_D));
+    A(d_part[0], (size_t)dfa::s6_matvec_blocks(max_D));
+    A(d_part[1], (size_t)dfa::s6_matvec_blocks(max_D));
 #undef A
     if (rc == DFA_OK) rc = plan6_alloc(s, &s->raw_w, N * k);
     if (rc == DFA_OK) rc = plan6_alloc(s, &s->raw_reg, D * (k + 1));

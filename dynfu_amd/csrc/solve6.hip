@@ -333,12 +333,46 @@ __device__ void inv6(const float* M, float* out) {
 // Sparsity pattern of block row a (fixed by the graphs of the frame, built once per set_problem):
 // the diagonal first, then every node that shares a vertex with a or is joined to it by a
 // regularisation edge, ascending.
+constexpr int S6_SORT_MAX = 4096;
+
 __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6State* st) {
     __shared__ int keys[S6_HASH];
     __shared__ int cnt_sh;
+    __shared__ uint32_t sortbuf[S6_SORT_MAX];
     const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
     for (int i = tid; i < S6_HASH; i += 256) keys[i] = -1;
     if (tid == 0) cnt_sh = 0;
+    // The transposition fills a node's list in whatever order its workgroups' atomics land; sort it so
+    // that the assembly adds the rows in ascending (vertex, slot) order: run-to-run reproducible sums.
+    {
+        const int beg = s.node_ptr[a], len = s.node_ptr[a + 1] - beg;
+        if (len > 1 && len <= S6_SORT_MAX) {
+            int n2 = 1;
+            while (n2 < len) n2 <<= 1;
+            for (int i = tid; i < n2; i += 256) sortbuf[i] = i < len ? s.node_list[beg + i] : 0xffffffffu;
+            __syncthreads();
+            for (int size = 2; size <= n2; size <<= 1)
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int i = tid; i < n2 / 2; i += 256) {
+                        const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+                        const bool up = (lo & size) == 0;
+                        const uint32_t x = sortbuf[lo], y = sortbuf[hi];
+                        if ((x > y) == up) sortbuf[lo] = y, sortbuf[hi] = x;
+                    }
+                    __syncthreads();
+                }
+            for (int i = tid; i < len; i += 256) s.node_list[beg + i] = sortbuf[i];
+        }
+        if (tid == 0) {  // the few regularisation edges arriving at a: insertion sort
+            const int rb = s.rnode_ptr[a], re = s.rnode_ptr[a + 1];
+            for (int i = rb + 1; i < re; ++i) {
+                const uint32_t x = s.rnode_list[i];
+                int j = i - 1;
+                for (; j >= rb && s.rnode_list[j] > x; --j) s.rnode_list[j + 1] = s.rnode_list[j];
+                s.rnode_list[j + 1] = x;
+            }
+        }
+    }
     __syncthreads();
     bool lost = false;
     for (int e = s.node_ptr[a] + tid; e < s.node_ptr[a + 1]; e += 256) {
@@ -365,6 +399,7 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
     }
     __syncthreads();
     const int nblk = cnt_sh + 1, stored = nblk < s.cap ? nblk : s.cap;
+    for (int i = stored + tid; i < s.cap; i += 256) s.bcols[(size_t)a * s.cap + i] = -1;  // the matvec reads no count
     if (tid == 0) {
         s.bcols[(size_t)a * s.cap] = a;
         s.bcnt[a] = stored;
@@ -550,6 +585,16 @@ __global__ __launch_bounds__(256) void s6_assemble_kernel(Solve6View s, Solve6St
 }
 
 // -------------------------------------------------------------------------------------- PCG
+// Chronopoulos-Gear form of preconditioned CG: the two inner products of an iteration are taken
+// together after the matrix product, so an iteration needs ONE grid-wide synchronisation — one
+// kernel launch (the textbook form needs two: 22 us per iteration at 4 k nodes, launch-bound).
+//   u = M^-1 r, w = A u, m = M^-1 w, t = M^-1 s (kept by the recurrence t_i = m_i + beta_i t_{i-1})
+//   p_i = u_i + beta_i p_{i-1};  s_i = w_i + beta_i s_{i-1};  x += alpha_i p_i;  r -= alpha_i s_i
+//   u_{i+1} = u_i - alpha_i t_i;  w_{i+1} = A u_{i+1};  gamma = (r, u), delta = (w, u)
+//   beta_{i+1} = gamma_{i+1} / gamma_i;  alpha_{i+1} = gamma_{i+1} / (delta_{i+1} - beta_{i+1} gamma_{i+1} / alpha_i)
+// The matrix product of launch i needs u_{i+1} of OTHER nodes, which their waves are only computing in
+// the same launch: the gather rebuilds it from u_i, m_i, t_{i-1} and the two scalars (18 floats per
+// neighbour block next to the block's own 36).  Same iterates as textbook PCG in exact arithmetic.
 __device__ __forceinline__ float sum_partials(const float* __restrict__ part, int n) {
     float acc = 0.f;
     for (int i = threadIdx.x & 63; i < n; i += 64) acc += part[i];
@@ -557,123 +602,133 @@ __device__ __forceinline__ float sum_partials(const float* __restrict__ part, in
 }
 
 __global__ __launch_bounds__(256) void s6_pcg_init_kernel(Solve6View s, Solve6State* st) {
-    __shared__ float sh[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (node, component)
-    float rz    = 0.f;
     if (i == 0) st->pcg_done = 0;
     if (i < 6 * s.D) {
         const int n = i / 6, c = i - 6 * n;
         const float* Mi = s.minv + 36 * (size_t)n + 6 * c;
         const float* gn = s.g + 6 * (size_t)n;
-        float z = 0.f;
+        float u = 0.f;
 #pragma unroll
-        for (int d = 0; d < 6; ++d) z += Mi[d] * gn[d];
-        s.x[i] = 0.f, s.r[0][i] = gn[c], s.z[i] = z;
-        rz = gn[c] * z;
+        for (int d = 0; d < 6; ++d) u += Mi[d] * gn[d];
+        s.x[i] = 0.f, s.r[i] = gn[c], s.u[0][i] = u;
+        s.p[i] = 0.f, s.s[i] = 0.f, s.t[0][i] = 0.f, s.t[1][i] = 0.f;
     }
-    rz = wave_sum_all(rz);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = rz;
-    __syncthreads();
-    if (threadIdx.x == 0) s.rz_part[0][blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-// q = H p with p = z + beta p_old formed on the fly; one wave per block row
-__global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_matvec_kernel(Solve6View s, Solve6State* st, int it,
-                                                                                float tol2) {
-    __shared__ float stage[S6_NODES_PER_BLOCK][64];
-    __shared__ float pq_sh[S6_NODES_PER_BLOCK];
+// launch `it` = -1: w_0 = A u_0, m_0, gamma_0, delta_0.   launch it >= 0: iteration `it` as above.
+__global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(Solve6View s, Solve6State* st, int it,
+                                                                              float tol2) {
+    __shared__ float stage[S6_NODES_PER_BLOCK][3][64];
+    __shared__ float gd_sh[S6_NODES_PER_BLOCK][2];
     if (st->pcg_done) return;
-    const int nub = s6_update_blocks(s.D);
-    const float rz_cur = sum_partials(s.rz_part[it & 1], nub);
-    float beta = 0.f;
-    if (it == 0) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) st->rz0 = rz_cur;
-    } else {
-        const float rz_prev = sum_partials(s.rz_part[(it - 1) & 1], nub);
-        beta                = rz_cur / rz_prev;
-    }
-    const float rz0 = it == 0 ? rz_cur : st->rz0;
-    if (!(rz_cur > 0.f) || rz_cur <= tol2 * rz0) {  // converged (or breakdown): same decision in every workgroup
-        if (blockIdx.x == 0 && threadIdx.x == 0) st->pcg_done = 1;
-        return;
-    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int a    = blockIdx.x * S6_NODES_PER_BLOCK + wave;
-    const float* pold = s.p[(it + 1) & 1];
-    float* pnew       = s.p[it & 1];
-    float total = 0.f, pn = 0.f;
-    if (a < s.D) {
+    const int cur = it >= 0 ? (it & 1) : 0, nxt = cur ^ 1;  // u, m: read [cur], write [nxt]; t: read [nxt], write [cur]
+    const float* ucur  = s.u[cur];
+    const float* mcur  = s.m[cur];
+    const float* tprev = s.t[nxt];
+    // The kernel is a chain of dependent memory round trips (~2 us each), so everything that does not
+    // depend on this iteration's scalars is issued first: the three products A u, A m, A t are gathered
+    // with the columns preloaded and the loop unrolled (all loads in flight together), and
+    // w = A u - alpha (A m + beta A t) is formed afterwards.
+    constexpr int MAXIT = 5;  // 10 slots per pass, plan capacity 48
+    float au = 0.f, am = 0.f, at = 0.f;
+    if (a < s.D && lane < 60) {
         const int ss = lane / 6, c = lane - 6 * ss;
-        float acc    = 0.f;
-        if (lane < 60) {
-            const int cnt = s.bcnt[a];
-            for (int sl = ss; sl < cnt; sl += 10) {
-                const int col  = s.bcols[(size_t)a * s.cap + sl];
-                const float* H = s.bvals + ((size_t)a * s.cap + sl) * 36 + 6 * c;
+        int cols[MAXIT];
 #pragma unroll
-                for (int d = 0; d < 6; ++d) {
-                    float pv = s.z[6 * (size_t)col + d];
-                    if (it > 0) pv += beta * pold[6 * (size_t)col + d];
-                    acc += H[d] * pv;
-                }
+        for (int q = 0; q < MAXIT; ++q) {
+            const int sl = ss + 10 * q;
+            cols[q]      = sl < s.cap ? s.bcols[(size_t)a * s.cap + sl] : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < MAXIT; ++q) {
+            if (cols[q] < 0) continue;
+            const float* H  = s.bvals + ((size_t)a * s.cap + ss + 10 * q) * 36 + 6 * c;
+            const size_t cb = 6 * (size_t)cols[q];
+#pragma unroll
+            for (int d = 0; d < 6; ++d) {
+                au += H[d] * ucur[cb + d];
+                if (it >= 0) am += H[d] * mcur[cb + d], at += H[d] * tprev[cb + d];
             }
         }
-        stage[wave][lane] = acc;
     }
-    __syncthreads();
+    float minv_row[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, own_u = 0.f, own_m = 0.f, own_t = 0.f, own_p = 0.f, own_s = 0.f,
+          own_w = 0.f, own_r = 0.f, own_x = 0.f;
     if (a < s.D && lane < 6) {
+        const size_t i = 6 * (size_t)a + lane;
 #pragma unroll
-        for (int ss = 0; ss < 10; ++ss) total += stage[wave][ss * 6 + lane];
-        pn = s.z[6 * (size_t)a + lane];
-        if (it > 0) pn += beta * pold[6 * (size_t)a + lane];
-        pnew[6 * (size_t)a + lane] = pn;
-        s.q[6 * (size_t)a + lane]  = total;
+        for (int d = 0; d < 6; ++d) minv_row[d] = s.minv[36 * (size_t)a + 6 * lane + d];
+        own_u = ucur[i], own_r = s.r[i];
+        if (it >= 0) own_m = mcur[i], own_t = tprev[i], own_p = s.p[i], own_s = s.s[i], own_w = s.w[i], own_x = s.x[i];
     }
-    const float pq = wave_sum_all(lane < 6 ? pn * total : 0.f);
-    if (lane == 0) pq_sh[wave] = pq;
+    // scalars of this iteration
+    const int nb = s6_matvec_blocks(s.D);
+    float alpha = 0.f, beta = 0.f;
+    if (it >= 0) {
+        const float gamma = sum_partials(s.g_part[it & 1], nb), delta = sum_partials(s.d_part[it & 1], nb);
+        float denom = delta;
+        if (it > 0) {
+            beta = gamma / st->gamma_prev[(it + 1) & 1];
+            denom -= beta * gamma / st->alpha_prev[(it + 1) & 1];
+        }
+        const float rz0 = it == 0 ? gamma : st->rz0;
+        // converged, or breakdown: the same decision in every workgroup
+        if (!(gamma > 0.f) || gamma <= tol2 * rz0 || !(denom > 0.f)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) st->pcg_done = 1;
+            return;
+        }
+        alpha = gamma / denom;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            st->gamma_prev[it & 1] = gamma, st->alpha_prev[it & 1] = alpha;
+            if (it == 0) st->rz0 = gamma;
+            st->pcg_iters += 1;
+        }
+    }
+    stage[wave][0][lane] = au, stage[wave][1][lane] = am, stage[wave][2][lane] = at;
+    __syncthreads();
+    float gpart = 0.f, dpart = 0.f;
+    if (a < s.D) {
+        float wn = 0.f;
+        if (lane < 6) {
+            float su = 0.f, sm = 0.f, stt = 0.f;
+#pragma unroll
+            for (int ss = 0; ss < 10; ++ss)
+                su += stage[wave][0][ss * 6 + lane], sm += stage[wave][1][ss * 6 + lane], stt += stage[wave][2][ss * 6 + lane];
+            wn = it >= 0 ? su - alpha * (sm + beta * stt) : su;
+        }
+        // m_new = M^-1 w_new needs the six components held by lanes 0..5
+        float mn = 0.f;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) mn += minv_row[d] * __shfl(wn, d, 64);
+        if (lane < 6) {
+            const size_t i = 6 * (size_t)a + lane;
+            float un = own_u, rn = own_r;
+            if (it >= 0) {
+                const float tn = own_m + beta * own_t;
+                const float pn = own_u + beta * own_p;
+                const float sn = own_w + beta * own_s;
+                un = own_u - alpha * tn;
+                rn = own_r - alpha * sn;
+                s.t[cur][i] = tn, s.p[i] = pn, s.s[i] = sn;
+                s.x[i] = own_x + alpha * pn;
+                s.r[i] = rn;
+                s.u[nxt][i] = un;
+            }
+            s.w[i] = wn;
+            s.m[it >= 0 ? nxt : 0][i] = mn;
+            gpart = rn * un, dpart = wn * un;
+        }
+    }
+    gpart = wave_sum_all(gpart), dpart = wave_sum_all(dpart);
+    if (lane == 0) gd_sh[wave][0] = gpart, gd_sh[wave][1] = dpart;
     __syncthreads();
     if (threadIdx.x == 0) {
-        float t = 0.f;
-        for (int w = 0; w < S6_NODES_PER_BLOCK; ++w) t += pq_sh[w];
-        s.pq_part[blockIdx.x] = t;
-    }
-}
-
-__global__ __launch_bounds__(256) void s6_pcg_update_kernel(Solve6View s, Solve6State* st, int it) {
-    __shared__ float sh[4];
-    if (st->pcg_done) return;
-    const float rz_cur = sum_partials(s.rz_part[it & 1], s6_update_blocks(s.D));
-    const float pq     = sum_partials(s.pq_part, s6_matvec_blocks(s.D));
-    if (!(pq > 0.f)) {  // breakdown: stop here, x keeps its value
-        if (blockIdx.x == 0 && threadIdx.x == 0) st->pcg_done = 1;
-        return;
-    }
-    const float alpha = rz_cur / pq;
-    const int i       = blockIdx.x * blockDim.x + threadIdx.x;
-    float rz          = 0.f;
-    const float* p    = s.p[it & 1];
-    const float* rold = s.r[it & 1];  // ping-pong: the six lanes of a node all read the whole old residual
-    float* rnew       = s.r[(it + 1) & 1];
-    if (i < 6 * s.D) {
-        const int n = i / 6, c = i - 6 * n;
-        s.x[i] += alpha * p[i];
-        float rn[6];
-#pragma unroll
-        for (int d = 0; d < 6; ++d) rn[d] = rold[6 * (size_t)n + d] - alpha * s.q[6 * (size_t)n + d];
-        const float* Mi = s.minv + 36 * (size_t)n + 6 * c;
-        float z = 0.f;
-#pragma unroll
-        for (int d = 0; d < 6; ++d) z += Mi[d] * rn[d];
-        rnew[i] = rn[c];
-        s.z[i]  = z;
-        rz      = rn[c] * z;
-    }
-    rz = wave_sum_all(rz);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = rz;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        s.rz_part[(it + 1) & 1][blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-        if (blockIdx.x == 0) st->pcg_iters += 1;
+        float g = 0.f, d = 0.f;
+        for (int w = 0; w < S6_NODES_PER_BLOCK; ++w) g += gd_sh[w][0], d += gd_sh[w][1];
+        const int slot = it >= 0 ? ((it + 1) & 1) : 0;
+        s.g_part[slot][blockIdx.x] = g, s.d_part[slot][blockIdx.x] = d;
     }
 }
 
@@ -816,10 +871,8 @@ hipError_t s6_pcg(const Solve6View& s, Solve6State* state, const Solve6Params& p
     const int ub = s6_update_blocks(s.D), mb = s6_matvec_blocks(s.D);
     s6_pcg_init_kernel<<<ub, 256, 0, st>>>(s, state);
     const float tol2 = p.pcg_tol * p.pcg_tol;
-    for (int it = 0; it < p.linear_iter; ++it) {
-        s6_pcg_matvec_kernel<<<mb, 64 * S6_NODES_PER_BLOCK, 0, st>>>(s, state, it, tol2);
-        s6_pcg_update_kernel<<<ub, 256, 0, st>>>(s, state, it);
-    }
+    // launch -1 forms w_0 = A u_0; launch it >= 0 is iteration it (x_{it+1} is complete when it returns)
+    for (int it = -1; it < p.linear_iter; ++it) s6_pcg_step_kernel<<<mb, 64 * S6_NODES_PER_BLOCK, 0, st>>>(s, state, it, tol2);
     return hipGetLastError();
 }
 

@@ -22,7 +22,8 @@ struct Solve6State {
     int overflow;        // a block row did not fit the plan's capacity / hash table
     int max_row_blocks;
     int pcg_done;        // sticky flag of the PCG in flight
-    float rz0;           // r.z of its first iteration
+    float rz0;           // (r, u) of its first iteration
+    float gamma_prev[2], alpha_prev[2];  // scalars of the previous iteration (ping-pong)
 };
 
 struct Solve6Image {  // live vertex / normal maps (borrowed): float4 pixels, NaN where undefined
@@ -68,9 +69,9 @@ struct Solve6View {
     float* minv;     // D x 36  inverse of the (damped) diagonal block
     float* g;        // D x 6   -J^T W r
     // PCG
-    float *x, *z, *q, *r[2], *p[2];  // D x 6 (r, p ping-pong between iterations)
-    float* pq_part;               // per matvec workgroup
-    float* rz_part[2];            // per update workgroup
+    float *x, *r, *p, *s, *w;   // D x 6, touched by the owning wave only
+    float *u[2], *t[2], *m[2];  // D x 6, ping-pong: read by every wave while the owner writes the other copy
+    float *g_part[2], *d_part[2];  // per matvec workgroup: partial (r, u) and (w, u)
 };
 
 constexpr int S6_NODES_PER_BLOCK = 8;  // matvec: one wave per node, 512 threads
