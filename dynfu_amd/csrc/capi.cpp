@@ -603,10 +603,12 @@ int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
     A(rnode_list, D * k);
     A(dq, D * 8);
     A(ghat, D * 3);
-    A(avec, N * k * 6);
-    A(res, N);
+    A(epos, N * k);
+    A(el, N * k * 8);
+    A(ef, N * k * k);
+    A(em, N * k * 2);
+    A(mnode, D * 48);
     A(rho, N);
-    A(wrow, N);
     A(rres, D * k * 3);
     A(rvec, D * k * 18);
     A(rhub, D * k);

@@ -126,8 +126,23 @@ __global__ __launch_bounds__(256) void s6_nodes_kernel(Solve6View s, Solve6State
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n == 0) st->cost = 0.0, st->valid = 0ull;
     if (n >= s.D) return;
-    const f3 g = dq_point(dq_load(s.dq + 8 * (size_t)n), mk3(s.node_pos[3 * n], s.node_pos[3 * n + 1], s.node_pos[3 * n + 2]));
+    const DQ q = dq_load(s.dq + 8 * (size_t)n);
+    const f3 g = dq_point(q, mk3(s.node_pos[3 * n], s.node_pos[3 * n + 1], s.node_pos[3 * n + 2]));
     s.ghat[3 * n] = g.x, s.ghat[3 * n + 1] = g.y, s.ghat[3 * n + 2] = g.z;
+    // M_n (6 x 8): the twist components of node n as dual-quaternion increments (W, Wd).  A data row's
+    // 6-vector for a neighbour n is f_vn * M_n l_v with the per-vertex functional l_v = (lW, lD) of
+    // s6_linearise — the assembly accumulates 8 x 8 moments of l and applies M afterwards.
+    float* M = s.mnode + 48 * (size_t)n;
+#pragma unroll
+    for (int col = 0; col < 3; ++col) {
+        const f3 e    = mk3(col == 0 ? 1.f : 0.f, col == 1 ? 1.f : 0.f, col == 2 ? 1.f : 0.f);
+        const Quat W  = basis_mul(col, q.r);                                         // omega = e_col
+        const Quat Wd = qadd(basis_mul(col, q.d), qmul(pureq(cross(g, e)), q.r));    // rotation about g^: v0 = g^ x e
+        float* r0 = M + 8 * col;
+        r0[0] = W.w, r0[1] = W.x, r0[2] = W.y, r0[3] = W.z, r0[4] = Wd.w, r0[5] = Wd.x, r0[6] = Wd.y, r0[7] = Wd.z;
+        float* r1 = M + 8 * (3 + col);                                               // translation e_col: (0, e^ r)
+        r1[0] = 0.f, r1[1] = 0.f, r1[2] = 0.f, r1[3] = 0.f, r1[4] = W.w, r1[5] = W.x, r1[6] = W.y, r1[7] = W.z;
+    }
 }
 
 __device__ __forceinline__ float tukey6(float err, float offset, float c) {  // opt_solver.cpp:204-231
@@ -171,7 +186,6 @@ __global__ __launch_bounds__(256) void s6_linearise_kernel(Solve6View s, Solve6S
             idx[j] = j < k ? s.idx[(size_t)v * k + j] : -1;
             wn[j]  = j < k ? s.wn[(size_t)v * k + j] : 0.f;
         }
-        float* av = s.avec + (size_t)v * k * 6;
         float w_eff = 0.f, rr = 0.f;
         bool ok     = false;
         Blend<K> B;
@@ -213,34 +227,32 @@ __global__ __launch_bounds__(256) void s6_linearise_kernel(Solve6View s, Solve6S
             const Quat lW = Quat{-(U.w + S.w) - np * B.a.w, (U.x + S.x) - np * B.a.x, (U.y + S.y) - np * B.a.y,
                                  (U.z + S.z) - np * B.a.z};
             const float im = 1.f / B.m;
+            // row of the Jacobian for neighbour j: f_j * M_j l with l = (lW, lD); see s6_nodes_kernel.  The row is
+            // written once per neighbour, at the row's position in that node's list (entry-major), so that the
+            // assembly streams each node's rows from contiguous memory instead of chasing vertex indices.
+            float f[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) f[j] = j < k ? wn[j] * B.s[j] * im : 0.f;
+            const float4 l0 = make_float4(lW.w, lW.x, lW.y, lW.z), l1 = make_float4(lD.w, lD.x, lD.y, lD.z);
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                if (j >= k) continue;
-                float o[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (B.s[j] != 0.f) {
-                    const int n  = idx[j];
-                    const DQ q   = dq_load(s.dq + 8 * (size_t)n);
-                    const f3 gh  = mk3(s.ghat[3 * n], s.ghat[3 * n + 1], s.ghat[3 * n + 2]);
-                    const float f = wn[j] * B.s[j] * im;
+                if (j >= k || idx[j] < 0) continue;
+                const size_t e = s.epos[(size_t)v * k + j];
+                float4* el = reinterpret_cast<float4*>(s.el + 8 * e);
+                el[0] = l0, el[1] = l1;
 #pragma unroll
-                    for (int col = 0; col < 3; ++col) {
-                        // rotation about g^: origin form v0 = g^ x e_col
-                        const f3 e  = mk3(col == 0 ? 1.f : 0.f, col == 1 ? 1.f : 0.f, col == 2 ? 1.f : 0.f);
-                        const f3 v0 = cross(gh, e);
-                        const Quat W  = basis_mul(col, q.r);
-                        const Quat Wd = qadd(basis_mul(col, q.d), qmul(pureq(v0), q.r));
-                        o[col]     = f * (qdot(lW, W) + qdot(lD, Wd));
-                        o[3 + col] = f * qdot(lD, W);  // translation e_col: (W, Wd) = (0, e_col^ r)
-                    }
-                }
-#pragma unroll
-                for (int col = 0; col < 6; ++col) av[j * 6 + col] = o[col];
+                for (int q = 0; q < K; ++q)
+                    if (q < k) s.ef[e * k + q] = f[q];
             }
             cost   = (double)w_eff * (double)rr * (double)rr;
             nvalid = w_eff > 0.f;
         }
-        s.res[v]  = rr;
-        s.wrow[v] = ok ? w_eff : 0.f;
+        const float w_out = ok ? w_eff : 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (j >= k || idx[j] < 0) continue;
+            *reinterpret_cast<float2*>(s.em + 2 * (size_t)s.epos[(size_t)v * k + j]) = make_float2(w_out, w_out * rr);
+        }
     }
     block_add_cost(cost, nvalid, st);
 }
@@ -412,6 +424,7 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
     // straight into the right 6x6 blocks
     const int32_t* cols = s.bcols + (size_t)a * s.cap;
     for (int e = s.node_ptr[a] + tid; e < s.node_ptr[a + 1]; e += 256) {
+        s.epos[s.node_list[e]] = (uint32_t)e;  // where the linearisation writes row (vertex, slot)
         const unsigned v = s.node_list[e] / (unsigned)k;
         for (int j = 0; j < k; ++j) {
             const int b = s.idx[(size_t)v * k + j];
@@ -425,24 +438,31 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
     }
 }
 
-// Values of block row a.  The rows of the energy that touch node a are staged through LDS 32 at a
-// time; a wave takes one staged row at a time and its lanes are the (neighbour j, row c) pairs of
-// that row: lane (j, c) adds w a_s[c] a_j[0..5] to row c of the 6x6 block in the slot of neighbour j
-// (slot precomputed by s6_pattern_kernel) with six LDS float adds.  The lanes of one instruction hit
-// distinct addresses (distinct neighbours -> distinct slots), so the adds only meet across waves.
-// (First version: one lane per row, 64 rows of the same node per instruction -> 64-way same-address
-// conflicts, 3.7 ms per assembly at 4 k nodes; a register version where every (slot, c) thread scanned
-// every row was VALU-bound at 2.2 ms.)
-constexpr int S6_STAGE = 64;
+// Values of block row a.  A data row's 6-vector for neighbour j factors as f_j * M_j l (l: 8 numbers per
+// vertex, M_j: 6 x 8 per node, s6_nodes_kernel), so the block H_ab = sum_v rho f_a f_b (M_a l)(M_b l)^T is
+// M_a S_ab M_b^T with the 8 x 8 moment S_ab = sum_v (rho f_a f_b) l l^T: the rows that touch node a are read
+// as 8 + k floats instead of 6 k (84 instead of 232 bytes at k = 8, and each row is read by the k workgroups
+// of its nodes), S is accumulated, and M is applied once per block at the end.
+// The rows are staged through LDS 64 at a time (software-pipelined: the loads of the next chunk fly while
+// this one is accumulated).  A wave takes one staged row at a time; lane (j, c) adds rho f_a f_j l_c l[0..7]
+// to row c of the moment in the slot of neighbour j (slot precomputed by s6_pattern_kernel).  The lanes of
+// one instruction hit distinct addresses (distinct neighbours -> distinct slots) and every wave owns a private
+// copy of the moments, so the updates are plain read-add-write: LDS float atomics run at ~0.5 lane / clock
+// on this part.  History at 4 k nodes, k = 8: one lane per row with LDS atomics 3.7 ms (64-way same-address
+// conflicts); every (slot, c) thread scanning every row 2.2 ms (VALU-bound); this layout with ds_add_f32
+// 4.6 ms; private copies 1.0 ms (HBM/L2-bound on 232-byte rows); factored rows: see DESIGN.md.
+constexpr int S6_STAGE   = 64;
 constexpr int S6_MAXSLOT = 48;  // = plan capacity of a block row
 
 template <int K>
 __global__ __launch_bounds__(256) void s6_assemble_kernel(Solve6View s, Solve6State* st, float wreg2, float damping) {
-    __shared__ float svec[S6_STAGE][K][6];
+    __shared__ float4 sl8[S6_STAGE][2];   // l = (lW, lD)
+    __shared__ float sfv[S6_STAGE][K];    // f_j
     __shared__ uint8_t sslot[S6_STAGE][K];
-    __shared__ float4 smeta[S6_STAGE];  // weight, weight * residual, slot of node a in the row
-    __shared__ float acc[4][S6_MAXSLOT][36];  // one private copy per wave: plain read-add-write, no atomics
-    __shared__ float gsh[4][6];
+    __shared__ float4 smeta[S6_STAGE];    // weight, weight * residual, slot of node a in the row
+    __shared__ float4 acc[4][S6_MAXSLOT][16];  // per wave: 8 x 8 moments per slot
+    __shared__ float g8[4][8];
+    __shared__ float diag[36];
     const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
     if (a == 0 && tid == 0) {  // bookkeeping of the linearisation that just finished
         if (!st->have_first) st->initial_cost = st->cost, st->valid_first = st->valid, st->have_first = 1;
@@ -451,38 +471,34 @@ __global__ __launch_bounds__(256) void s6_assemble_kernel(Solve6View s, Solve6St
     }
     const int cnt = s.bcnt[a];
     const int beg = s.node_ptr[a], end = s.node_ptr[a + 1];
-    for (int i = tid; i < 4 * S6_MAXSLOT * 36; i += 256) (&acc[0][0][0])[i] = 0.f;
-    if (tid < 24) (&gsh[0][0])[tid] = 0.f;
-    // lanes of a wave = the (neighbour j, row c) pairs of ONE row of the energy: their targets are distinct
-    // (distinct neighbours -> distinct slots), so a wave updates its private copy without atomics.
-    // (LDS float atomics run at ~0.5 lane per clock on this part: the ds_add_f32 version took 4.6 ms.)
+    for (int i = tid; i < 4 * S6_MAXSLOT * 16; i += 256) (&acc[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 32) (&g8[0][0])[tid] = 0.f;
     const int wave = tid >> 6, lane = tid & 63;
-    const int jl = lane / 6, c = lane - jl * 6;
+    const int jl = lane >> 3, c = lane & 7;
     const bool lane_on = jl < K;
-    // software pipeline: the global loads of chunk i + 1 are in flight while chunk i is accumulated
-    constexpr int VPT = (S6_STAGE * K * 6 + 255) / 256;  // staged 6-vector floats per thread
-    constexpr int SPT = (S6_STAGE * K + 255) / 256;      // staged slot bytes per thread
-    float pv[VPT];
-    uint8_t ps[SPT];
+    // software pipeline registers
+    constexpr int FPT = (S6_STAGE * K + 255) / 256;
+    float pl[2] = {0.f, 0.f}, pf[FPT];
+    uint8_t ps[FPT];
     float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
     auto fetch = [&](int base) {
         const int n = min(S6_STAGE, end - base);
 #pragma unroll
-        for (int q = 0; q < VPT; ++q) {
-            const int i = tid + 256 * q, r = i / (K * 6), o = i - r * (K * 6);
-            pv[q] = 0.f;
-            if (r < n && o < k * 6) pv[q] = s.avec[(size_t)(s.node_list[base + r] / (unsigned)k) * k * 6 + o];
+        for (int q = 0; q < 2; ++q) {  // S6_STAGE * 8 = 512 floats of l, contiguous from `base`
+            const int i = tid + 256 * q;
+            pl[q] = (i >> 3) < n ? s.el[8 * (size_t)base + i] : 0.f;
         }
 #pragma unroll
-        for (int q = 0; q < SPT; ++q) {
+        for (int q = 0; q < FPT; ++q) {
             const int i = tid + 256 * q, r = i / K, j = i - r * K;
-            ps[q] = (r < n && j < k) ? s.eslot[(size_t)(base + r) * k + j] : (uint8_t)255;
+            const bool in = r < n && j < k;
+            pf[q] = in ? s.ef[(size_t)(base + r) * k + j] : 0.f;
+            ps[q] = in ? s.eslot[(size_t)(base + r) * k + j] : (uint8_t)255;
         }
         if (tid < n) {
+            const float2 m = *reinterpret_cast<const float2*>(s.em + 2 * (size_t)(base + tid));
             const unsigned entry = s.node_list[base + tid];
-            const unsigned v     = entry / (unsigned)k;
-            const float w        = s.wrow[v];
-            pm = make_float4(w, w * s.res[v], __int_as_float((int)(entry - v * (unsigned)k)), 0.f);
+            pm = make_float4(m.x, m.y, __int_as_float((int)(entry % (unsigned)k)), 0.f);
         }
     };
     if (beg < end) fetch(beg);
@@ -490,51 +506,88 @@ __global__ __launch_bounds__(256) void s6_assemble_kernel(Solve6View s, Solve6St
         const int n = min(S6_STAGE, end - base);
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < VPT; ++q) {
-            const int i = tid + 256 * q;
-            if (i < S6_STAGE * K * 6) (&svec[0][0][0])[i] = pv[q];
-        }
+        for (int q = 0; q < 2; ++q) (&sl8[0][0].x)[tid + 256 * q] = pl[q];
 #pragma unroll
-        for (int q = 0; q < SPT; ++q) {
+        for (int q = 0; q < FPT; ++q) {
             const int i = tid + 256 * q;
-            if (i < S6_STAGE * K) (&sslot[0][0])[i] = ps[q];
+            if (i < S6_STAGE * K) (&sfv[0][0])[i] = pf[q], (&sslot[0][0])[i] = ps[q];
         }
         if (tid < n) smeta[tid] = pm;
         __syncthreads();
         if (base + S6_STAGE < end) fetch(base + S6_STAGE);
-        for (int r = wave; r < n && lane_on; r += 4) {
-            const float4 mt = smeta[r];
-            const int sl    = sslot[r][jl];
-            if (mt.x == 0.f || sl >= cnt) continue;
-            const int own  = __float_as_int(mt.z);
-            const float as = svec[r][own][c];
-            const float wa = mt.x * as;
-            float2* dst    = reinterpret_cast<float2*>(&acc[wave][sl][c * 6]);
-            const float2* src = reinterpret_cast<const float2*>(&svec[r][jl][0]);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                float2 t = dst[d];
-                const float2 v = src[d];
-                t.x += wa * v.x, t.y += wa * v.y;
-                dst[d] = t;
+        // two rows per step: the staged inputs of both are read together (one LDS latency instead of two); the
+        // read-add-writes stay in row order — row 1's neighbour j' may be row 0's neighbour j (another lane, same
+        // address), and LDS operations of a wave complete in order
+        for (int r = wave; r < n && lane_on; r += 8) {
+            const int r1    = r + 4 < n ? r + 4 : r;
+            const bool has1 = r + 4 < n;
+            const float4 mt0 = smeta[r], mt1 = smeta[r1];
+            const int sl0 = sslot[r][jl], sl1 = sslot[r1][jl];
+            const bool v0 = mt0.x != 0.f && sl0 < cnt, v1 = has1 && mt1.x != 0.f && sl1 < cnt;
+            const int own0 = __float_as_int(mt0.z), own1 = __float_as_int(mt1.z);
+            const float fa0 = sfv[r][own0], fa1 = sfv[r1][own1];
+            const float lc0 = (&sl8[r][0].x)[c], lc1 = (&sl8[r1][0].x)[c];
+            const float4 a0 = sl8[r][0], a1 = sl8[r][1], b0 = sl8[r1][0], b1 = sl8[r1][1];
+            const float fac0 = mt0.x * fa0 * sfv[r][jl] * lc0, fac1 = mt1.x * fa1 * sfv[r1][jl] * lc1;
+            if (v0) {
+                float4* dst = &acc[wave][sl0][2 * c];
+                float4 d0 = dst[0], d1 = dst[1];
+                d0.x += fac0 * a0.x, d0.y += fac0 * a0.y, d0.z += fac0 * a0.z, d0.w += fac0 * a0.w;
+                d1.x += fac0 * a1.x, d1.y += fac0 * a1.y, d1.z += fac0 * a1.z, d1.w += fac0 * a1.w;
+                dst[0] = d0, dst[1] = d1;
+                if (jl == own0) g8[wave][c] -= mt0.y * fa0 * lc0;
             }
-            if (jl == own) gsh[wave][c] -= mt.y * as;
+            if (v1) {
+                float4* dst = &acc[wave][sl1][2 * c];
+                float4 d0 = dst[0], d1 = dst[1];
+                d0.x += fac1 * b0.x, d0.y += fac1 * b0.y, d0.z += fac1 * b0.z, d0.w += fac1 * b0.w;
+                d1.x += fac1 * b1.x, d1.y += fac1 * b1.y, d1.z += fac1 * b1.z, d1.w += fac1 * b1.w;
+                dst[0] = d0, dst[1] = d1;
+                if (jl == own1) g8[wave][c] -= mt1.y * fa1 * lc1;
+            }
         }
     }
     __syncthreads();
-    // regularisation + output: thread (slot, row) finishes row `row` of the block in `slot`
-    __shared__ float diag[36];
+    // sum the four private copies into copy 0
+    for (int i = tid; i < cnt * 16; i += 256) {
+        float4* p0 = &acc[0][0][0] + i;
+        const float4 b = (&acc[1][0][0])[i], cc = (&acc[2][0][0])[i], dd = (&acc[3][0][0])[i];
+        float4 t = *p0;
+        t.x = (t.x + b.x) + (cc.x + dd.x), t.y = (t.y + b.y) + (cc.y + dd.y);
+        t.z = (t.z + b.z) + (cc.z + dd.z), t.w = (t.w + b.w) + (cc.w + dd.w);
+        *p0 = t;
+    }
+    if (tid < 8) g8[0][tid] = (g8[0][tid] + g8[1][tid]) + (g8[2][tid] + g8[3][tid]);
+    __syncthreads();
+    // H_ab = M_a S_ab M_b^T, regularisation, output: thread (slot, row) finishes row `row` of the block in `slot`
     for (int t0 = 0; t0 < cnt * 6; t0 += 256) {
         const int t = t0 + tid;
         if (t < cnt * 6) {
             const int slot = t / 6, my_row = t - 6 * slot;
             const int col  = s.bcols[(size_t)a * s.cap + slot];
+            float ma[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) ma[p] = s.mnode[48 * (size_t)a + 8 * my_row + p];
+            float vq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // row my_row of M_a S
+            const float* S0 = &acc[0][slot][0].x;
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vq[q] += ma[p] * S0[8 * p + q];
             float accr[6];
 #pragma unroll
-            for (int d = 0; d < 6; ++d)
-                accr[d] = (acc[0][slot][my_row * 6 + d] + acc[1][slot][my_row * 6 + d]) +
-                          (acc[2][slot][my_row * 6 + d] + acc[3][slot][my_row * 6 + d]);
-            float gacc = slot == 0 ? (gsh[0][my_row] + gsh[1][my_row]) + (gsh[2][my_row] + gsh[3][my_row]) : 0.f;
+            for (int d = 0; d < 6; ++d) {
+                const float* mb = s.mnode + 48 * (size_t)col + 8 * d;
+                float h = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) h += vq[q] * mb[q];
+                accr[d] = h;
+            }
+            float gacc = 0.f;
+            if (slot == 0) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) gacc += ma[p] * g8[0][p];
+            }
             // regularisation edges leaving a (a -> m): rows c of e = T_a g_m - g^_m with vectors (an_c at a, -e_{3+c} at m)
             for (int q = 0; q < k; ++q) {
                 const int e = a * k + q, m = s.reg_idx[e];
@@ -621,38 +674,39 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(So
                                                                               float tol2) {
     __shared__ float stage[S6_NODES_PER_BLOCK][3][64];
     __shared__ float gd_sh[S6_NODES_PER_BLOCK][2];
-    if (st->pcg_done) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int a    = blockIdx.x * S6_NODES_PER_BLOCK + wave;
     const int cur = it >= 0 ? (it & 1) : 0, nxt = cur ^ 1;  // u, m: read [cur], write [nxt]; t: read [nxt], write [cur]
     const float* ucur  = s.u[cur];
     const float* mcur  = s.m[cur];
     const float* tprev = s.t[nxt];
-    // The kernel is a chain of dependent memory round trips (~2 us each), so everything that does not
-    // depend on this iteration's scalars is issued first: the three products A u, A m, A t are gathered
-    // with the columns preloaded and the loop unrolled (all loads in flight together), and
-    // w = A u - alpha (A m + beta A t) is formed afterwards.
+    // The kernel is a chain of dependent memory round trips (~2 us each) and little else, so it is
+    // written as two rounds of loads: (1) everything addressable from the launch arguments — the
+    // stop flag, the partial inner products and scalars of the previous launch, this row's columns,
+    // its M^-1 and its own vector entries — and (2) the gathers through the columns.  The three
+    // products A u, A m, A t are gathered separately and w = A u - alpha (A m + beta A t) is formed at
+    // the end, so round (2) does not wait for the scalars either.
     constexpr int MAXIT = 5;  // 10 slots per pass, plan capacity 48
-    float au = 0.f, am = 0.f, at = 0.f;
-    if (a < s.D && lane < 60) {
-        const int ss = lane / 6, c = lane - 6 * ss;
-        int cols[MAXIT];
+    constexpr int MAXP  = 16; // partials per lane: 64 x 16 = 1024 workgroups = 8192 nodes
+    const int nb   = s6_matvec_blocks(s.D);
+    const int done = st->pcg_done;
+    float gp[MAXP], dp[MAXP];
+    float gamma_prev = 1.f, alpha_prev = 1.f, rz0 = 0.f;
+    if (it >= 0) {
 #pragma unroll
-        for (int q = 0; q < MAXIT; ++q) {
-            const int sl = ss + 10 * q;
-            cols[q]      = sl < s.cap ? s.bcols[(size_t)a * s.cap + sl] : -1;
+        for (int q = 0; q < MAXP; ++q) {
+            const int i = lane + 64 * q;
+            gp[q] = i < nb ? s.g_part[it & 1][i] : 0.f;
+            dp[q] = i < nb ? s.d_part[it & 1][i] : 0.f;
         }
+        if (it > 0) gamma_prev = st->gamma_prev[(it + 1) & 1], alpha_prev = st->alpha_prev[(it + 1) & 1], rz0 = st->rz0;
+    }
+    const int ss = lane / 6, c = lane - 6 * ss;
+    int cols[MAXIT];
 #pragma unroll
-        for (int q = 0; q < MAXIT; ++q) {
-            if (cols[q] < 0) continue;
-            const float* H  = s.bvals + ((size_t)a * s.cap + ss + 10 * q) * 36 + 6 * c;
-            const size_t cb = 6 * (size_t)cols[q];
-#pragma unroll
-            for (int d = 0; d < 6; ++d) {
-                au += H[d] * ucur[cb + d];
-                if (it >= 0) am += H[d] * mcur[cb + d], at += H[d] * tprev[cb + d];
-            }
-        }
+    for (int q = 0; q < MAXIT; ++q) {
+        const int sl = ss + 10 * q;
+        cols[q]      = (a < s.D && lane < 60 && sl < s.cap) ? s.bcols[(size_t)a * s.cap + sl] : -1;
     }
     float minv_row[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, own_u = 0.f, own_m = 0.f, own_t = 0.f, own_p = 0.f, own_s = 0.f,
           own_w = 0.f, own_r = 0.f, own_x = 0.f;
@@ -663,17 +717,41 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(So
         own_u = ucur[i], own_r = s.r[i];
         if (it >= 0) own_m = mcur[i], own_t = tprev[i], own_p = s.p[i], own_s = s.s[i], own_w = s.w[i], own_x = s.x[i];
     }
+    if (done) return;  // (uniform)
+    float au = 0.f, am = 0.f, at = 0.f;
+#pragma unroll
+    for (int q = 0; q < MAXIT; ++q) {
+        if (cols[q] < 0) continue;
+        const float2* H  = reinterpret_cast<const float2*>(s.bvals + ((size_t)a * s.cap + ss + 10 * q) * 36 + 6 * c);
+        const size_t cb  = 6 * (size_t)cols[q];
+        const float2* pu = reinterpret_cast<const float2*>(ucur + cb);
+        const float2* pm = reinterpret_cast<const float2*>(mcur + cb);
+        const float2* pt = reinterpret_cast<const float2*>(tprev + cb);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float2 h = H[d], uu = pu[d];
+            au += h.x * uu.x, au += h.y * uu.y;
+            if (it >= 0) {
+                const float2 mm = pm[d], tt = pt[d];
+                am += h.x * mm.x, am += h.y * mm.y;
+                at += h.x * tt.x, at += h.y * tt.y;
+            }
+        }
+    }
     // scalars of this iteration
-    const int nb = s6_matvec_blocks(s.D);
     float alpha = 0.f, beta = 0.f;
     if (it >= 0) {
-        const float gamma = sum_partials(s.g_part[it & 1], nb), delta = sum_partials(s.d_part[it & 1], nb);
+        float g = 0.f, d = 0.f;
+#pragma unroll
+        for (int q = 0; q < MAXP; ++q) g += gp[q], d += dp[q];
+        const float gamma = wave_sum_all(g), delta = wave_sum_all(d);  // the same value, the same order, in every wave
         float denom = delta;
         if (it > 0) {
-            beta = gamma / st->gamma_prev[(it + 1) & 1];
-            denom -= beta * gamma / st->alpha_prev[(it + 1) & 1];
+            beta = gamma / gamma_prev;
+            denom -= beta * gamma / alpha_prev;
+        } else {
+            rz0 = gamma;
         }
-        const float rz0 = it == 0 ? gamma : st->rz0;
         // converged, or breakdown: the same decision in every workgroup
         if (!(gamma > 0.f) || gamma <= tol2 * rz0 || !(denom > 0.f)) {
             if (blockIdx.x == 0 && threadIdx.x == 0) st->pcg_done = 1;
@@ -694,8 +772,8 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(So
         if (lane < 6) {
             float su = 0.f, sm = 0.f, stt = 0.f;
 #pragma unroll
-            for (int ss = 0; ss < 10; ++ss)
-                su += stage[wave][0][ss * 6 + lane], sm += stage[wave][1][ss * 6 + lane], stt += stage[wave][2][ss * 6 + lane];
+            for (int q = 0; q < 10; ++q)
+                su += stage[wave][0][q * 6 + lane], sm += stage[wave][1][q * 6 + lane], stt += stage[wave][2][q * 6 + lane];
             wn = it >= 0 ? su - alpha * (sm + beta * stt) : su;
         }
         // m_new = M^-1 w_new needs the six components held by lanes 0..5

@@ -54,10 +54,14 @@ struct Solve6View {
     float* dq;    // D x 8  current node transforms
     float* ghat;  // D x 3  current node positions T_i(g_i)
     // linearisation
-    float* avec;  // N x k x 6   n . dp/dxi per slot
-    float* res;   // N           n . (p - l)
+    // rows of the data term, ENTRY-major (position of (vertex, slot) in its node's list, `epos`): the row's
+    // 6-vector for neighbour j is f_j M_j l with the per-vertex functional l = (lW, lD)
+    uint32_t* epos;  // N x k   (vertex, slot) -> entry
+    float* el;       // (N k) x 8
+    float* ef;       // (N k) x k   f_j = w~_j s_j / |a|^2 of all k neighbours of the entry's vertex
+    float* em;       // (N k) x 2   robust weight (0 = no association), weight * residual
+    float* mnode;  // D x 6 x 8  M_n: twist components of node n as (W, Wd) increments
     float* rho;   // N           Tukey weight (frozen between re-weightings)
-    float* wrow;  // N           rho where the association is valid, else 0
     float* rres;  // D x k x 3   regularisation residuals
     float* rvec;  // D x k x 18  d e / d xi_n  (3 rows x 6)
     float* rhub;  // D x k       Huber weights (frozen)
