@@ -32,7 +32,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 for wide reads + WRITE_SIZE, corrected as
 # MI355X_MICROARCH.md prescribes) — profiles/r01_pmc_tsdf.md.  Collected offline: PMC needs its own runs.
-PMC_TRAFFIC_BYTES = {("C2", "fused_integrate"): 0.5439e9}
+PMC_TRAFFIC_BYTES = {("C2", "fused_integrate"): 0.5439e9,
+                     # profiles/r01_pmc_solve.md: (198.1 + 70.8) KiB per pcg_paired_kernel launch
+                     ("C2", "pcg"): 268.9 * 1024}
 
 
 def parse():
@@ -356,7 +358,11 @@ def main():
                       avg_launch_ms=round(fuse_ms, 4), launches_per_frame=1, algorithmic_bytes_per_launch=fuse_bytes)
     pcg_entry = dict(kernel="pcg_kernel (single-workgroup block-Jacobi PCG)", bound="hbm",
                      achieved=round(pcg_gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(pcg_gbs / HBM_PEAK_GBS, 6),
-                     traffic=None, avg_launch_ms=round(pcg_total_ms / max(1, tm["pcg_launches"]), 4),
+                     traffic=PMC_TRAFFIC_BYTES.get((args.config, "pcg")),
+                     traffic_source="profiles/r01_pmc_solve.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes): "
+                                    "per launch; the matrix is read once and kept in registers",
+                     algorithmic_bytes_per_launch=pcg_bytes / max(1, tm["pcg_launches"]),
+                     avg_launch_ms=round(pcg_total_ms / max(1, tm["pcg_launches"]), 4),
                      launches_per_frame=tm["pcg_launches"], pcg_iterations_per_frame=its, matrix_nnz=nnz,
                      algorithmic_bytes_per_frame=pcg_bytes,
                      lds_gather=dict(bytes_per_frame=16.0 * nnz * its, achieved_gbs=round(16.0 * nnz * its / (pcg_total_ms * 1e-3) / 1e9, 1) if pcg_total_ms > 0 else None,
