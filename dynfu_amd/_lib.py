@@ -11,6 +11,8 @@ SYMBOLS = [
     "dfa_last_error", "dfa_version", "dfa_compute_dists", "dfa_tsdf_clear", "dfa_tsdf_integrate",
     "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_knn", "dfa_warp_to_live",
     "dfa_correspond", "dfa_marching_cubes", "dfa_mc_default_tables",
+    "dfa_depth_bilateral_filter", "dfa_depth_truncate", "dfa_depth_build_pyramid", "dfa_compute_normals_mask_depth",
+    "dfa_resize_depth_normals", "dfa_resize_points_normals",
     "dfa_compute_points_normals", "dfa_solver6_create", "dfa_solver6_destroy", "dfa_solver6_set_problem",
     "dfa_solver6_solve", "dfa_solver6_node_dq", "dfa_solver6_warp", "dfa_solver6_get_stats",
     "dfa_solver_create", "dfa_solver_destroy", "dfa_solver_set_problem", "dfa_solver_solve",
@@ -92,6 +94,12 @@ def load():
     L.dfa_tsdf_raycast_depth.argtypes = ray
     L.dfa_knn.argtypes = [vp, vp, i, vp, i, i, vp, vp, vp]
     L.dfa_warp_to_live.argtypes = [vp, vp, vp, i, i, vp, vp, i, vp, vp, vp]
+    L.dfa_depth_bilateral_filter.argtypes = [vp, i, vp, i, i, i, i, f, f, vp]
+    L.dfa_depth_truncate.argtypes = [vp, i, i, i, f, vp]
+    L.dfa_depth_build_pyramid.argtypes = [vp, i, i, i, vp, i, f, vp]
+    L.dfa_compute_normals_mask_depth.argtypes = [vp, i, i, i, f, f, f, f, vp, i, vp]
+    L.dfa_resize_depth_normals.argtypes = [vp, i, vp, i, i, i, vp, i, vp, i, vp]
+    L.dfa_resize_points_normals.argtypes = [vp, i, vp, i, i, i, vp, i, vp, i, vp]
     L.dfa_compute_points_normals.argtypes = [vp, i, i, i, f, f, f, f, vp, i, vp, i, vp]
     L.dfa_solver6_create.argtypes = [i, i, i, C.POINTER(vp)]
     L.dfa_solver6_destroy.argtypes = [vp]
@@ -447,3 +455,61 @@ class Solver6:
         st = _Solve6Stats()
         _check(load().dfa_solver6_get_stats(self._h, C.byref(st), _stream()))
         return {n: getattr(st, n) for n, _ in _Solve6Stats._fields_}
+
+
+# ------------------------------------------------------------------- depth pre-processing seam
+def depth_bilateral_filter(depth, kernel_size, sigma_spatial, sigma_depth):
+    torch = _torch()
+    rows, cols = depth.shape
+    out = torch.empty_like(depth)
+    _check(load().dfa_depth_bilateral_filter(_dev(depth, torch.uint16, "depth"), depth.stride(0) * 2, _dev(out),
+                                             out.stride(0) * 2, cols, rows, kernel_size, sigma_spatial, sigma_depth,
+                                             _stream()))
+    return out
+
+
+def depth_truncate(depth, max_dist):
+    torch = _torch()
+    rows, cols = depth.shape
+    _check(load().dfa_depth_truncate(_dev(depth, torch.uint16, "depth"), depth.stride(0) * 2, cols, rows, max_dist, _stream()))
+
+
+def depth_build_pyramid(depth, sigma_depth):
+    torch = _torch()
+    rows, cols = depth.shape
+    out = torch.zeros((rows // 2, cols // 2), dtype=torch.uint16, device=depth.device)
+    _check(load().dfa_depth_build_pyramid(_dev(depth, torch.uint16, "depth"), depth.stride(0) * 2, cols, rows, _dev(out),
+                                          max(out.stride(0), 1) * 2, sigma_depth, _stream()))
+    return out
+
+
+def compute_normals_mask_depth(depth, fx, fy, cx, cy):
+    """in place on depth; returns the float4 normal map"""
+    torch = _torch()
+    rows, cols = depth.shape
+    nrm = torch.empty((rows, cols, 4), dtype=torch.float32, device=depth.device)
+    _check(load().dfa_compute_normals_mask_depth(_dev(depth, torch.uint16, "depth"), depth.stride(0) * 2, cols, rows, fx,
+                                                 fy, cx, cy, _dev(nrm), cols * 16, _stream()))
+    return nrm
+
+
+def resize_depth_normals(depth, normals):
+    torch = _torch()
+    rows, cols = depth.shape
+    d = torch.zeros((rows // 2, cols // 2), dtype=torch.uint16, device=depth.device)
+    n = torch.zeros((rows // 2, cols // 2, 4), dtype=torch.float32, device=depth.device)
+    _check(load().dfa_resize_depth_normals(_dev(depth, torch.uint16, "depth"), depth.stride(0) * 2,
+                                           _dev(normals, torch.float32, "normals"), normals.stride(0) * 4, cols, rows,
+                                           _dev(d), max(d.stride(0), 1) * 2, _dev(n), max(n.stride(0), 4) * 4, _stream()))
+    return d, n
+
+
+def resize_points_normals(points, normals):
+    torch = _torch()
+    rows, cols = points.shape[:2]
+    v = torch.zeros((rows // 2, cols // 2, 4), dtype=torch.float32, device=points.device)
+    n = torch.zeros_like(v)
+    _check(load().dfa_resize_points_normals(_dev(points, torch.float32, "points"), points.stride(0) * 4,
+                                            _dev(normals, torch.float32, "normals"), normals.stride(0) * 4, cols, rows,
+                                            _dev(v), max(v.stride(0), 4) * 4, _dev(n), max(n.stride(0), 4) * 4, _stream()))
+    return v, n

@@ -279,6 +279,71 @@ int dfa_tsdf_raycast_depth(const uint32_t* volume, int X, int Y, int Z, const fl
     return DFA_OK;
 }
 
+// -------------------------------------------------------------------- depth pre-processing seam
+
+int dfa_depth_bilateral_filter(const uint16_t* src, int src_step, uint16_t* dst, int dst_step, int cols, int rows,
+                               int kernel_size, float sigma_spatial, float sigma_depth, dfa_stream_t stream) {
+    REQUIRE(src && dst && cols > 0 && rows > 0, "bad images");
+    REQUIRE(src != dst, "the bilateral filter cannot run in place");
+    REQUIRE(src_step >= cols * 2 && dst_step >= cols * 2, "row step smaller than a row");
+    REQUIRE(kernel_size >= 1 && sigma_spatial > 0.f && sigma_depth > 0.f, "bad filter parameters");
+    HIP_TRY(dfa::launch_bilateral(src, src_step, dst, dst_step, cols, rows, kernel_size, sigma_spatial, sigma_depth,
+                                  S(stream)));
+    return DFA_OK;
+}
+
+int dfa_depth_truncate(uint16_t* depth, int depth_step, int cols, int rows, float max_dist, dfa_stream_t stream) {
+    REQUIRE(depth && cols > 0 && rows > 0 && depth_step >= cols * 2, "bad image");
+    REQUIRE(max_dist >= 0.f && max_dist < 65.536f, "max_dist out of the 16-bit millimetre range");
+    HIP_TRY(dfa::launch_truncate_depth(depth, depth_step, cols, rows, max_dist, S(stream)));
+    return DFA_OK;
+}
+
+int dfa_depth_build_pyramid(const uint16_t* src, int src_step, int cols, int rows, uint16_t* dst, int dst_step,
+                            float sigma_depth, dfa_stream_t stream) {
+    REQUIRE(src && cols > 0 && rows > 0, "bad images");
+    if (cols / 2 == 0 || rows / 2 == 0) return DFA_OK;  // empty output
+    REQUIRE(dst, "null output");
+    REQUIRE(src_step >= cols * 2 && dst_step >= (cols / 2) * 2, "row step smaller than a row");
+    HIP_TRY(dfa::launch_depth_pyr(src, src_step, cols, rows, dst, dst_step, sigma_depth, S(stream)));
+    return DFA_OK;
+}
+
+int dfa_compute_normals_mask_depth(uint16_t* depth, int depth_step, int cols, int rows, float fx, float fy, float cx,
+                                   float cy, float* normals, int normals_step, dfa_stream_t stream) {
+    REQUIRE(depth && normals && cols > 0 && rows > 0, "bad images");
+    REQUIRE(depth_step >= cols * 2 && normals_step >= cols * 16, "row step smaller than a row");
+    REQUIRE(fx != 0.f && fy != 0.f, "zero focal length");
+    HIP_TRY(dfa::launch_normals_mask_depth(depth, depth_step, cols, rows, fx, fy, cx, cy, normals, normals_step, S(stream)));
+    return DFA_OK;
+}
+
+int dfa_resize_depth_normals(const uint16_t* depth, int depth_step, const float* normals, int normals_step, int cols,
+                             int rows, uint16_t* depth_out, int depth_out_step, float* normals_out, int normals_out_step,
+                             dfa_stream_t stream) {
+    REQUIRE(depth && normals && cols > 0 && rows > 0, "bad images");
+    if (cols / 2 == 0 || rows / 2 == 0) return DFA_OK;  // empty output
+    REQUIRE(depth_out && normals_out, "null output");
+    REQUIRE(depth_step >= cols * 2 && normals_step >= cols * 16, "row step smaller than a row");
+    REQUIRE(depth_out_step >= (cols / 2) * 2 && normals_out_step >= (cols / 2) * 16, "output row step smaller than a row");
+    HIP_TRY(dfa::launch_resize_depth_normals(depth, depth_step, normals, normals_step, cols, rows, depth_out, depth_out_step,
+                                             normals_out, normals_out_step, S(stream)));
+    return DFA_OK;
+}
+
+int dfa_resize_points_normals(const float* points, int points_step, const float* normals, int normals_step, int cols,
+                              int rows, float* points_out, int points_out_step, float* normals_out, int normals_out_step,
+                              dfa_stream_t stream) {
+    REQUIRE(points && normals && cols > 0 && rows > 0, "bad images");
+    if (cols / 2 == 0 || rows / 2 == 0) return DFA_OK;  // empty output
+    REQUIRE(points_out && normals_out, "null output");
+    REQUIRE(points_step >= cols * 16 && normals_step >= cols * 16, "row step smaller than a row");
+    REQUIRE(points_out_step >= (cols / 2) * 16 && normals_out_step >= (cols / 2) * 16, "output row step smaller than a row");
+    HIP_TRY(dfa::launch_resize_points_normals(points, points_step, normals, normals_step, cols, rows, points_out,
+                                              points_out_step, normals_out, normals_out_step, S(stream)));
+    return DFA_OK;
+}
+
 // ------------------------------------------------------------------------ marching-cubes seam
 
 int dfa_marching_cubes(const uint32_t* volume, int X, int Y, int Z, const float cell_size[3],

@@ -72,4 +72,17 @@ hipError_t launch_marching_cubes(const uint32_t* vol, int X, int Y, int Z, const
                                  hipStream_t s);
 void mc_default_tables(int32_t tri_table[256 * 16], int32_t num_verts_table[256]);
 
+// img.hip
+hipError_t launch_bilateral(const uint16_t* src, int src_step, uint16_t* dst, int dst_step, int cols, int rows, int ksz,
+                            float sigma_spatial, float sigma_depth, hipStream_t s);
+hipError_t launch_truncate_depth(uint16_t* depth, int step, int cols, int rows, float max_dist, hipStream_t s);
+hipError_t launch_depth_pyr(const uint16_t* src, int src_step, int cols, int rows, uint16_t* dst, int dst_step,
+                            float sigma_depth, hipStream_t s);
+hipError_t launch_normals_mask_depth(uint16_t* depth, int depth_step, int cols, int rows, float fx, float fy, float cx,
+                                     float cy, float* normals, int normals_step, hipStream_t s);
+hipError_t launch_resize_depth_normals(const uint16_t* dsrc, int dsrc_step, const float* nsrc, int nsrc_step, int cols,
+                                       int rows, uint16_t* ddst, int ddst_step, float* ndst, int ndst_step, hipStream_t s);
+hipError_t launch_resize_points_normals(const float* vsrc, int vsrc_step, const float* nsrc, int nsrc_step, int cols,
+                                        int rows, float* vdst, int vdst_step, float* ndst, int ndst_step, hipStream_t s);
+
 }  // namespace dfa

@@ -87,6 +87,34 @@ int dfa_tsdf_raycast_depth(const uint32_t* volume, int X, int Y, int Z, const fl
                            int normals_step, int cols, int rows, dfa_stream_t stream);
 
 /* ===================================================================================== */
+/* Depth pre-processing seam — replaces the image kernels of kfusion::device declared in    */
+/* include/kfusion/internal.hpp:190-204 (src/kfusion/cuda/imgproc.cu), called by            */
+/* DynFusion::operator() (src/dynfu/dyn_fusion.cpp:58-66) and KinFu::operator()             */
+/* (src/kfusion/kinfu.cpp:150-175).  Images are pitched: *_step = bytes per row.            */
+
+/* cuda::depthBilateralFilter (imgproc.cpp:3-7, imgproc.cu:8-52).  sigma_depth in metres.
+ * The reference's __expf is replaced by a fixed IEEE operation sequence (csrc/img.hip). */
+int dfa_depth_bilateral_filter(const uint16_t* src, int src_step, uint16_t* dst, int dst_step, int cols, int rows,
+                               int kernel_size, float sigma_spatial, float sigma_depth, dfa_stream_t stream);
+/* cuda::depthTruncation (imgproc.cpp:9, imgproc.cu:60-79): depth > max_dist metres -> 0, in place. */
+int dfa_depth_truncate(uint16_t* depth, int depth_step, int cols, int rows, float max_dist, dfa_stream_t stream);
+/* cuda::depthBuildPyramid (imgproc.cpp:11-14, imgproc.cu:84-124): dst is (rows/2) x (cols/2). */
+int dfa_depth_build_pyramid(const uint16_t* src, int src_step, int cols, int rows, uint16_t* dst, int dst_step,
+                            float sigma_depth, dfa_stream_t stream);
+/* cuda::computeNormalsAndMaskDepth (imgproc.cpp:18-25, imgproc.cu:129-183): float4 normals (NaN where
+ * undefined), and depth zeroed where the normal is undefined. */
+int dfa_compute_normals_mask_depth(uint16_t* depth, int depth_step, int cols, int rows, float fx, float fy, float cx,
+                                   float cy, float* normals, int normals_step, dfa_stream_t stream);
+/* cuda::resizeDepthNormals (imgproc.cpp:43-52, imgproc.cu:258-311): outputs are (rows/2) x (cols/2). */
+int dfa_resize_depth_normals(const uint16_t* depth, int depth_step, const float* normals, int normals_step, int cols,
+                             int rows, uint16_t* depth_out, int depth_out_step, float* normals_out, int normals_out_step,
+                             dfa_stream_t stream);
+/* cuda::resizePointsNormals (imgproc.cpp:54-66, imgproc.cu:314-358). */
+int dfa_resize_points_normals(const float* points, int points_step, const float* normals, int normals_step, int cols,
+                              int rows, float* points_out, int points_out_step, float* normals_out, int normals_out_step,
+                              dfa_stream_t stream);
+
+/* ===================================================================================== */
 /* Marching-cubes seam — replaces kfusion::device::{bindTextures, getOccupiedVoxels,        */
 /* computeOffsetsAndTotalVertices, generateTriangles} (include/kfusion/internal.hpp:121-150, */
 /* src/kfusion/cuda/marching_cubes.cu), driven by cuda::MarchingCubes::run                  */

@@ -474,3 +474,74 @@ def cost6(node_pos, node_dq, node_w, k, canon, canon_n, vmap, nmap, intr, **para
     nv = C.c_long(0)
     c = lib6().orc6_cost(*args, C.byref(nv))
     return c, nv.value
+
+
+# --------------------------------------------------------------- depth pre-processing, img_oracle.c
+def _declare_img(L):
+    vp, i, f = C.c_void_p, C.c_int, C.c_float
+    L.orc_exp_neg.argtypes, L.orc_exp_neg.restype = [f], f
+    L.orc_bilateral.argtypes = [vp, i, vp, i, i, i, i, f, f]
+    L.orc_truncate_depth.argtypes = [vp, i, i, i, f]
+    L.orc_depth_pyr.argtypes = [vp, i, i, i, vp, i, f]
+    L.orc_normals_mask_depth.argtypes = [vp, i, i, i, f, f, f, f, vp, i]
+    L.orc_resize_depth_normals.argtypes = [vp, i, vp, i, i, i, vp, i, vp, i]
+    L.orc_resize_points_normals.argtypes = [vp, i, vp, i, i, i, vp, i, vp, i]
+    L._img = True
+
+
+def _libimg():
+    L = lib()
+    if not getattr(L, "_img", False):
+        _declare_img(L)
+    return L
+
+
+def bilateral(depth, ksz, sigma_spatial, sigma_depth):
+    depth = np.ascontiguousarray(depth, np.uint16)
+    H, W = depth.shape
+    out = np.zeros_like(depth)
+    _libimg().orc_bilateral(_p(depth), W * 2, _p(out), W * 2, W, H, ksz, sigma_spatial, sigma_depth)
+    return out
+
+
+def truncate_depth(depth, max_dist):
+    out = np.ascontiguousarray(depth, np.uint16).copy()
+    H, W = out.shape
+    _libimg().orc_truncate_depth(_p(out), W * 2, W, H, max_dist)
+    return out
+
+
+def depth_pyr(depth, sigma_depth):
+    depth = np.ascontiguousarray(depth, np.uint16)
+    H, W = depth.shape
+    out = np.zeros((H // 2, W // 2), np.uint16)
+    if out.size:
+        _libimg().orc_depth_pyr(_p(depth), W * 2, W, H, _p(out), (W // 2) * 2, sigma_depth)
+    return out
+
+
+def normals_mask_depth(depth, fx, fy, cx, cy):
+    """returns (masked depth copy, normals (H, W, 4))"""
+    d = np.ascontiguousarray(depth, np.uint16).copy()
+    H, W = d.shape
+    n = np.zeros((H, W, 4), np.float32)
+    _libimg().orc_normals_mask_depth(_p(d), W * 2, W, H, fx, fy, cx, cy, _p(n), W * 16)
+    return d, n
+
+
+def resize_depth_normals(depth, normals):
+    depth, normals = np.ascontiguousarray(depth, np.uint16), _f32(normals)
+    H, W = depth.shape
+    d, n = np.zeros((H // 2, W // 2), np.uint16), np.zeros((H // 2, W // 2, 4), np.float32)
+    if d.size:
+        _libimg().orc_resize_depth_normals(_p(depth), W * 2, _p(normals), W * 16, W, H, _p(d), (W // 2) * 2, _p(n), (W // 2) * 16)
+    return d, n
+
+
+def resize_points_normals(points, normals):
+    points, normals = _f32(points), _f32(normals)
+    H, W = points.shape[:2]
+    v, n = np.zeros((H // 2, W // 2, 4), np.float32), np.zeros((H // 2, W // 2, 4), np.float32)
+    if v.size:
+        _libimg().orc_resize_points_normals(_p(points), W * 16, _p(normals), W * 16, W, H, _p(v), (W // 2) * 16, _p(n), (W // 2) * 16)
+    return v, n

@@ -158,6 +158,20 @@ void orc_tukey_weights(const float* node_pos, const float* node_dq, const float*
 void orc_huber_weights(const float* node_pos, const float* node_dq, const float* node_w, int D, int k, float psi_reg,
                        float* huber);
 
+/* -------------------------------------------------- depth pre-processing -- */
+/* src/kfusion/cuda/imgproc.cu (see img_oracle.c); PARITY UNPINNED.  Steps are in bytes. */
+float orc_exp_neg(float x); /* the stand-in for __expf in the bilateral weight (x <= 0) */
+void orc_bilateral(const uint16_t* src, int src_step, uint16_t* dst, int dst_step, int cols, int rows, int ksz,
+                   float sigma_spatial, float sigma_depth);
+void orc_truncate_depth(uint16_t* depth, int step, int cols, int rows, float max_dist);
+void orc_depth_pyr(const uint16_t* src, int src_step, int cols, int rows, uint16_t* dst, int dst_step, float sigma_depth);
+void orc_normals_mask_depth(uint16_t* depth, int depth_step, int cols, int rows, float fx, float fy, float cx, float cy,
+                            float* normals, int normals_step);
+void orc_resize_depth_normals(const uint16_t* dsrc, int dsrc_step, const float* nsrc, int nsrc_step, int cols, int rows,
+                              uint16_t* ddst, int ddst_step, float* ndst, int ndst_step);
+void orc_resize_points_normals(const float* vsrc, int vsrc_step, const float* nsrc, int nsrc_step, int cols, int rows,
+                               float* vdst, int vdst_step, float* ndst, int ndst_step);
+
 /* ------------------------------------------------- north-star solve (6-DoF) -- */
 /* solve6_oracle.c: NOT in the reference's code (BASELINE.json north_star);
  * PARITY UNPINNED, formulas in DESIGN.md §4.5. */

@@ -3,6 +3,7 @@
 // TSDF tests; the call sequence is KinFu's (src/kfusion/kinfu.cpp:47-60,206-225).
 #include <cstring>
 
+#include <kfusion/cuda/imgproc.hpp>
 #include <kfusion/cuda/marching_cubes.hpp>
 #include <kfusion/cuda/tsdf_volume.hpp>
 
@@ -156,6 +157,59 @@ TEST(MarchingCubesTest, RunMatchesTheOracleBitExactly) {
     // an empty volume gives an empty array (marching_cubes.cpp:42-46)
     vol.clear();
     ASSERT_TRUE(mc.run(vol, buffer).empty());
+}
+
+// the depth pre-processing of DynFusion::operator() / KinFu::operator() (dyn_fusion.cpp:58-66, kinfu.cpp:150-175)
+// through the kfusion::cuda functions, against the oracle, bit for bit
+TEST(ImgprocTest, PreprocessingChainMatchesTheOracleBitExactly) {
+    const int W = 160, H = 120;
+    const Intr intr(131.25f, 131.25f, W / 2 - 0.5f, H / 2 - 0.5f);
+    std::vector<unsigned short> depth = make_depth(W, H);
+    for (int i = 0; i < W * H; i += 7) depth[i] = (unsigned short)(depth[i] + (i % 5));  // a little texture
+    cuda::Depth d_in, d_f, d_half;
+    d_in.upload(depth, W);
+    cuda::depthBilateralFilter(d_in, d_f, 7, 4.5f, 0.04f);  // kinfu.cpp:26-28
+    cuda::depthTruncation(d_f, 2.0f);
+    cuda::depthBuildPyramid(d_f, d_half, 0.04f);
+    cuda::Normals n_f;
+    cuda::computeNormalsAndMaskDepth(intr, d_f, n_f);
+    cuda::Depth d_q;
+    cuda::Normals n_q;
+    cuda::resizeDepthNormals(d_f, n_f, d_q, n_q);
+    cuda::Cloud pts, pts_q;
+    cuda::Normals nrm, nrm_q;
+    cuda::computePointNormals(intr, d_f, pts, nrm);
+    cuda::resizePointsNormals(pts, nrm, pts_q, nrm_q);
+
+    std::vector<unsigned short> o_f(depth.size()), o_half((size_t)(W / 2) * (H / 2)), o_q(o_half.size());
+    orc_bilateral(depth.data(), W * 2, o_f.data(), W * 2, W, H, 7, 4.5f, 0.04f);
+    orc_truncate_depth(o_f.data(), W * 2, W, H, 2.0f);
+    orc_depth_pyr(o_f.data(), W * 2, W, H, o_half.data(), (W / 2) * 2, 0.04f);
+    std::vector<float> o_n((size_t)W * H * 4), o_nq(o_half.size() * 4);
+    orc_normals_mask_depth(o_f.data(), W * 2, W, H, intr.fx, intr.fy, intr.cx, intr.cy, o_n.data(), W * 16);
+    orc_resize_depth_normals(o_f.data(), W * 2, o_n.data(), W * 16, W, H, o_q.data(), (W / 2) * 2, o_nq.data(), (W / 2) * 16);
+    std::vector<float> o_p((size_t)W * H * 4), o_pn(o_p.size()), o_pq(o_nq.size()), o_pnq(o_nq.size());
+    orc6_points_normals(o_f.data(), W * 2, W, H, intr.fx, intr.fy, intr.cx, intr.cy, o_p.data(), W * 16, o_pn.data(), W * 16);
+    orc_resize_points_normals(o_p.data(), W * 16, o_pn.data(), W * 16, W, H, o_pq.data(), (W / 2) * 16, o_pnq.data(), (W / 2) * 16);
+
+    std::vector<unsigned short> h;
+    int cols;
+    d_f.download(h, cols);
+    ASSERT_TRUE(h == o_f);
+    d_half.download(h, cols);
+    ASSERT_TRUE(cols == W / 2 && h == o_half);
+    d_q.download(h, cols);
+    ASSERT_TRUE(h == o_q);
+    std::vector<Normal> hn;
+    n_f.download(hn, cols);
+    ASSERT_TRUE(std::memcmp(hn.data(), o_n.data(), o_n.size() * 4) == 0);
+    n_q.download(hn, cols);
+    ASSERT_TRUE(std::memcmp(hn.data(), o_nq.data(), o_nq.size() * 4) == 0);
+    std::vector<Point> hp;
+    pts_q.download(hp, cols);
+    ASSERT_TRUE(std::memcmp(hp.data(), o_pq.data(), o_pq.size() * 4) == 0);
+    nrm_q.download(hn, cols);
+    ASSERT_TRUE(std::memcmp(hn.data(), o_pnq.data(), o_pnq.size() * 4) == 0);
 }
 
 int main(int argc, char** argv) { return mt::run_all(argc, argv); }

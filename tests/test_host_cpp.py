@@ -35,7 +35,9 @@ def test_host_library_exports_the_adaptor_classes(exes):
                  "kfusion::cuda::TsdfVolume::clear", "kfusion::cuda::computeDists", "Warpfield::calcDQB",
                  "Warpfield::warpToLive", "Warpfield::findNeighborsIndex", "CombinedSolver::initializeProblemInstance",
                  "CombinedSolver::solveAll", "DynFusion::warpCanonicalToLiveOpt", "DynFusion::findCorrespondingFrame",
-                 "DynFusion::init", "DynFusion::fuse", "kfusion::cuda::MarchingCubes::run"):
+                 "DynFusion::init", "DynFusion::fuse", "kfusion::cuda::MarchingCubes::run",
+                 "kfusion::cuda::depthBilateralFilter", "kfusion::cuda::computePointNormals",
+                 "kfusion::cuda::resizeDepthNormals"):
         assert name in syms, name
 
 
@@ -48,7 +50,7 @@ def test_host_combined_solver_runs_reference_opttests(exes):
 @pytest.mark.gpu
 def test_host_tsdf_volume_matches_oracle(exes):
     out = _run(exes["test_host_tsdf"])
-    assert "3 tests, 0 failed" in out
+    assert "4 tests, 0 failed" in out
 
 
 @pytest.mark.gpu
