@@ -10,6 +10,7 @@ _LIB = None
 SYMBOLS = [
     "dfa_last_error", "dfa_version", "dfa_compute_dists", "dfa_tsdf_clear", "dfa_tsdf_integrate",
     "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_knn", "dfa_warp_to_live",
+    "dfa_calc_dqb", "dfa_unsupported_vertices",
     "dfa_correspond", "dfa_marching_cubes", "dfa_mc_default_tables",
     "dfa_depth_bilateral_filter", "dfa_depth_truncate", "dfa_depth_build_pyramid", "dfa_compute_normals_mask_depth",
     "dfa_resize_depth_normals", "dfa_resize_points_normals",
@@ -112,6 +113,8 @@ def load():
     L.dfa_solver6_get_stats.argtypes = [vp, C.POINTER(_Solve6Stats), vp]
     L.dfa_marching_cubes.argtypes = [vp, i, i, i, vp, vp, vp, vp, i, vp, vp]
     L.dfa_mc_default_tables.argtypes = [vp, vp]
+    L.dfa_calc_dqb.argtypes = [vp, vp, vp, i, i, vp, i, vp, vp]
+    L.dfa_unsupported_vertices.argtypes = [vp, vp, i, i, vp, i, vp, vp]
     L.dfa_correspond.argtypes = [vp, vp, i, vp, i, vp, vp, vp, vp]
     L.dfa_solver_create.argtypes = [i, i, i, C.POINTER(vp)]
     L.dfa_solver_destroy.argtypes = [vp]
@@ -292,6 +295,27 @@ def warp_to_live(node_pos, node_dq, node_w, k, verts, normals=None):
                                    _dev(verts, torch.float32, "verts"), _dev(normals, torch.float32, "normals"),
                                    verts.shape[0], _dev(out_v), _dev(out_n), _stream()))
     return out_v, out_n
+
+
+def calc_dqb(node_pos, node_dq, node_w, k, points):
+    """Warpfield::calcDQB at n points -> (n, 8) dual quaternions"""
+    torch = _torch()
+    out = torch.empty((points.shape[0], 8), dtype=torch.float32, device=points.device)
+    _check(load().dfa_calc_dqb(_dev(node_pos, torch.float32, "node_pos"), _dev(node_dq, torch.float32, "node_dq"),
+                               _dev(node_w, torch.float32, "node_w"), node_pos.shape[0], k,
+                               _dev(points, torch.float32, "points"), points.shape[0], _dev(out), _stream()))
+    return out
+
+
+def unsupported_vertices(node_pos, node_w, k, verts):
+    """Warpfield::getUnsupportedVertices -> uint8 flags (N,)"""
+    torch = _torch()
+    flags = torch.empty((verts.shape[0],), dtype=torch.uint8, device=verts.device)
+    D = 0 if node_pos is None else node_pos.shape[0]
+    _check(load().dfa_unsupported_vertices(_dev(node_pos, torch.float32, "node_pos") if D else None,
+                                           _dev(node_w, torch.float32, "node_w") if D else None, D, k,
+                                           _dev(verts, torch.float32, "verts"), verts.shape[0], _dev(flags), _stream()))
+    return flags
 
 
 def correspond(canon_v, canon_n, live_v, want_index=True):

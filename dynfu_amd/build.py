@@ -107,7 +107,7 @@ def build_cpp_tests(force=False, verbose=False):
     oracle_dir = os.path.join(root, "oracle")
     built = {}
     for name, needs in (("test_host_dq", []), ("test_host_solver", ["host"]), ("test_host_tsdf", ["host", "oracle"]),
-                        ("test_host_dynfusion", ["host"])):
+                        ("test_host_dynfusion", ["host", "oracle"])):
         src = os.path.join(tdir, name + ".cpp")
         exe = os.path.join(out, name)
         deps = [src, os.path.join(tdir, "minitest.hpp"), host]

@@ -403,6 +403,40 @@ int dfa_warp_to_live(const float* node_pos, const float* node_dq, const float* n
     return DFA_OK;
 }
 
+int dfa_calc_dqb(const float* node_pos, const float* node_dq, const float* node_w, int D, int k, const float* points,
+                 int n, float* out_dq, dfa_stream_t stream) {
+    REQUIRE(node_pos && node_dq && node_w && D > 0, "no nodes");
+    REQUIRE(n >= 0 && (n == 0 || (points && out_dq)), "bad points / output");
+    REQUIRE(k >= 1 && k <= DFA_MAX_KNN, "k out of range 1..16");
+    const dfa::KnnGridView* grid = nullptr;
+    if (want_grid(D, n)) {
+        HIP_TRY(g_thread_grid.reserve(D));
+        HIP_TRY(dfa::knn_grid_build(g_thread_grid.v, node_pos, D, S(stream)));
+        grid = &g_thread_grid.v;
+    }
+    HIP_TRY(dfa::launch_dqb_support(node_pos, node_dq, node_w, D, k, points, n, out_dq, nullptr, grid, S(stream)));
+    return DFA_OK;
+}
+
+int dfa_unsupported_vertices(const float* node_pos, const float* node_w, int D, int k, const float* vertices, int N,
+                             uint8_t* flags, dfa_stream_t stream) {
+    REQUIRE(N >= 0 && (N == 0 || (vertices && flags)), "bad vertices / output");
+    REQUIRE(k >= 1 && k <= DFA_MAX_KNN, "k out of range 1..16");
+    if (D == 0) {  // no node supports anything (min stays HUGE_VALF, warp_field.cpp:40,53)
+        if (N > 0) HIP_TRY(hipMemsetAsync(flags, 1, (size_t)N, S(stream)));
+        return DFA_OK;
+    }
+    REQUIRE(node_pos && node_w && D > 0, "bad nodes");
+    const dfa::KnnGridView* grid = nullptr;
+    if (want_grid(D, N)) {
+        HIP_TRY(g_thread_grid.reserve(D));
+        HIP_TRY(dfa::knn_grid_build(g_thread_grid.v, node_pos, D, S(stream)));
+        grid = &g_thread_grid.v;
+    }
+    HIP_TRY(dfa::launch_dqb_support(node_pos, nullptr, node_w, D, k, vertices, N, nullptr, flags, grid, S(stream)));
+    return DFA_OK;
+}
+
 int dfa_correspond(const float* canon_vertices, const float* canon_normals, int n_canon, const float* live_vertices,
                    int n_live, float* out_vertices, float* out_normals, int32_t* out_index, dfa_stream_t stream) {
     REQUIRE(canon_vertices && n_canon > 0, "no canonical vertices");

@@ -63,6 +63,10 @@ hipError_t launch_correspond(const float* canon_v, const float* canon_n, int n_c
                              int n_live, float* out_v, float* out_n, int32_t* out_idx, const KnnGridView* grid,
                              hipStream_t s);
 
+hipError_t launch_dqb_support(const float* node_pos, const float* node_dq, const float* node_w, int D, int k,
+                              const float* pts, int n, float* out_dq, uint8_t* out_flag, const KnnGridView* grid,
+                              hipStream_t s);
+
 // mc.hip
 long mc_segments(int X, int Y, int Z, bool vec4);  // entries of seg_off (+1)
 long mc_scan_chunks(long nsegs);                   // entries of chunk_sums

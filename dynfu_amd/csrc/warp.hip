@@ -547,6 +547,48 @@ __global__ __launch_bounds__(256) void correspond_kernel(const float* __restrict
         out_n[dst] = canon_n[src], out_n[dst + 1] = canon_n[src + 1], out_n[dst + 2] = canon_n[src + 2];
 }
 
+// Warpfield::calcDQB (warp_field.cpp:127-148) at arbitrary points: the blended transform itself (new nodes
+// are seeded with it, warp_field.cpp:78) — and Warpfield::getUnsupportedVertices (warp_field.cpp:34-62):
+// a vertex is unsupported when min_j |v - g_j| / dg_w_j >= 1 over its k nearest nodes.
+template <int K, bool GRID>
+__global__ __launch_bounds__(256) void dqb_support_kernel(const float* __restrict__ node_pos,
+                                                          const float* __restrict__ node_dq,
+                                                          const float* __restrict__ node_w, int D, int k,
+                                                          const float* __restrict__ pts, int n,
+                                                          float* __restrict__ out_dq, uint8_t* __restrict__ out_flag,
+                                                          KnnGridView grid) {
+    __shared__ float4 tile[GRID ? 1 : KNN_TILE];
+    const int v       = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = v < n;
+    f3 p              = mk3(0.f, 0.f, 0.f);
+    if (active) p = mk3(pts[3 * (size_t)v], pts[3 * (size_t)v + 1], pts[3 * (size_t)v + 2]);
+    KnnList<K> best;
+    if (GRID) {
+        if (!active) return;
+        knn_grid_query<K>(*grid.desc, grid.cell_start, grid.sorted, p, best);
+    } else {
+        knn_scan<K>(node_pos, D, p, best, tile);
+        if (!active) return;
+    }
+    if (out_dq) dq_store(out_dq + 8 * (size_t)v, calc_dqb<K>(best, k, node_pos, node_dq, node_w, p));
+    if (out_flag) {
+        float mn = __builtin_huge_valf();  // :40
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (j < k && best.index(j) >= 0) {
+                const int m = best.index(j);
+                // :45-46 — pow(float, int) is double arithmetic, the root is rounded to float on assignment
+                const double dx = (double)(p.x - node_pos[3 * m]), dy = (double)(p.y - node_pos[3 * m + 1]),
+                             dz = (double)(p.z - node_pos[3 * m + 2]);
+                const float dist = (float)sqrt(dx * dx + dy * dy + dz * dz);
+                const float q    = dist / node_w[m];
+                if (q <= mn) mn = q;  // :48-50
+            }
+        }
+        out_flag[v] = mn >= 1.f ? 1 : 0;  // :53
+    }
+}
+
 // ------------------------------------------------------------------------------ launchers
 
 hipError_t point_grid_build(const PointGridView& pg, const float* pts, int n, hipStream_t s) {
@@ -620,6 +662,18 @@ hipError_t launch_correspond(const float* canon_v, const float* canon_n, int n_c
     dim3 block(256), gridDim((n_live + 255) / 256);
     if (grid) correspond_kernel<true><<<gridDim, block, 0, s>>>(canon_v, canon_n, n_canon, live_v, n_live, out_v, out_n, out_idx, *grid);
     else correspond_kernel<false><<<gridDim, block, 0, s>>>(canon_v, canon_n, n_canon, live_v, n_live, out_v, out_n, out_idx, KnnGridView{});
+    return hipGetLastError();
+}
+
+hipError_t launch_dqb_support(const float* node_pos, const float* node_dq, const float* node_w, int D, int k,
+                              const float* pts, int n, float* out_dq, uint8_t* out_flag, const KnnGridView* grid,
+                              hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    dim3 block(256), gridDim((n + 255) / 256);
+    const bool use_grid = grid != nullptr;
+    KnnGridView g       = use_grid ? *grid : KnnGridView{};
+    KGDISPATCH(dqb_support_kernel, k, use_grid,
+               <<<gridDim, block, 0, s>>>(node_pos, node_dq, node_w, D, k, pts, n, out_dq, out_flag, g));
     return hipGetLastError();
 }
 

@@ -109,6 +109,7 @@ struct PointCloud {
     std::vector<T> points;
     void push_back(const T& p) { points.push_back(p); }
     size_t size() const { return points.size(); }
+    bool empty() const { return points.empty(); }
     void clear() { points.clear(); }
     T& operator[](size_t i) { return points[i]; }
     const T& operator[](size_t i) const { return points[i]; }
@@ -124,6 +125,11 @@ struct Error : std::runtime_error {
     int code;
     Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
 };
-void check(int rc, const char* where);  // throws dfa::Error when rc != DFA_OK
+void check(int rc, const char* where);
+
+// pcl::VoxelGrid<pcl::PointXYZ> with default settings and a cubic leaf, as Warpfield::update uses it
+// (warp_field.cpp:68-72): one centroid per occupied leaf, in ascending leaf index.  Restates PCL's published
+// applyFilter (PCL is not available to this build); points of a leaf are summed in input order.
+PointCloud<PointXYZ> voxelGridFilter(const PointCloud<PointXYZ>& cloud, float leaf);  // throws dfa::Error when rc != DFA_OK
 
 }  // namespace dfa

@@ -14,11 +14,33 @@
 #include <dynfu/utils/frame.hpp>
 #include <dynfu/utils/opt_solver.hpp>
 #include <dynfu/warp_field.hpp>
+#include <kfusion/cuda/imgproc.hpp>
+#include <kfusion/cuda/marching_cubes.hpp>
 #include <kfusion/cuda/tsdf_volume.hpp>
 
-struct DynFuParams {  // dyn_fusion.hpp:25-42 (kinfuParams: only the camera intrinsics are used here)
+namespace kfusion {
+// the fields of kfusion::KinFuParams (include/kfusion/types.hpp, defaults src/kfusion/kinfu.cpp:10-44) that the
+// non-rigid pipeline reads; the ICP / rendering ones belong to the out-of-scope rigid tracker
+struct KinFuParams {
+    static KinFuParams default_params();
+    int cols, rows;
+    Intr intr;
+    Vec3i volume_dims;
+    Vec3f volume_size;
+    Affine3f volume_pose;
+    float bilateral_sigma_depth, bilateral_sigma_spatial;
+    int bilateral_kernel_size;
+    float icp_truncate_depth_dist;
+    float tsdf_trunc_dist;
+    int tsdf_max_weight;
+    float raycast_step_factor, gradient_delta_factor;
+};
+}  // namespace kfusion
+
+struct DynFuParams {  // dyn_fusion.hpp:25-42
     static DynFuParams defaultParams();  // dyn_fusion.cpp:6-31
-    kfusion::Intr intr;
+    kfusion::KinFuParams kinfuParams;
+    kfusion::Intr intr;  // = kinfuParams.intr (kept for callers of fuse())
     float tukeyOffset;
     float lambda;
     float psi_data;
@@ -34,6 +56,17 @@ public:
     ~DynFusion();
 
     DynFuParams& params();
+
+    // the whole per-frame sequence of the reference (dyn_fusion.cpp:48-145): pre-process the depth frame, fuse it,
+    // extract the zero level set by marching cubes; frame 0 seeds the canonical frame and the warp field, later
+    // frames become the live frame, the warp field is solved against it and grown.  Returns as the reference
+    // does: false for the first frame, true afterwards.  The volume, its dimensions and the case tables come from
+    // params().kinfuParams / the MarchingCubes passed to useMarchingCubes() (default: the library's tables).
+    bool operator()(const kfusion::cuda::Depth& depth);
+    void useMarchingCubes(std::shared_ptr<kfusion::cuda::MarchingCubes> mc) { mc_ = mc; }
+    kfusion::cuda::TsdfVolume& tsdf();
+    std::shared_ptr<dynfu::Frame> getLiveFrame() { return liveFrame; }
+    int frameCounter() const { return frame_counter_; }
 
     void init(dfa::PointCloud<dfa::PointXYZ>& canonicalVertices, dfa::PointCloud<dfa::Normal>& canonicalNormals);
     void initCanonicalFrame(dfa::PointCloud<dfa::PointXYZ>& vertices, dfa::PointCloud<dfa::Normal>& normals);
@@ -63,4 +96,10 @@ private:
     std::shared_ptr<dynfu::Frame> liveFrame;
     std::shared_ptr<Warpfield> warpfield;
     kfusion::cuda::Dists dists_;
+    kfusion::cuda::Depth depth_filtered_;
+    std::shared_ptr<kfusion::cuda::TsdfVolume> volume_;
+    std::shared_ptr<kfusion::cuda::MarchingCubes> mc_;
+    int frame_counter_ = 0;
+    // vertices of the volume's zero level set as a point cloud (dyn_fusion.cpp:73-88 / :119-134)
+    void extractSurface(dfa::PointCloud<dfa::PointXYZ>& vertices, dfa::PointCloud<dfa::Normal>& normals);
 };

@@ -1,8 +1,10 @@
 // dynfu/warp_field.hpp — class Warpfield with the reference's interface
 // (include/dynfu/warp_field.hpp:32-78, src/dynfu/warp_field.cpp).  The k-NN and the bulk warp
 // run on the GPU through dfa_knn / dfa_warp_to_live; the reference's nanoflann KD-tree is gone
-// (getKdTree() has no counterpart).  Node insertion (update / getUnsupportedVertices,
-// warp_field.cpp:34-95) is a "next" row of the scope table and not provided.
+// (getKdTree() has no counterpart).  Node insertion (getUnsupportedVertices / update, warp_field.cpp:34-95): the
+// support test runs on the GPU (dfa_unsupported_vertices), the pcl::VoxelGrid subsampling of the few unsupported
+// vertices is dfa::voxelGridFilter (host C++, restating PCL's algorithm), the new nodes' transforms come from
+// dfa_calc_dqb.
 #pragma once
 #include <memory>
 #include <vector>
@@ -26,6 +28,11 @@ public:
 
     std::shared_ptr<DualQuaternion<float>> calcDQB(dfa::PointXYZ point);
     std::shared_ptr<dynfu::Frame> warpToLive(std::shared_ptr<dynfu::Frame> canonicalFrame);
+
+    // warp_field.cpp:34-62 (returns the cloud by value instead of a pcl Ptr)
+    dfa::PointCloud<dfa::PointXYZ> getUnsupportedVertices(std::shared_ptr<dynfu::Frame> frame);
+    // warp_field.cpp:64-95: insert a node per 5 cm voxel of unsupported vertices
+    void update(std::shared_ptr<dynfu::Frame> frame);
 
     // number of neighbours (the reference's compile-time KNN; run-time here, default 8)
     void setKnn(int k) { knn_ = k; }

@@ -6,9 +6,25 @@
 
 #include "../../../include/dynfu_amd.h"
 
-DynFuParams DynFuParams::defaultParams() {  // dyn_fusion.cpp:6-31, kinfu.cpp:16-18
+kfusion::KinFuParams kfusion::KinFuParams::default_params() {  // src/kfusion/kinfu.cpp:10-44
+    KinFuParams p;
+    p.cols = 640, p.rows = 480;
+    p.intr        = Intr(525.f, 525.f, p.cols / 2 - 0.5f, p.rows / 2 - 0.5f);
+    p.volume_dims = Vec3i::all(512);
+    p.volume_size = Vec3f::all(3.f);
+    p.volume_pose = Affine3f().translate(Vec3f(-p.volume_size[0] / 2, -p.volume_size[1] / 2, 0.5f));
+    p.bilateral_sigma_depth = 0.04f, p.bilateral_sigma_spatial = 4.5f, p.bilateral_kernel_size = 7;
+    p.icp_truncate_depth_dist = 0.f;
+    p.tsdf_trunc_dist = 0.04f, p.tsdf_max_weight = 64;
+    p.raycast_step_factor = 0.75f, p.gradient_delta_factor = 0.5f;
+    return p;
+}
+
+DynFuParams DynFuParams::defaultParams() {  // dyn_fusion.cpp:6-31
     DynFuParams p;
-    p.intr        = kfusion::Intr(525.f, 525.f, 319.5f, 239.5f);
+    p.kinfuParams             = kfusion::KinFuParams::default_params();
+    p.kinfuParams.volume_dims = kfusion::Vec3i::all(128);  // :10
+    p.intr        = p.kinfuParams.intr;
     p.tukeyOffset = 4.652f;
     p.lambda      = 200.f;
     p.psi_data    = 0.01f;
@@ -99,4 +115,55 @@ void DynFusion::fuse(const kfusion::cuda::Depth& depth, kfusion::cuda::TsdfVolum
                      const dfa::Affine3f& camera_pose) {
     kfusion::cuda::computeDists(depth, dists_, dynfuParams.intr);       // :58
     volume.clearAndIntegrate(dists_, camera_pose, dynfuParams.intr);   // :113-114
+}
+
+// ------------------------------------------------------------------------- the per-frame sequence
+
+kfusion::cuda::TsdfVolume& DynFusion::tsdf() {
+    if (!volume_) {  // KinFu::KinFu, src/kfusion/kinfu.cpp:47-58
+        const kfusion::KinFuParams& p = dynfuParams.kinfuParams;
+        volume_ = std::make_shared<kfusion::cuda::TsdfVolume>(p.volume_dims);
+        volume_->setTruncDist(p.tsdf_trunc_dist);
+        volume_->setMaxWeight(p.tsdf_max_weight);
+        volume_->setSize(p.volume_size);
+        volume_->setPose(p.volume_pose);
+        volume_->setRaycastStepFactor(p.raycast_step_factor);
+        volume_->setGradientDeltaFactor(p.gradient_delta_factor);
+    }
+    return *volume_;
+}
+
+void DynFusion::extractSurface(dfa::PointCloud<dfa::PointXYZ>& vertices, dfa::PointCloud<dfa::Normal>& normals) {
+    if (!mc_) mc_ = std::make_shared<kfusion::cuda::MarchingCubes>();
+    dfa::DeviceArray<kfusion::cuda::MarchingCubes::PointType> buffer;
+    auto triangles = mc_->run(tsdf(), buffer);  // :73-75 / :119-121
+    std::vector<kfusion::cuda::MarchingCubes::PointType> host;
+    if (!triangles.empty()) triangles.download(host);
+    for (auto& p : host) vertices.push_back(dfa::PointXYZ(p.x, p.y, p.z));
+    // pcl::copyPointCloud<PointXYZ, Normal> (:87-88 / :133-134) copies the fields the two types share — none:
+    // the normals are default-constructed, one per vertex
+    for (size_t i = 0; i < host.size(); ++i) normals.push_back(dfa::Normal());
+}
+
+bool DynFusion::operator()(const kfusion::cuda::Depth& depth) {
+    const kfusion::KinFuParams& p = dynfuParams.kinfuParams;
+    kfusion::cuda::computeDists(depth, dists_, p.intr);                                            // :58
+    kfusion::cuda::depthBilateralFilter(depth, depth_filtered_, p.bilateral_kernel_size, p.bilateral_sigma_spatial,
+                                        p.bilateral_sigma_depth);                                  // :60-61
+    if (p.icp_truncate_depth_dist > 0) kfusion::cuda::depthTruncation(depth_filtered_, p.icp_truncate_depth_dist);  // :64-66
+    const dfa::Affine3f camera;  // poses_.back(): the rigid tracker is skipped, the camera stays at the origin (:100-105)
+    dfa::PointCloud<dfa::PointXYZ> vertices;
+    dfa::PointCloud<dfa::Normal> normals;
+    if (frame_counter_ == 0) {
+        tsdf().integrate(dists_, camera, p.intr);  // :71
+        extractSurface(vertices, normals);
+        init(vertices, normals);                   // :95
+        return ++frame_counter_, false;
+    }
+    tsdf().clearAndIntegrate(dists_, camera, p.intr);  // :113-114 as one sweep
+    extractSurface(vertices, normals);
+    addLiveFrame(frame_counter_, vertices, normals);  // :137
+    warpCanonicalToLiveOpt(camera);                   // :140
+    warpfield->update(getCanonicalWarpedToLive());    // :142
+    return ++frame_counter_, true;
 }

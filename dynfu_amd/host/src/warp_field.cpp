@@ -1,6 +1,9 @@
 // warp_field.cpp — Warpfield on the dynfu_amd C ABI (reference: src/dynfu/warp_field.cpp).
 #include <dynfu/warp_field.hpp>
 
+#include <algorithm>
+#include <cmath>
+
 #include <dfa_host/device.hpp>
 
 #include "../../../include/dynfu_amd.h"
@@ -105,4 +108,97 @@ std::shared_ptr<dynfu::Frame> Warpfield::warpToLive(std::shared_ptr<dynfu::Frame
         wn.push_back(dfa::Normal(hn[3 * i], hn[3 * i + 1], hn[3 * i + 2]));
     }
     return std::make_shared<dynfu::Frame>(0, wv, wn);
+}
+
+// ------------------------------------------------------------------------------- node insertion
+
+dfa::PointCloud<dfa::PointXYZ> dfa::voxelGridFilter(const dfa::PointCloud<dfa::PointXYZ>& cloud, float leaf) {
+    dfa::PointCloud<dfa::PointXYZ> out;
+    const float inv = 1.0f / leaf;
+    float lo[3] = {HUGE_VALF, HUGE_VALF, HUGE_VALF}, hi[3] = {-HUGE_VALF, -HUGE_VALF, -HUGE_VALF};
+    std::vector<int> keep;
+    for (size_t i = 0; i < cloud.size(); ++i) {
+        const float p[3] = {cloud[i].x, cloud[i].y, cloud[i].z};
+        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+        keep.push_back((int)i);
+        for (int c = 0; c < 3; ++c) lo[c] = std::min(lo[c], p[c]), hi[c] = std::max(hi[c], p[c]);
+    }
+    if (keep.empty()) return out;
+    long min_b[3], div_b[3];
+    for (int c = 0; c < 3; ++c) {
+        min_b[c] = (long)std::floor(lo[c] * inv);
+        div_b[c] = (long)std::floor(hi[c] * inv) - min_b[c] + 1;
+    }
+    std::vector<std::pair<long, int>> cells;  // (leaf index, point)
+    cells.reserve(keep.size());
+    for (int i : keep) {
+        const long i0 = (long)std::floor(cloud[i].x * inv) - min_b[0], i1 = (long)std::floor(cloud[i].y * inv) - min_b[1],
+                   i2 = (long)std::floor(cloud[i].z * inv) - min_b[2];
+        cells.emplace_back(i0 + i1 * div_b[0] + i2 * div_b[0] * div_b[1], i);
+    }
+    std::sort(cells.begin(), cells.end());  // by leaf, then by input order
+    for (size_t i = 0; i < cells.size();) {
+        size_t j = i;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (; j < cells.size() && cells[j].first == cells[i].first; ++j)
+            sx += cloud[cells[j].second].x, sy += cloud[cells[j].second].y, sz += cloud[cells[j].second].z;
+        const float n = (float)(j - i);
+        out.push_back(dfa::PointXYZ(sx / n, sy / n, sz / n));
+        i = j;
+    }
+    return out;
+}
+
+dfa::PointCloud<dfa::PointXYZ> Warpfield::getUnsupportedVertices(std::shared_ptr<dynfu::Frame> frame) {  // :34-62
+    dfa::PointCloud<dfa::PointXYZ> out;
+    auto& verts = frame->getVertices();
+    const int N = (int)verts.size();
+    if (N == 0) return out;
+    std::vector<float> hv(3 * (size_t)N);
+    for (int i = 0; i < N; ++i) hv[3 * i] = verts[i].x, hv[3 * i + 1] = verts[i].y, hv[3 * i + 2] = verts[i].z;
+    dfa::DeviceArray<float> dv;
+    dfa::DeviceArray<unsigned char> df((size_t)N);
+    dv.upload(hv);
+    const int D = dev ? dev->D : 0;
+    dfa::check(dfa_unsupported_vertices(D ? dev->pos.ptr() : nullptr, D ? dev->w.ptr() : nullptr, D, knn_, dv.ptr(), N,
+                                        df.ptr(), nullptr),
+               "Warpfield::getUnsupportedVertices");
+    std::vector<unsigned char> flags;
+    df.download(flags);
+    for (int i = 0; i < N; ++i)
+        if (flags[i]) out.push_back(verts[i]);
+    return out;
+}
+
+void Warpfield::update(std::shared_ptr<dynfu::Frame> frame) {  // :64-95
+    const dfa::PointCloud<dfa::PointXYZ> unsupported = getUnsupportedVertices(frame);
+    const dfa::PointCloud<dfa::PointXYZ> seeds       = dfa::voxelGridFilter(unsupported, 0.05f);  // :68-72
+    const int n = (int)seeds.size();
+    if (n == 0) return;
+    // dg_se3 of a new node = calcDQB(dg_v) over the nodes that existed BEFORE this update (the reference's KD-tree
+    // is rebuilt only after the loop, :85-94); with no node yet calcDQB is the identity
+    std::vector<float> hq(8 * (size_t)n, 0.f);
+    for (int i = 0; i < n; ++i) hq[8 * (size_t)i] = 1.f;
+    if (dev && dev->D > 0) {
+        std::vector<float> hp(3 * (size_t)n), hdq(8 * nodes.size());
+        for (int i = 0; i < n; ++i) hp[3 * i] = seeds[i].x, hp[3 * i + 1] = seeds[i].y, hp[3 * i + 2] = seeds[i].z;
+        for (size_t i = 0; i < nodes.size(); ++i) {
+            const auto& dq = *nodes[i]->getTransformation();
+            const auto r = dq.getReal(), d = dq.getDual();
+            float* o = &hdq[8 * i];
+            o[0] = r.a, o[1] = r.b, o[2] = r.c, o[3] = r.d, o[4] = d.a, o[5] = d.b, o[6] = d.c, o[7] = d.d;
+        }
+        dfa::DeviceArray<float> dp, dq_out(8 * (size_t)n);
+        dp.upload(hp), dev->dq.upload(hdq);
+        dfa::check(dfa_calc_dqb(dev->pos.ptr(), dev->dq.ptr(), dev->w.ptr(), dev->D, knn_, dp.ptr(), n, dq_out.ptr(), nullptr),
+                   "Warpfield::update (calcDQB)");
+        dq_out.download(hq);
+    }
+    for (int i = 0; i < n; ++i) {
+        const float* q = &hq[8 * (size_t)i];
+        auto dq = std::make_shared<DualQuaternion<float>>(dfa::quaternion<float>(q[0], q[1], q[2], q[3]),
+                                                          dfa::quaternion<float>(q[4], q[5], q[6], q[7]));
+        nodes.emplace_back(std::make_shared<Node>(seeds[i], dq, 2 * epsilon));  // :79-82
+    }
+    syncPositions();  // :85-94
 }

@@ -162,6 +162,16 @@ int dfa_warp_to_live(const float* node_pos, const float* node_dq, const float* n
                      const float* vertices, const float* normals, int N, float* out_vertices, float* out_normals,
                      dfa_stream_t stream);
 
+/* Warpfield::calcDQB (warp_field.cpp:127-148) at n points: the blended dual quaternion itself, n x 8 floats
+ * (Warpfield::update seeds a new node with it, warp_field.cpp:78).  node_dq may be NULL only if out_dq is. */
+int dfa_calc_dqb(const float* node_pos, const float* node_dq, const float* node_w, int D, int k, const float* points,
+                 int n, float* out_dq, dfa_stream_t stream);
+
+/* Warpfield::getUnsupportedVertices (warp_field.cpp:34-62): flag[v] = 1 when min over the k nearest nodes of
+ * |v - dg_v| / dg_w is >= 1 (also when there is no node at all).  The reference's KNN is 8. */
+int dfa_unsupported_vertices(const float* node_pos, const float* node_w, int D, int k, const float* vertices, int N,
+                             uint8_t* flags, dfa_stream_t stream);
+
 /* DynFusion::findCorrespondingFrame (src/dynfu/dyn_fusion.cpp:212-242): for each of the
  * n_live live vertices the nearest of the n_canon (warped) canonical vertices — exact 1-NN,
  * ties to the lower index — and the canonical vertex / normal at that index gathered into

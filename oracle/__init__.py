@@ -545,3 +545,25 @@ def resize_points_normals(points, normals):
     if v.size:
         _libimg().orc_resize_points_normals(_p(points), W * 16, _p(normals), W * 16, W, H, _p(v), (W // 2) * 16, _p(n), (W // 2) * 16)
     return v, n
+
+
+# ------------------------------------------------------------------ node insertion (warp_oracle.c)
+def unsupported_flags(node_pos, node_w, k, verts, threads=1):
+    verts = _f32(verts)
+    D = 0 if node_pos is None else len(node_pos)
+    flags = np.zeros(len(verts), np.uint8)
+    L = lib()
+    L.orc_unsupported_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.orc_unsupported_flags(_p(_f32(node_pos)) if D else None, _p(_f32(node_w)) if D else None, D, k, _p(verts),
+                            len(verts), _p(flags), threads)
+    return flags
+
+
+def voxel_grid(points, leaf):
+    points = _f32(points).reshape(-1, 3)
+    out = np.zeros((max(len(points), 1), 3), np.float32)
+    L = lib()
+    L.orc_voxel_grid.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    L.orc_voxel_grid.restype = C.c_int
+    m = L.orc_voxel_grid(_p(points), len(points), leaf, _p(out))
+    return out[:m].copy()

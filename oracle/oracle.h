@@ -116,6 +116,13 @@ void orc_warp_to_live(const float* node_pos, const float* node_dq, const float* 
                       const float* verts, const float* normals, int N, float* out_verts, float* out_normals,
                       int threads);
 
+/* warp_field.cpp:34-62 */
+void orc_unsupported_flags(const float* node_pos, const float* node_w, int D, int k, const float* verts, int N,
+                           uint8_t* flags, int threads);
+/* pcl::VoxelGrid as Warpfield::update uses it (warp_field.cpp:68-72); restated from PCL's published algorithm,
+ * un-vendored dependency, PARITY UNPINNED (see warp_oracle.c).  Returns the number of output points. */
+int orc_voxel_grid(const float* pts, int n, float leaf, float* out);
+
 /* ----------------------------------------------------------------- solve -- */
 typedef struct {
     int num_iter;        /* outer iterations: Tukey/Huber re-weighting (CombinedSolverParameters.numIter)      */

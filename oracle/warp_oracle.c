@@ -104,3 +104,89 @@ void orc_warp_to_live(const float* node_pos, const float* node_dq, const float* 
             orc_dq_transform_vertex(dq, normals + 3 * (size_t)i, out_normals + 3 * (size_t)i);
     }
 }
+
+/* Warpfield::getUnsupportedVertices (src/dynfu/warp_field.cpp:34-62): flag = 1 when the smallest
+ * |v - dg_v| / dg_w over the k nearest nodes is >= 1 (or there is no node). */
+void orc_unsupported_flags(const float* node_pos, const float* node_w, int D, int k, const float* verts, int N,
+                           uint8_t* flags, int threads) {
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+    for (int v = 0; v < N; ++v) {
+        int32_t idx[64];
+        float d2[64];
+        float mn = HUGE_VALF; /* :40 */
+        if (D > 0) {
+            knn_one(node_pos, D, verts + 3 * (size_t)v, k, idx, d2);
+            for (int j = 0; j < k && idx[j] >= 0; ++j) {
+                const float* g = node_pos + 3 * (size_t)idx[j];
+                /* :45-46: pow(float difference, 2) is double; the root is assigned to a float */
+                const double dx = (double)(verts[3 * (size_t)v] - g[0]), dy = (double)(verts[3 * (size_t)v + 1] - g[1]),
+                             dz = (double)(verts[3 * (size_t)v + 2] - g[2]);
+                const float dist = (float)sqrt(dx * dx + dy * dy + dz * dz);
+                const float q    = dist / node_w[idx[j]];
+                if (q <= mn) mn = q;
+            }
+        }
+        flags[v] = mn >= 1.f;
+    }
+}
+
+/* pcl::VoxelGrid<pcl::PointXYZ>::applyFilter as Warpfield::update uses it (warp_field.cpp:68-72: leaf 0.05,
+ * every other setting default).  PCL is an un-vendored dependency of the reference (no version pin in the
+ * tree: whatever libpcl-dev the Dockerfile's apt installs — 1.7 / 1.8); this restates its published
+ * algorithm (filters/include/pcl/filters/impl/voxel_grid.hpp, applyFilter):
+ *   min_b = floor(min_p * inverse_leaf), max_b likewise, div_b = max_b - min_b + 1,
+ *   cell of a point = floor(p * inverse_leaf) - min_b, linear index x + y div_b.x + z div_b.x div_b.y,
+ *   points sorted by cell index, one output point per occupied cell in ascending index:
+ *   the centroid (float sum / count).
+ * PCL's std::sort leaves the order INSIDE a cell unspecified, so the float sum's last bit is not defined by
+ * PCL; here the points of a cell are added in ascending input order.  PARITY UNPINNED.
+ * Returns the number of output points (out must hold n x 3). */
+typedef struct {
+    long cell;
+    int point;
+} vg_pair;
+static int vg_cmp(const void* a, const void* b) {
+    const vg_pair *x = (const vg_pair*)a, *y = (const vg_pair*)b;
+    if (x->cell != y->cell) return x->cell < y->cell ? -1 : 1;
+    return x->point < y->point ? -1 : (x->point > y->point);
+}
+int orc_voxel_grid(const float* pts, int n, float leaf, float* out) {
+    if (n <= 0) return 0;
+    const float inv = 1.0f / leaf; /* inverse_leaf_size_ = 1 / leaf_size_ (float) */
+    float mn[3] = {HUGE_VALF, HUGE_VALF, HUGE_VALF}, mx[3] = {-HUGE_VALF, -HUGE_VALF, -HUGE_VALF};
+    int finite = 0;
+    for (int i = 0; i < n; ++i) {
+        const float* p = pts + 3 * (size_t)i;
+        if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+        ++finite;
+        for (int c = 0; c < 3; ++c) mn[c] = p[c] < mn[c] ? p[c] : mn[c], mx[c] = p[c] > mx[c] ? p[c] : mx[c];
+    }
+    if (!finite) return 0;
+    long minb[3], divb[3];
+    for (int c = 0; c < 3; ++c) {
+        minb[c] = (long)floorf(mn[c] * inv);
+        divb[c] = (long)floorf(mx[c] * inv) - minb[c] + 1;
+    }
+    vg_pair* pr = (vg_pair*)malloc(sizeof(vg_pair) * (size_t)finite);
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        const float* p = pts + 3 * (size_t)i;
+        if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+        const long i0 = (long)floorf(p[0] * inv) - minb[0], i1 = (long)floorf(p[1] * inv) - minb[1],
+                   i2 = (long)floorf(p[2] * inv) - minb[2];
+        pr[m].cell = i0 + i1 * divb[0] + i2 * divb[0] * divb[1], pr[m].point = i, ++m;
+    }
+    qsort(pr, (size_t)m, sizeof(vg_pair), vg_cmp);
+    int nout = 0;
+    for (int i = 0; i < m;) {
+        int j = i;
+        float s[3] = {0.f, 0.f, 0.f};
+        for (; j < m && pr[j].cell == pr[i].cell; ++j)
+            for (int c = 0; c < 3; ++c) s[c] += pts[3 * (size_t)pr[j].point + c];
+        const float cnt = (float)(j - i);
+        for (int c = 0; c < 3; ++c) out[3 * (size_t)nout + c] = s[c] / cnt;
+        ++nout, i = j;
+    }
+    free(pr);
+    return nout;
+}

@@ -181,3 +181,30 @@ def test_correspond_point_grid_is_exact_on_awkward_geometry(A, kind):
     _, _, idx = A.correspond(dev(cv), None, dev(lv))
     _, _, ridx = O.correspond(cv, None, lv, threads=8)
     assert np.array_equal(host(idx), ridx)
+
+
+# ------------------------------------------------------------- node insertion pieces (warp_field.cpp:34-95)
+@pytest.mark.parametrize("D,k,n", [(300, 8, 20000), (2048, 8, 60000), (3, 8, 500)])
+def test_unsupported_vertices_and_calc_dqb_match_the_oracle(A, D, k, n):
+    rng = np.random.default_rng(D)
+    nodes = rng.uniform(-1, 1, (D, 3)).astype(np.float32)
+    node_w = rng.uniform(0.05, 0.3, D).astype(np.float32)
+    verts = rng.uniform(-1.3, 1.3, (n, 3)).astype(np.float32)
+    verts[:D] = nodes  # distance 0: supported
+    flags = host(A.unsupported_vertices(dev(nodes), dev(node_w), k, dev(verts)))
+    ref = O.unsupported_flags(nodes, node_w, k, verts, threads=8)
+    assert np.array_equal(flags, ref) and 0 < ref.mean() < 1 and not ref[:D].any()
+    # blended transforms at the first points
+    dq = np.zeros((D, 8), np.float32)
+    for i in range(D):
+        dq[i] = O.dq_from_euler(*rng.uniform(-0.3, 0.3, 3), *rng.uniform(-0.05, 0.05, 3))
+    m = min(n, 400)
+    got = host(A.calc_dqb(dev(nodes), dev(dq), dev(node_w), k, dev(verts[:m])))
+    want = np.stack([O.calc_dqb(nodes, dq, node_w, k, verts[i]) for i in range(m)])
+    assert np.abs(got - want).max() < 2e-6
+
+
+def test_unsupported_vertices_without_nodes(A):
+    import torch
+    v = torch.zeros((7, 3), device="cuda")
+    assert host(A.unsupported_vertices(None, None, 8, v)).tolist() == [1] * 7  # min stays HUGE_VALF (:40,:53)

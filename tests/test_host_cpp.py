@@ -35,7 +35,8 @@ def test_host_library_exports_the_adaptor_classes(exes):
                  "kfusion::cuda::TsdfVolume::clear", "kfusion::cuda::computeDists", "Warpfield::calcDQB",
                  "Warpfield::warpToLive", "Warpfield::findNeighborsIndex", "CombinedSolver::initializeProblemInstance",
                  "CombinedSolver::solveAll", "DynFusion::warpCanonicalToLiveOpt", "DynFusion::findCorrespondingFrame",
-                 "DynFusion::init", "DynFusion::fuse", "kfusion::cuda::MarchingCubes::run",
+                 "DynFusion::init", "DynFusion::fuse", "DynFusion::operator()", "Warpfield::update",
+                 "Warpfield::getUnsupportedVertices", "dfa::voxelGridFilter", "kfusion::cuda::MarchingCubes::run",
                  "kfusion::cuda::depthBilateralFilter", "kfusion::cuda::computePointNormals",
                  "kfusion::cuda::resizeDepthNormals"):
         assert name in syms, name
@@ -56,4 +57,4 @@ def test_host_tsdf_volume_matches_oracle(exes):
 @pytest.mark.gpu
 def test_host_dynfusion_sequence(exes):
     out = _run(exes["test_host_dynfusion"])
-    assert "3 tests, 0 failed" in out
+    assert "6 tests, 0 failed" in out
