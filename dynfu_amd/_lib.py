@@ -10,7 +10,7 @@ _LIB = None
 SYMBOLS = [
     "dfa_last_error", "dfa_version", "dfa_compute_dists", "dfa_tsdf_clear", "dfa_tsdf_integrate",
     "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_knn", "dfa_warp_to_live",
-    "dfa_calc_dqb", "dfa_unsupported_vertices",
+    "dfa_calc_dqb", "dfa_unsupported_vertices", "dfa_icp_sums",
     "dfa_correspond", "dfa_marching_cubes", "dfa_mc_default_tables",
     "dfa_depth_bilateral_filter", "dfa_depth_truncate", "dfa_depth_build_pyramid", "dfa_compute_normals_mask_depth",
     "dfa_resize_depth_normals", "dfa_resize_points_normals",
@@ -113,6 +113,7 @@ def load():
     L.dfa_solver6_get_stats.argtypes = [vp, C.POINTER(_Solve6Stats), vp]
     L.dfa_marching_cubes.argtypes = [vp, i, i, i, vp, vp, vp, vp, i, vp, vp]
     L.dfa_mc_default_tables.argtypes = [vp, vp]
+    L.dfa_icp_sums.argtypes = [i, vp, i, vp, i, vp, i, vp, i, i, i, vp, f, f, f, f, f, f, vp, vp, vp]
     L.dfa_calc_dqb.argtypes = [vp, vp, vp, i, i, vp, i, vp, vp]
     L.dfa_unsupported_vertices.argtypes = [vp, vp, i, i, vp, i, vp, vp]
     L.dfa_correspond.argtypes = [vp, vp, i, vp, i, vp, vp, vp, vp]
@@ -537,3 +538,19 @@ def resize_points_normals(points, normals):
                                             _dev(normals, torch.float32, "normals"), normals.stride(0) * 4, cols, rows,
                                             _dev(v), max(v.stride(0), 4) * 4, _dev(n), max(n.stride(0), 4) * 4, _stream()))
     return v, n
+
+
+# --------------------------------------------------------------------------------- rigid-ICP seam
+def icp_sums(curr, ncurr, prev, nprev, aff12, fx, fy, cx, cy, dist_thres=0.1, angle_thres=0.3490658503988659):
+    """one linearisation of the rigid projective ICP -> (27 sums CUDA float tensor, matched pixels CUDA int tensor)"""
+    torch = _torch()
+    depth_variant = curr.dtype == torch.uint16
+    rows, cols = curr.shape[:2]
+    esz = 2 if depth_variant else 4
+    sums = torch.zeros(27, dtype=torch.float32, device=curr.device)
+    matched = torch.zeros(1, dtype=torch.int32, device=curr.device)
+    _check(load().dfa_icp_sums(1 if depth_variant else 0, _dev(curr), curr.stride(0) * esz, _dev(ncurr, torch.float32, "ncurr"),
+                               ncurr.stride(0) * 4, _dev(prev), prev.stride(0) * esz, _dev(nprev, torch.float32, "nprev"),
+                               nprev.stride(0) * 4, cols, rows, _aff12(aff12), fx, fy, cx, cy, dist_thres, angle_thres,
+                               _dev(sums), _dev(matched), _stream()))
+    return sums, matched

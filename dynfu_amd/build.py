@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libdynfu_amd.so")
-SOURCES = ["tsdf.hip", "warp.hip", "solve.hip", "solve6.hip", "mc.hip", "img.hip", "capi.cpp"]
+SOURCES = ["tsdf.hip", "warp.hip", "solve.hip", "solve6.hip", "mc.hip", "img.hip", "icp.hip", "capi.cpp"]
 ARCH = "gfx950"
 EXTRA = os.environ.get("DFA_EXTRA_CXXFLAGS", "").split()
 FLAGS = EXTRA + ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function",
@@ -72,7 +72,7 @@ def build(force=False, verbose=False):
 HOST = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(HERE, "libdynfu_amd_host.so")
 HOST_SOURCES = ["device.cpp", "tsdf_volume.cpp", "warp_field.cpp", "opt_solver.cpp", "dyn_fusion.cpp",
-                "marching_cubes.cpp", "imgproc.cpp"]
+                "marching_cubes.cpp", "imgproc.cpp", "projective_icp.cpp"]
 
 
 def build_host(force=False, verbose=False):
@@ -107,7 +107,7 @@ def build_cpp_tests(force=False, verbose=False):
     oracle_dir = os.path.join(root, "oracle")
     built = {}
     for name, needs in (("test_host_dq", []), ("test_host_solver", ["host"]), ("test_host_tsdf", ["host", "oracle"]),
-                        ("test_host_dynfusion", ["host", "oracle"])):
+                        ("test_host_dynfusion", ["host", "oracle"]), ("test_host_icp", ["host"])):
         src = os.path.join(tdir, name + ".cpp")
         exe = os.path.join(out, name)
         deps = [src, os.path.join(tdir, "minitest.hpp"), host]

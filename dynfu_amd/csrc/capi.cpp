@@ -344,6 +344,41 @@ int dfa_resize_points_normals(const float* points, int points_step, const float*
     return DFA_OK;
 }
 
+// ------------------------------------------------------------------------------ rigid-ICP seam
+
+namespace {
+struct IcpScratch {
+    float* partial = nullptr;
+    size_t cap     = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        (void)hipFree(partial);
+        partial = nullptr, cap = 0;
+        hipError_t e = hipMalloc((void**)&partial, sizeof(float) * n);
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+};
+thread_local IcpScratch g_thread_icp;
+}  // namespace
+
+int dfa_icp_sums(int depth_variant, const void* curr, int curr_step, const float* ncurr, int ncurr_step, const void* prev,
+                 int prev_step, const float* nprev, int nprev_step, int cols, int rows, const float aff[12], float fx,
+                 float fy, float cx, float cy, float dist_thres, float angle_thres, float* sums27, unsigned int* matched,
+                 dfa_stream_t stream) {
+    REQUIRE(curr && ncurr && prev && nprev && sums27 && aff, "null argument");
+    REQUIRE(cols > 0 && rows > 0, "bad image size");
+    const int px = depth_variant ? 2 : 16;
+    REQUIRE(curr_step >= cols * px && prev_step >= cols * px && ncurr_step >= cols * 16 && nprev_step >= cols * 16,
+            "row step smaller than a row");
+    REQUIRE(fx != 0.f && fy != 0.f && dist_thres >= 0.f, "bad intrinsics / threshold");
+    HIP_TRY(g_thread_icp.reserve(dfa::icp_partial_floats(cols, rows)));
+    HIP_TRY(dfa::launch_icp_sums(depth_variant != 0, curr, curr_step, ncurr, ncurr_step, prev, prev_step, nprev, nprev_step,
+                                 cols, rows, aff, fx, fy, cx, cy, dist_thres, angle_thres, g_thread_icp.partial, sums27,
+                                 matched, S(stream)));
+    return DFA_OK;
+}
+
 // ------------------------------------------------------------------------ marching-cubes seam
 
 int dfa_marching_cubes(const uint32_t* volume, int X, int Y, int Z, const float cell_size[3],

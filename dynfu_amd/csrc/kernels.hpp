@@ -89,4 +89,11 @@ hipError_t launch_resize_depth_normals(const uint16_t* dsrc, int dsrc_step, cons
 hipError_t launch_resize_points_normals(const float* vsrc, int vsrc_step, const float* nsrc, int nsrc_step, int cols,
                                         int rows, float* vdst, int vdst_step, float* ndst, int ndst_step, hipStream_t s);
 
+// icp.hip
+size_t icp_partial_floats(int cols, int rows);
+hipError_t launch_icp_sums(bool depth_variant, const void* curr, int curr_step, const float* ncurr, int ncurr_step,
+                           const void* prev, int prev_step, const float* nprev, int nprev_step, int cols, int rows,
+                           const float aff[12], float fx, float fy, float cx, float cy, float dist_thres, float angle_thres,
+                           float* partial, float* sums27, unsigned int* matched, hipStream_t s);
+
 }  // namespace dfa

@@ -115,6 +115,22 @@ int dfa_resize_points_normals(const float* points, int points_step, const float*
                               dfa_stream_t stream);
 
 /* ===================================================================================== */
+/* Rigid-ICP seam — replaces device::ComputeIcpHelper::operator() (include/kfusion/internal.hpp:121-156,   */
+/* src/kfusion/cuda/proj_icp.cu), one linearisation of cuda::ProjectiveICP::estimateTransform              */
+/* (src/kfusion/projective_icp.cpp:118-200).  The reference's DynFusion skips the rigid tracker             */
+/* (dyn_fusion.cpp:100-105); KinFu::operator() uses it.                                                     */
+
+/* sums27 (device, 27 floats): for i in 0..5, for j in i..6 the sum over the current frame's pixels of
+ * row[i] * row[j], row = (s x n, n, n.(d - s)) — the buffer layout ProjectiveICP::StreamHelper::get reads
+ * (projective_icp.cpp:39-57).  depth_variant != 0: curr / prev are u16 depth images (proj_icp.cu:41-71), else
+ * float4 vertex maps (:73-101); normals are float4 maps.  aff = current estimate (R row-major, then t);
+ * fx..cy = intrinsics OF THE PYRAMID LEVEL (setLevelIntr); matched (device, optional) = pixels used. */
+int dfa_icp_sums(int depth_variant, const void* curr, int curr_step, const float* ncurr, int ncurr_step, const void* prev,
+                 int prev_step, const float* nprev, int nprev_step, int cols, int rows, const float aff[12], float fx,
+                 float fy, float cx, float cy, float dist_thres, float angle_thres, float* sums27, unsigned int* matched,
+                 dfa_stream_t stream);
+
+/* ===================================================================================== */
 /* Marching-cubes seam — replaces kfusion::device::{bindTextures, getOccupiedVoxels,        */
 /* computeOffsetsAndTotalVertices, generateTriangles} (include/kfusion/internal.hpp:121-150, */
 /* src/kfusion/cuda/marching_cubes.cu), driven by cuda::MarchingCubes::run                  */

@@ -567,3 +567,23 @@ def voxel_grid(points, leaf):
     L.orc_voxel_grid.restype = C.c_int
     m = L.orc_voxel_grid(_p(points), len(points), leaf, _p(out))
     return out[:m].copy()
+
+
+# ------------------------------------------------------------------------- rigid ICP (icp_oracle.c)
+def icp_sums(curr, ncurr, prev, nprev, aff12, intr, dist_thres=0.1, angle_thres=0.3490658503988659):
+    """27 sums + number of matched pixels of one linearisation; curr/prev: uint16 depth (H, W) or float32 (H, W, 4)"""
+    depth_variant = curr.dtype == np.uint16
+    curr, prev = np.ascontiguousarray(curr), np.ascontiguousarray(prev)
+    ncurr, nprev, aff = _f32(ncurr), _f32(nprev), _f32(aff12)
+    H, W = curr.shape[:2]
+    step = W * (2 if depth_variant else 16)
+    sums = np.zeros(27, np.float64)
+    m = C.c_long(0)
+    L = lib()
+    L.orc_icp_sums.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                               C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                               C.c_float, C.c_void_p, C.c_void_p]
+    fx, fy, cx, cy = intr
+    L.orc_icp_sums(1 if depth_variant else 0, _p(curr), step, _p(ncurr), W * 16, _p(prev), step, _p(nprev), W * 16, W, H,
+                   _p(aff), fx, fy, cx, cy, dist_thres, angle_thres, _p(sums), C.byref(m))
+    return sums, m.value

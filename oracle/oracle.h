@@ -179,6 +179,13 @@ void orc_resize_depth_normals(const uint16_t* dsrc, int dsrc_step, const float* 
 void orc_resize_points_normals(const float* vsrc, int vsrc_step, const float* nsrc, int nsrc_step, int cols, int rows,
                                float* vdst, int vdst_step, float* ndst, int ndst_step);
 
+/* ------------------------------------------------------------- rigid ICP -- */
+/* one linearisation of src/kfusion/cuda/proj_icp.cu (see icp_oracle.c); PARITY UNPINNED.
+ * depth_variant: curr / prev are u16 depth images; otherwise float4 vertex maps.  aff: R row-major then t. */
+void orc_icp_sums(int depth_variant, const void* curr, int curr_step, const float* ncurr, int ncurr_step, const void* prev,
+                  int prev_step, const float* nprev, int nprev_step, int cols, int rows, const float aff[12], float fx,
+                  float fy, float cx, float cy, float dist_thres, float angle_thres, double sums[27], long* matched);
+
 /* ------------------------------------------------- north-star solve (6-DoF) -- */
 /* solve6_oracle.c: NOT in the reference's code (BASELINE.json north_star);
  * PARITY UNPINNED, formulas in DESIGN.md §4.5. */

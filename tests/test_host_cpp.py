@@ -38,7 +38,7 @@ def test_host_library_exports_the_adaptor_classes(exes):
                  "DynFusion::init", "DynFusion::fuse", "DynFusion::operator()", "Warpfield::update",
                  "Warpfield::getUnsupportedVertices", "dfa::voxelGridFilter", "kfusion::cuda::MarchingCubes::run",
                  "kfusion::cuda::depthBilateralFilter", "kfusion::cuda::computePointNormals",
-                 "kfusion::cuda::resizeDepthNormals"):
+                 "kfusion::cuda::resizeDepthNormals", "kfusion::cuda::ProjectiveICP::estimateTransform"):
         assert name in syms, name
 
 
@@ -58,3 +58,9 @@ def test_host_tsdf_volume_matches_oracle(exes):
 def test_host_dynfusion_sequence(exes):
     out = _run(exes["test_host_dynfusion"])
     assert "6 tests, 0 failed" in out
+
+
+@pytest.mark.gpu
+def test_host_projective_icp(exes):
+    out = _run(exes["test_host_icp"])
+    assert "2 tests, 0 failed" in out
