@@ -107,8 +107,9 @@ class Sequence:
         A = self.A
         self.solver.set_problem(self.nodes, self.node_dq, self.node_w, self.verts, self.live[f % self.n_frames])
         self.solver.solve(self.params)
-        self.warped, _ = A.warp_to_live(self.nodes, self.solver.node_dq(), self.node_w, self.k, self.verts,
-                                        self.normals)
+        # post-solve warpToLive of the canonical frame, through the plan's k-NN graph (same output as the stand-alone
+        # dfa_warp_to_live, which would search the 262 144 x 2 048 neighbours a second time)
+        self.warped, _ = self.solver.warp_to_live(self.normals)
 
     def frame(self, f, serial=False, timed_events=None):
         torch = self.torch

@@ -19,7 +19,7 @@ SYMBOLS = [
     "dfa_solver_create", "dfa_solver_destroy", "dfa_solver_set_problem", "dfa_solver_solve",
     "dfa_solver_translations", "dfa_solver_node_dq", "dfa_solver_tukey_weights", "dfa_solver_huber_weights",
     "dfa_solver_data_graph", "dfa_solver_reg_graph", "dfa_solver_get_stats", "dfa_solver_enable_timing",
-    "dfa_solver_get_timing",
+    "dfa_solver_get_timing", "dfa_solver_warp_to_live",
 ]
 
 
@@ -126,6 +126,7 @@ def load():
         fn = getattr(L, "dfa_solver_" + n)
         fn.argtypes = [vp]
         fn.restype = vp
+    L.dfa_solver_warp_to_live.argtypes = [vp, vp, vp, vp, vp]
     L.dfa_solver_get_stats.argtypes = [vp, C.POINTER(_SolveStats), vp]
     L.dfa_solver_enable_timing.argtypes = [vp, i]
     L.dfa_solver_get_timing.argtypes = [vp, C.POINTER(_SolveTiming), vp]
@@ -399,6 +400,15 @@ class Solver:
 
     def reg_graph(self):
         return self._view("reg_graph", (self.D, self.k), _torch().int32)
+
+    def warp_to_live(self, normals=None):
+        """canonical vertices of the problem warped by the solved transforms (plan graph, no second search)"""
+        torch = _torch()
+        out_v = torch.empty((self.N, 3), dtype=torch.float32, device="cuda")
+        out_n = torch.empty_like(out_v) if normals is not None else None
+        _check(load().dfa_solver_warp_to_live(self._h, _dev(normals, torch.float32, "normals"), _dev(out_v), _dev(out_n),
+                                              _stream()))
+        return out_v, out_n
 
     def enable_timing(self, on=True):
         _check(load().dfa_solver_enable_timing(self._h, 1 if on else 0))

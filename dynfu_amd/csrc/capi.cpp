@@ -643,6 +643,15 @@ const float* dfa_solver_huber_weights(const dfa_solver* s) { return s ? s->v.hub
 const int32_t* dfa_solver_data_graph(const dfa_solver* s) { return s ? s->v.ridx : nullptr; }
 const int32_t* dfa_solver_reg_graph(const dfa_solver* s) { return s ? s->v.reg_idx : nullptr; }
 
+int dfa_solver_warp_to_live(dfa_solver* s, const float* normals, float* out_vertices, float* out_normals,
+                            dfa_stream_t stream) {
+    REQUIRE(s && s->has_problem, "no problem set");
+    REQUIRE(out_vertices || s->v.N == 0, "null output");
+    HIP_TRY(dfa::launch_warp_graph(s->v.node_pos, s->v.node_dq_out, s->v.node_w, s->k, s->v.ridx, s->v.canon, normals,
+                                   s->v.N, out_vertices, out_normals, S(stream)));
+    return DFA_OK;
+}
+
 int dfa_solver_get_stats(dfa_solver* s, dfa_solve_stats* host_out, dfa_stream_t stream) {
     REQUIRE(s && host_out, "null plan / out");
     dfa::SolveState h;

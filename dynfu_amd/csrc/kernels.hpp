@@ -67,6 +67,10 @@ hipError_t launch_dqb_support(const float* node_pos, const float* node_dq, const
                               const float* pts, int n, float* out_dq, uint8_t* out_flag, const KnnGridView* grid,
                               hipStream_t s);
 
+hipError_t launch_warp_graph(const float* node_pos, const float* node_dq, const float* node_w, int k, const int32_t* idx,
+                             const float* verts, const float* normals, int N, float* out_verts, float* out_normals,
+                             hipStream_t s);
+
 // mc.hip
 long mc_segments(int X, int Y, int Z, bool vec4);  // entries of seg_off (+1)
 long mc_scan_chunks(long nsegs);                   // entries of chunk_sums

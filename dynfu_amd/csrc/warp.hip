@@ -515,6 +515,35 @@ __global__ __launch_bounds__(256) void warp_to_live_kernel(const float* __restri
     }
 }
 
+// warpToLive with a neighbour list that is already known (the solver plan's data graph of the same vertices and
+// nodes): the same calcDQB and transform as warp_to_live_kernel, without searching again
+template <int K>
+__global__ __launch_bounds__(256) void warp_graph_kernel(const float* __restrict__ node_pos,
+                                                         const float* __restrict__ node_dq,
+                                                         const float* __restrict__ node_w, int k,
+                                                         const int32_t* __restrict__ idx, const float* __restrict__ verts,
+                                                         const float* __restrict__ normals, int N,
+                                                         float* __restrict__ out_verts, float* __restrict__ out_normals) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    KnnList<K> nb;
+    nb.init();
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if (j < k) {
+            const int n = idx[(size_t)v * k + j];
+            nb.i[j]     = n < 0 ? 0x7fffffff : n;
+        }
+    const f3 p  = mk3(verts[3 * (size_t)v], verts[3 * (size_t)v + 1], verts[3 * (size_t)v + 2]);
+    const DQ dq = calc_dqb<K>(nb, k, node_pos, node_dq, node_w, p);
+    const f3 o  = dq_transform(dq, p);
+    out_verts[3 * (size_t)v] = o.x, out_verts[3 * (size_t)v + 1] = o.y, out_verts[3 * (size_t)v + 2] = o.z;
+    if (normals && out_normals) {
+        const f3 nn = dq_transform(dq, mk3(normals[3 * (size_t)v], normals[3 * (size_t)v + 1], normals[3 * (size_t)v + 2]));
+        out_normals[3 * (size_t)v] = nn.x, out_normals[3 * (size_t)v + 1] = nn.y, out_normals[3 * (size_t)v + 2] = nn.z;
+    }
+}
+
 // DynFusion::findCorrespondingFrame (dyn_fusion.cpp:212-242): for every LIVE vertex the nearest
 // vertex of the (warped) canonical cloud, by the same exact (distance, index) order as the k-NN
 // above with k = 1; the canonical vertex and normal at that index are gathered into a cloud that
@@ -674,6 +703,17 @@ hipError_t launch_dqb_support(const float* node_pos, const float* node_dq, const
     KnnGridView g       = use_grid ? *grid : KnnGridView{};
     KGDISPATCH(dqb_support_kernel, k, use_grid,
                <<<gridDim, block, 0, s>>>(node_pos, node_dq, node_w, D, k, pts, n, out_dq, out_flag, g));
+    return hipGetLastError();
+}
+
+hipError_t launch_warp_graph(const float* node_pos, const float* node_dq, const float* node_w, int k, const int32_t* idx,
+                             const float* verts, const float* normals, int N, float* out_verts, float* out_normals,
+                             hipStream_t s) {
+    if (N == 0) return hipSuccess;
+    dim3 block(256), gridDim((N + 255) / 256);
+    if (k <= 4) warp_graph_kernel<4><<<gridDim, block, 0, s>>>(node_pos, node_dq, node_w, k, idx, verts, normals, N, out_verts, out_normals);
+    else if (k <= 8) warp_graph_kernel<8><<<gridDim, block, 0, s>>>(node_pos, node_dq, node_w, k, idx, verts, normals, N, out_verts, out_normals);
+    else warp_graph_kernel<16><<<gridDim, block, 0, s>>>(node_pos, node_dq, node_w, k, idx, verts, normals, N, out_verts, out_normals);
     return hipGetLastError();
 }
 

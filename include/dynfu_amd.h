@@ -257,6 +257,13 @@ const int32_t* dfa_solver_data_graph(const dfa_solver* s); /* N x k */
 const int32_t* dfa_solver_reg_graph(const dfa_solver* s);  /* D x k */
 
 /* Copies the statistics of the last solve to host memory; synchronises `stream`. */
+/* Warpfield::warpToLive (warp_field.cpp:150-171) of the plan's canonical vertices with the SOLVED node transforms
+ * (the step DynFusion takes next, dyn_fusion.cpp:196), re-using the plan's k-NN graph of the same vertices instead
+ * of searching again: identical output to dfa_warp_to_live(node_pos, dfa_solver_node_dq(s), ...).  normals /
+ * out_normals may be NULL. */
+int dfa_solver_warp_to_live(dfa_solver* s, const float* normals, float* out_vertices, float* out_normals,
+                            dfa_stream_t stream);
+
 int dfa_solver_get_stats(dfa_solver* s, dfa_solve_stats* host_out, dfa_stream_t stream);
 
 /* Optional per-kernel timing for roofline reports (no reference counterpart; Opt has

@@ -100,6 +100,10 @@ def test_translations_match_oracle_well_posed(A, name, lam):
     # the regulariser barely bends a smooth field: the ground truth is recovered
     if lam <= 1.0:
         assert np.abs(t - t_true).max() < 2e-3
+    # the post-solve warpToLive through the plan's graph == the stand-alone entry point, bit for bit
+    wv, wn = s.warp_to_live(dev(c["normals"]))
+    rv, rn = A.warp_to_live(dev(c["node_pos"]), s.node_dq(), dev(c["node_w"]), k, dev(verts), dev(c["normals"]))
+    assert np.array_equal(host(wv), host(rv)) and np.array_equal(host(wn), host(rn))
     s.close()
 
 
