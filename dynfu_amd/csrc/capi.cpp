@@ -152,6 +152,13 @@ struct dfa_solver6 {
     std::vector<void*> blocks;
     GridScratch grid;
     bool has_problem;
+    // the PCG of one Gauss-Newton iteration (linear_iter + 2 dependent launches) captured as a HIP graph:
+    // re-captured when the problem size or the iteration parameters change
+    hipGraphExec_t pcg_graph = nullptr;
+    hipStream_t capture_stream = nullptr;  // capture is not allowed on the legacy default stream
+    dfa::Solve6View pcg_key_view;
+    int pcg_key_iter = -1;
+    float pcg_key_tol = -1.f;
 };
 
 namespace {
@@ -794,6 +801,8 @@ int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
 
 void dfa_solver6_destroy(dfa_solver6* s) {
     if (!s) return;
+    if (s->pcg_graph) (void)hipGraphExecDestroy(s->pcg_graph);
+    if (s->capture_stream) (void)hipStreamDestroy(s->capture_stream);
     for (void* p : s->blocks) (void)hipFree(p);
     s->grid.release();
     delete s;
@@ -841,7 +850,26 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
         for (int gn = 0; gn < p.gn_iter; ++gn) {
             HIP_TRY(dfa::s6_linearise(s->v, s->state, img, p, gn == 0, st));
             HIP_TRY(dfa::s6_assemble(s->v, s->state, p, st));
-            HIP_TRY(dfa::s6_pcg(s->v, s->state, p, st));
+            if (getenv("DFA_S6_NO_GRAPH")) {
+                HIP_TRY(dfa::s6_pcg(s->v, s->state, p, st));
+            } else {
+                if (!s->pcg_graph || s->pcg_key_iter != p.linear_iter || s->pcg_key_tol != p.pcg_tol ||
+                    std::memcmp(&s->pcg_key_view, &s->v, sizeof(s->v)) != 0) {
+                    if (s->pcg_graph) (void)hipGraphExecDestroy(s->pcg_graph), s->pcg_graph = nullptr;
+                    hipGraph_t g = nullptr;
+                    if (!s->capture_stream) HIP_TRY(hipStreamCreateWithFlags(&s->capture_stream, hipStreamNonBlocking));
+                    HIP_TRY(hipStreamBeginCapture(s->capture_stream, hipStreamCaptureModeThreadLocal));
+                    const hipError_t le = dfa::s6_pcg(s->v, s->state, p, s->capture_stream);
+                    const hipError_t ce = hipStreamEndCapture(s->capture_stream, &g);
+                    if (le != hipSuccess) return hip_fail(le, "s6_pcg (capture)");
+                    HIP_TRY(ce);
+                    const hipError_t ie = hipGraphInstantiate(&s->pcg_graph, g, nullptr, nullptr, 0);
+                    (void)hipGraphDestroy(g);
+                    HIP_TRY(ie);
+                    s->pcg_key_view = s->v, s->pcg_key_iter = p.linear_iter, s->pcg_key_tol = p.pcg_tol;
+                }
+                HIP_TRY(hipGraphLaunch(s->pcg_graph, st));
+            }
             HIP_TRY(dfa::s6_update(s->v, s->state, st));
         }
     return DFA_OK;
