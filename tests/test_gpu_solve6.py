@@ -149,3 +149,35 @@ def test_no_live_data_regulariser_only_and_errors(A):
     small = A.Solver6(8, 10, 4)
     with pytest.raises(A.DynfuAmdError):
         small.set_problem(*keep)  # larger than the plan
+
+
+def test_degenerate_problems(A):
+    import torch
+    cfg, c, intr, depth = _scene("T0", 2)
+    P, Nm = A.compute_points_normals(dev(depth), *intr)
+    kw = dict(num_iter=1, gn_iter=2, linear_iter=30, lambda_=100.0)
+    # fewer nodes than k: neighbour lists are padded with -1
+    D, k = 3, 4
+    nodes, dq, w = c["node_pos"][:D].copy(), c["node_dq"][:D].copy(), np.full(D, 0.4, np.float32)
+    verts, normals = c["verts"][::16].copy(), c["normals"][::16].copy()
+    s = A.Solver6(D, len(verts), k)
+    keep = [dev(nodes), dev(dq), dev(w), dev(verts), dev(normals)]
+    s.set_problem(*keep)
+    s.solve(P, Nm, *intr, A.Solve6Params(**kw))
+    st = s.stats()
+    ref, st_ref = O.solve6(nodes, dq, w, k, verts, normals, host(P), host(Nm), intr, **kw)
+    assert st["overflow"] == 0 and st["valid_first"] == st_ref["valid_first"]
+    assert st["initial_cost"] == pytest.approx(st_ref["initial_cost"], rel=1e-4)
+    assert np.isfinite(host(s.node_dq())).all() and np.abs(host(s.node_dq()) - ref).max() < 5e-3
+    # a single node, no vertices at all: nothing to do, transforms unchanged
+    s1 = A.Solver6(1, 0, 1)
+    one = [dev(nodes[:1]), dev(dq[:1]), dev(w[:1]), torch.zeros((0, 3), device="cuda")]
+    s1.set_problem(*one)
+    s1.solve(P, Nm, *intr, A.Solve6Params(**kw))
+    assert np.allclose(host(s1.node_dq()), dq[:1], atol=1e-6)
+    # vertices behind the camera / far outside the image are simply not associated
+    far = verts.copy()
+    far[:, 2] = -1.0
+    s.set_problem(keep[0], keep[1], keep[2], dev(far), keep[4])
+    s.solve(P, Nm, *intr, A.Solve6Params(**kw))
+    assert s.stats()["valid_first"] == 0 and np.isfinite(host(s.node_dq())).all()
