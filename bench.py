@@ -32,7 +32,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 for wide reads + WRITE_SIZE, corrected as
 # MI355X_MICROARCH.md prescribes) — profiles/r01_pmc_tsdf.md.  Collected offline: PMC needs its own runs.
-PMC_TRAFFIC_BYTES = {("C2", "fused_integrate"): 0.5439e9,
+PMC_TRAFFIC_BYTES = {("C2", "fused_integrate"): 0.5439e9, ("C3", "fused_integrate"): 0.5439e9,
+                     # profiles/r01_pmc_northstar.md (FETCH x2 + WRITE per dispatch)
+                     ("C3", "s6_assemble"): 0.411e9, ("C3", "s6_pcg_step"): 0.0242e9,
                      # profiles/r01_pmc_solve.md: (198.1 + 70.8) KiB per pcg_paired_kernel launch
                      ("C2", "pcg"): 268.9 * 1024}
 
@@ -195,18 +197,11 @@ def main_northstar(args, torch, replicas, rank, world, device):
         for f in range(K):
             seq.frame(Wm + f, args.serial, fuse_events)
 
+    seq.solver.enable_timing(True)
     dt_max = replicas.timed_region(timed, device)
     st = seq.solver.stats()
-    # phase timings of one more (untimed) solve, hipEvents on the solve stream
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    P, Nm = seq.A.compute_points_normals(seq.depth[0], *seq.intr)
-    ev[0].record()
-    seq.solver.set_problem(seq.nodes, seq.node_dq, seq.node_w, seq.verts, seq.normals)
-    ev[1].record()
-    seq.solver.solve(P, Nm, *seq.intr, seq.params)
-    ev[2].record()
-    torch.cuda.synchronize()
-    graph_ms, solve_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    tm = seq.solver.timing()  # hipEvents on the solve stream around every launch group of the LAST timed frame
+    seq.solver.enable_timing(False)
     if rank != 0:
         replicas.shutdown()
         return
@@ -215,22 +210,34 @@ def main_northstar(args, torch, replicas, rank, world, device):
     fuse_ms = float(np.mean([a.elapsed_time(b) for a, b in fuse_events])) if fuse_events else float("nan")
     fuse_bytes = 4.0 * V + 2.0 * Wd * Hd
     fuse_gbs = fuse_bytes / (fuse_ms * 1e-3) / 1e9
-    its, rowb = st["pcg_iters"], st["max_row_blocks"]
-    # PCG matvec: the block matrix (36 floats + 1 column id per 6x6 block) + gathered vectors, per iteration
-    nnzb_upper = seq.D * rowb
-    pcg_bytes = its * (nnzb_upper * (36 * 4 + 4 + 2 * 24) + 8 * 24.0 * seq.D)
+    its, gn, nblk, k = st["pcg_iters"], max(1, tm["gn_iterations"]), tm["matrix_blocks"], seq.k
+    # algorithmic bytes: assembly reads every row once per node it touches (l 32 B + f 4k B + weights 8 B
+    # + slots k B) and writes the block matrix; a PCG iteration reads the matrix (36 floats + a column id per block), three
+    # gathered 6-vectors per block and ~12 vectors of 6 D floats
+    asm_bytes = seq.N * k * (32 + 4 * k + 8 + k) + nblk * (36 * 4 + 4)
+    pcg_bytes_it = nblk * (36 * 4 + 4 + 3 * 24) + 12 * 24.0 * seq.D
+    asm_ms, pcg_ms = tm["assemble_ms"] / gn, tm["pcg_ms"] / max(1, its + gn)
     fuse_entry = dict(kernel="integrate_kernel<FUSED_CLEAR,4> (clear+integrate %d^3)" % dim, bound="hbm",
                       achieved=round(fuse_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(fuse_gbs / HBM_PEAK_GBS, 4),
                       traffic=PMC_TRAFFIC_BYTES.get((args.config, "fused_integrate")), avg_launch_ms=round(fuse_ms, 4),
                       launches_per_frame=1, algorithmic_bytes_per_launch=fuse_bytes)
-    solve_gbs = pcg_bytes / (solve_ms * 1e-3) / 1e9
-    solve_entry = dict(kernel="dfa_solver6_solve (s6_linearise / s6_assemble / s6_pcg_matvec+update x %d)" % its,
-                       bound="hbm", achieved=round(solve_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                       frac=round(solve_gbs / HBM_PEAK_GBS, 5), traffic=None, avg_launch_ms=None,
-                       solve_ms=round(solve_ms, 3), graph_build_ms=round(graph_ms, 3), pcg_iterations_per_frame=its,
-                       max_blocks_per_row=rowb, algorithmic_bytes_per_frame_upper_bound=pcg_bytes,
-                       note="launch-bound: 2 kernels per PCG iteration; bytes = upper bound from the longest block row")
-    dominant, other = (solve_entry, fuse_entry) if solve_ms > fuse_ms else (fuse_entry, solve_entry)
+    asm_gbs = asm_bytes / (asm_ms * 1e-3) / 1e9
+    asm_entry = dict(kernel="s6_assemble_kernel<%d> (block normal matrix of one Gauss-Newton iteration)" % (4 if k <= 4 else 8),
+                     bound="hbm", achieved=round(asm_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                     frac=round(asm_gbs / HBM_PEAK_GBS, 4), traffic=PMC_TRAFFIC_BYTES.get((args.config, "s6_assemble")),
+                     avg_launch_ms=round(asm_ms, 4), launches_per_frame=gn, algorithmic_bytes_per_launch=asm_bytes,
+                     ms_per_frame=round(tm["assemble_ms"], 3),
+                     note="LDS-bandwidth-bound (DESIGN.md 4.5): per-wave 8x8 moment accumulators in LDS")
+    pcg_gbs = pcg_bytes_it / (pcg_ms * 1e-3) / 1e9
+    pcg_entry = dict(kernel="s6_pcg_step_kernel (one Chronopoulos-Gear PCG iteration per launch)", bound="hbm",
+                     achieved=round(pcg_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(pcg_gbs / HBM_PEAK_GBS, 4),
+                     traffic=PMC_TRAFFIC_BYTES.get((args.config, "s6_pcg_step")), avg_launch_ms=round(pcg_ms, 5),
+                     launches_per_frame=its + gn, algorithmic_bytes_per_launch=pcg_bytes_it, matrix_blocks=nblk,
+                     ms_per_frame=round(tm["pcg_ms"], 3),
+                     note="launch/latency-bound below ~2k nodes (two dependent memory round trips + the inter-kernel gap)")
+    lin_entry = dict(kernel="s6_linearise_kernel", ms_per_frame=round(tm["linearise_ms"], 3), launches_per_frame=gn)
+    cands = sorted([(tm["assemble_ms"], asm_entry), (tm["pcg_ms"], pcg_entry), (fuse_ms, fuse_entry)], key=lambda t: -t[0])
+    dominant, other = cands[0][1], [c[1] for c in cands[1:]] + [lin_entry]
     out = dict(metric="frames/sec (warp-solve + TSDF fuse), 512^3 vol / 2k nodes / VGA depth",
                value=round(n_gpus * K / dt_max, 2), unit="frames/s", n_gpus=n_gpus, steps=K, warmup=Wm,
                ms_per_step=round(dt_max / K * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
@@ -243,7 +250,7 @@ def main_northstar(args, torch, replicas, rank, world, device):
                            streams="serial" if args.serial else "fuse || solve on two HIP streams",
                            pcg_iterations_last_frame=its, gn_iterations_last_frame=st["gn_iters"],
                            valid_rows_last_frame=st["valid_last"], cost_first=st["initial_cost"], cost_last=st["final_cost"]),
-               roofline=dominant, roofline_other=[other])
+               roofline=dominant, roofline_other=other)
     if not args.no_cpu_baseline and world == 1:
         params = seq.params
         del seq

@@ -16,6 +16,7 @@ SYMBOLS = [
     "dfa_resize_depth_normals", "dfa_resize_points_normals",
     "dfa_compute_points_normals", "dfa_solver6_create", "dfa_solver6_destroy", "dfa_solver6_set_problem",
     "dfa_solver6_solve", "dfa_solver6_node_dq", "dfa_solver6_warp", "dfa_solver6_get_stats",
+    "dfa_solver6_enable_timing", "dfa_solver6_get_timing",
     "dfa_solver_create", "dfa_solver_destroy", "dfa_solver_set_problem", "dfa_solver_solve",
     "dfa_solver_translations", "dfa_solver_node_dq", "dfa_solver_tukey_weights", "dfa_solver_huber_weights",
     "dfa_solver_data_graph", "dfa_solver_reg_graph", "dfa_solver_get_stats", "dfa_solver_enable_timing",
@@ -42,6 +43,11 @@ class _Solve6Stats(C.Structure):
     _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("gn_iters", C.c_int), ("pcg_iters", C.c_int),
                 ("valid_first", C.c_longlong), ("valid_last", C.c_longlong), ("max_row_blocks", C.c_int),
                 ("overflow", C.c_int)]
+
+
+class _Solve6Timing(C.Structure):
+    _fields_ = [("linearise_ms", C.c_float), ("assemble_ms", C.c_float), ("pcg_ms", C.c_float),
+                ("gn_iterations", C.c_int), ("matrix_blocks", C.c_longlong)]
 
 
 class DynfuAmdError(RuntimeError):
@@ -111,6 +117,8 @@ def load():
     L.dfa_solver6_node_dq.restype = vp
     L.dfa_solver6_warp.argtypes = [vp, vp, vp, vp]
     L.dfa_solver6_get_stats.argtypes = [vp, C.POINTER(_Solve6Stats), vp]
+    L.dfa_solver6_enable_timing.argtypes = [vp, i]
+    L.dfa_solver6_get_timing.argtypes = [vp, C.POINTER(_Solve6Timing), vp]
     L.dfa_marching_cubes.argtypes = [vp, i, i, i, vp, vp, vp, vp, i, vp, vp]
     L.dfa_mc_default_tables.argtypes = [vp, vp]
     L.dfa_icp_sums.argtypes = [i, vp, i, vp, i, vp, i, vp, i, i, i, vp, f, f, f, f, f, f, vp, vp, vp]
@@ -485,6 +493,14 @@ class Solver6:
         out_n = torch.empty_like(out_v) if want_normals and self._keep[4] is not None else None
         _check(load().dfa_solver6_warp(self._h, _dev(out_v), _dev(out_n), _stream()))
         return out_v, out_n
+
+    def enable_timing(self, on=True):
+        _check(load().dfa_solver6_enable_timing(self._h, 1 if on else 0))
+
+    def timing(self):
+        t = _Solve6Timing()
+        _check(load().dfa_solver6_get_timing(self._h, C.byref(t), _stream()))
+        return {n: getattr(t, n) for n, _ in _Solve6Timing._fields_}
 
     def stats(self):
         st = _Solve6Stats()

@@ -156,6 +156,9 @@ struct dfa_solver6 {
     // re-captured when the problem size or the iteration parameters change
     hipGraphExec_t pcg_graph = nullptr;
     hipStream_t capture_stream = nullptr;  // capture is not allowed on the legacy default stream
+    bool timing = false;  // hipEvent brackets around linearise / assemble / PCG of every Gauss-Newton iteration
+    std::vector<hipEvent_t> events;
+    size_t ev_used = 0;
     dfa::Solve6View pcg_key_view;
     int pcg_key_iter = -1;
     float pcg_key_tol = -1.f;
@@ -803,6 +806,7 @@ void dfa_solver6_destroy(dfa_solver6* s) {
     if (!s) return;
     if (s->pcg_graph) (void)hipGraphExecDestroy(s->pcg_graph);
     if (s->capture_stream) (void)hipStreamDestroy(s->capture_stream);
+    for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     for (void* p : s->blocks) (void)hipFree(p);
     s->grid.release();
     delete s;
@@ -845,11 +849,24 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
                         prm->psi_reg, prm->dist_thresh, prm->cos_thresh, prm->damping, prm->pcg_tol};
     dfa::Solve6Image img{live_vertex_map, live_normal_map, vertex_step, normal_step, cols, rows, fx, fy, cx, cy};
     hipStream_t st = S(stream);
+    s->ev_used = 0;
     HIP_TRY(dfa::s6_begin(s->v, s->state, s->node_dq, st));
     for (int outer = 0; outer < p.num_iter; ++outer)
         for (int gn = 0; gn < p.gn_iter; ++gn) {
+            auto mark = [&]() {  // 4 events per Gauss-Newton iteration: | linearise | assemble | pcg |
+                if (!s->timing) return;
+                if (s->ev_used == s->events.size()) {
+                    hipEvent_t e;
+                    if (hipEventCreate(&e) != hipSuccess) return;
+                    s->events.push_back(e);
+                }
+                (void)hipEventRecord(s->events[s->ev_used++], st);
+            };
+            mark();
             HIP_TRY(dfa::s6_linearise(s->v, s->state, img, p, gn == 0, st));
+            mark();
             HIP_TRY(dfa::s6_assemble(s->v, s->state, p, st));
+            mark();
             if (getenv("DFA_S6_NO_GRAPH")) {
                 HIP_TRY(dfa::s6_pcg(s->v, s->state, p, st));
             } else {
@@ -870,8 +887,35 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
                 }
                 HIP_TRY(hipGraphLaunch(s->pcg_graph, st));
             }
+            mark();
             HIP_TRY(dfa::s6_update(s->v, s->state, st));
         }
+    return DFA_OK;
+}
+
+int dfa_solver6_enable_timing(dfa_solver6* s, int enable) {
+    REQUIRE(s, "null plan");
+    s->timing = enable != 0;
+    return DFA_OK;
+}
+
+int dfa_solver6_get_timing(dfa_solver6* s, dfa_solve6_timing* out, dfa_stream_t stream) {
+    REQUIRE(s && out, "null plan / out");
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    std::memset(out, 0, sizeof(*out));
+    for (size_t i = 0; i + 3 < s->ev_used; i += 4) {
+        float a = 0.f, b = 0.f, c = 0.f;
+        HIP_TRY(hipEventElapsedTime(&a, s->events[i], s->events[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&b, s->events[i + 1], s->events[i + 2]));
+        HIP_TRY(hipEventElapsedTime(&c, s->events[i + 2], s->events[i + 3]));
+        out->linearise_ms += a, out->assemble_ms += b, out->pcg_ms += c;
+        out->gn_iterations += 1;
+    }
+    if (s->has_problem && s->v.D > 0) {
+        std::vector<int32_t> cnt((size_t)s->v.D);
+        HIP_TRY(hipMemcpy(cnt.data(), s->v.bcnt, sizeof(int32_t) * cnt.size(), hipMemcpyDeviceToHost));
+        for (int32_t c : cnt) out->matrix_blocks += c;
+    }
     return DFA_OK;
 }
 

@@ -422,7 +422,9 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
     __syncthreads();  // (the column list of this row was written by this workgroup: visible after the barrier)
     // slot of every neighbour of every row that touches a: the assembly adds a row's k x k products
     // straight into the right 6x6 blocks
-    const int32_t* cols = s.bcols + (size_t)a * s.cap;
+    __shared__ int cols[64];  // the finished column list of this row (searched 8 times per row of the energy)
+    if (tid < 64) cols[tid] = tid < stored ? s.bcols[(size_t)a * s.cap + tid] : -1;
+    __syncthreads();
     for (int e = s.node_ptr[a] + tid; e < s.node_ptr[a + 1]; e += 256) {
         s.epos[s.node_list[e]] = (uint32_t)e;  // where the linearisation writes row (vertex, slot)
         const unsigned v = s.node_list[e] / (unsigned)k;

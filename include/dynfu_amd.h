@@ -336,6 +336,15 @@ const float* dfa_solver6_node_dq(const dfa_solver6* s); /* device, D x 8: solved
 int dfa_solver6_warp(dfa_solver6* s, float* out_vertices, float* out_normals, dfa_stream_t stream);
 int dfa_solver6_get_stats(dfa_solver6* s, dfa_solve6_stats* out, dfa_stream_t stream);
 
+/* hipEvent timings of the LAST solve, summed over its Gauss-Newton iterations (for bench.py's roofline) */
+typedef struct dfa_solve6_timing {
+    float linearise_ms, assemble_ms, pcg_ms;
+    int gn_iterations;
+    long long matrix_blocks; /* 6x6 blocks of the assembled normal matrix */
+} dfa_solve6_timing;
+int dfa_solver6_enable_timing(dfa_solver6* s, int enable);
+int dfa_solver6_get_timing(dfa_solver6* s, dfa_solve6_timing* out, dfa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
