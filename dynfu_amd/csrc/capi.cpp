@@ -155,6 +155,7 @@ struct dfa_solver6 {
     // the PCG of one Gauss-Newton iteration (linear_iter + 2 dependent launches) captured as a HIP graph:
     // re-captured when the problem size or the iteration parameters change
     hipGraphExec_t pcg_graph = nullptr;
+    bool graph_disabled = false;
     hipStream_t capture_stream = nullptr;  // capture is not allowed on the legacy default stream
     bool timing = false;  // hipEvent brackets around linearise / assemble / PCG of every Gauss-Newton iteration
     std::vector<hipEvent_t> events;
@@ -867,26 +868,36 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
             mark();
             HIP_TRY(dfa::s6_assemble(s->v, s->state, p, st));
             mark();
-            if (getenv("DFA_S6_NO_GRAPH")) {
-                HIP_TRY(dfa::s6_pcg(s->v, s->state, p, st));
-            } else {
+            // the PCG launches of one Gauss-Newton iteration are replayed as a HIP graph; if capture is not possible
+            // here (it never is on some stream configurations) the launches are issued one by one — same kernels
+            bool replayed = false;
+            if (!s->graph_disabled && !getenv("DFA_S6_NO_GRAPH")) {
                 if (!s->pcg_graph || s->pcg_key_iter != p.linear_iter || s->pcg_key_tol != p.pcg_tol ||
                     std::memcmp(&s->pcg_key_view, &s->v, sizeof(s->v)) != 0) {
                     if (s->pcg_graph) (void)hipGraphExecDestroy(s->pcg_graph), s->pcg_graph = nullptr;
                     hipGraph_t g = nullptr;
-                    if (!s->capture_stream) HIP_TRY(hipStreamCreateWithFlags(&s->capture_stream, hipStreamNonBlocking));
-                    HIP_TRY(hipStreamBeginCapture(s->capture_stream, hipStreamCaptureModeThreadLocal));
-                    const hipError_t le = dfa::s6_pcg(s->v, s->state, p, s->capture_stream);
-                    const hipError_t ce = hipStreamEndCapture(s->capture_stream, &g);
-                    if (le != hipSuccess) return hip_fail(le, "s6_pcg (capture)");
-                    HIP_TRY(ce);
-                    const hipError_t ie = hipGraphInstantiate(&s->pcg_graph, g, nullptr, nullptr, 0);
-                    (void)hipGraphDestroy(g);
-                    HIP_TRY(ie);
-                    s->pcg_key_view = s->v, s->pcg_key_iter = p.linear_iter, s->pcg_key_tol = p.pcg_tol;
+                    bool ok = s->capture_stream || hipStreamCreateWithFlags(&s->capture_stream, hipStreamNonBlocking) == hipSuccess;
+                    ok = ok && hipStreamBeginCapture(s->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                    if (ok) {
+                        const hipError_t le = dfa::s6_pcg(s->v, s->state, p, s->capture_stream);
+                        const hipError_t ce = hipStreamEndCapture(s->capture_stream, &g);
+                        ok = le == hipSuccess && ce == hipSuccess && g &&
+                             hipGraphInstantiate(&s->pcg_graph, g, nullptr, nullptr, 0) == hipSuccess;
+                        if (g) (void)hipGraphDestroy(g);
+                    }
+                    if (ok) {
+                        s->pcg_key_view = s->v, s->pcg_key_iter = p.linear_iter, s->pcg_key_tol = p.pcg_tol;
+                    } else {
+                        (void)hipGetLastError();  // clear the sticky error of the failed attempt
+                        s->pcg_graph = nullptr, s->graph_disabled = true;
+                    }
                 }
-                HIP_TRY(hipGraphLaunch(s->pcg_graph, st));
+                if (s->pcg_graph) {
+                    HIP_TRY(hipGraphLaunch(s->pcg_graph, st));
+                    replayed = true;
+                }
             }
+            if (!replayed) HIP_TRY(dfa::s6_pcg(s->v, s->state, p, st));
             mark();
             HIP_TRY(dfa::s6_update(s->v, s->state, st));
         }
