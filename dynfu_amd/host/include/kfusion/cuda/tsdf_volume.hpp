@@ -1,72 +1,80 @@
-// kfusion/cuda/tsdf_volume.hpp — kfusion::cuda::TsdfVolume with the reference's public interface
-// (include/kfusion/cuda/tsdf_volume.hpp:7-73, src/kfusion/tsdf_volume.cpp:18-129), implemented on
-// the dynfu_amd C ABI (dfa_tsdf_*).  fetchCloud / fetchNormals are out of the hot path
-// (not called by DynFusion) and not provided.
+// kfusion/cuda/tsdf_volume.hpp — kfusion::cuda::TsdfVolume: the public interface of the reference's class
+// (include/kfusion/cuda/tsdf_volume.hpp:7-73; behaviour src/kfusion/tsdf_volume.cpp:18-129) on the dynfu_amd C ABI.
+//
+// Layout of this adaptor: the volume's settings live in one plain struct, trivial accessors are inline, the
+// three operations that touch the GPU (clear / integrate / raycast) are one dfa_tsdf_* call each.
+// Not provided: fetchCloud / fetchNormals / get,setGridOrigin (not on the DynFusion path).
 #pragma once
+#include <algorithm>
+
 #include <kfusion/types.hpp>
 
 namespace kfusion {
 namespace cuda {
+
 class TsdfVolume {
+    struct Settings {
+        Vec3i dims;
+        Vec3f size          = Vec3f::all(3.f);      // metres            (tsdf_volume.cpp:22)
+        Affine3f pose       = Affine3f::Identity(); // volume -> world   (:23)
+        float trunc         = 0.03f;                // metres            (:19), clamped by setTruncDist
+        int max_weight      = 128;                  //                   (:20)
+        float ray_step      = 0.75f;                // in truncation distances (:25)
+        float grad_delta    = 0.75f;                // in voxels         (:24)
+    } cfg_;
+    CudaData blob_;  // X*Y*Z packed voxels {fp16 tsdf, u16 weight}
+
 public:
-    explicit TsdfVolume(const Vec3i& dims);
-    virtual ~TsdfVolume();
+    // --- construction / storage -----------------------------------------------------------------------------
+    explicit TsdfVolume(const Vec3i& dims) { cfg_.dims = dims, create(dims); }
+    virtual ~TsdfVolume() {}
+    void create(const Vec3i& dims);            // allocates and clears
+    void swap(CudaData& data) { blob_.swap(data); }
+    CudaData data() { return blob_; }
+    const CudaData data() const { return blob_; }
 
-    void create(const Vec3i& dims);
-
-    Vec3i getDims() const;
-    Vec3f getVoxelSize() const;
-
-    const CudaData data() const;
-    CudaData data();
-
-    Vec3f getSize() const;
-    void setSize(const Vec3f& size);
-
-    float getTruncDist() const;
-    void setTruncDist(float distance);
-
-    int getMaxWeight() const;
-    void setMaxWeight(int weight);
-
-    Affine3f getPose() const;
-    void setPose(const Affine3f& pose);
-
-    float getRaycastStepFactor() const;
-    void setRaycastStepFactor(float factor);
-
-    float getGradientDeltaFactor() const;
-    void setGradientDeltaFactor(float factor);
-
+    // --- the GPU work -----------------------------------------------------------------------------------------
     virtual void clear();
-    virtual void applyAffine(const Affine3f& affine);
     virtual void integrate(const Dists& dists, const Affine3f& camera_pose, const Intr& intr);
+    // clear() then integrate() as ONE sweep (what DynFusion::operator() does every frame, dyn_fusion.cpp:113-116):
+    // same voxels bit for bit, half the HBM traffic.  Extension of the reference's interface.
+    void clearAndIntegrate(const Dists& dists, const Affine3f& camera_pose, const Intr& intr);
     virtual void raycast(const Affine3f& camera_pose, const Intr& intr, Depth& depth, Normals& normals);
     virtual void raycast(const Affine3f& camera_pose, const Intr& intr, Cloud& points, Normals& normals);
+    virtual void applyAffine(const Affine3f& affine) { cfg_.pose = affine * cfg_.pose; }
 
-    // clear() + integrate() in one sweep: what DynFusion::operator() does every frame
-    // (src/dynfu/dyn_fusion.cpp:113-116); bit-identical result, half the HBM traffic.  Extension.
-    void clearAndIntegrate(const Dists& dists, const Affine3f& camera_pose, const Intr& intr);
+    // --- settings ---------------------------------------------------------------------------------------------
+    Vec3i getDims() const { return cfg_.dims; }
+    Vec3f getSize() const { return cfg_.size; }
+    Vec3f getVoxelSize() const {
+        return Vec3f(cfg_.size[0] / cfg_.dims[0], cfg_.size[1] / cfg_.dims[1], cfg_.size[2] / cfg_.dims[2]);
+    }
+    Affine3f getPose() const { return cfg_.pose; }
+    float getTruncDist() const { return cfg_.trunc; }
+    int getMaxWeight() const { return cfg_.max_weight; }
+    float getRaycastStepFactor() const { return cfg_.ray_step; }
+    float getGradientDeltaFactor() const { return cfg_.grad_delta; }
 
-    void swap(CudaData& data);
+    void setPose(const Affine3f& pose) { cfg_.pose = pose; }
+    void setMaxWeight(int weight) { cfg_.max_weight = weight; }
+    void setRaycastStepFactor(float factor) { cfg_.ray_step = factor; }
+    void setGradientDeltaFactor(float factor) { cfg_.grad_delta = factor; }
+    // never below 2.1 voxel edges (tsdf_volume.cpp:57-61); re-applied when the size changes (:47-50)
+    void setTruncDist(float distance) {
+        const Vec3f v = getVoxelSize();
+        cfg_.trunc    = std::max(distance, 2.1f * std::max(std::max(v[0], v[1]), v[2]));
+    }
+    void setSize(const Vec3f& size) { cfg_.size = size, setTruncDist(cfg_.trunc); }
 
-    struct Entry {  // tsdf_volume.hpp:53-62 (the reference's converters throw "Not implemented")
+    // the packed voxel (tsdf_volume.hpp:53-62); the reference's two converters throw "Not implemented"
+    struct Entry {
         typedef unsigned short half;
         half tsdf;
         unsigned short weight;
-        static float half2float(half value);
         static half float2half(float value);
+        static float half2float(half value);
     };
-
-private:
-    CudaData data_;
-    float trunc_dist_;
-    int max_weight_;
-    Vec3i dims_;
-    Vec3f size_;
-    Affine3f pose_;
-    float gradient_delta_factor_;
-    float raycast_step_factor_;
 };
+
 }  // namespace cuda
 }  // namespace kfusion

@@ -9,20 +9,20 @@
 namespace kfusion {
 namespace cuda {
 
-ProjectiveICP::ProjectiveICP() : angle_thres_(20.f * 0.017453293f), dist_thres_(0.1f) {  // :62
+ProjectiveICP::ProjectiveICP() : gate_angle_(20.f * 0.017453293f), gate_dist_(0.1f) {  // :62
     setIterationsNum({10, 5, 4, 0});                                                      // :63-65
     sums_.create(27);
 }
 ProjectiveICP::~ProjectiveICP() {}
 
 void ProjectiveICP::setIterationsNum(const std::vector<int>& iters) {  // :82-89
-    iters_.assign(MAX_PYRAMID_LEVELS, 0);
-    for (size_t i = 0; i < iters.size() && i < (size_t)MAX_PYRAMID_LEVELS; ++i) iters_[i] = iters[i];
+    schedule_.assign(MAX_PYRAMID_LEVELS, 0);
+    for (size_t i = 0; i < iters.size() && i < (size_t)MAX_PYRAMID_LEVELS; ++i) schedule_[i] = iters[i];
 }
 
 int ProjectiveICP::getUsedLevelsNum() const {  // :91-96
     int i = MAX_PYRAMID_LEVELS - 1;
-    for (; i >= 0 && !iters_[i]; --i) {
+    for (; i >= 0 && !schedule_[i]; --i) {
     }
     return i + 1;
 }
@@ -79,16 +79,16 @@ Affine3f from_rvec(const double r[3], const double t[3]) {
 }
 }  // namespace
 
-bool ProjectiveICP::iterate(Affine3f& affine, const Intr& intr, int level, bool depth_variant, const void* curr, int curr_step,
+bool ProjectiveICP::runLevel(Affine3f& affine, const Intr& intr, int level, bool depth_variant, const void* curr, int curr_step,
                             const float* ncurr, int ncurr_step, const void* prev, int prev_step, const float* nprev,
                             int nprev_step, int cols, int rows) {
     const int div = 1 << level;  // setLevelIntr, :15-20
-    for (int iter = 0; iter < iters_[level]; ++iter) {
+    for (int iter = 0; iter < schedule_[level]; ++iter) {
         float aff[12];
         affine.to12(aff);
         dfa::check(dfa_icp_sums(depth_variant ? 1 : 0, curr, curr_step, ncurr, ncurr_step, prev, prev_step, nprev, nprev_step,
-                                cols, rows, aff, intr.fx / div, intr.fy / div, intr.cx / div, intr.cy / div, dist_thres_,
-                                angle_thres_, sums_.ptr(), nullptr, nullptr),
+                                cols, rows, aff, intr.fx / div, intr.fy / div, intr.cx / div, intr.cy / div, gate_dist_,
+                                gate_angle_, sums_.ptr(), nullptr, nullptr),
                    "ProjectiveICP::estimateTransform");
         std::vector<float> h;
         sums_.download(h);  // synchronises (StreamHelper::get, :39-57)
@@ -112,7 +112,7 @@ bool ProjectiveICP::estimateTransform(Affine3f& affine, const Intr& intr, const 
     affine = Affine3f::Identity();  // :124
     for (int level = getUsedLevelsNum() - 1; level >= 0; --level) {
         const Normals& n = nprev[level];
-        if (!iterate(affine, intr, level, true, dcurr[level].ptr(), (int)dcurr[level].step(), (const float*)ncurr[level].ptr(),
+        if (!runLevel(affine, intr, level, true, dcurr[level].ptr(), (int)dcurr[level].step(), (const float*)ncurr[level].ptr(),
                      (int)ncurr[level].step(), dprev[level].ptr(), (int)dprev[level].step(), (const float*)n.ptr(),
                      (int)n.step(), n.cols(), n.rows()))
             return false;
@@ -125,7 +125,7 @@ bool ProjectiveICP::estimateTransform(Affine3f& affine, const Intr& intr, const 
     affine = Affine3f::Identity();  // :159
     for (int level = getUsedLevelsNum() - 1; level >= 0; --level) {
         const Normals& n = nprev[level];
-        if (!iterate(affine, intr, level, false, vcurr[level].ptr(), (int)vcurr[level].step(), (const float*)ncurr[level].ptr(),
+        if (!runLevel(affine, intr, level, false, vcurr[level].ptr(), (int)vcurr[level].step(), (const float*)ncurr[level].ptr(),
                      (int)ncurr[level].step(), vprev[level].ptr(), (int)vprev[level].step(), (const float*)n.ptr(),
                      (int)n.step(), n.cols(), n.rows()))
             return false;
