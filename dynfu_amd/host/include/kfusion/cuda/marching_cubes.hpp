@@ -1,36 +1,41 @@
-// kfusion/cuda/marching_cubes.hpp — class kfusion::cuda::MarchingCubes with the reference's
-// interface (include/kfusion/cuda/marching_cubes.hpp:19-60, src/kfusion/marching_cubes.cpp:12-61)
-// on dfa_marching_cubes.  Differences: any volume dimensions (the reference's kernels are fixed to
-// 128^3); the vertices come out in ascending linear voxel order (the reference's order depends on
-// atomics); one host synchronisation per run() (to size the returned array) instead of three.
+// kfusion/cuda/marching_cubes.hpp — kfusion::cuda::MarchingCubes (reference interface:
+// include/kfusion/cuda/marching_cubes.hpp:19-60; behaviour: src/kfusion/marching_cubes.cpp:12-61) on
+// dfa_marching_cubes.
+//
+// What differs from the reference, all visible here:
+//   * any volume dimensions (the reference's kernels are fixed to 128^3);
+//   * vertices come out in ascending linear voxel order (the reference's order depends on atomics);
+//   * ONE host synchronisation per run() — to size the returned array — instead of three;
+//   * the case tables are a constructor argument: none = the library's derived tables
+//     (dfa_mc_default_tables), or the reference's `triTable` / `numVertsTable`
+//     (src/kfusion/marching_cubes.cpp:86-354) for meshes identical to the reference's.
 #pragma once
 #include <kfusion/cuda/tsdf_volume.hpp>
 #include <kfusion/types.hpp>
 
 namespace kfusion {
 namespace cuda {
-class MarchingCubes {
-public:
-    enum { POINTS_PER_TRIANGLE = 3, DEFAULT_TRIANGLES_BUFFER_SIZE = 2 * 1000 * 1000 * POINTS_PER_TRIANGLE };
-    typedef dfa::PointXYZ PointType;  // 16 bytes {x, y, z, 1}, as pcl::PointXYZ
 
-    // the library's derived case tables (dfa_mc_default_tables)
+class MarchingCubes {
+    dfa::DeviceArray<int> tri_dev_, nverts_dev_, total_dev_;  // 256 x 16, 256, 1
+    int last_total_ = 0;
+    void uploadTables(const int* tri, const int* nverts);
+
+public:
+    typedef dfa::PointXYZ PointType;  // 16 bytes {x, y, z, 1}, the layout of pcl::PointXYZ
+    enum { POINTS_PER_TRIANGLE = 3, DEFAULT_TRIANGLES_BUFFER_SIZE = 2 * 1000 * 1000 * POINTS_PER_TRIANGLE };
+
     MarchingCubes();
-    // caller-supplied tables: pass the reference's `triTable` / `numVertsTable`
-    // (src/kfusion/marching_cubes.cpp:86-354) for meshes identical to the reference's
-    MarchingCubes(const int* triTable /* 256 x 16 */, const int* numVertsTable /* 256 */);
+    MarchingCubes(const int* triTable /* 256 x 16, -1 padded */, const int* numVertsTable /* 256 */);
     ~MarchingCubes();
 
-    // marching_cubes.cpp:20-61: allocates triangles_buffer at its default size when empty; returns a
-    // (non-owning) array over the first total-vertices points of triangles_buffer
+    // Extracts the zero level set into `triangles_buffer` (allocated at DEFAULT_TRIANGLES_BUFFER_SIZE when empty,
+    // marching_cubes.cpp:23-25) and returns a NON-owning array over the vertices written: three per triangle.
     dfa::DeviceArray<PointType> run(const TsdfVolume& volume, dfa::DeviceArray<PointType>& triangles_buffer);
 
-    // vertices the last run() found (may exceed the buffer: then only the buffer's worth was written)
-    int totalVertices() const { return total_; }
-
-private:
-    dfa::DeviceArray<int> triTable_, numVertsTable_, total_dev_;
-    int total_ = 0;
+    // vertices the last run() found; larger than the buffer means only the buffer's worth was written
+    int totalVertices() const { return last_total_; }
 };
+
 }  // namespace cuda
 }  // namespace kfusion

@@ -9,18 +9,19 @@
 namespace kfusion {
 namespace cuda {
 
-MarchingCubes::MarchingCubes() {
-    std::vector<int> tri(256 * 16), nv(256);
-    dfa::check(dfa_mc_default_tables(tri.data(), nv.data()), "MarchingCubes: default tables");
-    triTable_.upload(tri), numVertsTable_.upload(nv);
+void MarchingCubes::uploadTables(const int* tri, const int* nverts) {
+    tri_dev_.upload(std::vector<int>(tri, tri + 256 * 16));
+    nverts_dev_.upload(std::vector<int>(nverts, nverts + 256));
     total_dev_.create(1);
 }
 
-MarchingCubes::MarchingCubes(const int* triTable, const int* numVertsTable) {
-    triTable_.upload(std::vector<int>(triTable, triTable + 256 * 16));
-    numVertsTable_.upload(std::vector<int>(numVertsTable, numVertsTable + 256));
-    total_dev_.create(1);
+MarchingCubes::MarchingCubes() {
+    std::vector<int> tri(256 * 16), nv(256);
+    dfa::check(dfa_mc_default_tables(tri.data(), nv.data()), "MarchingCubes: default tables");
+    uploadTables(tri.data(), nv.data());
 }
+
+MarchingCubes::MarchingCubes(const int* triTable, const int* numVertsTable) { uploadTables(triTable, numVertsTable); }
 
 MarchingCubes::~MarchingCubes() = default;
 
@@ -31,14 +32,14 @@ dfa::DeviceArray<MarchingCubes::PointType> MarchingCubes::run(const TsdfVolume& 
     const Vec3f size = volume.getSize();
     // the reference divides by its hard-coded 128 (marching_cubes.cu:283-285) = the voxel size there
     const float cell[3] = {size[0] / dims[0], size[1] / dims[1], size[2] / dims[2]};
-    dfa::check(dfa_marching_cubes(volume.data().ptr<uint32_t>(), dims[0], dims[1], dims[2], cell, triTable_.ptr(),
-                                  numVertsTable_.ptr(), (float*)triangles_buffer.ptr(), (int)triangles_buffer.size(),
+    dfa::check(dfa_marching_cubes(volume.data().ptr<uint32_t>(), dims[0], dims[1], dims[2], cell, tri_dev_.ptr(),
+                                  nverts_dev_.ptr(), (float*)triangles_buffer.ptr(), (int)triangles_buffer.size(),
                                   total_dev_.ptr(), nullptr),
                "MarchingCubes::run");
     std::vector<int> t;
     total_dev_.download(t);  // synchronises
-    total_ = t[0];
-    const size_t n = (size_t)total_ < triangles_buffer.size() ? (size_t)total_ : triangles_buffer.size();
+    last_total_ = t[0];
+    const size_t n = (size_t)last_total_ < triangles_buffer.size() ? (size_t)last_total_ : triangles_buffer.size();
     if (n == 0) return dfa::DeviceArray<PointType>();  // :42-46
     return dfa::DeviceArray<PointType>(triangles_buffer.ptr(), n);
 }
