@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded CPU sample")
     ap.add_argument("--serial", action="store_true", help="run fuse and solve on one stream (A/B of the overlap)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="ref mode: build frame f+1's graphs (k-NN, transposition) on a third stream while frame f is "
+                         "being solved (two solver plans); every frame still does all of its work")
     ap.add_argument("--mode", default="ref", choices=["ref", "northstar"],
                     help="ref: the reference's translation-only energy (energy.t); northstar: 6-DoF DQ-blend / "
                          "projective point-to-plane / ARAP solve (DESIGN.md 4.5) against the live depth map")
@@ -123,8 +126,50 @@ class Sequence:
         self.s_fuse.wait_stream(cur)
         with torch.cuda.stream(self.s_fuse):
             self.fuse(f, timed_events)
-        self.solve(f)
+        if getattr(self, "pipelined", False):
+            self.solve_pipelined(f)
+        else:
+            self.solve(f)
         cur.wait_stream(self.s_fuse)
+
+    # ---- software pipeline across frames (--pipeline): two plans; the graphs of frame f+1 (a function of the node
+    # positions and the new frame's vertices only) are built on a third stream while frame f is solved
+    def enable_pipeline(self):
+        torch = self.torch
+        self.pipelined = True
+        self.plans = [self.solver, self.A.Solver(self.D, self.N, self.k)]
+        self.s_graph = torch.cuda.Stream()
+        self.graph_ready = [None, None]   # event: plan i holds the graphs of its next frame
+        self.plan_free = [None, None]     # event: plan i's last solve (and warp) has finished
+        self.next_graph = None            # frame whose graphs plan[f % 2] holds
+
+    def _build_graph(self, f):
+        torch = self.torch
+        i = f % 2
+        with torch.cuda.stream(self.s_graph):
+            if self.plan_free[i] is not None:
+                self.s_graph.wait_event(self.plan_free[i])
+            self.plans[i].set_problem(self.nodes, self.node_dq, self.node_w, self.verts, self.live[f % self.n_frames])
+            ev = torch.cuda.Event()
+            ev.record(self.s_graph)
+            self.graph_ready[i] = ev
+
+    def solve_pipelined(self, f):
+        torch = self.torch
+        cur = torch.cuda.current_stream()
+        i = f % 2
+        if self.next_graph != f:          # first frame (or a jump in the sequence): no graphs built ahead
+            self.s_graph.wait_stream(cur)
+            self._build_graph(f)
+        self._build_graph(f + 1)          # runs concurrently with the solve below
+        self.next_graph = f + 1
+        cur.wait_event(self.graph_ready[i])
+        self.solver = self.plans[i]
+        self.solver.solve(self.params)
+        self.warped, _ = self.solver.warp_to_live(self.normals)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.plan_free[i] = ev
 
 
 class Sequence6(Sequence):
@@ -321,13 +366,16 @@ def main():
     if args.mode == "northstar":
         return main_northstar(args, torch, replicas, rank, world, device)
     seq = Sequence(args.config, device)
+    if args.pipeline and not args.serial:
+        seq.enable_pipeline()
     cfg = seq.cfg
     K, Wm = args.steps, args.warmup
 
     for f in range(Wm):
         seq.frame(f, args.serial)
     fuse_events = []
-    seq.solver.enable_timing(True)
+    for plan in getattr(seq, "plans", [seq.solver]):
+        plan.enable_timing(True)
 
     def timed():
         for f in range(K):
@@ -388,7 +436,9 @@ def main():
                                     "%d GN iterations x PCG<=256 (tol 1e-6), reference-parity energy (energy.t), "
                                     "lambda=200" % (args.config, dim, Wd, Hd, seq.D, seq.k, seq.N, cfg["gn_iters"]),
                            parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus,
-                           streams="serial" if args.serial else "fuse || solve on two HIP streams",
+                           streams="serial" if args.serial else ("fuse || graph build of frame f+1 || solve of frame f on three "
+                                                                 "HIP streams, two solver plans" if args.pipeline else
+                                                                 "fuse || solve on two HIP streams"),
                            pcg_iterations_last_frame=its, gn_iterations_last_frame=st["gn_iters"],
                            max_abs_translation_error_vs_ground_truth_m=round(t_err, 6)),
                roofline=dominant, roofline_other=[other],
