@@ -10,21 +10,19 @@
 // the RBF weight (src/dynfu/utils/node.cpp:29-36), the Tukey / Huber weights
 // (src/dynfu/utils/opt_solver.cpp:204-268), w_reg^2 = lambda / (D k) (opt_solver.cpp:30).
 //
+// Once per frame (s6_build_graph): k-NN + normalised weights, regularisation graph, node -> rows transposition
+// (sorted: reproducible sums), and s6_pattern — the block row pattern of the normal matrix and, per row of the
+// energy, the slot of each of its neighbours in that pattern.
 // Per Gauss-Newton iteration (all launches on one stream, nothing returns to the host):
-//   s6_nodes      g^_i = T_i(g_i), clears the cost accumulators
-//   s6_linearise  one lane per vertex: blend, project, gate, residual, Tukey weight, and the row's
-//                 k 6-vectors n . dp/dxi_j through two per-vertex linear functionals (8 MACs per
-//                 column instead of three quaternion products)
+//   s6_nodes      g^_i = T_i(g_i), M_i (the node's twist as dual-quaternion increments), clears the cost accumulators
+//   s6_linearise  one lane per vertex: blend, project, gate, residual, Tukey weight; the row's 6-vector for
+//                 neighbour j factors as f_j M_j l — l (8 numbers) and the k scalars f are written entry-major
 //   s6_reg        one lane per regularisation edge
-//   s6_assemble   one workgroup per node: gathers the rows that touch the node through the
-//                 transposed graph, reduces their 6x6 outer products into an LDS hash keyed by the
-//                 column node (diagonal block in registers), writes a block-ELL row, the inverse of
-//                 the damped diagonal block and the gradient.  No global atomics on the matrix.
-//   s6_pcg_*      two launches per PCG iteration (kernel boundaries are the grid barriers: 3 us each,
-//                 a hand-rolled grid barrier is >= 4 us on this part): matvec with p = z + beta p
-//                 folded into the gather, one WAVE per block row (lane = (slot mod 10, row of the
-//                 6x6 block): 1.4 KB contiguous per wave load); then x, r, z = M^-1 r.  Scalars are
-//                 re-summed from per-workgroup partials by every workgroup (deterministic).
+//   s6_assemble   one workgroup per node: streams the node's rows, accumulates the 8x8 moments sum rho f_a f_b l l^T
+//                 per column slot in per-wave private LDS copies (no atomics), then H_ab = M_a S_ab M_b^T, the
+//                 regulariser, damping, the inverse of the diagonal block and the gradient
+//   s6_pcg_step   ONE launch per PCG iteration (Chronopoulos-Gear form), one wave per block row; replayed as a HIP
+//                 graph.  Scalars are re-summed from per-workgroup partials by every wave (deterministic).
 //   s6_update     T_i <- twist about g^_i applied on the left
 #include <hip/hip_runtime.h>
 
@@ -650,12 +648,6 @@ __global__ __launch_bounds__(256) void s6_assemble_kernel(Solve6View s, Solve6St
 // The matrix product of launch i needs u_{i+1} of OTHER nodes, which their waves are only computing in
 // the same launch: the gather rebuilds it from u_i, m_i, t_{i-1} and the two scalars (18 floats per
 // neighbour block next to the block's own 36).  Same iterates as textbook PCG in exact arithmetic.
-__device__ __forceinline__ float sum_partials(const float* __restrict__ part, int n) {
-    float acc = 0.f;
-    for (int i = threadIdx.x & 63; i < n; i += 64) acc += part[i];
-    return wave_sum_all(acc);  // every wave computes the same value in the same order
-}
-
 __global__ __launch_bounds__(256) void s6_pcg_init_kernel(Solve6View s, Solve6State* st) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (node, component)
     if (i == 0) st->pcg_done = 0;
