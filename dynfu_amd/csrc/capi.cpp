@@ -140,6 +140,7 @@ struct dfa_solver {
     std::vector<hipEvent_t> events;  // pool of timing events, reused every solve
     std::vector<int> ev_pcg, ev_asm; // indices of the begin events of each bracketed launch
     size_t ev_used;
+    int* host_flag = nullptr;        // pinned: stop flag of the many-workgroup PCG, read back between launch chunks
 };
 
 struct dfa_solver6 {
@@ -510,7 +511,7 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
     *out = nullptr;
     REQUIRE(max_D > 0 && max_N >= 0, "bad sizes");
     REQUIRE(k >= 1 && k <= DFA_MAX_KNN, "k out of range 1..16");
-    REQUIRE(max_D <= dfa::solve_pcg_max_nodes(), "more nodes than the single-workgroup PCG supports (8192)");
+    REQUIRE(max_D <= dfa::solve_pcg_max_nodes(), "more nodes than a plan supports (32768)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DFA_ERR_NO_GPU, "no HIP device");
     dfa_solver* s = new (std::nothrow) dfa_solver();
@@ -543,6 +544,21 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
     A(pk_perm, D);
     A(pk_vals, D * s->ell_cap);
     A(pk_cols, D * s->ell_cap);
+    A(mb_x, D);
+    A(mb_r, D);
+    A(mb_p, D);
+    A(mb_s, D);
+    A(mb_w, D);
+    A(mb_u[0], D);
+    A(mb_u[1], D);
+    A(mb_m[0], D);
+    A(mb_m[1], D);
+    A(mb_t[0], D);
+    A(mb_t[1], D);
+    A(mb_gpart[0], (size_t)dfa::solve_mb_blocks(max_D));
+    A(mb_gpart[1], (size_t)dfa::solve_mb_blocks(max_D));
+    A(mb_dpart[0], (size_t)dfa::solve_mb_blocks(max_D));
+    A(mb_dpart[1], (size_t)dfa::solve_mb_blocks(max_D));
     A(t, D * 3);
     A(huber, D);
     A(node_dq_out, D * 8);
@@ -552,6 +568,7 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
         if (e != hipSuccess) rc = hip_fail(e, "hipMalloc (node grid)");
     }
     if (rc == DFA_OK) rc = plan_alloc(s, &s->state, 1);
+    if (rc == DFA_OK && hipHostMalloc((void**)&s->host_flag, sizeof(int), hipHostMallocDefault) != hipSuccess) s->host_flag = nullptr;
     if (rc == DFA_OK) rc = plan_alloc(s, &s->cost_partials, (R + 255) / 256 + 1);
     if (rc == DFA_OK) rc = plan_alloc(s, &s->ticket, 64);
     if (rc == DFA_OK && hipMemset(s->ticket, 0, 64 * sizeof(unsigned int)) != hipSuccess)
@@ -569,6 +586,7 @@ void dfa_solver_destroy(dfa_solver* s) {
     for (void* p : s->blocks) (void)hipFree(p);
     s->grid.release();
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
+    if (s->host_flag) (void)hipHostFree(s->host_flag);
     delete s;
 }
 
@@ -632,7 +650,7 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
             timing_end(s, ev, st);
             if (ev >= 0) s->ev_asm.push_back(ev);
             ev = s->timing ? timing_begin(s, st) : -1;
-            HIP_TRY(dfa::solve_pcg(v, s->state, p->linear_iter, p->pcg_tol, st));
+            HIP_TRY(dfa::solve_pcg(v, s->state, p->linear_iter, p->pcg_tol, s->host_flag, st));
             timing_end(s, ev, st);
             if (ev >= 0) s->ev_pcg.push_back(ev);
         }

@@ -29,6 +29,8 @@
 //     registers and dot products reduced by wave shuffles in double.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <float.h>
 
 #include "dq_device.hpp"
@@ -1059,7 +1061,186 @@ hipError_t solve_assemble(const SolveView& s, SolveState* state, hipStream_t st)
     return hipGetLastError();
 }
 
-int solve_pcg_max_nodes() { return 1024 * 8; }
+// ------------------------------------------------------------------------------------------
+// PCG across many workgroups, for plans with more than 2048 nodes (above 8192 the single-workgroup kernels cannot
+// hold p in one CU's LDS at all; between 2048 and 8192 they spend ~1 ms per launch sorting and repacking the matrix).
+// Textbook preconditioned CG, same stopping rules as the kernels above, two launches per iteration — kernel
+// boundaries are the grid barriers (a software barrier over 512 workgroups costs 9 - 41 us on this part, a boundary
+// ~4 us: tools/microbench_gridbarrier.hip):
+//   A(it)  beta from the partial r.z sums of the two previous updates; q = A p with p = z + beta p_old formed in the
+//          gather (16 lanes per row over the slot-major ELL as assembled, no repacking); partial p.q
+//   B(it)  alpha; x += alpha p; r -= alpha q; z = M^-1 r; partial r.z
+// (The one-launch Chronopoulos-Gear form used for the 6x6-block system in solve6.hip was tried here first: in fp32 its
+// recurrences stall just above the 1e-6 residual target and it took ~30 iterations where this form takes ~11.)
+// Vector roles in the plan's mb_* buffers: x, r, z = mb_u[0], q = mb_w, p ping-pong = mb_p / mb_s.
+constexpr int MB_LPR = 16;  // lanes per row
+
+__device__ __forceinline__ float sum_partials_mb(const float* __restrict__ part, int n) {
+    float acc = 0.f;
+    for (int i = threadIdx.x & 63; i < n; i += 64) acc += part[i];
+    return wave_sum_all(acc);  // the same value, the same order, in every wave
+}
+
+__global__ __launch_bounds__(256) void pcg_mb_init_kernel(SolveView s, SolveState* __restrict__ st) {
+    __shared__ float sh[4];
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a == 0) st->mb_done = st->done ? 1 : 0, st->mb_skip = st->done ? 1 : 0, st->mb_iters = 0, st->mb_rz0 = 0.f;
+    float rz = 0.f;
+    if (a < s.D) {
+        const float d    = s.diag[a];
+        const float minv = d > FLT_EPSILON ? 1.0f / d : 1.0f;
+        const float4 r   = make_float4(s.g[3 * a], s.g[3 * a + 1], s.g[3 * a + 2], 0.f);
+        const float4 z   = make_float4(minv * r.x, minv * r.y, minv * r.z, 0.f);
+        s.mb_r[a] = r, s.mb_u[0][a] = z, s.mb_x[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rz = fmaf(r.z, z.z, fmaf(r.y, z.y, r.x * z.x));
+    }
+    rz = wave_sum_all(rz);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = rz;
+    __syncthreads();
+    if (threadIdx.x == 0) s.mb_gpart[0][blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void pcg_mb_matvec_kernel(SolveView s, SolveState* __restrict__ st, int it, float pcg_tol) {
+    __shared__ float sh[4];
+    if (st->mb_done) return;
+    const int nbu = (s.D + 255) / 256;  // workgroups of the init / update kernels
+    const float rz_cur = sum_partials_mb(s.mb_gpart[it & 1], nbu);
+    const float floor_ = 1e-12f;
+    const float tol2   = pcg_tol * pcg_tol > floor_ ? pcg_tol * pcg_tol : floor_;
+    float beta = 0.f;
+    bool stop  = !(rz_cur > 0.f);
+    if (it == 0) {
+        stop = stop || (st->grad_first > 0.0 && (double)rz_cur <= (double)floor_ * st->grad_first);  // nothing left to solve
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->mb_rz0 = rz_cur;
+    } else {
+        const float rz_prev = sum_partials_mb(s.mb_gpart[(it + 1) & 1], nbu);
+        beta                = rz_cur / rz_prev;
+        stop                = stop || rz_cur <= tol2 * st->mb_rz0;
+    }
+    if (stop) {  // the same decision in every workgroup
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->mb_done = 1;
+        return;
+    }
+    const int lane16 = threadIdx.x & (MB_LPR - 1);
+    const int a      = (blockIdx.x * 256 + threadIdx.x) / MB_LPR;
+    const float4* z    = s.mb_u[0];
+    const float4* pold = (it & 1) ? s.mb_p : s.mb_s;  // written by launch it - 1
+    float4* pnew       = (it & 1) ? s.mb_s : s.mb_p;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    const bool row_ok = a < s.D;
+    const int cnt     = row_ok ? s.ell_cnt[a] : 0;
+    for (int q = lane16; q < cnt; q += MB_LPR) {
+        const int col   = s.ell_cols[(size_t)q * s.D + a];
+        const float val = s.ell_vals[(size_t)q * s.D + a];
+        float4 pv       = z[col];
+        if (it > 0) {
+            const float4 po = pold[col];
+            pv.x = fmaf(beta, po.x, pv.x), pv.y = fmaf(beta, po.y, pv.y), pv.z = fmaf(beta, po.z, pv.z);
+        }
+        ax = fmaf(val, pv.x, ax), ay = fmaf(val, pv.y, ay), az = fmaf(val, pv.z, az);
+    }
+    ax = group16_sum(ax), ay = group16_sum(ay), az = group16_sum(az);
+    float pq = 0.f;
+    if (row_ok && lane16 == 0) {
+        float4 pv = z[a];
+        if (it > 0) {
+            const float4 po = pold[a];
+            pv.x = fmaf(beta, po.x, pv.x), pv.y = fmaf(beta, po.y, pv.y), pv.z = fmaf(beta, po.z, pv.z);
+        }
+        pnew[a]   = pv;
+        s.mb_w[a] = make_float4(ax, ay, az, 0.f);
+        pq        = fmaf(pv.z, az, fmaf(pv.y, ay, pv.x * ax));
+    }
+    pq = wave_sum_all(pq);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = pq;
+    __syncthreads();
+    if (threadIdx.x == 0) s.mb_dpart[0][blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void pcg_mb_update_kernel(SolveView s, SolveState* __restrict__ st, int it) {
+    __shared__ float sh[4];
+    if (st->mb_done) return;
+    const float rz_cur = sum_partials_mb(s.mb_gpart[it & 1], (s.D + 255) / 256);
+    const float pq     = sum_partials_mb(s.mb_dpart[0], solve_mb_blocks(s.D));
+    if (!(pq > 0.f)) {  // breakdown: keep x
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->mb_done = 1;
+        return;
+    }
+    const float alpha = rz_cur / pq;
+    const int a       = blockIdx.x * blockDim.x + threadIdx.x;
+    float rz          = 0.f;
+    if (a < s.D) {
+        const float4 p = ((it & 1) ? s.mb_s : s.mb_p)[a], q = s.mb_w[a];
+        float4 x = s.mb_x[a], r = s.mb_r[a];
+        x.x = fmaf(alpha, p.x, x.x), x.y = fmaf(alpha, p.y, x.y), x.z = fmaf(alpha, p.z, x.z);
+        r.x = fmaf(-alpha, q.x, r.x), r.y = fmaf(-alpha, q.y, r.y), r.z = fmaf(-alpha, q.z, r.z);
+        const float d    = s.diag[a];
+        const float minv = d > FLT_EPSILON ? 1.0f / d : 1.0f;
+        const float4 z   = make_float4(minv * r.x, minv * r.y, minv * r.z, 0.f);
+        s.mb_x[a] = x, s.mb_r[a] = r, s.mb_u[0][a] = z;
+        rz = fmaf(r.z, z.z, fmaf(r.y, z.y, r.x * z.x));
+    }
+    rz = wave_sum_all(rz);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = rz;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s.mb_gpart[(it + 1) & 1][blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        if (blockIdx.x == 0) st->mb_iters += 1;
+    }
+}
+
+// t += delta and the counters the single-workgroup kernels keep
+__global__ __launch_bounds__(256) void pcg_mb_finish_kernel(SolveView s, SolveState* __restrict__ st) {
+    if (st->mb_skip) return;
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < s.D) {
+        const float4 x = s.mb_x[a];
+        s.t[3 * a] += x.x, s.t[3 * a + 1] += x.y, s.t[3 * a + 2] += x.z;
+    }
+    if (a == 0) {
+        if (st->grad_first == 0.0) st->grad_first = (double)st->mb_rz0;
+        st->pcg_iters += st->mb_iters;
+        st->gn_iters += 1;
+    }
+}
+
+// The iteration count is only known on the device.  With a pinned host word the launches go out in chunks (16, 32,
+// 64, ...) and the stop flag is read back between chunks — one stream synchronisation per chunk instead of up to
+// max_iter launches that return at once (3 us each: 0.7 ms per Gauss-Newton iteration at the usual cap of 256).
+static hipError_t launch_mb_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag,
+                                hipStream_t st) {
+    const int nb = solve_mb_blocks(s.D), nbu = (s.D + 255) / 256;
+    pcg_mb_init_kernel<<<nbu, 256, 0, st>>>(s, state);
+    int chunk = 16;
+    for (int it = 0; it < max_iter;) {
+        const int end = host_flag ? std::min(max_iter, it + chunk) : max_iter;
+        for (; it < end; ++it) {
+            pcg_mb_matvec_kernel<<<nb, 256, 0, st>>>(s, state, it, pcg_tol);
+            pcg_mb_update_kernel<<<nbu, 256, 0, st>>>(s, state, it);
+        }
+        if (host_flag && it < max_iter) {
+            // one more matvec launch evaluates the stopping rule on the last update's residual
+            pcg_mb_matvec_kernel<<<nb, 256, 0, st>>>(s, state, it, pcg_tol);
+            hipError_t e = hipMemcpyAsync(host_flag, &state->mb_done, sizeof(int), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return e;
+            if (*host_flag) break;
+            pcg_mb_update_kernel<<<nbu, 256, 0, st>>>(s, state, it);  // the matvec above was iteration `it`
+            ++it;
+            chunk *= 2;
+        }
+    }
+    pcg_mb_finish_kernel<<<nbu, 256, 0, st>>>(s, state);
+    return hipGetLastError();
+}
+
+int solve_pcg_max_nodes() { return 32768; }  // bounded by the transposition's LDS histogram (4 B x D)
 
 template <class Kernel>
 static hipError_t allow_big_lds(Kernel* k, bool& done) {
@@ -1093,11 +1274,13 @@ static hipError_t launch_paired_pcg(const SolveView& s, SolveState* state, int m
     return hipGetLastError();
 }
 
-hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, hipStream_t st) {
+hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag, hipStream_t st) {
     // DFA_PCG_VARIANT=0 forces the streaming kernel (A/B baseline)
     static const bool force_streaming = getenv("DFA_PCG_VARIANT") && atoi(getenv("DFA_PCG_VARIANT")) == 0;
     const int D = s.D;
     hipError_t e;
+    if (getenv("DFA_PCG_VARIANT") && atoi(getenv("DFA_PCG_VARIANT")) == 3)
+        return launch_mb_pcg(s, state, max_iter, pcg_tol, host_flag, st);
     if (D <= 2048 && !force_streaming) {
         // Register-resident matrix.  512 threads leave 256 VGPRs per lane (64 slots per row pair: k = 8
         // rows fit), 1024 threads 128 VGPRs (32 slots: k = 4).  A pair that does not fit sets
@@ -1113,9 +1296,13 @@ hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float 
     }
     if (D <= 1024) return launch_streaming_pcg<1, false>(s, state, max_iter, pcg_tol, st);
     if (D <= 2048) return launch_streaming_pcg<2, false>(s, state, max_iter, pcg_tol, st);
-    if (D <= 4096) return launch_streaming_pcg<4, false>(s, state, max_iter, pcg_tol, st);
-    if (D <= 8192) return launch_streaming_pcg<8, false>(s, state, max_iter, pcg_tol, st);
-    return hipErrorInvalidValue;
+    // Above 2048 nodes the single-workgroup streaming kernel spends ~1 ms per launch sorting and repacking the matrix
+    // by itself (measured: 1.2 ms per launch at 8 k nodes for ~12 iterations); the many-workgroup PCG reads the
+    // assembled ELL directly.  DFA_PCG_VARIANT=4 keeps the streaming kernel (A/B), possible up to 8192 nodes.
+    static const bool keep_streaming = getenv("DFA_PCG_VARIANT") && atoi(getenv("DFA_PCG_VARIANT")) == 4;
+    if (keep_streaming && D <= 4096) return launch_streaming_pcg<4, false>(s, state, max_iter, pcg_tol, st);
+    if (keep_streaming && D <= 8192) return launch_streaming_pcg<8, false>(s, state, max_iter, pcg_tol, st);
+    return launch_mb_pcg(s, state, max_iter, pcg_tol, host_flag, st);
 }
 
 hipError_t solve_writeback(const SolveView& s, hipStream_t st) {

@@ -18,6 +18,9 @@ struct SolveState {
     int max_row_nnz;
     int overflow;       // a row of the normal matrix did not fit the plan's ELL capacity
     int pcg_fallback;   // set by the register-resident PCG when a row pair exceeds its slots
+    // multi-workgroup PCG: flags and scalars carried from one launch to the next
+    int mb_done, mb_skip, mb_iters;
+    float mb_rz0, mb_gamma_prev[2], mb_alpha_prev[2];
     long long prof[8];  // DFA_PCG_PROFILE builds: shader cycles per PCG phase (thread 0)
 };
 
@@ -52,6 +55,9 @@ struct SolveView {
     float* pk_vals;     // ell_cap x D
     uint16_t* pk_cols;  // ell_cap x D
     // unknown and outputs
+    // multi-workgroup PCG (more than 8192 nodes): vectors as float4 per node, ping-pong where other rows read them
+    float4 *mb_x, *mb_r, *mb_p, *mb_s, *mb_w, *mb_u[2], *mb_m[2], *mb_t[2];
+    float *mb_gpart[2], *mb_dpart[2];  // per-workgroup partial (r, u), (w, u)
     float* t;            // D x 3
     float* huber;        // D
     float* node_dq_out;  // D x 8
@@ -72,7 +78,11 @@ hipError_t solve_huber(const SolveView& s, float psi_reg, hipStream_t st);
 hipError_t solve_reset(const SolveView& s, SolveState* state, unsigned int* ticket, int nticket, hipStream_t st);
 hipError_t solve_assemble(const SolveView& s, SolveState* state, hipStream_t st);
 int solve_pcg_max_nodes();
-hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, hipStream_t st);
+__host__ __device__ inline int solve_mb_rows_per_block() { return 16; }  // multi-workgroup PCG: 16 lanes per row, 256 threads
+__host__ __device__ inline int solve_mb_blocks(int D) { return (D + 15) / 16; }
+// host_flag: pinned host word (may be null); with it, plans above 2048 nodes synchronise with the stream once per
+// chunk of PCG launches to stop launching after convergence
+hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag, hipStream_t st);
 hipError_t solve_writeback(const SolveView& s, hipStream_t st);
 
 }  // namespace dfa

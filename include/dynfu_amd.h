@@ -226,7 +226,7 @@ typedef struct {
 } dfa_solve_stats;
 
 /* Plan for up to max_D nodes / max_N vertices with k neighbours (1..16). */
-int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out);
+int dfa_solver_create(int max_D /* <= 32768 */, int max_N, int k, dfa_solver** out);
 void dfa_solver_destroy(dfa_solver* s);
 
 /* CombinedSolver::initializeProblemInstance (opt_solver.cpp:15-54): uploads nothing (inputs
@@ -241,7 +241,9 @@ int dfa_solver_set_problem(dfa_solver* s, const float* node_pos, const float* no
 
 /* CombinedSolverBase::solveAll() with the hooks of opt_solver.cpp:107-147: per outer
  * iteration Tukey + Huber weights, then Gauss-Newton with a block-Jacobi PCG on the normal
- * equations of energy.t.  Everything is enqueued on `stream`; no host synchronisation. */
+ * equations of energy.t.  Up to 2048 nodes everything is enqueued on `stream` without any host
+ * synchronisation; larger problems use a many-workgroup PCG whose launches go out in chunks, and the
+ * call waits for `stream` about once per Gauss-Newton iteration to read the stop flag. */
 int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* params, dfa_stream_t stream);
 
 /* Results (device pointers, valid until the next set_problem/solve on this plan):

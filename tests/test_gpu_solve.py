@@ -240,3 +240,53 @@ def test_config_c2_full_size_properties(A):
     assert np.abs(res[0] - res[1]).max() < 1e-5
     assert s.stats()["max_row_nnz"] <= 256
     s.close()
+
+
+def test_multi_workgroup_pcg_matches_the_oracle_and_the_single_workgroup_kernels(A, monkeypatch):
+    """DFA_PCG_VARIANT=3 forces the many-workgroup PCG (the path of plans above 8192 nodes) on a small problem"""
+    cfg, c, verts, live, t_true = _problem("T1")
+    k = cfg["k"]
+    kw = dict(num_iter=3, nonlinear_iter=2, linear_iter=200, lambda_=200.0, pcg_tol=1e-6)
+    t_ref, dq_ref, st_ref = O.solve_ref(c["node_pos"], c["node_dq"], c["node_w"], k, verts, live, use_double=True,
+                                        threads=8, **kw)
+    out = {}
+    for variant in ("default", "3"):
+        if variant == "3":
+            monkeypatch.setenv("DFA_PCG_VARIANT", "3")
+        s = A.Solver(cfg["D"], len(verts), k)
+        s.set_problem(dev(c["node_pos"]), dev(c["node_dq"]), dev(c["node_w"]), dev(verts), dev(live))
+        s.solve(_params(A, **kw))
+        out[variant] = (host(s.translations()), s.stats())
+        s.close()
+    monkeypatch.delenv("DFA_PCG_VARIANT", raising=False)
+    t3, st3 = out["3"]
+    assert np.abs(t3 - t_ref).max() <= 2e-5 and np.abs(t3 - out["default"][0]).max() <= 2e-5
+    assert st3["gn_iters"] == st_ref["gn_iters"] == out["default"][1]["gn_iters"]
+    assert abs(st3["pcg_iters"] - out["default"][1]["pcg_iters"]) <= 0.1 * out["default"][1]["pcg_iters"] + 3
+    np.testing.assert_allclose(st3["final_cost"], st_ref["final_cost"], rtol=1e-3, atol=1e-9)
+
+
+def test_more_than_8192_nodes(A):
+    """12 288 nodes: beyond the single-workgroup PCG; the ground-truth field is recovered"""
+    cfg = dict(synth.CONFIGS["T1"], D=12288, k=4)
+    c = synth.canonical(cfg)
+    k = cfg["k"]
+    verts = c["verts"][::8].copy()  # 16 vertices per node
+    idx = O.knn(c["node_pos"], verts, k, threads=8)
+    d2 = ((verts[:, None, :].astype(np.float64) - c["node_pos"][idx].astype(np.float64)) ** 2).sum(-1)
+    w = np.exp(-d2 / (2 * float(c["node_w"][0]) ** 2)).astype(np.float32)
+    t_true = synth.true_translations(c["node_pos"], 3, k)
+    live = synth.live_vertices(verts, idx, w, t_true)
+    s = A.Solver(cfg["D"], len(verts), k)
+    s.set_problem(dev(c["node_pos"]), dev(c["node_dq"]), dev(c["node_w"]), dev(verts), dev(live))
+    s.solve(_params(A, num_iter=2, nonlinear_iter=1, linear_iter=150, lambda_=200.0, pcg_tol=1e-6))
+    st = s.stats()
+    t = host(s.translations())
+    assert st["gn_iters"] == 2 and st["pcg_iters"] > 10 and np.isfinite(t).all()
+    assert st["final_cost"] < 1e-2 * st["initial_cost"]
+    t_ref, _, st_ref = O.solve_ref(c["node_pos"], c["node_dq"], c["node_w"], k, verts, live, num_iter=2, nonlinear_iter=1,
+                                   linear_iter=150, lambda_=200.0, pcg_tol=1e-6, use_double=True, threads=8,
+                                   tukey_offset=synth.SOLVER["tukey_offset"], psi_data=synth.SOLVER["psi_data"],
+                                   psi_reg=synth.SOLVER["psi_reg"])
+    assert np.abs(t - t_ref).max() <= 5e-5
+    s.close()
