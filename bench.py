@@ -32,11 +32,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 for wide reads + WRITE_SIZE, corrected as
 # MI355X_MICROARCH.md prescribes) — profiles/r01_pmc_tsdf.md.  Collected offline: PMC needs its own runs.
+TIMING_SAMPLE = 8  # every 8th timed frame carries the hipEvent brackets of the per-kernel report
 PMC_TRAFFIC_BYTES = {("C2", "fused_integrate"): 0.5439e9, ("C3", "fused_integrate"): 0.5439e9,
                      # profiles/r01_pmc_northstar.md (FETCH x2 + WRITE per dispatch)
                      ("C3", "s6_assemble"): 0.411e9, ("C3", "s6_pcg_step"): 0.0242e9,
-                     # profiles/r01_pmc_solve.md: (198.1 + 70.8) KiB per pcg_paired_kernel launch
-                     ("C2", "pcg"): 268.9 * 1024}
+                     # profiles/r01_pmc_solve.md: (540.3 + 464.8) KiB per pcg_paired_kernel<1024,1,32,1> launch
+                     ("C2", "pcg"): 1005.1 * 1024}
 
 
 def parse():
@@ -293,7 +294,7 @@ def main_northstar(args, torch, replicas, rank, world, device):
                                     % (args.config, dim, Wd, Hd, seq.D, seq.k, seq.N, seq.gn_total, lin),
                            parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus,
                            streams="serial" if args.serial else "fuse || solve on two HIP streams",
-                           pcg_iterations_last_frame=its, gn_iterations_last_frame=st["gn_iters"],
+                           pcg_iterations_last_frame=st["pcg_iters"], gn_iterations_last_frame=st["gn_iters"],
                            valid_rows_last_frame=st["valid_last"], cost_first=st["initial_cost"], cost_last=st["final_cost"]),
                roofline=dominant, roofline_other=other)
     if not args.no_cpu_baseline and world == 1:
@@ -373,20 +374,28 @@ def main():
 
     for f in range(Wm):
         seq.frame(f, args.serial)
+    # Per-kernel durations come from hipEvent brackets INSIDE the timed region, on the streams the kernels run on.
+    # An event costs ~5 us of stream time (15 of them per frame would be 6 % of a C2 frame), so every
+    # TIMING_SAMPLE-th frame is bracketed and the others run as a caller without instrumentation would.
     fuse_events = []
-    for plan in getattr(seq, "plans", [seq.solver]):
-        plan.enable_timing(True)
+    plans = getattr(seq, "plans", [seq.solver])
+    for plan in plans:
+        plan.enable_timing(1)  # new measurement ...
+        plan.enable_timing(0)  # ... paused
 
     def timed():
         for f in range(K):
-            seq.frame(Wm + f, args.serial, fuse_events)
+            sampled = f % TIMING_SAMPLE == 0
+            for plan in plans:
+                plan.enable_timing(2 if sampled else 0)
+            seq.frame(Wm + f, args.serial, fuse_events if sampled else None)
 
     # barrier + synchronize on both sides, MAX over ranks
     dt_max = replicas.timed_region(timed, device)
-    # per-kernel numbers of the LAST timed frame's solve + all timed fuse launches
-    tm = seq.solver.timing()
-    st = seq.solver.stats()
-    seq.solver.enable_timing(False)
+    for plan in plans:
+        plan.enable_timing(0)
+    tm = max((plan.timing() for plan in plans), key=lambda t: t["solves"])  # sums over the sampled frames
+    st = seq.solver.stats()  # last frame
 
     # ---- parity spot check of the last frame (outside the timed region)
     t_err = float((seq.solver.translations() - seq.t_true[(Wm + K - 1) % seq.n_frames]).abs().max())
@@ -401,31 +410,43 @@ def main():
     fuse_ms = float(np.mean([a.elapsed_time(b) for a, b in fuse_events])) if fuse_events else float("nan")
     fuse_bytes = 4.0 * V + 2.0 * Wd * Hd  # fused clear+integrate writes every voxel once
     fuse_gbs = fuse_bytes / (fuse_ms * 1e-3) / 1e9
+    # per-kernel numbers: hipEvent brackets on the solve stream, summed over ALL K timed frames (plans of the
+    # pipelined variant: the measured one)
     nnz = tm["matrix_nnz"]
-    its = st["pcg_iters"]
+    frames_timed = max(1, tm["solves"])
+    its_total = tm["pcg_iters"]
+    its = its_total / frames_timed  # PCG iterations per frame (mean)
     # PCG: per iteration the matrix (4 B value + 4 B column per non-zero) + 6 vectors of 3D floats
-    pcg_bytes = its * (8.0 * nnz + 24.0 * 3 * seq.D)
-    pcg_total_ms = tm["pcg_ms"]
+    pcg_bytes = its * (8.0 * nnz + 24.0 * 3 * seq.D)  # per frame
+    pcg_total_ms = tm["pcg_ms"] / frames_timed        # per frame
     pcg_gbs = pcg_bytes / (pcg_total_ms * 1e-3) / 1e9 if pcg_total_ms > 0 else float("nan")
+    launches_pf = tm["pcg_launches"] / frames_timed
     fuse_entry = dict(kernel="integrate_kernel<FUSED_CLEAR,4> (clear+integrate %d^3)" % dim, bound="hbm",
                       achieved=round(fuse_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(fuse_gbs / HBM_PEAK_GBS, 4),
                       traffic=PMC_TRAFFIC_BYTES.get((args.config, "fused_integrate")),
                       traffic_source="profiles/r01_pmc_tsdf.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                       avg_launch_ms=round(fuse_ms, 4), launches_per_frame=1, algorithmic_bytes_per_launch=fuse_bytes)
-    pcg_entry = dict(kernel="pcg_kernel (single-workgroup block-Jacobi PCG)", bound="hbm",
+    split = seq.D <= 2048  # register-resident kernel, one workgroup per coordinate
+    pcg_entry = dict(kernel=("pcg_paired_kernel<..,NC=1> (Jacobi PCG, matrix in registers, 3 workgroups = 3 coordinates)" if split
+                             else "pcg_mb_* (many-workgroup Jacobi PCG)"), bound="hbm",
                      achieved=round(pcg_gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(pcg_gbs / HBM_PEAK_GBS, 6),
                      traffic=PMC_TRAFFIC_BYTES.get((args.config, "pcg")),
                      traffic_source="profiles/r01_pmc_solve.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes): "
-                                    "per launch; the matrix is read once and kept in registers",
-                     algorithmic_bytes_per_launch=pcg_bytes / max(1, tm["pcg_launches"]),
-                     avg_launch_ms=round(pcg_total_ms / max(1, tm["pcg_launches"]), 4),
-                     launches_per_frame=tm["pcg_launches"], pcg_iterations_per_frame=its, matrix_nnz=nnz,
-                     algorithmic_bytes_per_frame=pcg_bytes,
-                     lds_gather=dict(bytes_per_frame=16.0 * nnz * its, achieved_gbs=round(16.0 * nnz * its / (pcg_total_ms * 1e-3) / 1e9, 1) if pcg_total_ms > 0 else None,
-                                     peak_gbs=614.4, note="single-CU LDS peak 256 B/clk x 2.4 GHz"),
-                     note="register/LDS-resident and synchronisation-bound by design: ONE workgroup, %d "
-                          "barrier-separated iterations; its ceiling is the single-CU LDS gather rate, the HBM "
-                          "fraction is shown because the contract asks for it" % its)
+                                    "per launch; every workgroup reads the matrix once and keeps it in registers",
+                     algorithmic_bytes_per_launch=round(pcg_bytes / max(1e-9, launches_pf), 1),
+                     avg_launch_ms=round(pcg_total_ms / max(1e-9, launches_pf), 4),
+                     launches_per_frame=round(launches_pf, 2), pcg_iterations_per_frame=round(its, 1), matrix_nnz=nnz,
+                     algorithmic_bytes_per_frame=round(pcg_bytes, 1), frames_measured=frames_timed)
+    if split:
+        # what bounds it: the gather of p from LDS, 4 B per non-zero and coordinate, on three CUs
+        lds_bytes = 12.0 * nnz * its
+        pcg_entry["lds_gather"] = dict(bytes_per_frame=lds_bytes, peak_gbs=921.6,
+                                       achieved_gbs=round(lds_bytes / (pcg_total_ms * 1e-3) / 1e9, 1) if pcg_total_ms > 0 else None,
+                                       note="3 CUs x 128 B/clk (ds_read_b32, conflict-free) x 2.4 GHz; random 4-byte gathers "
+                                            "measure ~6.5 clk per wave instruction against 2 (bank conflicts)")
+        pcg_entry["note"] = ("register/LDS-resident and synchronisation-bound by design: one workgroup per coordinate, %d "
+                             "barrier-separated iterations per frame; the ceiling is the LDS gather rate of a CU, the HBM fraction "
+                             "is shown because the contract asks for it" % round(its))
     dominant, other = (pcg_entry, fuse_entry) if pcg_total_ms > fuse_ms else (fuse_entry, pcg_entry)
 
     out = dict(metric="frames/sec (warp-solve + TSDF fuse), 512^3 vol / 2k nodes / VGA depth",
@@ -439,10 +460,10 @@ def main():
                            streams="serial" if args.serial else ("fuse || graph build of frame f+1 || solve of frame f on three "
                                                                  "HIP streams, two solver plans" if args.pipeline else
                                                                  "fuse || solve on two HIP streams"),
-                           pcg_iterations_last_frame=its, gn_iterations_last_frame=st["gn_iters"],
+                           pcg_iterations_last_frame=st["pcg_iters"], gn_iterations_last_frame=st["gn_iters"],
                            max_abs_translation_error_vs_ground_truth_m=round(t_err, 6)),
                roofline=dominant, roofline_other=[other],
-               solve_kernels_ms_last_frame=dict(pcg=round(tm["pcg_ms"], 4), assemble=round(tm["assemble_ms"], 4)))
+               solve_kernels_ms_per_frame=dict(pcg=round(pcg_total_ms, 4), assemble=round(tm["assemble_ms"] / frames_timed, 4)))
     if not args.no_cpu_baseline and world == 1:
         del seq
         torch.cuda.empty_cache()

@@ -68,7 +68,8 @@ class _SolveStats(C.Structure):
 
 class _SolveTiming(C.Structure):
     _fields_ = [("pcg_ms", C.c_float), ("assemble_ms", C.c_float), ("pcg_launches", C.c_int),
-                ("assemble_launches", C.c_int), ("matrix_nnz", C.c_longlong)]
+                ("assemble_launches", C.c_int), ("matrix_nnz", C.c_longlong), ("pcg_iters", C.c_longlong),
+                ("solves", C.c_int), ("reserved", C.c_int)]
 
 
 def lib_path():
@@ -419,13 +420,14 @@ class Solver:
         return out_v, out_n
 
     def enable_timing(self, on=True):
-        _check(load().dfa_solver_enable_timing(self._h, 1 if on else 0))
+        """True / 1 starts a new measurement, 2 resumes a paused one, False / 0 pauses"""
+        _check(load().dfa_solver_enable_timing(self._h, int(on)))
 
     def timing(self):
         t = _SolveTiming()
         _check(load().dfa_solver_get_timing(self._h, C.byref(t), _stream()))
         return dict(pcg_ms=t.pcg_ms, assemble_ms=t.assemble_ms, pcg_launches=t.pcg_launches,
-                    assemble_launches=t.assemble_launches, matrix_nnz=t.matrix_nnz)
+                    assemble_launches=t.assemble_launches, matrix_nnz=t.matrix_nnz, pcg_iters=t.pcg_iters, solves=t.solves)
 
     def stats(self):
         st = _SolveStats()

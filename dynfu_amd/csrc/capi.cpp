@@ -137,9 +137,11 @@ struct dfa_solver {
     GridScratch grid;           // node grid of the current problem
     bool has_problem;
     bool timing;
-    std::vector<hipEvent_t> events;  // pool of timing events, reused every solve
+    std::vector<hipEvent_t> events;  // pool of timing events: they accumulate from enable_timing(1) on
     std::vector<int> ev_pcg, ev_asm; // indices of the begin events of each bracketed launch
     size_t ev_used;
+    int timed_solves = 0;
+    long long* iters_total = nullptr;  // device: PCG iterations of all solves since enable_timing(1)
     int* host_flag = nullptr;        // pinned: stop flag of the many-workgroup PCG, read back between launch chunks
 };
 
@@ -568,6 +570,8 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
         if (e != hipSuccess) rc = hip_fail(e, "hipMalloc (node grid)");
     }
     if (rc == DFA_OK) rc = plan_alloc(s, &s->state, 1);
+    if (rc == DFA_OK) rc = plan_alloc(s, &s->iters_total, 1);
+    if (rc == DFA_OK && hipMemset(s->iters_total, 0, sizeof(long long)) != hipSuccess) rc = DFA_ERR_HIP;
     if (rc == DFA_OK && hipHostMalloc((void**)&s->host_flag, sizeof(int), hipHostMallocDefault) != hipSuccess) s->host_flag = nullptr;
     if (rc == DFA_OK) rc = plan_alloc(s, &s->cost_partials, (R + 255) / 256 + 1);
     if (rc == DFA_OK) rc = plan_alloc(s, &s->ticket, 64);
@@ -635,9 +639,7 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
     const double w_reg    = std::sqrt((double)p->lambda / ((double)v.D * (double)v.k));
     const float w_reg_f   = (float)w_reg;
     const float w_reg_sq  = w_reg_f * w_reg_f;
-    s->ev_used = 0;
-    s->ev_pcg.clear();
-    s->ev_asm.clear();
+    if (s->timing) s->timed_solves += 1;
     for (int outer = 0; outer < p->num_iter; ++outer) {
         // preNonlinearSolve (opt_solver.cpp:135-140): the Huber weights are only observable after
         // the solve, so they are evaluated for the last outer iteration alone
@@ -649,9 +651,9 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
             HIP_TRY(dfa::solve_assemble(v, s->state, st));
             timing_end(s, ev, st);
             if (ev >= 0) s->ev_asm.push_back(ev);
-            ev = s->timing ? timing_begin(s, st) : -1;
-            HIP_TRY(dfa::solve_pcg(v, s->state, p->linear_iter, p->pcg_tol, s->host_flag, st));
-            timing_end(s, ev, st);
+            ev = s->timing ? timing_begin(s, st) : -1;  // closed behind the solving kernel, before the fallback launch
+            HIP_TRY(dfa::solve_pcg(v, s->state, p->linear_iter, p->pcg_tol, s->host_flag,
+                                   ev >= 0 ? s->events[ev + 1] : nullptr, st));
             if (ev >= 0) s->ev_pcg.push_back(ev);
         }
     }
@@ -661,7 +663,7 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
     HIP_TRY(dfa::solve_linearise(v, s->state, s->cost_partials, s->ticket, no_weights ? 1 : 0, 2, 0.f,
                                  p->tukey_offset, p->psi_data, w_reg_sq, st));
     // postSingleSolve -> copyResultToCPUFromFloat3 (opt_solver.cpp:133,270-285), composed once
-    HIP_TRY(dfa::solve_writeback(v, st));
+    HIP_TRY(dfa::solve_writeback(v, s->state, s->timing ? s->iters_total : nullptr, st));
     return DFA_OK;
 }
 
@@ -707,6 +709,11 @@ int dfa_solver_get_stats(dfa_solver* s, dfa_solve_stats* host_out, dfa_stream_t 
 int dfa_solver_enable_timing(dfa_solver* s, int enable) {
     REQUIRE(s, "null plan");
     s->timing = enable != 0;
+    if (enable == 1) {  // a new measurement: forget the brackets collected so far (2 = resume, keeps them)
+        s->ev_used = 0, s->timed_solves = 0;
+        s->ev_pcg.clear(), s->ev_asm.clear();
+        if (s->iters_total) HIP_TRY(hipMemset(s->iters_total, 0, sizeof(long long)));
+    }
     return DFA_OK;
 }
 
@@ -726,6 +733,8 @@ int dfa_solver_get_timing(dfa_solver* s, dfa_solve_timing* out, dfa_stream_t str
     }
     out->pcg_launches      = (int)s->ev_pcg.size();
     out->assemble_launches = (int)s->ev_asm.size();
+    out->solves            = s->timed_solves;
+    if (s->iters_total) HIP_TRY(hipMemcpy(&out->pcg_iters, s->iters_total, sizeof(long long), hipMemcpyDeviceToHost));
     if (s->has_problem && s->v.D > 0) {
         std::vector<int32_t> cnt((size_t)s->v.D);
         HIP_TRY(hipMemcpy(cnt.data(), s->v.ell_cnt, sizeof(int32_t) * cnt.size(), hipMemcpyDeviceToHost));

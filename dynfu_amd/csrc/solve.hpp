@@ -18,6 +18,8 @@ struct SolveState {
     int max_row_nnz;
     int overflow;       // a row of the normal matrix did not fit the plan's ELL capacity
     int pcg_fallback;   // set by the register-resident PCG when a row pair exceeds its slots
+    int split_iters;    // per-coordinate PCG: most iterations any coordinate took in the launch in flight
+    unsigned int split_ticket;  // ... and how many of its three workgroups have finished
     // multi-workgroup PCG: flags and scalars carried from one launch to the next
     int mb_done, mb_skip, mb_iters;
     float mb_rz0, mb_gamma_prev[2], mb_alpha_prev[2];
@@ -82,7 +84,10 @@ __host__ __device__ inline int solve_mb_rows_per_block() { return 16; }  // mult
 __host__ __device__ inline int solve_mb_blocks(int D) { return (D + 15) / 16; }
 // host_flag: pinned host word (may be null); with it, plans above 2048 nodes synchronise with the stream once per
 // chunk of PCG launches to stop launching after convergence
-hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag, hipStream_t st);
-hipError_t solve_writeback(const SolveView& s, hipStream_t st);
+// `main_done` (optional) is recorded behind the solving kernel(s), before the fallback launch that usually returns at once
+hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag, hipEvent_t main_done,
+                     hipStream_t st);
+// also adds the solve's PCG iterations to *iters_total (optional, device)
+hipError_t solve_writeback(const SolveView& s, const SolveState* state, long long* iters_total, hipStream_t st);
 
 }  // namespace dfa

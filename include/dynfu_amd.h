@@ -269,15 +269,21 @@ int dfa_solver_warp_to_live(dfa_solver* s, const float* normals, float* out_vert
 int dfa_solver_get_stats(dfa_solver* s, dfa_solve_stats* host_out, dfa_stream_t stream);
 
 /* Optional per-kernel timing for roofline reports (no reference counterpart; Opt has
- * profileSolve, opt_solver.cpp:144-147).  When enabled, dfa_solver_solve brackets every PCG
- * and assembly launch with hipEvents on the launch stream.  dfa_solver_get_timing synchronises
- * the stream and returns, for the LAST solve: summed kernel milliseconds and launch counts. */
+ * profileSolve, opt_solver.cpp:144-147).  dfa_solver_enable_timing(s, 1) starts a measurement: from then on
+ * dfa_solver_solve brackets every assembly launch and every PCG kernel with hipEvents on the launch stream
+ * (an event costs ~5 us of stream time: enable = 0 pauses and enable = 2 resumes without discarding, so that
+ * a caller can sample some of its solves).
+ * dfa_solver_get_timing synchronises the stream and returns the sums over ALL solves since the measurement
+ * started: kernel milliseconds, launch counts, solves and PCG iterations. */
 typedef struct {
     float pcg_ms;
     float assemble_ms;
     int pcg_launches;
     int assemble_launches;
     long long matrix_nnz; /* non-zeros of the assembled normal matrix (last linearisation) */
+    long long pcg_iters;  /* PCG iterations of the measured solves */
+    int solves;
+    int reserved;
 } dfa_solve_timing;
 int dfa_solver_enable_timing(dfa_solver* s, int enable);
 int dfa_solver_get_timing(dfa_solver* s, dfa_solve_timing* host_out, dfa_stream_t stream);

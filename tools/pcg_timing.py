@@ -16,11 +16,11 @@ t_true = synth.true_translations(c["node_pos"], 7, cfg["k"])
 live = dev(synth.live_vertices(c["verts"], idx.cpu().numpy(), w.cpu().numpy(), t_true))
 s = A.Solver(cfg["D"], len(c["verts"]), k)
 s.set_problem(nodes, node_dq, node_w, verts, live)
-s.enable_timing(True)
 for iters in (0, 1, 2, 8, 32, 128, 256):
     prm = A.SolveParams(num_iter=1, nonlinear_iter=1, linear_iter=iters, pcg_tol=0.0, gn_tol=0.0, **synth.SOLVER)
     best = 1e9
     for rep in range(5):
+        s.enable_timing(True)  # starts a new measurement (timings accumulate over solves otherwise)
         s.solve(prm)
         tm = s.timing()
         best = min(best, tm["pcg_ms"])
