@@ -454,13 +454,15 @@ def main():
                ms_per_step=round(dt_max / K * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="f32", data="synthetic",
                config=dict(workload="%s: %d^3 TSDF (4 B voxels), %dx%d depth, %d nodes, k=%d, %d vertices, "
-                                    "%d GN iterations x PCG<=256 (tol 1e-6), reference-parity energy (energy.t), "
+                                    "%d GN iterations (those behind a gradient at the round-off floor are no-ops and return at "
+                                    "entry) x PCG<=256 (tol 1e-6), reference-parity energy (energy.t), "
                                     "lambda=200" % (args.config, dim, Wd, Hd, seq.D, seq.k, seq.N, cfg["gn_iters"]),
                            parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus,
                            streams="serial" if args.serial else ("fuse || graph build of frame f+1 || solve of frame f on three "
                                                                  "HIP streams, two solver plans" if args.pipeline else
                                                                  "fuse || solve on two HIP streams"),
                            pcg_iterations_last_frame=st["pcg_iters"], gn_iterations_last_frame=st["gn_iters"],
+                           gn_iterations_noop_last_frame=st["gn_noop"],
                            max_abs_translation_error_vs_ground_truth_m=round(t_err, 6)),
                roofline=dominant, roofline_other=[other],
                solve_kernels_ms_per_frame=dict(pcg=round(pcg_total_ms, 4), assemble=round(tm["assemble_ms"] / frames_timed, 4)))

@@ -63,7 +63,7 @@ class SolveParams(C.Structure):
 
 class _SolveStats(C.Structure):
     _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("gn_iters", C.c_int),
-                ("pcg_iters", C.c_int), ("max_row_nnz", C.c_int), ("reserved", C.c_int)]
+                ("pcg_iters", C.c_int), ("max_row_nnz", C.c_int), ("gn_noop", C.c_int)]
 
 
 class _SolveTiming(C.Structure):
@@ -433,7 +433,7 @@ class Solver:
         st = _SolveStats()
         _check(load().dfa_solver_get_stats(self._h, C.byref(st), _stream()))
         return dict(initial_cost=st.initial_cost, final_cost=st.final_cost, gn_iters=st.gn_iters,
-                    pcg_iters=st.pcg_iters, max_row_nnz=st.max_row_nnz)
+                    pcg_iters=st.pcg_iters, max_row_nnz=st.max_row_nnz, gn_noop=st.gn_noop)
 
 
 # ------------------------------------------------------------------------ north-star solver seam

@@ -142,7 +142,8 @@ struct dfa_solver {
     size_t ev_used;
     int timed_solves = 0;
     long long* iters_total = nullptr;  // device: PCG iterations of all solves since enable_timing(1)
-    int* host_flag = nullptr;        // pinned: stop flag of the many-workgroup PCG, read back between launch chunks
+    int* host_flag = nullptr;        // pinned int[2]: stop flag of the many-workgroup PCG and the plan's converged flag,
+                                     // read back between launch chunks
 };
 
 struct dfa_solver6 {
@@ -572,7 +573,7 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
     if (rc == DFA_OK) rc = plan_alloc(s, &s->state, 1);
     if (rc == DFA_OK) rc = plan_alloc(s, &s->iters_total, 1);
     if (rc == DFA_OK && hipMemset(s->iters_total, 0, sizeof(long long)) != hipSuccess) rc = DFA_ERR_HIP;
-    if (rc == DFA_OK && hipHostMalloc((void**)&s->host_flag, sizeof(int), hipHostMallocDefault) != hipSuccess) s->host_flag = nullptr;
+    if (rc == DFA_OK && hipHostMalloc((void**)&s->host_flag, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) s->host_flag = nullptr;
     if (rc == DFA_OK) rc = plan_alloc(s, &s->cost_partials, (R + 255) / 256 + 1);
     if (rc == DFA_OK) rc = plan_alloc(s, &s->ticket, 64);
     if (rc == DFA_OK && hipMemset(s->ticket, 0, 64 * sizeof(unsigned int)) != hipSuccess)
@@ -640,11 +641,17 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
     const float w_reg_f   = (float)w_reg;
     const float w_reg_sq  = w_reg_f * w_reg_f;
     if (s->timing) s->timed_solves += 1;
+    if (s->host_flag) s->host_flag[0] = s->host_flag[1] = 0;
+    int not_launched = 0;  // iterations after the host has seen the converged flag (many-workgroup path only)
     for (int outer = 0; outer < p->num_iter; ++outer) {
         // preNonlinearSolve (opt_solver.cpp:135-140): the Huber weights are only observable after
         // the solve, so they are evaluated for the last outer iteration alone
         if (outer == p->num_iter - 1) HIP_TRY(dfa::solve_huber(v, p->psi_reg, st));
         for (int gn = 0; gn < p->nonlinear_iter; ++gn) {
+            if (s->host_flag && s->host_flag[1]) {  // t can no longer change: every further iteration is a no-op
+                ++not_launched;
+                continue;
+            }
             HIP_TRY(dfa::solve_linearise(v, s->state, s->cost_partials, s->ticket, gn == 0, gn == 0 ? 0 : 1,
                                          p->gn_tol, p->tukey_offset, p->psi_data, w_reg_sq, st));
             int ev = s->timing ? timing_begin(s, st) : -1;
@@ -657,6 +664,7 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
             if (ev >= 0) s->ev_pcg.push_back(ev);
         }
     }
+    if (not_launched) HIP_TRY(dfa::solve_count_noop(s->state, not_launched, st));
     // final cost at the solved t; weights re-evaluated only if no iteration ever did
     const bool no_weights = p->num_iter == 0 || p->nonlinear_iter == 0;
     if (p->num_iter == 0) HIP_TRY(dfa::solve_huber(v, p->psi_reg, st));
@@ -693,7 +701,7 @@ int dfa_solver_get_stats(dfa_solver* s, dfa_solve_stats* host_out, dfa_stream_t 
     host_out->gn_iters     = h.gn_iters;
     host_out->pcg_iters    = h.pcg_iters;
     host_out->max_row_nnz  = h.max_row_nnz;
-    host_out->reserved     = 0;
+    host_out->gn_noop      = h.gn_noop;
     if (getenv("DFA_PCG_PROFILE_PRINT"))
         fprintf(stderr, "pcg phase cycles: spmv %lld  red_pAp %lld  update %lld  red_rz %lld  p_update+barrier %lld  loop %lld  (iters %d)\n",
                 h.prof[0], h.prof[1], h.prof[2], h.prof[3], h.prof[4], h.prof[5], h.pcg_iters);

@@ -199,6 +199,9 @@ __global__ __launch_bounds__(256) void linearise_kernel(SolveView s, SolveState*
                                                         LineariseArgs a) {
     __shared__ double wsum[4];
     __shared__ int is_last;
+    // after convergence t no longer changes: weights, residual records and cost of this linearisation exist already
+    // (mode 2, the solve's closing evaluation, always runs)
+    if (a.mode != 2 && st->converged) return;
     const size_t R = (size_t)s.N + (size_t)s.D * s.k;
     double c       = 0.0;
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (size_t)gridDim.x * blockDim.x) {
@@ -272,6 +275,9 @@ __global__ __launch_bounds__(256) void linearise_kernel(SolveView s, SolveState*
             st->done = 1;
         st->cost       = cost;
         st->final_cost = cost;
+        // robust weights evaluated at THIS t: a gradient at the floor now means the whole solve has converged (with
+        // stale weights it only ends the current outer iteration: the next one re-weights at the moved t)
+        if (a.mode != 2) st->weights_fresh = a.update_weights;
     }
 }
 
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
     __shared__ float gpart[4][3];
     __shared__ int wave_cnt[4];
     __shared__ int ovf;
-    if (st->done) return;
+    if (st->done || st->converged) return;
     const int a    = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #ifdef DFA_PCG_PROFILE
@@ -555,6 +561,10 @@ __global__ __launch_bounds__(NT) void pcg_kernel(SolveView s, SolveState* __rest
     if (FALLBACK_ONLY && !st->pcg_fallback) return;  // the register-resident kernel handled it
     const int tid = threadIdx.x;
     const int D   = s.D;
+    if (st->converged) {  // no-op iteration (see SolveState::converged)
+        if (tid == 0) st->gn_iters += 1, st->gn_noop += 1;
+        return;
+    }
 
     // ---- rows sorted by length (descending): rank -> row in s.pk_perm
     for (int i = tid; i < 260; i += NT) hist[i] = 0;
@@ -718,6 +728,7 @@ __global__ __launch_bounds__(NT) void pcg_kernel(SolveView s, SolveState* __rest
         if (st->grad_first == 0.0) st->grad_first = rz0;
         st->pcg_iters += it;
         st->gn_iters += 1;
+        if (skip && st->weights_fresh) st->converged = 1;
     }
 }
 
@@ -757,6 +768,10 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
     int* perm       = hist + 260;         // D row ids, longest row first
     if (st->done) return;
     const int tid = threadIdx.x;
+    if (st->converged) {  // no-op iteration (see SolveState::converged); booked once, by whoever solves this plan
+        if (tid == 0 && blockIdx.x == 0 && !st->pcg_fallback) st->gn_iters += 1, st->gn_noop += 1;
+        return;
+    }
     constexpr int R = 2 * P;  // rows per thread
 
     // ---- rows sorted by length (descending), counting sort in LDS
@@ -1107,6 +1122,7 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
             if (st->grad_first == 0.0) st->grad_first = (double)rz0;
             st->pcg_iters += it;
             st->gn_iters += 1;
+            if (skip && st->weights_fresh) st->converged = 1;
         } else {
             // iterations of this launch = those of its slowest coordinate; the last workgroup to arrive books them
             atomicMax(&st->split_iters, it);
@@ -1117,6 +1133,7 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
                 st->split_ticket = 0u;
                 if (st->grad_first == 0.0) st->grad_first = (double)rz0;
                 st->gn_iters += 1;
+                if (skip && st->weights_fresh) st->converged = 1;  // the same decision in all three workgroups (joint (r0, z0))
             }
         }
     }
@@ -1222,7 +1239,10 @@ __device__ __forceinline__ float sum_partials_mb(const float* __restrict__ part,
 __global__ __launch_bounds__(256) void pcg_mb_init_kernel(SolveView s, SolveState* __restrict__ st) {
     __shared__ float sh[4];
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a == 0) st->mb_done = st->done ? 1 : 0, st->mb_skip = st->done ? 1 : 0, st->mb_iters = 0, st->mb_rz0 = 0.f;
+    if (a == 0) {
+        st->mb_done = st->done || st->converged ? 1 : 0, st->mb_skip = st->done ? 1 : 0, st->mb_iters = 0, st->mb_rz0 = 0.f;
+        if (st->converged) st->gn_noop += 1;  // (the finish kernel books the iteration itself)
+    }
     float rz = 0.f;
     if (a < s.D) {
         const float d    = s.diag[a];
@@ -1254,8 +1274,12 @@ __global__ __launch_bounds__(256) void pcg_mb_matvec_kernel(SolveView s, SolveSt
     float beta = 0.f;
     bool stop  = !(rz_cur > 0.f);
     if (it == 0) {
-        stop = stop || (st->grad_first > 0.0 && (double)rz_cur <= (double)floor_ * st->grad_first);  // nothing left to solve
-        if (blockIdx.x == 0 && threadIdx.x == 0) st->mb_rz0 = rz_cur;
+        const bool at_floor = st->grad_first > 0.0 && (double)rz_cur <= (double)floor_ * st->grad_first;
+        stop                = stop || at_floor;  // nothing left to solve
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            st->mb_rz0 = rz_cur;
+            if (at_floor && st->weights_fresh) st->converged = 1;
+        }
     } else {
         const float rz_prev = sum_partials_mb(s.mb_gpart[(it + 1) & 1], nbu);
         beta                = rz_cur / rz_prev;
@@ -1365,7 +1389,8 @@ static hipError_t launch_mb_pcg(const SolveView& s, SolveState* state, int max_i
         if (host_flag && it < max_iter) {
             // one more matvec launch evaluates the stopping rule on the last update's residual
             pcg_mb_matvec_kernel<<<nb, 256, 0, st>>>(s, state, it, pcg_tol);
-            hipError_t e = hipMemcpyAsync(host_flag, &state->mb_done, sizeof(int), hipMemcpyDeviceToHost, st);
+            // mb_done and, directly behind it, converged (the caller stops launching Gauss-Newton iterations on it)
+            hipError_t e = hipMemcpyAsync(host_flag, &state->mb_done, 2 * sizeof(int), hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) return e;
             if (*host_flag) break;
@@ -1458,6 +1483,12 @@ hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float 
     const hipError_t e = route_pcg(s, state, max_iter, pcg_tol, host_flag, main_done, st);
     if (main_done) (void)hipEventRecord(main_done, st);  // paths without a fallback launch
     return e;
+}
+
+__global__ void count_noop_kernel(SolveState* __restrict__ st, int n) { st->gn_iters += n, st->gn_noop += n; }
+hipError_t solve_count_noop(SolveState* state, int n, hipStream_t st) {
+    count_noop_kernel<<<1, 1, 0, st>>>(state, n);
+    return hipGetLastError();
 }
 
 hipError_t solve_writeback(const SolveView& s, const SolveState* state, long long* iters_total, hipStream_t st) {

@@ -21,7 +21,14 @@ struct SolveState {
     int split_iters;    // per-coordinate PCG: most iterations any coordinate took in the launch in flight
     unsigned int split_ticket;  // ... and how many of its three workgroups have finished
     // multi-workgroup PCG: flags and scalars carried from one launch to the next
-    int mb_done, mb_skip, mb_iters;
+    int mb_done;
+    int converged;  // sticky for the rest of the solve: the gradient of a linearisation with freshly evaluated robust
+                    // weights was at the floor.  t can no longer change (re-weighting at the same t gives the same
+                    // system), so every later Gauss-Newton iteration is a no-op and its kernels return at entry;
+                    // directly behind mb_done: the many-workgroup path reads both back with one copy
+    int mb_skip, mb_iters;
+    int weights_fresh;  // the last linearisation re-evaluated the robust weights (at the t it linearised about)
+    int gn_noop;    // Gauss-Newton iterations that returned at entry this way (counted in gn_iters too)
     float mb_rz0, mb_gamma_prev[2], mb_alpha_prev[2];
     long long prof[8];  // DFA_PCG_PROFILE builds: shader cycles per PCG phase (thread 0)
 };
@@ -85,8 +92,10 @@ __host__ __device__ inline int solve_mb_blocks(int D) { return (D + 15) / 16; }
 // host_flag: pinned host word (may be null); with it, plans above 2048 nodes synchronise with the stream once per
 // chunk of PCG launches to stop launching after convergence
 // `main_done` (optional) is recorded behind the solving kernel(s), before the fallback launch that usually returns at once
-hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag, hipEvent_t main_done,
+hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag /* pinned int[2] or null */, hipEvent_t main_done,
                      hipStream_t st);
+// books n Gauss-Newton iterations that the host did not launch because the plan had converged (SolveState::converged)
+hipError_t solve_count_noop(SolveState* state, int n, hipStream_t st);
 // also adds the solve's PCG iterations to *iters_total (optional, device)
 hipError_t solve_writeback(const SolveView& s, const SolveState* state, long long* iters_total, hipStream_t st);
 

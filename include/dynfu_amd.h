@@ -222,7 +222,8 @@ typedef struct {
     int gn_iters;  /* Gauss-Newton iterations executed in total */
     int pcg_iters; /* PCG iterations executed in total */
     int max_row_nnz; /* widest row of the assembled normal matrix (blocks) */
-    int reserved;
+    int gn_noop;   /* of gn_iters: iterations behind one whose gradient was at the round-off floor.  The unknown can
+                      no longer change, so their kernels return at entry (same result as running them) */
 } dfa_solve_stats;
 
 /* Plan for up to max_D nodes / max_N vertices with k neighbours (1..16). */
