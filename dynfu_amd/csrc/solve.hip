@@ -774,6 +774,33 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
     }
     constexpr int R = 2 * P;  // rows per thread
 
+    // ---- (r0, z0) of the joint system first, rows in natural order: it scales both stopping rules, and a gradient at
+    // the round-off floor ends the launch here, before the sort and the 25 us of loading the matrix into registers
+    float rzj_loc = 0.f;
+#pragma unroll
+    for (int h = 0; h < R; ++h) {
+        const int row = tid + NT * h;
+        if (row < D) {
+            const float d    = s.diag[row];
+            const float minv = d > FLT_EPSILON ? 1.0f / d : 1.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float g = s.g[3 * row + c];
+                rzj_loc       = fmaf(g, minv * g, rzj_loc);
+            }
+        }
+    }
+    const float rz0 = block_sum_f<NT / 64>(rzj_loc, red1);
+    const bool skip = st->grad_first > 0.0 && (double)rz0 <= 1e-12 * st->grad_first;
+    if (skip) {  // the same decision in every workgroup; the first one books the (empty) iteration
+        if (tid == 0 && blockIdx.x == 0) {
+            st->gn_iters += 1;
+            st->pcg_fallback = 0;  // nothing left for the streaming kernel launched behind this one
+            if (st->weights_fresh) st->converged = 1;
+        }
+        return;
+    }
+
     // ---- rows sorted by length (descending), counting sort in LDS
     for (int i = tid; i < 260; i += NT) hist[i] = 0;
     __syncthreads();
@@ -867,7 +894,6 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
     if (unfit) return;
 
     float xA[P][NC], rA_[P][NC], pA[P][NC], xB[P][NC], rB_[P][NC], pB[P][NC], minvA[P], minvB[P];
-    float rzj_loc = 0.f;
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         minvA[j] = minvB[j] = 0.f;
@@ -880,16 +906,13 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
             minvB[j]      = d > FLT_EPSILON ? 1.0f / d : 1.0f;
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {  // (r0, z0) of the joint system, summed in the same order by every variant
+        for (int cc = 0; cc < NC; ++cc) {
+            const int c    = c0 + cc;
             const float ga = rowA[j] >= 0 ? s.g[3 * rowA[j] + c] : 0.f;
             const float gb = rowB[j] >= 0 ? s.g[3 * rowB[j] + c] : 0.f;
-            rzj_loc        = fmaf(ga, minvA[j] * ga, fmaf(gb, minvB[j] * gb, rzj_loc));
-            if (NC == 3 || c == c0) {
-                const int cc = NC == 3 ? c : 0;
-                xA[j][cc] = xB[j][cc] = 0.f;
-                rA_[j][cc] = ga, rB_[j][cc] = gb;
-                pA[j][cc] = minvA[j] * ga, pB[j][cc] = minvB[j] * gb;
-            }
+            xA[j][cc] = xB[j][cc] = 0.f;
+            rA_[j][cc] = ga, rB_[j][cc] = gb;
+            pA[j][cc] = minvA[j] * ga, pB[j][cc] = minvB[j] * gb;
         }
         if (NC == 3) {
             if (rowA[j] >= 0) p_s[rowA[j]] = make_float4(pA[j][0], pA[j][1], pA[j][NC - 1], 0.f);
@@ -899,15 +922,14 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
             if (rowB[j] >= 0) p_s1[rowB[j]] = pB[j][0];
         }
     }
-    const float rz0 = block_sum_f<NT / 64>(rzj_loc, red1);  // joint (r0, z0): scale of both stopping rules
-    float rz        = rz0;                                  // (NC = 1 forms its own (r, z) inside the loop)
+    __syncthreads();  // p in LDS
+    float rz = rz0;   // (NC = 1 forms its own (r, z) inside the loop)
     const float floor_ = 1e-12f;
     const float tol2   = pcg_tol * pcg_tol > floor_ ? pcg_tol * pcg_tol : floor_;
     // NC = 1: this coordinate's share of the joint target; a coordinate already below it does no iteration
     const float target = NC == 3 ? tol2 * rz0 : tol2 * rz0 * (1.0f / 3.0f);
     const float rz_min = NC == 3 ? 0.f : target;
     int it             = 0;
-    const bool skip    = st->grad_first > 0.0 && (double)rz0 <= 1e-12 * st->grad_first;
     const char* pbase   = (const char*)p_s;
 #ifdef DFA_PCG_PROFILE
     long long pc_[6] = {0, 0, 0, 0, 0, 0};
@@ -996,7 +1018,7 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
             }
         }
     };
-    if (!skip && NC == 3) {
+    if (NC == 3) {
         // textbook PCG: two reductions and the publication of p = three barriers per iteration
         while (it < max_iter) {
             if (!(rz > rz_min)) break;
@@ -1043,7 +1065,7 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
             PROF_MARK(4);
         }
     }
-    if (!skip && NC == 1) {
+    if (NC == 1) {
         // Chronopoulos-Gear form of the same recurrence: the matrix multiplies u = M^-1 r, both inner products
         // (r, u) and (A u, u) come out of ONE reduction, and s = A p follows by recurrence — two barriers per
         // iteration instead of three (a reduction costs ~550 clocks of a ~4 700-clock iteration here).
@@ -1122,7 +1144,6 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
             if (st->grad_first == 0.0) st->grad_first = (double)rz0;
             st->pcg_iters += it;
             st->gn_iters += 1;
-            if (skip && st->weights_fresh) st->converged = 1;
         } else {
             // iterations of this launch = those of its slowest coordinate; the last workgroup to arrive books them
             atomicMax(&st->split_iters, it);
@@ -1133,7 +1154,6 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
                 st->split_ticket = 0u;
                 if (st->grad_first == 0.0) st->grad_first = (double)rz0;
                 st->gn_iters += 1;
-                if (skip && st->weights_fresh) st->converged = 1;  // the same decision in all three workgroups (joint (r0, z0))
             }
         }
     }
