@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4", "T0", "T1"])
+    ap.add_argument("--fuse-first", action="store_true",
+                    help="launch the TSDF sweep at the start of the frame (A/B; default: behind the graph build)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded CPU sample")
     ap.add_argument("--serial", action="store_true", help="run fuse and solve on one stream (A/B of the overlap)")
@@ -109,9 +111,13 @@ class Sequence:
             e1.record()
             timed_events.append((e0, e1))
 
-    def solve(self, f):
-        A = self.A
+    def build_graph(self, f):
         self.solver.set_problem(self.nodes, self.node_dq, self.node_w, self.verts, self.live[f % self.n_frames])
+
+    def solve(self, f, graph_built=False):
+        A = self.A
+        if not graph_built:
+            self.build_graph(f)
         self.solver.solve(self.params)
         # post-solve warpToLive of the canonical frame, through the plan's k-NN graph (same output as the stand-alone
         # dfa_warp_to_live, which would search the 262 144 x 2 048 neighbours a second time)
@@ -124,13 +130,24 @@ class Sequence:
             self.fuse(f, timed_events)
             self.solve(f)
             return
-        self.s_fuse.wait_stream(cur)
-        with torch.cuda.stream(self.s_fuse):
-            self.fuse(f, timed_events)
-        if getattr(self, "pipelined", False):
-            self.solve_pipelined(f)
+        if getattr(self, "pipelined", False) or getattr(self, "fuse_first", False):
+            self.s_fuse.wait_stream(cur)
+            with torch.cuda.stream(self.s_fuse):
+                self.fuse(f, timed_events)
+            if getattr(self, "pipelined", False):
+                self.solve_pipelined(f)
+            else:
+                self.solve(f)
         else:
-            self.solve(f)
+            # The graph build (grid, k-NN, transposition: short kernels that fill the chip) runs alone; the volume
+            # sweep (all CUs for 0.27 ms) starts behind it and overlaps the Gauss-Newton iterations, most of whose
+            # time is the PCG on three CUs.  Same work per frame as launching both at once (--fuse-first), where the
+            # sweep slows the graph build's kernels by ~2x and the chip idles during the PCG.
+            self.build_graph(f)
+            self.s_fuse.wait_stream(cur)
+            with torch.cuda.stream(self.s_fuse):
+                self.fuse(f, timed_events)
+            self.solve(f, graph_built=True)
         cur.wait_stream(self.s_fuse)
 
     # ---- software pipeline across frames (--pipeline): two plans; the graphs of frame f+1 (a function of the node
@@ -188,10 +205,14 @@ class Sequence6(Sequence):
                                      **self.synth.SOLVER)
         self.gn_total = outer * (gn // outer)
 
-    def solve(self, f):
-        A = self.A
-        P, Nm = A.compute_points_normals(self.depth[f % self.n_frames], *self.intr)
+    def build_graph(self, f):
         self.solver.set_problem(self.nodes, self.node_dq, self.node_w, self.verts, self.normals)
+
+    def solve(self, f, graph_built=False):
+        A = self.A
+        if not graph_built:
+            self.build_graph(f)
+        P, Nm = A.compute_points_normals(self.depth[f % self.n_frames], *self.intr)
         self.solver.solve(P, Nm, *self.intr, self.params)
         self.warped, self.warped_n = self.solver.warp()
 
@@ -233,6 +254,7 @@ def main_northstar(args, torch, replicas, rank, world, device):
     n_gpus = world
     lin = args.linear_iter or 64
     seq = Sequence6(args.config, device, lin)
+    seq.fuse_first = args.fuse_first
     cfg = seq.cfg
     K, Wm = args.steps, args.warmup
     for f in range(Wm):
@@ -293,7 +315,8 @@ def main_northstar(args, torch, replicas, rank, world, device):
                                     "point-to-plane / ARAP energy, lambda=200"
                                     % (args.config, dim, Wd, Hd, seq.D, seq.k, seq.N, seq.gn_total, lin),
                            parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus,
-                           streams="serial" if args.serial else "fuse || solve on two HIP streams",
+                           streams="serial" if args.serial else ("fuse || graph build + solve on two HIP streams" if args.fuse_first else
+                                                                 "graph build, then fuse || solve on two HIP streams"),
                            pcg_iterations_last_frame=st["pcg_iters"], gn_iterations_last_frame=st["gn_iters"],
                            valid_rows_last_frame=st["valid_last"], cost_first=st["initial_cost"], cost_last=st["final_cost"]),
                roofline=dominant, roofline_other=other)
@@ -367,6 +390,7 @@ def main():
     if args.mode == "northstar":
         return main_northstar(args, torch, replicas, rank, world, device)
     seq = Sequence(args.config, device)
+    seq.fuse_first = args.fuse_first
     if args.pipeline and not args.serial:
         seq.enable_pipeline()
     cfg = seq.cfg
@@ -460,7 +484,8 @@ def main():
                            parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus,
                            streams="serial" if args.serial else ("fuse || graph build of frame f+1 || solve of frame f on three "
                                                                  "HIP streams, two solver plans" if args.pipeline else
-                                                                 "fuse || solve on two HIP streams"),
+                                                                 ("fuse || graph build + solve on two HIP streams" if args.fuse_first
+                                                                  else "graph build, then fuse || solve on two HIP streams")),
                            pcg_iterations_last_frame=st["pcg_iters"], gn_iterations_last_frame=st["gn_iters"],
                            gn_iterations_noop_last_frame=st["gn_noop"],
                            max_abs_translation_error_vs_ground_truth_m=round(t_err, 6)),
