@@ -428,6 +428,18 @@ def main():
         replicas.shutdown()
         return
 
+    # ---- per-frame latency (SURVEY.md §8d asks for median and p95): a separate pass OUTSIDE the timed region, every
+    # frame bracketed by two events and synchronised, so that a frame cannot hide behind the launches of the next
+    lat = []
+    for f in range(min(K, 50)):
+        e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+        e0.record()
+        seq.frame(Wm + f, args.serial)
+        e1.record()
+        e1.synchronize()
+        lat.append(e0.elapsed_time(e1))
+    lat.sort()
+
     # ---- roofline of the kernels measured live with HIP events on their launch streams
     dim, Wd, Hd = cfg["dim"], cfg["width"], cfg["height"]
     V = dim ** 3
@@ -489,6 +501,8 @@ def main():
                            pcg_iterations_last_frame=st["pcg_iters"], gn_iterations_last_frame=st["gn_iters"],
                            gn_iterations_noop_last_frame=st["gn_noop"],
                            max_abs_translation_error_vs_ground_truth_m=round(t_err, 6)),
+               frame_latency_ms=dict(median=round(lat[len(lat) // 2], 4), p95=round(lat[min(len(lat) - 1, int(0.95 * len(lat)))], 4),
+                                     frames=len(lat), note="each frame synchronised, measured after the timed region"),
                roofline=dominant, roofline_other=[other],
                solve_kernels_ms_per_frame=dict(pcg=round(pcg_total_ms, 4), assemble=round(tm["assemble_ms"] / frames_timed, 4)))
     if not args.no_cpu_baseline and world == 1:

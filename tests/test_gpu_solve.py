@@ -334,3 +334,29 @@ def test_iterations_behind_a_converged_one_are_no_ops(A, monkeypatch, variant):
         assert np.abs(out[4][0] - out[12][0]).max() < 1e-6
         np.testing.assert_allclose(out[4][1]["final_cost"], st12["final_cost"], rtol=1e-5)
     assert np.abs(out[12][0] - t_true).max() < 1e-4  # the regulariser (lambda = 200) moves the optimum by 5e-5
+
+
+def test_solver_timing_accumulates_pauses_and_resumes(A):
+    """dfa_solver_enable_timing: 1 starts a measurement, 0 pauses it, 2 resumes; dfa_solver_get_timing returns the
+    sums over the measured solves (bench.py brackets every 8th frame this way)"""
+    cfg, c, verts, live, t_true = _problem("T0")
+    k = cfg["k"]
+    s = A.Solver(cfg["D"], len(verts), k)
+    args = (dev(c["node_pos"]), dev(c["node_dq"]), dev(c["node_w"]), dev(verts), dev(live))
+    prm = _params(A, num_iter=2, nonlinear_iter=1, linear_iter=64, lambda_=200.0)
+    per_solve = []
+    for mode in (1, 0, 2, 2, 0):
+        s.enable_timing(mode)
+        s.set_problem(*args)
+        s.solve(prm)
+        per_solve.append(s.stats()["pcg_iters"])
+    tm = s.timing()
+    assert tm["solves"] == 3 and tm["pcg_launches"] == 3 * 2 and tm["assemble_launches"] == 3 * 2
+    assert tm["pcg_iters"] == per_solve[0] + per_solve[2] + per_solve[3]
+    assert tm["pcg_ms"] > 0 and tm["assemble_ms"] > 0 and tm["matrix_nnz"] > 0
+    s.enable_timing(1)  # a new measurement forgets the old one
+    s.set_problem(*args)
+    s.solve(prm)
+    tm = s.timing()
+    assert tm["solves"] == 1 and tm["pcg_launches"] == 2
+    s.close()
