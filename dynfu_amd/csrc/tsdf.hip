@@ -386,11 +386,17 @@ hipError_t launch_tsdf_clear(uint32_t* vol, int X, int Y, int Z, hipStream_t s) 
 
 // z-chunk heuristic: enough workgroups to fill 256 CUs several times over, while keeping the
 // replayed-additions prologue (z0 adds per chunk) a small fraction of a chunk's work.
-static int pick_zchunk(int X, int Y, int Z, int vx) {
+static int pick_zchunk(int X, int Y, int Z, int vx, bool fused_clear) {
     const long columns_wg = (long)((X + 64 * vx - 1) / (64 * vx)) * ((Y + 3) / 4);
     int zchunk            = Z;
-    // want >= 8 workgroups per CU (2048 in total), chunks no shorter than 32 slices
-    while (columns_wg * ((Z + zchunk - 1) / zchunk) < 2048 && zchunk > 32) zchunk /= 2;
+    // want >= 8 workgroups per CU (2048 in total), chunks no shorter than 32 slices.  The fused sweep (no loads to
+    // hide) is as fast with 4 per CU (0.288 vs 0.292 ms at 512^3) and then leaves wave slots to the kernels of other
+    // streams: the per-frame sweep runs beside the solve, whose short full-chip kernels otherwise queue behind 2048
+    // resident workgroups (C2 frame 0.986 -> 0.956 ms, tools/ab_zchunk.sh)
+    const long want = fused_clear ? 1024 : 2048;
+    while (columns_wg * ((Z + zchunk - 1) / zchunk) < want && zchunk > 32) zchunk /= 2;
+    // (1024^3 has 1024 columns of workgroups: unsplit, the sweep runs at half occupancy — 1.74 vs 1.49 ms)
+    if (zchunk == Z && columns_wg < 2048 && Z >= 64) zchunk = Z / 2;
     zchunk = (zchunk + 3) & ~3;
     if (const char* e = getenv("DFA_TSDF_ZCHUNK")) {
         int v = atoi(e);
@@ -415,7 +421,7 @@ hipError_t launch_tsdf_integrate(bool fused_clear, const uint16_t* dists, int di
     a.fx = fx, a.fy = fy, a.cx = cx, a.cy = cy;
     const bool vec4 = (X % 4 == 0) && (((uintptr_t)vol & 15) == 0);
     const int vx    = vec4 ? 4 : 1;
-    a.zchunk        = pick_zchunk(X, Y, Z, vx);
+    a.zchunk        = pick_zchunk(X, Y, Z, vx, fused_clear);
     dim3 block(64, 4), grid((X + 64 * vx - 1) / (64 * vx), (Y + 3) / 4, (Z + a.zchunk - 1) / a.zchunk);
     if (vec4) {
         if (fused_clear) integrate_kernel<true, 4><<<grid, block, 0, s>>>(a);
