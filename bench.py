@@ -33,11 +33,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 for wide reads + WRITE_SIZE, corrected as
 # MI355X_MICROARCH.md prescribes) — profiles/r01_pmc_tsdf.md.  Collected offline: PMC needs its own runs.
 TIMING_SAMPLE = 8  # every 8th timed frame carries the hipEvent brackets of the per-kernel report
-PMC_TRAFFIC_BYTES = {("C2", "fused_integrate"): 0.5439e9, ("C3", "fused_integrate"): 0.5439e9,
+PMC_TRAFFIC_BYTES = {("C2", "fused_integrate"): 0.5411e9, ("C3", "fused_integrate"): 0.5411e9,
                      # profiles/r01_pmc_northstar.md (FETCH x2 + WRITE per dispatch)
                      ("C3", "s6_assemble"): 0.411e9, ("C3", "s6_pcg_step"): 0.0242e9,
-                     # profiles/r01_pmc_solve.md: (540.3 + 464.8) KiB per pcg_paired_kernel<1024,1,32,1> launch
-                     ("C2", "pcg"): 1005.1 * 1024}
+                     # profiles/r01_pmc_solve.md: (331.4 + 268.4) KiB per pcg_paired_kernel<1024,1,32,1> launch, mean over
+                     # the five launches of a frame (those that return at entry included)
+                     ("C2", "pcg"): 599.8 * 1024}
 
 
 def parse():
@@ -285,7 +286,7 @@ def main_northstar(args, torch, replicas, rank, world, device):
     asm_bytes = seq.N * k * (32 + 4 * k + 8 + k) + nblk * (36 * 4 + 4)
     pcg_bytes_it = nblk * (36 * 4 + 4 + 3 * 24) + 12 * 24.0 * seq.D
     asm_ms, pcg_ms = tm["assemble_ms"] / gn, tm["pcg_ms"] / max(1, its + gn)
-    fuse_entry = dict(kernel="integrate_kernel<FUSED_CLEAR,4> (clear+integrate %d^3)" % dim, bound="hbm",
+    fuse_entry = dict(kernel="integrate_kernel<FUSED_CLEAR,1> (clear+integrate %d^3)" % dim, bound="hbm",
                       achieved=round(fuse_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(fuse_gbs / HBM_PEAK_GBS, 4),
                       traffic=PMC_TRAFFIC_BYTES.get((args.config, "fused_integrate")), avg_launch_ms=round(fuse_ms, 4),
                       launches_per_frame=1, algorithmic_bytes_per_launch=fuse_bytes)
@@ -457,7 +458,7 @@ def main():
     pcg_total_ms = tm["pcg_ms"] / frames_timed        # per frame
     pcg_gbs = pcg_bytes / (pcg_total_ms * 1e-3) / 1e9 if pcg_total_ms > 0 else float("nan")
     launches_pf = tm["pcg_launches"] / frames_timed
-    fuse_entry = dict(kernel="integrate_kernel<FUSED_CLEAR,4> (clear+integrate %d^3)" % dim, bound="hbm",
+    fuse_entry = dict(kernel="integrate_kernel<FUSED_CLEAR,1> (clear+integrate %d^3)" % dim, bound="hbm",
                       achieved=round(fuse_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(fuse_gbs / HBM_PEAK_GBS, 4),
                       traffic=PMC_TRAFFIC_BYTES.get((args.config, "fused_integrate")),
                       traffic_source="profiles/r01_pmc_tsdf.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",

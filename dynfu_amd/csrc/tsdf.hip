@@ -389,14 +389,13 @@ hipError_t launch_tsdf_clear(uint32_t* vol, int X, int Y, int Z, hipStream_t s) 
 static int pick_zchunk(int X, int Y, int Z, int vx, bool fused_clear) {
     const long columns_wg = (long)((X + 64 * vx - 1) / (64 * vx)) * ((Y + 3) / 4);
     int zchunk            = Z;
-    // want >= 8 workgroups per CU (2048 in total), chunks no shorter than 32 slices.  The fused sweep (no loads to
-    // hide) is as fast with 4 per CU (0.288 vs 0.292 ms at 512^3) and then leaves wave slots to the kernels of other
-    // streams: the per-frame sweep runs beside the solve, whose short full-chip kernels otherwise queue behind 2048
-    // resident workgroups (C2 frame 0.986 -> 0.956 ms, tools/ab_zchunk.sh)
-    const long want = fused_clear ? 1024 : 2048;
+    // Chunks no shorter than 32 slices.  Measured with one voxel per lane (tools/tsdf_kernels.py): the read+write sweep
+    // wants >= 16 workgroups per CU (512^3: 0.265 ms with 4 chunks, 0.386 unsplit); the fused sweep has no loads to hide
+    // and is as fast with 4 per CU (512^3 unsplit 0.24 ms, 4 chunks 0.23) — and then half of the chip's wave slots stay
+    // free for the kernels of other streams: the per-frame sweep runs beside the solve, whose short full-chip kernels
+    // otherwise wait for resident sweep waves to retire (C2 frame 0.969 -> 0.957 ms, C3 4.27 -> 4.10).
+    const long want = fused_clear ? 1024 : 4096;
     while (columns_wg * ((Z + zchunk - 1) / zchunk) < want && zchunk > 32) zchunk /= 2;
-    // (1024^3 has 1024 columns of workgroups: unsplit, the sweep runs at half occupancy — 1.74 vs 1.49 ms)
-    if (zchunk == Z && columns_wg < 2048 && Z >= 64) zchunk = Z / 2;
     zchunk = (zchunk + 3) & ~3;
     if (const char* e = getenv("DFA_TSDF_ZCHUNK")) {
         int v = atoi(e);
@@ -419,7 +418,11 @@ hipError_t launch_tsdf_integrate(bool fused_clear, const uint16_t* dists, int di
     for (int i = 0; i < 9; ++i) a.vol2cam.m[i] = vol2cam[i];
     for (int i = 0; i < 3; ++i) a.vol2cam.t[i] = vol2cam[9 + i];
     a.fx = fx, a.fy = fy, a.cx = cx, a.cy = cy;
-    const bool vec4 = (X % 4 == 0) && (((uintptr_t)vol & 15) == 0);
+    // One voxel per lane.  Four consecutive voxels per lane (16-byte accesses; DFA_TSDF_VX4=1, the first design) lose
+    // everywhere: a lane then walks its four voxels one after the other, each with its own early exits, and a wave
+    // waits for its slowest lane four times per slice (fused sweep 0.289 -> 0.229 ms at 512^3, 1.49 -> 1.38 ms at
+    // 1024^3, 0.061 -> 0.044 ms at 256^3); a wave's 256-byte stores are wide enough for HBM.
+    const bool vec4 = getenv("DFA_TSDF_VX4") && (X % 4 == 0) && (((uintptr_t)vol & 15) == 0);
     const int vx    = vec4 ? 4 : 1;
     a.zchunk        = pick_zchunk(X, Y, Z, vx, fused_clear);
     dim3 block(64, 4), grid((X + 64 * vx - 1) / (64 * vx), (Y + 3) / 4, (Z + a.zchunk - 1) / a.zchunk);
