@@ -63,6 +63,28 @@ struct IntegrateArgs {
     int zchunk;
 };
 
+// x / z and y / z, correctly rounded.  hipcc expands an fp32 division into
+//   s0 = div_scale(den), s1 = div_scale(num), r = rcp(s0), e = fma(-s0, r, 1), r1 = fma(e, r, r), q = s1 * r1,
+//   e2 = fma(-s0, q, s1), q1 = fma(e2, r1, q), e3 = fma(-s0, q1, s1), div_fixup(div_fmas(e3, r1, q1))
+// (11 instructions; div_scale / div_fmas / div_fixup only act on operands near the ends of the exponent range).  For
+// operands well inside the range the two quotients share everything that depends on z alone — the same instructions
+// on the same values, hence the same bits, in 13 instead of 22; anything else takes the plain divisions.
+__device__ __forceinline__ void div_xy_by_z(float x, float y, float z, float& qx, float& qy) {
+    const float big = fmaxf(fmaxf(fabsf(x), fabsf(y)), z);
+    if (big <= 1048576.f && z >= 9.5367431640625e-07f) {  // 2^20, 2^-20 (z > 0 here)
+        const float r  = __builtin_amdgcn_rcpf(z);
+        const float r1 = fmaf(fmaf(-z, r, 1.0f), r, r);
+        float q        = x * r1;
+        q              = fmaf(fmaf(-z, q, x), r1, q);
+        qx             = fmaf(fmaf(-z, q, x), r1, q);
+        q              = y * r1;
+        q              = fmaf(fmaf(-z, q, y), r1, q);
+        qy             = fmaf(fmaf(-z, q, y), r1, q);
+    } else {
+        qx = x / z, qy = y / z;
+    }
+}
+
 // One voxel of one slice (tsdf_volume.cu:65-91).  `old` is the packed voxel (0 when the clear
 // is fused); returns the packed voxel after the update and sets `changed`.
 template <bool FUSED_CLEAR>
@@ -71,8 +93,10 @@ __device__ __forceinline__ uint32_t integrate_voxel(const IntegrateArgs& a, f3 v
     // free) projection and texture fetch, the outcome is the same and NaN/inf never form.
     if (!(vc.z > 0.f)) return old;
     // Projector (device.hpp:40-45): correctly rounded divisions stand in for __fdividef
-    const float coox = fmaf(a.fx, vc.x / vc.z, a.cx);
-    const float cooy = fmaf(a.fy, vc.y / vc.z, a.cy);
+    float qx, qy;
+    div_xy_by_z(vc.x, vc.y, vc.z, qx, qy);
+    const float coox = fmaf(a.fx, qx, a.cx);
+    const float cooy = fmaf(a.fy, qy, a.cy);
     if (!(coox >= 0.f && cooy >= 0.f && coox < (float)a.cols && cooy < (float)a.rows)) return old;  // :70
     // :73 point-sampled, un-normalised texture fetch == texel (floor x, floor y); coordinates
     // are non-negative here so the truncating convert is the floor
@@ -81,7 +105,13 @@ __device__ __forceinline__ uint32_t integrate_voxel(const IntegrateArgs& a, f3 v
     const uint16_t* drow = (const uint16_t*)((const char*)a.dists + (size_t)py * a.dists_step);
     const float Dp       = half_bits_to_float(drow[px]);
     if (Dp == 0.f) return old;                      // :74
-    const float sdf = Dp - sqrtf(dot(vc, vc));      // :77
+    // Voxels far behind the surface (a third of the volume) leave before the correctly rounded square root: when
+    // |vc|^2 exceeds (Dp + trunc)^2 by more than 1e-5 relative, sqrt exceeds Dp + trunc by 5e-6 relative — two orders
+    // above the rounding of the three operations below, so the test of :79 fails for certain.
+    const float d2  = dot(vc, vc);
+    const float lim = Dp + a.trunc;
+    if (d2 > lim * lim * 1.00001f) return old;
+    const float sdf = Dp - sqrtf(d2);               // :77
     if (!(sdf >= -a.trunc)) return old;             // :79
     const float tsdf = fminf(1.f, sdf * a.trunc_inv);  // :80
     int weight_prev;
