@@ -804,6 +804,8 @@ int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
     A(bcols, D * cap);
     A(bcnt, D);
     A(eslot, N * k * k);
+    A(pair_list, N * k * k);
+    A(pair_ptr, D * (cap + 1));
     A(bvals, D * cap * 36);
     A(minv, D * 36);
     A(g, D * 6);

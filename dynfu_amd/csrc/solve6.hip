@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "dq_device.hpp"
 #include "kernels.hpp"
@@ -436,6 +437,43 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
             s.eslot[(size_t)e * k + j] = (uint8_t)sl;
         }
     }
+    // ---- the same relation by slot (s6_assemble2_kernel): a stable split of the node's (row, neighbour) pairs by
+    // slot.  Counts by LDS atomics, then wave w compacts the lists of slots 1 + w, 5 + w, ... in ascending pair
+    // order with ballots: run-to-run identical lists, hence identical sums.
+    __shared__ int pcnt[64], pstart[64];
+    if (tid < 64) pcnt[tid] = 0;
+    __syncthreads();  // also: this workgroup's eslot bytes are visible to all of its threads
+    const int pbeg = s.node_ptr[a], plen = s.node_ptr[a + 1] - pbeg, npairs = plen * k;
+    const uint8_t* es = s.eslot + (size_t)pbeg * k;
+    for (int p = tid; p < npairs; p += 256) {
+        const int sl = es[p];
+        if (sl >= 1 && sl < stored) atomicAdd(&pcnt[sl], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = pbeg * k;  // the lists of node a live in pair_list[pbeg k, (pbeg + plen) k)
+        for (int q = 1; q < stored; ++q) pstart[q] = run, run += pcnt[q];
+        pstart[stored] = run;
+        pstart[0]      = pbeg * k;
+    }
+    __syncthreads();
+    if (tid <= stored) s.pair_ptr[(size_t)a * (s.cap + 1) + tid] = pstart[tid];
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int q = 1 + wave; q < stored; q += 4) {
+            int out = pstart[q];
+            for (int base = 0; base < npairs; base += 64) {
+                const int p       = base + lane;
+                const bool match  = p < npairs && es[p] == q;
+                const uint64_t mk = __ballot(match);
+                if (match) {
+                    const int r = p / k;
+                    s.pair_list[out + __popcll(mk & ((1ull << lane) - 1ull))] = ((uint32_t)r << 4) | (uint32_t)(p - r * k);
+                }
+                out += __popcll(mk);
+            }
+        }
+    }
 }
 
 // Values of block row a.  A data row's 6-vector for neighbour j factors as f_j * M_j l (l: 8 numbers per
@@ -587,6 +625,279 @@ __global__ __launch_bounds__(256) void s6_assemble_kernel(Solve6View s, Solve6St
             if (slot == 0) {
 #pragma unroll
                 for (int p = 0; p < 8; ++p) gacc += ma[p] * g8[0][p];
+            }
+            // regularisation edges leaving a (a -> m): rows c of e = T_a g_m - g^_m with vectors (an_c at a, -e_{3+c} at m)
+            for (int q = 0; q < k; ++q) {
+                const int e = a * k + q, m = s.reg_idx[e];
+                if (m < 0 || (slot != 0 && col != m)) continue;
+                const float wt = wreg2 * s.rhub[e];
+                for (int cc = 0; cc < 3; ++cc) {
+                    const float* an = s.rvec + 18 * (size_t)e + 6 * cc;
+                    if (slot == 0) {
+                        gacc -= wt * an[my_row] * s.rres[3 * (size_t)e + cc];
+#pragma unroll
+                        for (int d = 0; d < 6; ++d) accr[d] += wt * an[my_row] * an[d];
+                    } else {
+                        accr[3 + cc] -= wt * an[my_row];
+                    }
+                }
+            }
+            // regularisation edges arriving at a (n -> a)
+            if (my_row >= 3) {
+                const int cc = my_row - 3;
+                for (int e = s.rnode_ptr[a]; e < s.rnode_ptr[a + 1]; ++e) {
+                    const unsigned entry = s.rnode_list[e];
+                    const int n          = (int)(entry / (unsigned)k);
+                    if (slot != 0 && col != n) continue;
+                    const float wt = wreg2 * s.rhub[entry];
+                    if (slot == 0) {
+                        gacc += wt * s.rres[3 * (size_t)entry + cc];
+                        accr[my_row] += wt;
+                    } else {
+                        const float* an = s.rvec + 18 * (size_t)entry + 6 * cc;
+#pragma unroll
+                        for (int d = 0; d < 6; ++d) accr[d] -= wt * an[d];
+                    }
+                }
+            }
+            if (slot == 0) {
+                accr[my_row] += damping;
+                s.g[6 * (size_t)a + my_row] = gacc;
+#pragma unroll
+                for (int d = 0; d < 6; ++d) diag[my_row * 6 + d] = accr[d];
+            }
+            float* out = s.bvals + ((size_t)a * s.cap + slot) * 36 + 6 * my_row;
+#pragma unroll
+            for (int d = 0; d < 6; ++d) out[d] = accr[d];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) inv6(diag, s.minv + 36 * (size_t)a);
+}
+
+// Second form of the assembly: the moments are accumulated in REGISTERS, slot by slot.
+//
+// The kernel above adds every row into the LDS copies of up to k slots: 4 KiB read + 4 KiB written per row and wave,
+// LDS-bandwidth-bound (0.82 ms per Gauss-Newton iteration at 4 k nodes, k = 8).  Here a wave takes ONE slot at a time and
+// walks the list of the (row, neighbour) pairs that land in it (s6_pattern_kernel, once per frame): 8 pairs per step,
+// lane (g, c) adds rho f_a f_j l_c l[0..7] of pair g to row c of the slot's moment — 8 registers, LDS is only read
+// (broadcasts of the staged rows).  After the list the 8 groups are summed with three shuffles and lanes 0..7 add the
+// moment to the slot's 8 x 8 in LDS.  Slot 0 (every row's own neighbour) is shared by the four waves.
+// Rows are staged S6_RC at a time (f_own and rho f_own precomputed, rows without association zeroed); a node with
+// more rows takes several passes, each slot's cursor continues where the pass before stopped (lists are ascending).
+template <int K, int S6_RC>
+__global__ __launch_bounds__(256) void s6_assemble2_kernel(Solve6View s, Solve6State* st, float wreg2, float damping) {
+    extern __shared__ __attribute__((aligned(16))) char s6_dyn[];
+    float4(*sl8)[2] = reinterpret_cast<float4(*)[2]>(s6_dyn);                                   // l = (lW, lD)
+    float(*sfv)[K]  = reinterpret_cast<float(*)[K]>(s6_dyn + sizeof(float4) * 2 * S6_RC);        // f_j
+    float2* sra     = reinterpret_cast<float2*>(s6_dyn + (sizeof(float4) * 2 + sizeof(float) * K) * S6_RC);  // rho f_own, rho res f_own
+    __shared__ float accS[S6_MAXSLOT][64];
+    __shared__ float part0[4][72];        // slot 0 per wave: 8 x 8 moment + g8
+    __shared__ float g8s[8];
+    __shared__ float diag[36];
+    __shared__ int cur[S6_MAXSLOT + 1];
+    const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
+    if (a == 0 && tid == 0) {  // bookkeeping of the linearisation that just finished
+        if (!st->have_first) st->initial_cost = st->cost, st->valid_first = st->valid, st->have_first = 1;
+        st->final_cost = st->cost, st->valid_last = st->valid;
+        st->gn_iters += 1;
+    }
+    const int cnt = s.bcnt[a];
+    const int beg = s.node_ptr[a], len = s.node_ptr[a + 1] - beg;
+    const int wave = tid >> 6, lane = tid & 63, grp = lane >> 3, c = lane & 7;
+    const int32_t* pptr = s.pair_ptr + (size_t)a * (s.cap + 1);
+    for (int i = tid; i < cnt * 64; i += 256) (&accS[0][0])[i] = 0.f;
+    if (tid <= cnt && tid <= S6_MAXSLOT) cur[tid] = pptr[tid];
+    float own8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // row c of the slot-0 moment, this lane's share
+    float ownG    = 0.f;                                        // component c of -J^T r (data part)
+    for (int r0 = 0; r0 < len; r0 += S6_RC) {
+        const int nr = min(S6_RC, len - r0);
+        __syncthreads();  // the pass before is done with the staged rows (first pass: accS / cur are set)
+        const size_t e0 = (size_t)(beg + r0);
+        {   // every load of the pass is issued before the first LDS store (a thread's ~13 loads fly together)
+            constexpr int NL = (S6_RC * 2 + 255) / 256, NF = (S6_RC * K / 4 + 255) / 256, NM = (S6_RC + 255) / 256;
+            float4 vl[NL], vf[NF];
+            float2 vm[NM];
+            float vfa[NM];
+            const float4* gl = reinterpret_cast<const float4*>(s.el + 8 * e0);  // 32 bytes per row
+            const bool wide  = k == K;  // f rows are K floats: 16-byte loads (el / ef rows start 16-byte aligned)
+            const float4* gf = reinterpret_cast<const float4*>(s.ef + e0 * k);
+#pragma unroll
+            for (int q = 0; q < NL; ++q) {
+                const int i = tid + 256 * q;
+                vl[q]       = i < nr * 2 ? gl[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < NF; ++q) {
+                const int i = tid + 256 * q;
+                vf[q]       = wide && i < nr * (K / 4) ? gf[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < NM; ++q) {
+                const int i = tid + 256 * q;
+                vm[q] = make_float2(0.f, 0.f), vfa[q] = 0.f;
+                if (i < nr) {
+                    vm[q]         = *reinterpret_cast<const float2*>(s.em + 2 * (e0 + i));
+                    const int own = (int)(s.node_list[e0 + i] % (unsigned)k);
+                    vfa[q]        = s.ef[(e0 + i) * k + own];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NL; ++q) {
+                const int i = tid + 256 * q;
+                if (i < nr * 2) (&sl8[0][0])[i] = vl[q];
+            }
+            if (wide) {
+#pragma unroll
+                for (int q = 0; q < NF; ++q) {
+                    const int i = tid + 256 * q;
+                    if (i < nr * (K / 4)) reinterpret_cast<float4*>(&sfv[0][0])[i] = vf[q];
+                }
+            } else {
+                for (int i = tid; i < nr * k; i += 256) {
+                    const int r = i / k, j = i - r * k;
+                    sfv[r][j]   = s.ef[e0 * k + i];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NM; ++q) {
+                const int i = tid + 256 * q;
+                if (i < nr) sra[i] = vm[q].x != 0.f ? make_float2(vm[q].x * vfa[q], vm[q].y * vfa[q]) : make_float2(0.f, 0.f);
+            }
+        }
+        __syncthreads();
+        // rows without association hold stale numbers (0 * NaN is NaN): zero what the products read
+        for (int i = tid; i < nr; i += 256)
+            if (sra[i].x == 0.f) {
+                sl8[i][0] = sl8[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int j = 0; j < K; ++j) sfv[i][j] = 0.f;
+            }
+        __syncthreads();
+        // the first block of this wave's first list flies while slot 0 is worked on (a list start is an exposed global
+        // load otherwise: ~8 slots x passes of them per wave and node were most of the kernel's time)
+        int q = 1 + wave, c0 = 0, qe = 0;
+        uint32_t mine = 0xffffffffu;
+        if (q < cnt) {
+            qe = pptr[q + 1], c0 = cur[q];
+            if (c0 + lane < qe) mine = s.pair_list[c0 + lane];
+        }
+        // ---- slot 0: 8 rows per wave and step, the waves interleave
+        for (int rb = 8 * wave; rb < nr; rb += 32) {
+            const int rr = rb + grp;
+            if (rr < nr) {
+                const int own   = (int)(s.node_list[e0 + rr] % (unsigned)k);
+                const float2 ra = sra[rr];
+                const float lc  = (&sl8[rr][0].x)[c];
+                const float4 l0 = sl8[rr][0], l1 = sl8[rr][1];
+                const float fac = ra.x * sfv[rr][own] * lc;
+                own8[0] += fac * l0.x, own8[1] += fac * l0.y, own8[2] += fac * l0.z, own8[3] += fac * l0.w;
+                own8[4] += fac * l1.x, own8[5] += fac * l1.y, own8[6] += fac * l1.z, own8[7] += fac * l1.w;
+                ownG -= ra.y * lc;
+            }
+        }
+        // ---- slots 1 + wave, 5 + wave, ...
+        const unsigned rlim = (unsigned)(r0 + nr);
+        for (; q < cnt; q += 4) {
+            float m8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            // the next list's first block
+            int c0n = 0, qen = 0;
+            uint32_t nmine = 0xffffffffu;
+            if (q + 4 < cnt) {
+                qen = pptr[q + 5], c0n = cur[q + 4];
+                if (c0n + lane < qen) nmine = s.pair_list[c0n + lane];
+            }
+            // 64 pairs per load (lane i holds pair c0 + i; the next block is in flight while this one is used), then
+            // 8 steps of 8 pairs: group g of step t takes the pair of lane 8 t + g
+            while (c0 < qe) {
+                const uint32_t nxt = c0 + 64 + lane < qe ? s.pair_list[c0 + 64 + lane] : 0xffffffffu;
+                const int nin      = __popcll(__ballot((mine >> 4) < rlim));  // pairs of this block inside the pass: a prefix
+                auto step = [&](const int t, const bool guard) __attribute__((always_inline)) {
+                    const uint32_t pr = (uint32_t)__shfl((int)mine, 8 * t + grp, 64);
+                    if (!guard || 8 * t + grp < nin) {
+                        const int rr    = (int)(pr >> 4) - r0, j = (int)(pr & 15u);
+                        const float lc  = (&sl8[rr][0].x)[c];
+                        const float4 l0 = sl8[rr][0], l1 = sl8[rr][1];
+                        const float fac = sra[rr].x * sfv[rr][j] * lc;
+                        m8[0] += fac * l0.x, m8[1] += fac * l0.y, m8[2] += fac * l0.z, m8[3] += fac * l0.w;
+                        m8[4] += fac * l1.x, m8[5] += fac * l1.y, m8[6] += fac * l1.z, m8[7] += fac * l1.w;
+                    }
+                };
+                if (nin == 64) {  // a full block: no tests, the loads of the eight steps can overlap
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) step(t, false);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        if (8 * t < nin) step(t, true);  // wave-uniform
+                }
+                c0 += nin;
+                if (nin < 64) break;
+                mine = nxt;
+            }
+            if (lane == 0) cur[q] = c0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                m8[e] += __shfl_xor(m8[e], 8, 64);
+                m8[e] += __shfl_xor(m8[e], 16, 64);
+                m8[e] += __shfl_xor(m8[e], 32, 64);
+            }
+            if (grp == 0) {
+                float4* dst = reinterpret_cast<float4*>(&accS[q][8 * c]);
+                float4 d0 = dst[0], d1 = dst[1];
+                d0.x += m8[0], d0.y += m8[1], d0.z += m8[2], d0.w += m8[3];
+                d1.x += m8[4], d1.y += m8[5], d1.z += m8[6], d1.w += m8[7];
+                dst[0] = d0, dst[1] = d1;
+            }
+            mine = nmine, c0 = c0n, qe = qen;
+        }
+    }
+    // slot 0: groups, then waves (fixed order)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        own8[e] += __shfl_xor(own8[e], 8, 64);
+        own8[e] += __shfl_xor(own8[e], 16, 64);
+        own8[e] += __shfl_xor(own8[e], 32, 64);
+    }
+    ownG += __shfl_xor(ownG, 8, 64);
+    ownG += __shfl_xor(ownG, 16, 64);
+    ownG += __shfl_xor(ownG, 32, 64);
+    if (grp == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part0[wave][8 * c + e] = own8[e];
+        part0[wave][64 + c] = ownG;
+    }
+    __syncthreads();
+    if (tid < 64 && cnt > 0) accS[0][tid] = (part0[0][tid] + part0[1][tid]) + (part0[2][tid] + part0[3][tid]);
+    if (tid >= 64 && tid < 72) g8s[tid - 64] = (part0[0][tid] + part0[1][tid]) + (part0[2][tid] + part0[3][tid]);
+    __syncthreads();
+    // H_ab = M_a S_ab M_b^T, regularisation, output: thread (slot, row) finishes row `row` of the block in `slot`
+    for (int t0 = 0; t0 < cnt * 6; t0 += 256) {
+        const int t = t0 + tid;
+        if (t < cnt * 6) {
+            const int slot = t / 6, my_row = t - 6 * slot;
+            const int col  = s.bcols[(size_t)a * s.cap + slot];
+            float ma[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) ma[p] = s.mnode[48 * (size_t)a + 8 * my_row + p];
+            float vq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // row my_row of M_a S
+            const float* S0 = &accS[slot][0];
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vq[q] += ma[p] * S0[8 * p + q];
+            float accr[6];
+#pragma unroll
+            for (int d = 0; d < 6; ++d) {
+                const float* mb = s.mnode + 48 * (size_t)col + 8 * d;
+                float h = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) h += vq[q] * mb[q];
+                accr[d] = h;
+            }
+            float gacc = 0.f;
+            if (slot == 0) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) gacc += ma[p] * g8s[p];
             }
             // regularisation edges leaving a (a -> m): rows c of e = T_a g_m - g^_m with vectors (an_c at a, -e_{3+c} at m)
             for (int q = 0; q < k; ++q) {
@@ -935,7 +1246,36 @@ hipError_t s6_linearise(const Solve6View& s, Solve6State* state, const Solve6Ima
 
 hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Params& p, hipStream_t st) {
     const float wreg2 = p.lambda / ((float)s.D * (float)s.k);
-    K6DISPATCH(s6_assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, wreg2, p.damping));
+    static const bool lds_form = getenv("DFA_S6_ASSEMBLE") && atoi(getenv("DFA_S6_ASSEMBLE")) == 1;  // A/B: first form
+    if (lds_form) K6DISPATCH(s6_assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, wreg2, p.damping));
+    else {
+        // rows staged per pass (DFA_S6_RC for A/B): fewer rows = more workgroups per CU, more passes per node
+        static const int rc_env = getenv("DFA_S6_RC") ? atoi(getenv("DFA_S6_RC")) : 0;
+        const int rc = rc_env ? rc_env : 640;
+#define S6A2(KK, RC)                                                                                              \
+    do {                                                                                                          \
+        const size_t sh = (size_t)(RC) * (32 + 4 * (KK) + 8);                                                     \
+        static bool attr = false;                                                                                 \
+        if (!attr && sh > 48 * 1024) {                                                                            \
+            (void)hipFuncSetAttribute((const void*)s6_assemble2_kernel<KK, RC>,                                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);                       \
+            attr = true;                                                                                          \
+        }                                                                                                         \
+        s6_assemble2_kernel<KK, RC><<<s.D, 256, sh, st>>>(s, state, wreg2, p.damping);                            \
+    } while (0)
+        if (s.k <= 4) {
+            if (rc <= 192) S6A2(4, 192);
+            else if (rc <= 320) S6A2(4, 320);
+            else if (rc <= 640) S6A2(4, 640);
+            else S6A2(4, 1152);
+        } else {
+            if (rc <= 192) S6A2(8, 192);
+            else if (rc <= 320) S6A2(8, 320);
+            else if (rc <= 640) S6A2(8, 640);
+            else S6A2(8, 1152);
+        }
+#undef S6A2
+    }
     return hipGetLastError();
 }
 

@@ -69,6 +69,10 @@ struct Solve6View {
     int32_t* bcols;  // D x cap
     int32_t* bcnt;   // D
     uint8_t* eslot;  // (N k) x k: slot, in the block row of the entry's node, of each neighbour of the entry's vertex
+    // the same relation by slot: for node a and slot q >= 1, pair_list[pair_ptr[a (cap+1) + q] .. pair_ptr[.. q+1]) are
+    // the (row of a's list << 4 | neighbour) pairs that land in slot q, ascending (slot 0 = every row's own neighbour)
+    uint32_t* pair_list;  // (N k) x k
+    int32_t* pair_ptr;    // D x (cap + 1)
     float* bvals;    // D x cap x 36
     float* minv;     // D x 36  inverse of the (damped) diagonal block
     float* g;        // D x 6   -J^T W r
