@@ -685,12 +685,31 @@ __global__ __launch_bounds__(256) void s6_assemble_kernel(Solve6View s, Solve6St
 // moment to the slot's 8 x 8 in LDS.  Slot 0 (every row's own neighbour) is shared by the four waves.
 // Rows are staged S6_RC at a time (f_own and rho f_own precomputed, rows without association zeroed); a node with
 // more rows takes several passes, each slot's cursor continues where the pass before stopped (lists are ascending).
+// value of lane QQ of the caller's quad (DPP quad_perm broadcast: a VALU move, no LDS)
+template <int QQ>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), QQ | (QQ << 2) | (QQ << 4) | (QQ << 6), 0xf, 0xf, true));
+}
+// Sum over the 16 quads of a wave of 16 registers per lane, scattered: lane (quad g, c4) returns the total of v[g]
+// over the lanes with its c4.  Halving exchange: 8 + 4 + 2 + 1 shuffles instead of 16 x 4.
+__device__ __forceinline__ float quads_reduce_scatter(float (&v)[16], int lane) {
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+    float w8[8], w4[4], w2[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w8[i] = (b5 ? v[i + 8] : v[i]) + __shfl_xor(b5 ? v[i] : v[i + 8], 32, 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w4[i] = (b4 ? w8[i + 4] : w8[i]) + __shfl_xor(b4 ? w8[i] : w8[i + 4], 16, 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w2[i] = (b3 ? w4[i + 2] : w4[i]) + __shfl_xor(b3 ? w4[i] : w4[i + 2], 8, 64);
+    return (b2 ? w2[1] : w2[0]) + __shfl_xor(b2 ? w2[0] : w2[1], 4, 64);
+}
+
 template <int K, int S6_RC>
 __global__ __launch_bounds__(256) void s6_assemble2_kernel(Solve6View s, Solve6State* st, float wreg2, float damping) {
     extern __shared__ __attribute__((aligned(16))) char s6_dyn[];
-    float4(*sl8)[2] = reinterpret_cast<float4(*)[2]>(s6_dyn);                                   // l = (lW, lD)
-    float(*sfv)[K]  = reinterpret_cast<float(*)[K]>(s6_dyn + sizeof(float4) * 2 * S6_RC);        // f_j
-    float2* sra     = reinterpret_cast<float2*>(s6_dyn + (sizeof(float4) * 2 + sizeof(float) * K) * S6_RC);  // rho f_own, rho res f_own
+    float(*sl8)[8]  = reinterpret_cast<float(*)[8]>(s6_dyn);                                      // l = (lW, lD)
+    float(*sfv)[K]  = reinterpret_cast<float(*)[K]>(s6_dyn + sizeof(float) * 8 * S6_RC);          // f_j
+    float4* sra     = reinterpret_cast<float4*>(s6_dyn + sizeof(float) * (8 + K) * S6_RC);       // rho f_own, rho res f_own, rho f_own^2
     __shared__ float accS[S6_MAXSLOT][64];
     __shared__ float part0[4][72];        // slot 0 per wave: 8 x 8 moment + g8
     __shared__ float g8s[8];
@@ -704,12 +723,24 @@ __global__ __launch_bounds__(256) void s6_assemble2_kernel(Solve6View s, Solve6S
     }
     const int cnt = s.bcnt[a];
     const int beg = s.node_ptr[a], len = s.node_ptr[a + 1] - beg;
-    const int wave = tid >> 6, lane = tid & 63, grp = lane >> 3, c = lane & 7;
+    const int wave = tid >> 6, lane = tid & 63, g16 = lane >> 2, c4 = lane & 3;
     const int32_t* pptr = s.pair_ptr + (size_t)a * (s.cap + 1);
     for (int i = tid; i < cnt * 64; i += 256) (&accS[0][0])[i] = 0.f;
     if (tid <= cnt && tid <= S6_MAXSLOT) cur[tid] = pptr[tid];
-    float own8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // row c of the slot-0 moment, this lane's share
-    float ownG    = 0.f;                                        // component c of -J^T r (data part)
+    // Lane (g, c4): pair g of a step, rows c4 and c4 + 4 of its 8 x 8 outer product.  It reads l_c4 and l_(c4+4) from
+    // LDS and gets the other six from its quad by DPP: 4 narrow LDS reads per 16 pairs instead of 5 (two of them
+    // 16 bytes wide) per 8 — the loop was bound by the LDS pipe.
+    auto add_pair = [&](float lo, float hi, float cf, float (&m)[16]) __attribute__((always_inline)) {
+        float l[8];
+        l[0] = quad_bcast<0>(lo), l[1] = quad_bcast<1>(lo), l[2] = quad_bcast<2>(lo), l[3] = quad_bcast<3>(lo);
+        l[4] = quad_bcast<0>(hi), l[5] = quad_bcast<1>(hi), l[6] = quad_bcast<2>(hi), l[7] = quad_bcast<3>(hi);
+        const float fl = cf * lo, fh = cf * hi;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaf(fl, l[e], m[e]), m[8 + e] = fmaf(fh, l[e], m[8 + e]);
+    };
+    float own[16], ownG[2] = {0.f, 0.f};  // slot 0 (every row's own neighbour) and -J^T r, this lane's share
+#pragma unroll
+    for (int e = 0; e < 16; ++e) own[e] = 0.f;
     for (int r0 = 0; r0 < len; r0 += S6_RC) {
         const int nr = min(S6_RC, len - r0);
         __syncthreads();  // the pass before is done with the staged rows (first pass: accS / cur are set)
@@ -738,14 +769,14 @@ __global__ __launch_bounds__(256) void s6_assemble2_kernel(Solve6View s, Solve6S
                 vm[q] = make_float2(0.f, 0.f), vfa[q] = 0.f;
                 if (i < nr) {
                     vm[q]         = *reinterpret_cast<const float2*>(s.em + 2 * (e0 + i));
-                    const int own = (int)(s.node_list[e0 + i] % (unsigned)k);
-                    vfa[q]        = s.ef[(e0 + i) * k + own];
+                    const int own_j = (int)(s.node_list[e0 + i] % (unsigned)k);
+                    vfa[q]        = s.ef[(e0 + i) * k + own_j];
                 }
             }
 #pragma unroll
             for (int q = 0; q < NL; ++q) {
                 const int i = tid + 256 * q;
-                if (i < nr * 2) (&sl8[0][0])[i] = vl[q];
+                if (i < nr * 2) reinterpret_cast<float4*>(&sl8[0][0])[i] = vl[q];
             }
             if (wide) {
 #pragma unroll
@@ -762,43 +793,43 @@ __global__ __launch_bounds__(256) void s6_assemble2_kernel(Solve6View s, Solve6S
 #pragma unroll
             for (int q = 0; q < NM; ++q) {
                 const int i = tid + 256 * q;
-                if (i < nr) sra[i] = vm[q].x != 0.f ? make_float2(vm[q].x * vfa[q], vm[q].y * vfa[q]) : make_float2(0.f, 0.f);
+                if (i < nr) {
+                    const float rf = vm[q].x * vfa[q];
+                    sra[i] = vm[q].x != 0.f ? make_float4(rf, vm[q].y * vfa[q], rf * vfa[q], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
         }
         __syncthreads();
         // rows without association hold stale numbers (0 * NaN is NaN): zero what the products read
         for (int i = tid; i < nr; i += 256)
             if (sra[i].x == 0.f) {
-                sl8[i][0] = sl8[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int j = 0; j < 8; ++j) sl8[i][j] = 0.f;
                 for (int j = 0; j < K; ++j) sfv[i][j] = 0.f;
             }
         __syncthreads();
-        // the first block of this wave's first list flies while slot 0 is worked on (a list start is an exposed global
-        // load otherwise: ~8 slots x passes of them per wave and node were most of the kernel's time)
+        // the first block of this wave's first list flies while slot 0 is worked on
         int q = 1 + wave, c0 = 0, qe = 0;
         uint32_t mine = 0xffffffffu;
         if (q < cnt) {
             qe = pptr[q + 1], c0 = cur[q];
             if (c0 + lane < qe) mine = s.pair_list[c0 + lane];
         }
-        // ---- slot 0: 8 rows per wave and step, the waves interleave
-        for (int rb = 8 * wave; rb < nr; rb += 32) {
-            const int rr = rb + grp;
-            if (rr < nr) {
-                const int own   = (int)(s.node_list[e0 + rr] % (unsigned)k);
-                const float2 ra = sra[rr];
-                const float lc  = (&sl8[rr][0].x)[c];
-                const float4 l0 = sl8[rr][0], l1 = sl8[rr][1];
-                const float fac = ra.x * sfv[rr][own] * lc;
-                own8[0] += fac * l0.x, own8[1] += fac * l0.y, own8[2] += fac * l0.z, own8[3] += fac * l0.w;
-                own8[4] += fac * l1.x, own8[5] += fac * l1.y, own8[6] += fac * l1.z, own8[7] += fac * l1.w;
-                ownG -= ra.y * lc;
+        // ---- slot 0: 16 rows per wave and step, the waves interleave
+        for (int rb = 16 * wave; rb < nr; rb += 64) {
+            const int rr = rb + g16;
+            if (rr < nr) {  // (whole quads)
+                const float4 ra = sra[rr];
+                const float lo = sl8[rr][c4], hi = sl8[rr][4 + c4];
+                add_pair(lo, hi, ra.z, own);
+                ownG[0] = fmaf(-ra.y, lo, ownG[0]), ownG[1] = fmaf(-ra.y, hi, ownG[1]);
             }
         }
         // ---- slots 1 + wave, 5 + wave, ...
         const unsigned rlim = (unsigned)(r0 + nr);
         for (; q < cnt; q += 4) {
-            float m8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float m[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) m[e] = 0.f;
             // the next list's first block
             int c0n = 0, qen = 0;
             uint32_t nmine = 0xffffffffu;
@@ -807,70 +838,64 @@ __global__ __launch_bounds__(256) void s6_assemble2_kernel(Solve6View s, Solve6S
                 if (c0n + lane < qen) nmine = s.pair_list[c0n + lane];
             }
             // 64 pairs per load (lane i holds pair c0 + i; the next block is in flight while this one is used), then
-            // 8 steps of 8 pairs: group g of step t takes the pair of lane 8 t + g
+            // 4 steps of 16 pairs: quad g of step t takes the pair of lane 16 t + g
             while (c0 < qe) {
                 const uint32_t nxt = c0 + 64 + lane < qe ? s.pair_list[c0 + 64 + lane] : 0xffffffffu;
                 const int nin      = __popcll(__ballot((mine >> 4) < rlim));  // pairs of this block inside the pass: a prefix
                 auto step = [&](const int t, const bool guard) __attribute__((always_inline)) {
-                    const uint32_t pr = (uint32_t)__shfl((int)mine, 8 * t + grp, 64);
-                    if (!guard || 8 * t + grp < nin) {
-                        const int rr    = (int)(pr >> 4) - r0, j = (int)(pr & 15u);
-                        const float lc  = (&sl8[rr][0].x)[c];
-                        const float4 l0 = sl8[rr][0], l1 = sl8[rr][1];
-                        const float fac = sra[rr].x * sfv[rr][j] * lc;
-                        m8[0] += fac * l0.x, m8[1] += fac * l0.y, m8[2] += fac * l0.z, m8[3] += fac * l0.w;
-                        m8[4] += fac * l1.x, m8[5] += fac * l1.y, m8[6] += fac * l1.z, m8[7] += fac * l1.w;
+                    const uint32_t pr = (uint32_t)__shfl((int)mine, 16 * t + g16, 64);
+                    if (!guard || 16 * t + g16 < nin) {
+                        const int rr   = (int)(pr >> 4) - r0, j = (int)(pr & 15u);
+                        const float lo = sl8[rr][c4], hi = sl8[rr][4 + c4];
+                        add_pair(lo, hi, sra[rr].x * sfv[rr][j], m);
                     }
                 };
-                if (nin == 64) {  // a full block: no tests, the loads of the eight steps can overlap
+                if (nin == 64) {  // a full block: no tests, the loads of the four steps can overlap
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) step(t, false);
+                    for (int t = 0; t < 4; ++t) step(t, false);
                 } else {
 #pragma unroll
-                    for (int t = 0; t < 8; ++t)
-                        if (8 * t < nin) step(t, true);  // wave-uniform
+                    for (int t = 0; t < 4; ++t)
+                        if (16 * t < nin) step(t, true);  // wave-uniform
                 }
                 c0 += nin;
                 if (nin < 64) break;
                 mine = nxt;
             }
             if (lane == 0) cur[q] = c0;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                m8[e] += __shfl_xor(m8[e], 8, 64);
-                m8[e] += __shfl_xor(m8[e], 16, 64);
-                m8[e] += __shfl_xor(m8[e], 32, 64);
-            }
-            if (grp == 0) {
-                float4* dst = reinterpret_cast<float4*>(&accS[q][8 * c]);
-                float4 d0 = dst[0], d1 = dst[1];
-                d0.x += m8[0], d0.y += m8[1], d0.z += m8[2], d0.w += m8[3];
-                d1.x += m8[4], d1.y += m8[5], d1.z += m8[6], d1.w += m8[7];
-                dst[0] = d0, dst[1] = d1;
-            }
+            const float tot = quads_reduce_scatter(m, lane);  // element g16 of (row c4 | row c4 + 4) of the slot's moment
+            const int row = g16 < 8 ? c4 : c4 + 4, col = g16 & 7;
+            accS[q][8 * row + col] += tot;
             mine = nmine, c0 = c0n, qe = qen;
         }
     }
-    // slot 0: groups, then waves (fixed order)
+    // slot 0: quads, then waves (fixed order)
+    {
+        const float tot = quads_reduce_scatter(own, lane);
+        const int row = g16 < 8 ? c4 : c4 + 4, col = g16 & 7;
+        part0[wave][8 * row + col] = tot;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        own8[e] += __shfl_xor(own8[e], 8, 64);
-        own8[e] += __shfl_xor(own8[e], 16, 64);
-        own8[e] += __shfl_xor(own8[e], 32, 64);
-    }
-    ownG += __shfl_xor(ownG, 8, 64);
-    ownG += __shfl_xor(ownG, 16, 64);
-    ownG += __shfl_xor(ownG, 32, 64);
-    if (grp == 0) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) part0[wave][8 * c + e] = own8[e];
-        part0[wave][64 + c] = ownG;
+        for (int e = 0; e < 2; ++e) {
+            ownG[e] += __shfl_xor(ownG[e], 4, 64);
+            ownG[e] += __shfl_xor(ownG[e], 8, 64);
+            ownG[e] += __shfl_xor(ownG[e], 16, 64);
+            ownG[e] += __shfl_xor(ownG[e], 32, 64);
+        }
+        if (g16 == 0) part0[wave][64 + c4] = ownG[0], part0[wave][68 + c4] = ownG[1];
     }
     __syncthreads();
     if (tid < 64 && cnt > 0) accS[0][tid] = (part0[0][tid] + part0[1][tid]) + (part0[2][tid] + part0[3][tid]);
     if (tid >= 64 && tid < 72) g8s[tid - 64] = (part0[0][tid] + part0[1][tid]) + (part0[2][tid] + part0[3][tid]);
     __syncthreads();
     // H_ab = M_a S_ab M_b^T, regularisation, output: thread (slot, row) finishes row `row` of the block in `slot`
+    // M of the row's column nodes: staged in the rows' area (the passes are over), 48 floats per slot, coalesced
+    float* smb = reinterpret_cast<float*>(s6_dyn);
+    static_assert((size_t)S6_RC * (8 + K + 4) >= (size_t)S6_MAXSLOT * 48, "the staged rows' area holds the column nodes' M");
+    for (int i = tid; i < cnt * 48; i += 256) {
+        const int slot = i / 48;
+        smb[i]         = s.mnode[48 * (size_t)s.bcols[(size_t)a * s.cap + slot] + (i - 48 * slot)];
+    }
+    __syncthreads();
     for (int t0 = 0; t0 < cnt * 6; t0 += 256) {
         const int t = t0 + tid;
         if (t < cnt * 6) {
@@ -878,20 +903,20 @@ __global__ __launch_bounds__(256) void s6_assemble2_kernel(Solve6View s, Solve6S
             const int col  = s.bcols[(size_t)a * s.cap + slot];
             float ma[8];
 #pragma unroll
-            for (int p = 0; p < 8; ++p) ma[p] = s.mnode[48 * (size_t)a + 8 * my_row + p];
+            for (int p = 0; p < 8; ++p) ma[p] = smb[8 * my_row + p];  // slot 0 is node a itself
             float vq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // row my_row of M_a S
             const float* S0 = &accS[slot][0];
 #pragma unroll
             for (int p = 0; p < 8; ++p)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) vq[q] += ma[p] * S0[8 * p + q];
+                for (int q = 0; q < 8; ++q) vq[q] = fmaf(ma[p], S0[8 * p + q], vq[q]);
             float accr[6];
 #pragma unroll
             for (int d = 0; d < 6; ++d) {
-                const float* mb = s.mnode + 48 * (size_t)col + 8 * d;
+                const float* mb = smb + 48 * slot + 8 * d;
                 float h = 0.f;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) h += vq[q] * mb[q];
+                for (int q = 0; q < 8; ++q) h = fmaf(vq[q], mb[q], h);
                 accr[d] = h;
             }
             float gacc = 0.f;
@@ -1249,12 +1274,13 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
     static const bool lds_form = getenv("DFA_S6_ASSEMBLE") && atoi(getenv("DFA_S6_ASSEMBLE")) == 1;  // A/B: first form
     if (lds_form) K6DISPATCH(s6_assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, wreg2, p.damping));
     else {
-        // rows staged per pass (DFA_S6_RC for A/B): fewer rows = more workgroups per CU, more passes per node
+        // rows staged per pass (DFA_S6_RC for A/B): fewer rows = more workgroups per CU, more passes per node; measured
+        // best at 320 for k = 4 and k = 8 (192: 0.163 / 0.673 ms at C2 / C3, 320: 0.157 / 0.642, 640: 0.177 / 0.755)
         static const int rc_env = getenv("DFA_S6_RC") ? atoi(getenv("DFA_S6_RC")) : 0;
-        const int rc = rc_env ? rc_env : 640;
+        const int rc = rc_env ? rc_env : 320;
 #define S6A2(KK, RC)                                                                                              \
     do {                                                                                                          \
-        const size_t sh = (size_t)(RC) * (32 + 4 * (KK) + 8);                                                     \
+        const size_t sh = (size_t)(RC) * (32 + 4 * (KK) + 16);                                                     \
         static bool attr = false;                                                                                 \
         if (!attr && sh > 48 * 1024) {                                                                            \
             (void)hipFuncSetAttribute((const void*)s6_assemble2_kernel<KK, RC>,                                   \
@@ -1264,15 +1290,11 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
         s6_assemble2_kernel<KK, RC><<<s.D, 256, sh, st>>>(s, state, wreg2, p.damping);                            \
     } while (0)
         if (s.k <= 4) {
-            if (rc <= 192) S6A2(4, 192);
-            else if (rc <= 320) S6A2(4, 320);
-            else if (rc <= 640) S6A2(4, 640);
-            else S6A2(4, 1152);
+            if (rc <= 320) S6A2(4, 320);
+            else S6A2(4, 640);
         } else {
-            if (rc <= 192) S6A2(8, 192);
-            else if (rc <= 320) S6A2(8, 320);
-            else if (rc <= 640) S6A2(8, 640);
-            else S6A2(8, 1152);
+            if (rc <= 320) S6A2(8, 320);
+            else S6A2(8, 640);
         }
 #undef S6A2
     }
