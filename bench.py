@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 TIMING_SAMPLE = 8  # every 8th timed frame carries the hipEvent brackets of the per-kernel report
 PMC_TRAFFIC_BYTES = {("C2", "fused_integrate"): 0.5411e9, ("C3", "fused_integrate"): 0.5411e9,
                      # profiles/r01_pmc_northstar.md (FETCH x2 + WRITE per dispatch)
-                     ("C3", "s6_assemble"): 0.411e9, ("C3", "s6_pcg_step"): 0.0242e9,
+                     ("C3", "s6_assemble"): 0.510e9, ("C3", "s6_pcg_step"): 0.0242e9,
                      # profiles/r01_pmc_solve.md: (331.4 + 268.4) KiB per pcg_paired_kernel<1024,1,32,1> launch, mean over
                      # the five launches of a frame (those that return at entry included)
                      ("C2", "pcg"): 599.8 * 1024}
@@ -291,12 +291,12 @@ def main_northstar(args, torch, replicas, rank, world, device):
                       traffic=PMC_TRAFFIC_BYTES.get((args.config, "fused_integrate")), avg_launch_ms=round(fuse_ms, 4),
                       launches_per_frame=1, algorithmic_bytes_per_launch=fuse_bytes)
     asm_gbs = asm_bytes / (asm_ms * 1e-3) / 1e9
-    asm_entry = dict(kernel="s6_assemble_kernel<%d> (block normal matrix of one Gauss-Newton iteration)" % (4 if k <= 4 else 8),
+    asm_entry = dict(kernel="s6_assemble2_kernel<%d,320> (block normal matrix of one Gauss-Newton iteration)" % (4 if k <= 4 else 8),
                      bound="hbm", achieved=round(asm_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                      frac=round(asm_gbs / HBM_PEAK_GBS, 4), traffic=PMC_TRAFFIC_BYTES.get((args.config, "s6_assemble")),
                      avg_launch_ms=round(asm_ms, 4), launches_per_frame=gn, algorithmic_bytes_per_launch=asm_bytes,
                      ms_per_frame=round(tm["assemble_ms"], 3),
-                     note="LDS-bandwidth-bound (DESIGN.md 4.5): per-wave 8x8 moment accumulators in LDS")
+                     note="moments accumulated in registers over per-slot pair lists; LDS-issue / latency-bound (DESIGN.md 4.5)")
     pcg_gbs = pcg_bytes_it / (pcg_ms * 1e-3) / 1e9
     pcg_entry = dict(kernel="s6_pcg_step_kernel (one Chronopoulos-Gear PCG iteration per launch)", bound="hbm",
                      achieved=round(pcg_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(pcg_gbs / HBM_PEAK_GBS, 4),

@@ -345,6 +345,7 @@ __device__ void inv6(const float* M, float* out) {
 // the diagonal first, then every node that shares a vertex with a or is joined to it by a
 // regularisation edge, ascending.
 constexpr int S6_SORT_MAX = 4096;
+constexpr int S6_MAXSLOT_PATTERN = 48;  // = S6_MAXSLOT (declared below), the plan capacity of a block row
 
 __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6State* st) {
     __shared__ int keys[S6_HASH];
@@ -445,8 +446,12 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
     __syncthreads();  // also: this workgroup's eslot bytes are visible to all of its threads
     const int pbeg = s.node_ptr[a], plen = s.node_ptr[a + 1] - pbeg, npairs = plen * k;
     const uint8_t* es = s.eslot + (size_t)pbeg * k;
+    // the node's slot bytes are scanned once per slot below: from LDS when they fit the (now idle) sort buffer
+    uint8_t* es_lds      = reinterpret_cast<uint8_t*>(sortbuf);
+    const bool in_lds    = npairs <= (int)sizeof(sortbuf);
     for (int p = tid; p < npairs; p += 256) {
         const int sl = es[p];
+        if (in_lds) es_lds[p] = (uint8_t)sl;
         if (sl >= 1 && sl < stored) atomicAdd(&pcnt[sl], 1);
     }
     __syncthreads();
@@ -458,19 +463,27 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
     }
     __syncthreads();
     if (tid <= stored) s.pair_ptr[(size_t)a * (s.cap + 1) + tid] = pstart[tid];
-    {
+    {   // one pass over the pairs per wave: a chunk's slot bytes are read once and matched against the wave's (at most
+        // 12) slots — independent ballots instead of one dependent read-compare-ballot chain per slot and chunk
         const int wave = tid >> 6, lane = tid & 63;
-        for (int q = 1 + wave; q < stored; q += 4) {
-            int out = pstart[q];
-            for (int base = 0; base < npairs; base += 64) {
-                const int p       = base + lane;
-                const bool match  = p < npairs && es[p] == q;
-                const uint64_t mk = __ballot(match);
-                if (match) {
-                    const int r = p / k;
-                    s.pair_list[out + __popcll(mk & ((1ull << lane) - 1ull))] = ((uint32_t)r << 4) | (uint32_t)(p - r * k);
+        constexpr int SPW = (S6_MAXSLOT_PATTERN + 3) / 4;
+        int out[SPW];
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) out[i] = 1 + wave + 4 * i < stored ? pstart[1 + wave + 4 * i] : 0;
+        for (int base = 0; base < npairs; base += 64) {
+            const int p  = base + lane;
+            const int sl = p < npairs ? (int)(in_lds ? es_lds[p] : es[p]) : 255;
+            const int r  = p / k;
+            const uint32_t packed = ((uint32_t)r << 4) | (uint32_t)(p - r * k);
+#pragma unroll
+            for (int i = 0; i < SPW; ++i) {
+                const int q = 1 + wave + 4 * i;
+                if (q < stored) {  // wave-uniform
+                    const bool match  = sl == q;
+                    const uint64_t mk = __ballot(match);
+                    if (match) s.pair_list[out[i] + __popcll(mk & ((1ull << lane) - 1ull))] = packed;
+                    out[i] += __popcll(mk);
                 }
-                out += __popcll(mk);
             }
         }
     }
@@ -490,7 +503,7 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
 // conflicts); every (slot, c) thread scanning every row 2.2 ms (VALU-bound); this layout with ds_add_f32
 // 4.6 ms; private copies 1.0 ms (HBM/L2-bound on 232-byte rows); factored rows: see DESIGN.md.
 constexpr int S6_STAGE   = 64;
-constexpr int S6_MAXSLOT = 48;  // = plan capacity of a block row
+constexpr int S6_MAXSLOT = S6_MAXSLOT_PATTERN;  // = plan capacity of a block row
 
 template <int K>
 __global__ __launch_bounds__(256) void s6_assemble_kernel(Solve6View s, Solve6State* st, float wreg2, float damping) {
