@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 for wide reads + WRITE_SIZE, corrected as
 # MI355X_MICROARCH.md prescribes) — profiles/r01_pmc_tsdf.md.  Collected offline: PMC needs its own runs.
 TIMING_SAMPLE = 8  # every 8th timed frame carries the hipEvent brackets of the per-kernel report
-PMC_TRAFFIC_BYTES = {("C2", "fused_integrate"): 0.5411e9, ("C3", "fused_integrate"): 0.5411e9,
+PMC_TRAFFIC_BYTES = {("C2", "fused_integrate"): 0.5415e9, ("C3", "fused_integrate"): 0.5415e9,
                      # profiles/r01_pmc_northstar.md (FETCH x2 + WRITE per dispatch)
                      ("C3", "s6_assemble"): 0.510e9, ("C3", "s6_pcg_step"): 0.0242e9,
                      # profiles/r01_pmc_solve.md: (331.4 + 268.4) KiB per pcg_paired_kernel<1024,1,32,1> launch, mean over
