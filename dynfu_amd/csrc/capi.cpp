@@ -141,6 +141,7 @@ struct dfa_solver {
     std::vector<int> ev_pcg, ev_asm; // indices of the begin events of each bracketed launch
     size_t ev_used;
     int timed_solves = 0;
+    bool just_reset = false;  // the unknowns and the state block were zeroed by set_problem and not touched since
     long long* iters_total = nullptr;  // device: PCG iterations of all solves since enable_timing(1)
     int* host_flag = nullptr;        // pinned int[2]: stop flag of the many-workgroup PCG and the plan's converged flag,
                                      // read back between launch chunks
@@ -624,6 +625,7 @@ int dfa_solver_set_problem(dfa_solver* s, const float* node_pos, const float* no
     // resetGPUMemory (:149-202): unknowns start at zero
     HIP_TRY(dfa::solve_reset(v, s->state, s->ticket, 64, st));
     s->has_problem = true;
+    s->just_reset  = true;
     return DFA_OK;
 }
 
@@ -635,7 +637,8 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
     REQUIRE(p->lambda >= 0.f, "lambda must be non-negative");
     const dfa::SolveView& v = s->v;
     hipStream_t st          = S(stream);
-    HIP_TRY(dfa::solve_reset(v, s->state, s->ticket, 64, st));
+    if (!s->just_reset) HIP_TRY(dfa::solve_reset(v, s->state, s->ticket, 64, st));  // (set_problem has just done it)
+    s->just_reset = false;
     // w_reg = sqrt(lambda / (D * KNN))  (opt_solver.cpp:30); rows carry tau = w_reg^2
     const double w_reg    = std::sqrt((double)p->lambda / ((double)v.D * (double)v.k));
     const float w_reg_f   = (float)w_reg;
