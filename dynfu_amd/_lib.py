@@ -9,7 +9,7 @@ _LIB = None
 # every symbol include/dynfu_amd.h declares (tests/test_capi_symbols.py checks the .so exports them)
 SYMBOLS = [
     "dfa_last_error", "dfa_version", "dfa_compute_dists", "dfa_tsdf_clear", "dfa_tsdf_integrate",
-    "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_knn", "dfa_warp_to_live",
+    "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_tsdf_vertex_normals", "dfa_knn", "dfa_warp_to_live",
     "dfa_calc_dqb", "dfa_unsupported_vertices", "dfa_icp_sums",
     "dfa_correspond", "dfa_marching_cubes", "dfa_mc_default_tables",
     "dfa_depth_bilateral_filter", "dfa_depth_truncate", "dfa_depth_build_pyramid", "dfa_compute_normals_mask_depth",
@@ -100,6 +100,7 @@ def load():
     ray = [vp, i, i, i, vp, f, vp, vp, f, f, f, f, f, f, vp, i, vp, i, i, i, vp]
     L.dfa_tsdf_raycast_points.argtypes = ray
     L.dfa_tsdf_raycast_depth.argtypes = ray
+    L.dfa_tsdf_vertex_normals.argtypes = [vp, i, i, i, vp, f, vp, i, vp, vp]
     L.dfa_knn.argtypes = [vp, vp, i, vp, i, i, vp, vp, vp]
     L.dfa_warp_to_live.argtypes = [vp, vp, vp, i, i, vp, vp, i, vp, vp, vp]
     L.dfa_depth_bilateral_filter.argtypes = [vp, i, vp, i, i, i, i, f, f, vp]
@@ -256,6 +257,19 @@ def tsdf_raycast_depth(vol, voxel_size, trunc, cam2vol, Rinv, fx, fy, cx, cy, st
                                          delta_factor, _dev(depth, torch.uint16, "depth"), depth.stride(0) * 2,
                                          _dev(normals, torch.float32, "normals"), normals.stride(0) * 4, cols, rows,
                                          _stream()))
+
+
+def tsdf_vertex_normals(vol, voxel_size, delta_factor, points):
+    """normals of surface points (n x 4 float32 CUDA tensor, the volume's metric frame — what marching_cubes returns)
+    from the TSDF gradient; returns an n x 4 tensor (xyz, 0), NaN where the gradient stencil leaves the volume"""
+    torch = _torch()
+    X, Y, Z = _vol_dims(vol)
+    n = int(points.shape[0])
+    normals = torch.empty((max(n, 1), 4), dtype=torch.float32, device=vol.device)
+    _check(load().dfa_tsdf_vertex_normals(_dev(vol), X, Y, Z, _farr(voxel_size, 3), float(delta_factor),
+                                          _dev(points, torch.float32, "points") if n else None, n,
+                                          _dev(normals) if n else None, _stream()))
+    return normals[:n]
 
 
 # ----------------------------------------------------------------------- marching-cubes seam

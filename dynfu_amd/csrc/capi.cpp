@@ -263,6 +263,19 @@ int dfa_tsdf_clear_integrate(const uint16_t* dists, int dists_step, int cols, in
                             vol2cam, fx, fy, cx, cy, stream);
 }
 
+int dfa_tsdf_vertex_normals(const uint32_t* volume, int X, int Y, int Z, const float voxel_size[3],
+                            float gradient_delta_factor, const float* points, int n, float* normals,
+                            dfa_stream_t stream) {
+    REQUIRE(volume && voxel_size, "null volume / voxel_size");
+    REQUIRE(X > 1 && Y > 1 && Z > 1, "the volume needs two voxels per axis");
+    REQUIRE(n >= 0 && (n == 0 || (points && normals)), "null points / normals");
+    REQUIRE(voxel_size[0] > 0.f && voxel_size[1] > 0.f && voxel_size[2] > 0.f && gradient_delta_factor > 0.f,
+            "voxel size and gradient delta must be positive");
+    REQUIRE((((uintptr_t)points | (uintptr_t)normals) & 15) == 0, "points / normals must be 16-byte aligned");
+    HIP_TRY(dfa::launch_vertex_normals(volume, X, Y, Z, voxel_size, gradient_delta_factor, points, n, normals, S(stream)));
+    return DFA_OK;
+}
+
 int dfa_tsdf_raycast_points(const uint32_t* volume, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
                             const float cam2vol[12], const float Rinv[9], float fx, float fy, float cx, float cy,
                             float step_factor, float delta_factor, float* points, int points_step, float* normals,

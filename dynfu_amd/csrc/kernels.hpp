@@ -14,6 +14,8 @@ hipError_t launch_tsdf_integrate(bool fused_clear, const uint16_t* dists, int di
                                  uint32_t* vol, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
                                  int max_weight, const float vol2cam[12], float fx, float fy, float cx, float cy,
                                  hipStream_t s);
+hipError_t launch_vertex_normals(const uint32_t* vol, int X, int Y, int Z, const float voxel_size[3], float delta_factor,
+                                 const float* points, int n, float* normals, hipStream_t s);
 hipError_t launch_raycast_points(const uint32_t* vol, int X, int Y, int Z, const float voxel_size[3],
                                  float trunc_dist, const float cam2vol[12], const float Rinv[9], float fx, float fy,
                                  float cx, float cy, float step_factor, float delta_factor, float* points,

@@ -485,6 +485,28 @@ static RaycastArgs make_raycast_args(const uint32_t* vol, int X, int Y, int Z, c
     return a;
 }
 
+// Normals of surface points (marching-cubes vertices) from the TSDF gradient: the raycaster's own compute_normal
+// (tsdf_volume.cu:320-336 — central differences of the trilinear interpolant, `delta_factor` voxels apart) applied
+// to points given in the volume's metric frame.  The reference leaves the extracted mesh without normals
+// (dyn_fusion.cpp:80-88 "temporary workaround until normals are computed via mc"): this is SURVEY 8f rank 2.
+__global__ __launch_bounds__(256) void vertex_normals_kernel(const RaycastArgs a, const float4* __restrict__ points, int n,
+                                                             float4* __restrict__ normals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = points[i];
+    const f3 nn    = compute_normal(a, mk3(p.x, p.y, p.z));  // NaN where a sample leaves the interpolation range
+    normals[i]     = make_float4(nn.x, nn.y, nn.z, 0.f);
+}
+
+hipError_t launch_vertex_normals(const uint32_t* vol, int X, int Y, int Z, const float voxel_size[3], float delta_factor,
+                                 const float* points, int n, float* normals, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const float id12[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, id9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    RaycastArgs a = make_raycast_args(vol, X, Y, Z, voxel_size, 1.f, id12, id9, 1.f, 1.f, 0.f, 0.f, 1.f, delta_factor, 0, 0);
+    vertex_normals_kernel<<<(n + 255) / 256, 256, 0, s>>>(a, (const float4*)points, n, (float4*)normals);
+    return launch_status();
+}
+
 hipError_t launch_raycast_points(const uint32_t* vol, int X, int Y, int Z, const float voxel_size[3],
                                  float trunc_dist, const float cam2vol[12], const float Rinv[9], float fx, float fy,
                                  float cx, float cy, float step_factor, float delta_factor, float* points,

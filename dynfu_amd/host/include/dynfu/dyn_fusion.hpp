@@ -48,6 +48,9 @@ struct DynFuParams {  // dyn_fusion.hpp:25-42
     int L;
     int beta;
     float epsilon;
+    // Extension (off = the reference's behaviour: default-constructed normals, dyn_fusion.cpp:80-88): normals of the
+    // extracted vertices from the TSDF gradient (MarchingCubes::computeNormals)
+    bool mesh_normals = false;
 };
 
 class DynFusion {

@@ -35,6 +35,12 @@ public:
 
     // vertices the last run() found; larger than the buffer means only the buffer's worth was written
     int totalVertices() const { return last_total_; }
+
+    // Normals of the extracted vertices from the gradient of the TSDF (the raycaster's compute_normal,
+    // tsdf_volume.cu:320-336, with the volume's gradient delta factor).  Extension: the reference leaves the mesh
+    // without normals (dyn_fusion.cpp:80-88 "temporary workaround until normals are computed via mc").
+    void computeNormals(const TsdfVolume& volume, const dfa::DeviceArray<PointType>& vertices,
+                        dfa::DeviceArray<dfa::Normal>& normals);
 };
 
 }  // namespace cuda

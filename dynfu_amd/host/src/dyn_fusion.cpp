@@ -140,6 +140,14 @@ void DynFusion::extractSurface(dfa::PointCloud<dfa::PointXYZ>& vertices, dfa::Po
     std::vector<kfusion::cuda::MarchingCubes::PointType> host;
     if (!triangles.empty()) triangles.download(host);
     for (auto& p : host) vertices.push_back(dfa::PointXYZ(p.x, p.y, p.z));
+    if (dynfuParams.mesh_normals && !host.empty()) {  // extension: gradient of the TSDF at the vertices
+        dfa::DeviceArray<dfa::Normal> dn;
+        mc_->computeNormals(tsdf(), triangles, dn);
+        std::vector<dfa::Normal> hn;
+        dn.download(hn);
+        for (size_t i = 0; i < host.size(); ++i) normals.push_back(hn[i]);
+        return;
+    }
     // pcl::copyPointCloud<PointXYZ, Normal> (:87-88 / :133-134) copies the fields the two types share — none:
     // the normals are default-constructed, one per vertex
     for (size_t i = 0; i < host.size(); ++i) normals.push_back(dfa::Normal());

@@ -44,5 +44,18 @@ dfa::DeviceArray<MarchingCubes::PointType> MarchingCubes::run(const TsdfVolume& 
     return dfa::DeviceArray<PointType>(triangles_buffer.ptr(), n);
 }
 
+void MarchingCubes::computeNormals(const TsdfVolume& volume, const dfa::DeviceArray<PointType>& vertices,
+                                   dfa::DeviceArray<dfa::Normal>& normals) {
+    if (normals.size() < vertices.size()) normals.create(vertices.size());
+    if (vertices.empty()) return;
+    const Vec3i dims = volume.getDims();
+    const Vec3f size = volume.getSize();
+    const float voxel[3] = {size[0] / dims[0], size[1] / dims[1], size[2] / dims[2]};
+    dfa::check(dfa_tsdf_vertex_normals(volume.data().ptr<uint32_t>(), dims[0], dims[1], dims[2], voxel,
+                                       volume.getGradientDeltaFactor(), (const float*)vertices.ptr(),
+                                       (int)vertices.size(), (float*)normals.ptr(), nullptr),
+               "MarchingCubes::computeNormals");
+}
+
 }  // namespace cuda
 }  // namespace kfusion

@@ -72,6 +72,16 @@ int dfa_tsdf_clear_integrate(const uint16_t* dists, int dists_step, int cols, in
                              int Z, const float voxel_size[3], float trunc_dist, int max_weight,
                              const float vol2cam[12], float fx, float fy, float cx, float cy, dfa_stream_t stream);
 
+/* Normals of surface points from the TSDF gradient (the reference extracts the mesh without
+ * normals, dyn_fusion.cpp:80-88 "temporary workaround until normals are computed via mc").  The raycaster's own
+ * compute_normal (tsdf_volume.cu:320-336): central differences of the trilinear interpolant, gradient_delta_factor
+ * voxels apart, normalised; NaN where a sample leaves the interpolation range [0, dim - 1).
+ * points / normals: n float4 (xyz + pad), device, 16-byte aligned; points in the volume's metric frame, as
+ * dfa_marching_cubes emits them. */
+int dfa_tsdf_vertex_normals(const uint32_t* volume, int X, int Y, int Z, const float voxel_size[3],
+                            float gradient_delta_factor, const float* points, int n, float* normals,
+                            dfa_stream_t stream);
+
 /* raycast (points variant) — internal.hpp:165-166, tsdf_volume.cu:258-318,371-386.
  * points / normals: float4 images; misses are quiet NaN. */
 int dfa_tsdf_raycast_points(const uint32_t* volume, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,

@@ -102,6 +102,8 @@ def _declare(L):
     L.orc_tsdf_integrate.restype = C.c_long
     L.orc_tsdf_raycast_points.argtypes = [vp, i, i, i, vp, f, vp, vp, f, f, f, f, f, f, vp, i, vp, i, i, i, i]
     L.orc_tsdf_raycast_points.restype = None
+    L.orc_tsdf_vertex_normals.argtypes = [vp, i, i, i, vp, f, vp, i, vp]
+    L.orc_tsdf_vertex_normals.restype = None
     L.orc_tsdf_raycast_depth.argtypes = [vp, i, i, i, vp, f, vp, vp, f, f, f, f, f, f, vp, i, vp, i, i, i, i]
     L.orc_tsdf_raycast_depth.restype = None
     L.orc_dq_from_euler.argtypes = [f, f, f, f, f, f, vp]
@@ -174,6 +176,15 @@ def tsdf_raycast_points(vol, voxel_size, trunc, cam2vol, Rinv, fx, fy, cx, cy, s
     lib().orc_tsdf_raycast_points(_p(vol), X, Y, Z, _p(vs), trunc, _p(a), _p(ri), fx, fy, cx, cy, step_factor,
                                   delta_factor, _p(pts), pts.strides[0], _p(nrm), nrm.strides[0], cols, rows, threads)
     return pts, nrm
+
+
+def tsdf_vertex_normals(vol, voxel_size, delta_factor, points):
+    """normals (n x 4) of `points` (n x 4, volume metric frame) from the TSDF gradient: compute_normal of the raycaster"""
+    Z, Y, X = vol.shape
+    pts = np.ascontiguousarray(points, np.float32)
+    out = np.empty_like(pts)
+    lib().orc_tsdf_vertex_normals(_p(vol), X, Y, Z, _p(_f32(voxel_size)), delta_factor, _p(pts), len(pts), _p(out))
+    return out
 
 
 def tsdf_raycast_depth(vol, voxel_size, trunc, cam2vol, Rinv, fx, fy, cx, cy, step_factor, delta_factor, cols, rows,

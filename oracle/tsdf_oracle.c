@@ -348,6 +348,22 @@ static void make_raycaster(raycaster* rc, const uint32_t* vol, int X, int Y, int
     rc->cy    = cy;
 }
 
+/* normals of given points (volume metric frame) by the raycaster's compute_normal (:320-336); points / normals are
+ * n x 4 floats */
+void orc_tsdf_vertex_normals(const uint32_t* vol, int X, int Y, int Z, const float voxel_size[3], float delta_factor,
+                             const float* points, int n, float* normals) {
+    static const float id12[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, id9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    raycaster rc;
+    make_raycaster(&rc, vol, X, Y, Z, voxel_size, 1.f, id12, id9, 1.f, 1.f, 0.f, 0.f, 1.f, delta_factor);
+    for (int i = 0; i < n; ++i) {
+        const f3 nn        = compute_normal(&rc, mk3(points[4 * i], points[4 * i + 1], points[4 * i + 2]));
+        normals[4 * i]     = nn.x;
+        normals[4 * i + 1] = nn.y;
+        normals[4 * i + 2] = nn.z;
+        normals[4 * i + 3] = 0.f;
+    }
+}
+
 void orc_tsdf_raycast_points(const uint32_t* vol, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
                              const float cam2vol[12], const float Rinv[9], float fx, float fy, float cx, float cy,
                              float step_factor, float delta_factor, float* points, int points_step, float* normals,

@@ -201,4 +201,54 @@ TEST(DynFusionTest, OperatorRunsTheWholeFrameSequence) {
     ASSERT_TRUE(moved > 5 && tz / moved < -0.002);
 }
 
+// extension of the interface: with DynFuParams::mesh_normals the canonical frame carries the
+// gradient of the TSDF at its vertices; off (the default) the normals are default-constructed as in the reference
+TEST(DynFusionTest, MeshNormalsFromTheTsdfGradientFaceTheCamera) {
+    const int W = 160, H = 120;
+    std::vector<unsigned short> d((size_t)W * H);
+    const float f = 131.25f, cx = W / 2 - 0.5f, cy = H / 2 - 0.5f, R = 0.5f, cz = 1.5f;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            float dir[3] = {(x - cx) / f, (y - cy) / f, 1.f};
+            const float n = std::sqrt(dir[0] * dir[0] + dir[1] * dir[1] + 1.f);
+            for (float& v : dir) v /= n;
+            const float b = dir[2] * cz, disc = b * b - (cz * cz - R * R);
+            float z = 0.f;  // no background: only the sphere is observed
+            if (disc > 0) z = (b - std::sqrt(disc)) * dir[2];
+            d[(size_t)y * W + x] = (unsigned short)std::lround(z * 1000.f);
+        }
+    for (int with = 0; with < 2; ++with) {
+        DynFuParams p = DynFuParams::defaultParams();
+        p.kinfuParams.cols = W, p.kinfuParams.rows = H;
+        p.kinfuParams.intr = kfusion::Intr(f, f, cx, cy);
+        p.kinfuParams.volume_dims = kfusion::Vec3i::all(64);
+        p.mesh_normals = with != 0;
+        DynFusion df(p);
+        kfusion::cuda::Depth d0;
+        d0.upload(d, W);
+        ASSERT_TRUE(df(d0) == false);
+        auto frame = df.getCanonicalWarpedToLive();
+        const auto& verts = frame->getVertices();
+        const auto& norms = frame->getNormals();
+        ASSERT_TRUE(verts.size() > 1000 && norms.size() == verts.size());
+        // the volume's frame: the sphere's centre sits at camera (0, 0, 1.5) = volume pose^-1 applied; the observed cap
+        // faces the camera, so the outward normal has a negative z component there
+        int facing = 0, finite = 0, nonzero = 0;
+        for (size_t i = 0; i < verts.size(); ++i) {
+            const dfa::Normal& n = norms[i];
+            if (n.normal_x != 0.f || n.normal_y != 0.f || n.normal_z != 0.f) ++nonzero;
+            if (std::isfinite(n.normal_x) && std::isfinite(n.normal_y) && std::isfinite(n.normal_z)) {
+                ++finite;
+                if (n.normal_z < 0.f) ++facing;
+            }
+        }
+        if (!with) {
+            ASSERT_EQ(nonzero, 0);  // the reference's behaviour
+        } else {
+            ASSERT_TRUE(finite > (int)(0.9 * verts.size()));
+            ASSERT_TRUE(facing > (int)(0.9 * finite));
+        }
+    }
+}
+
 int main(int argc, char** argv) { return mt::run_all(argc, argv); }

@@ -102,3 +102,23 @@ def test_marching_cubes_capacity_count_only_and_errors(A):
     assert int(host(A.marching_cubes(dev(pos), cell, dev(tri), dev(nv), 10)[1])[0]) == 0
     with pytest.raises(A.DynfuAmdError):
         A.marching_cubes(dev(vol), cell, None, dev(nv), 10)
+
+
+@pytest.mark.parametrize("dims,delta", [((64, 64, 64), 0.5), ((50, 38, 44), 0.75), ((128, 128, 128), 0.5)])
+def test_vertex_normals_bit_exact(A, dims, delta):
+    """dfa_tsdf_vertex_normals vs the oracle's compute_normal on the vertices marching cubes emits,
+    plus points whose gradient stencil leaves the volume (NaN on both sides)"""
+    tri, nv = default_tables()
+    vol = blob_volume(dims, seed=7, holes=False)
+    cell = np.array([3.0 / dims[0], 2.5 / dims[1], 3.5 / dims[2]], np.float32)
+    pts, total, _ = O.marching_cubes(vol, cell, tri, nv)
+    assert total > 100
+    extra = np.array([[0, 0, 0, 1], [cell[0] * (dims[0] - 1), 0.5, 0.5, 1], [-1, 0.5, 0.5, 1]], np.float32)
+    pts = np.concatenate([pts, extra]).astype(np.float32)
+    ref = O.tsdf_vertex_normals(vol, cell, delta, pts)
+    got = host(A.tsdf_vertex_normals(dev(vol), cell, delta, dev(pts)))
+    assert np.isnan(ref[-3:, 0]).all()
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert np.array_equal(bits(got)[ok], bits(ref)[ok])
+    assert host(A.tsdf_vertex_normals(dev(vol), cell, delta, dev(pts[:0]))).shape == (0, 4)

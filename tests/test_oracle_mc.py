@@ -106,3 +106,27 @@ def test_oracle_weight_zero_rule_bounds_and_capacity():
     lo = 0.5 * cell
     hi = (np.array([24, 20, 28]) - 0.5) * cell
     assert np.all(pts[:, :3] >= lo - 1e-6) and np.all(pts[:, :3] <= hi + 1e-6)
+
+
+def test_vertex_normals_of_a_sphere_point_outwards():
+    """normals of the extracted vertices from the TSDF gradient (the raycaster's compute_normal).
+    On the truncated distance field of a sphere they are the radial directions."""
+    dims = (48, 48, 48)
+    X, Y, Z = dims
+    cell = np.array([2.0 / X, 2.0 / Y, 2.0 / Z], np.float32)
+    z, y, x = np.meshgrid(np.arange(Z) * cell[2], np.arange(Y) * cell[1], np.arange(X) * cell[0], indexing="ij")
+    centre, radius, trunc = np.array([1.0, 0.9, 1.1]), 0.55, 0.25
+    d = np.sqrt((x - centre[0]) ** 2 + (y - centre[1]) ** 2 + (z - centre[2]) ** 2) - radius
+    vol = pack(np.clip(d / trunc, -1, 1), np.full(d.shape, 5, np.uint32))
+    tri, nv = default_tables()
+    pts, total, _ = O.marching_cubes(vol, cell, tri, nv)
+    assert total > 1000
+    nrm = O.tsdf_vertex_normals(vol, cell, 0.5, pts)
+    assert nrm.shape == pts.shape and np.isfinite(nrm[:, :3]).all() and (nrm[:, 3] == 0).all()
+    np.testing.assert_allclose(np.linalg.norm(nrm[:, :3], axis=1), 1.0, atol=1e-5)
+    radial = pts[:, :3] - centre
+    radial /= np.linalg.norm(radial, axis=1, keepdims=True)
+    assert (np.sum(radial * nrm[:, :3], axis=1) > 0.99).all()  # outward: the field grows away from the surface
+    # a stencil that leaves the interpolation range [0, dim - 1) yields NaN, as in the raycaster
+    edge = np.array([[0.0, 1.0, 1.0, 1.0], [(X - 1) * cell[0], 1.0, 1.0, 1.0]], np.float32)
+    assert np.isnan(O.tsdf_vertex_normals(vol, cell, 0.5, edge)[:, 0]).all()
