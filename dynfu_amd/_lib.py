@@ -9,7 +9,7 @@ _LIB = None
 # every symbol include/dynfu_amd.h declares (tests/test_capi_symbols.py checks the .so exports them)
 SYMBOLS = [
     "dfa_last_error", "dfa_version", "dfa_compute_dists", "dfa_tsdf_clear", "dfa_tsdf_integrate",
-    "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_tsdf_vertex_normals", "dfa_knn", "dfa_warp_to_live",
+    "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_tsdf_vertex_normals", "dfa_correspond_projective", "dfa_knn", "dfa_warp_to_live",
     "dfa_calc_dqb", "dfa_unsupported_vertices", "dfa_icp_sums",
     "dfa_correspond", "dfa_marching_cubes", "dfa_mc_default_tables",
     "dfa_depth_bilateral_filter", "dfa_depth_truncate", "dfa_depth_build_pyramid", "dfa_compute_normals_mask_depth",
@@ -101,6 +101,7 @@ def load():
     L.dfa_tsdf_raycast_points.argtypes = ray
     L.dfa_tsdf_raycast_depth.argtypes = ray
     L.dfa_tsdf_vertex_normals.argtypes = [vp, i, i, i, vp, f, vp, i, vp, vp]
+    L.dfa_correspond_projective.argtypes = [vp, vp, i, vp, i, vp, i, i, i, f, f, f, f, f, f, vp, vp, vp, vp]
     L.dfa_knn.argtypes = [vp, vp, i, vp, i, i, vp, vp, vp]
     L.dfa_warp_to_live.argtypes = [vp, vp, vp, i, i, vp, vp, i, vp, vp, vp]
     L.dfa_depth_bilateral_filter.argtypes = [vp, i, vp, i, i, i, i, f, f, vp]
@@ -298,6 +299,23 @@ def marching_cubes(vol, cell_size, tri_table, num_verts_table, max_vertices):
 def _flat(m):
     import numpy as np
     return np.asarray(m, dtype=np.float32).reshape(-1)
+
+
+def correspond_projective(vertices, normals, vmap, nmap, fx, fy, cx, cy, dist_thresh, min_cosine):
+    """projective association of n vertices (n x 3, camera frame) into the live maps (rows x cols x 4 float32 CUDA
+    tensors, nmap / normals may be None).  Returns (live vertices n x 3, live normals n x 3 or None, pixel index n)."""
+    torch = _torch()
+    n = int(vertices.shape[0])
+    rows, cols = vmap.shape[:2]
+    out_v = torch.empty((n, 3), dtype=torch.float32, device=vmap.device)
+    out_n = torch.empty((n, 3), dtype=torch.float32, device=vmap.device) if nmap is not None else None
+    pix = torch.empty((n,), dtype=torch.int32, device=vmap.device)
+    _check(load().dfa_correspond_projective(_dev(vertices, torch.float32, "vertices") if n else None,
+                                            _dev(normals, torch.float32, "normals"), n, _dev(vmap, torch.float32, "vmap"),
+                                            vmap.stride(0) * 4, _dev(nmap, torch.float32, "nmap"),
+                                            nmap.stride(0) * 4 if nmap is not None else 0, cols, rows, fx, fy, cx, cy,
+                                            dist_thresh, min_cosine, _dev(out_v), _dev(out_n), _dev(pix), _stream()))
+    return out_v, out_n, pix
 
 
 # -------------------------------------------------------------------------- warp-field seam

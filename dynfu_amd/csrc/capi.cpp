@@ -521,6 +521,23 @@ int dfa_correspond(const float* canon_vertices, const float* canon_normals, int 
     return DFA_OK;
 }
 
+int dfa_correspond_projective(const float* vertices, const float* normals, int n, const float* vmap, int vmap_step,
+                              const float* nmap, int nmap_step, int cols, int rows, float fx, float fy, float cx, float cy,
+                              float dist_thresh, float min_cosine, float* out_vertices, float* out_normals,
+                              int32_t* out_pixel, dfa_stream_t stream) {
+    REQUIRE(n >= 0 && (n == 0 || vertices), "bad vertices");
+    REQUIRE(vmap && cols > 0 && rows > 0 && vmap_step >= 16 * cols, "bad vertex map");
+    REQUIRE(!nmap || nmap_step >= 16 * cols, "bad normal map pitch");
+    REQUIRE(!out_normals || nmap, "normals requested without a normal map");
+    REQUIRE(fx > 0.f && fy > 0.f && dist_thresh >= 0.f, "bad intrinsics / threshold");
+    REQUIRE(((uintptr_t)vmap & 15) == 0 && (vmap_step & 15) == 0 && ((uintptr_t)nmap & 15) == 0 && (!nmap || (nmap_step & 15) == 0),
+            "maps must be 16-byte aligned float4 images");
+    HIP_TRY(dfa::launch_correspond_projective(vertices, normals, n, vmap, vmap_step, nmap, nmap_step, cols, rows, fx, fy, cx,
+                                              cy, dist_thresh, min_cosine, out_vertices, out_normals, out_pixel,
+                                              S(stream)));
+    return DFA_OK;
+}
+
 // ------------------------------------------------------------------------------- solver seam
 
 int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {

@@ -61,6 +61,10 @@ hipError_t launch_warp_to_live(const float* node_pos, const float* node_dq, cons
                                const float* verts, const float* normals, int N, float* out_verts, float* out_normals,
                                const KnnGridView* grid, hipStream_t s);
 
+hipError_t launch_correspond_projective(const float* verts, const float* normals, int n, const float* vmap, int vmap_step,
+                                        const float* nmap, int nmap_step, int cols, int rows, float fx, float fy, float cx,
+                                        float cy, float dist_thres, float min_cosine, float* out_v, float* out_n,
+                                        int32_t* out_pixel, hipStream_t s);
 hipError_t launch_correspond(const float* canon_v, const float* canon_n, int n_canon, const float* live_v,
                              int n_live, float* out_v, float* out_n, int32_t* out_idx, const KnnGridView* grid,
                              hipStream_t s);

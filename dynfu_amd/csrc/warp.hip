@@ -684,6 +684,61 @@ hipError_t launch_warp_to_live(const float* node_pos, const float* node_dq, cons
     return hipGetLastError();
 }
 
+// Projective association: the O(N) alternative to the nearest-neighbour search above.  Every
+// (warped canonical) vertex is projected into the live frame's vertex map and takes the vertex / normal of the pixel it
+// lands on, under the gates of ComputeIcpHelper::find_coresp (proj_icp.cu:72-98: point-sampled fetch, squared-distance
+// threshold, |n . n'| >= min_cosine).  NaN / -1 where there is no association.
+__global__ __launch_bounds__(256) void correspond_projective_kernel(const float* __restrict__ verts,
+                                                                    const float* __restrict__ normals, int n,
+                                                                    const float* __restrict__ vmap, int vmap_step,
+                                                                    const float* __restrict__ nmap, int nmap_step, int cols,
+                                                                    int rows, float fx, float fy, float cx, float cy,
+                                                                    float dist2_thres, float min_cosine,
+                                                                    float* __restrict__ out_v, float* __restrict__ out_n,
+                                                                    int32_t* __restrict__ out_pixel) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float qn = __uint_as_float(0x7fc00000u);
+    const f3 s     = mk3(verts[3 * (size_t)i], verts[3 * (size_t)i + 1], verts[3 * (size_t)i + 2]);
+    f3 d = mk3(qn, qn, qn), nd = mk3(qn, qn, qn);
+    int pix = -1;
+    if (s.z > 0.f) {
+        const float u = fmaf(fx, s.x / s.z, cx), w = fmaf(fy, s.y / s.z, cy);  // proj, proj_icp.cu:28-33
+        if (u >= 0.f && w >= 0.f && u < (float)cols && w < (float)rows) {
+            const int iu = (int)floorf(u), iw = (int)floorf(w);  // point-sampled
+            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(vmap) + (size_t)iw * vmap_step + 16 * (size_t)iu);
+            bool ok = v.x == v.x;
+            const f3 dd = mk3(v.x, v.y, v.z), sd = s - dd;
+            ok = ok && !(dot(sd, sd) > dist2_thres);
+            f3 nn = mk3(qn, qn, qn);
+            if (ok && nmap) {
+                const float4 nv = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nmap) + (size_t)iw * nmap_step + 16 * (size_t)iu);
+                nn = mk3(nv.x, nv.y, nv.z);
+                ok = nv.x == nv.x;
+                if (ok && normals) {
+                    const f3 ns = mk3(normals[3 * (size_t)i], normals[3 * (size_t)i + 1], normals[3 * (size_t)i + 2]);
+                    ok          = !(fabsf(dot(ns, nn)) < min_cosine);
+                }
+            }
+            if (ok) d = dd, nd = nn, pix = iw * cols + iu;
+        }
+    }
+    if (out_v) out_v[3 * (size_t)i] = d.x, out_v[3 * (size_t)i + 1] = d.y, out_v[3 * (size_t)i + 2] = d.z;
+    if (out_n) out_n[3 * (size_t)i] = nd.x, out_n[3 * (size_t)i + 1] = nd.y, out_n[3 * (size_t)i + 2] = nd.z;
+    if (out_pixel) out_pixel[i] = pix;
+}
+
+hipError_t launch_correspond_projective(const float* verts, const float* normals, int n, const float* vmap, int vmap_step,
+                                        const float* nmap, int nmap_step, int cols, int rows, float fx, float fy, float cx,
+                                        float cy, float dist_thres, float min_cosine, float* out_v, float* out_n,
+                                        int32_t* out_pixel, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    correspond_projective_kernel<<<(n + 255) / 256, 256, 0, s>>>(verts, normals, n, vmap, vmap_step, nmap, nmap_step, cols,
+                                                                 rows, fx, fy, cx, cy, dist_thres * dist_thres, min_cosine,
+                                                                 out_v, out_n, out_pixel);
+    return hipGetLastError();
+}
+
 hipError_t launch_correspond(const float* canon_v, const float* canon_n, int n_canon, const float* live_v,
                              int n_live, float* out_v, float* out_n, int32_t* out_idx, const KnnGridView* grid,
                              hipStream_t s) {

@@ -208,6 +208,18 @@ int dfa_unsupported_vertices(const float* node_pos, const float* node_w, int D, 
 int dfa_correspond(const float* canon_vertices, const float* canon_normals, int n_canon, const float* live_vertices,
                    int n_live, float* out_vertices, float* out_normals, int32_t* out_index, dfa_stream_t stream);
 
+/* Projective association — the O(N) alternative to dfa_correspond: every vertex (camera frame of the
+ * live maps; typically the warped canonical cloud) is projected with the intrinsics and takes the live vertex / normal
+ * of the pixel it lands on, under the gates of ComputeIcpHelper::find_coresp (proj_icp.cu:72-98): point-sampled fetch,
+ * |v - v'| <= dist_thresh, and — when both `normals` and `nmap` are given — |n . n'| >= min_cosine.
+ * vmap / nmap: rows x cols float4 images (NaN x = undefined), pitches in bytes, as dfa_compute_points_normals writes
+ * them.  Outputs n x 3 floats (NaN where there is no association) and the pixel index y * cols + x (-1: none);
+ * normals, nmap, out_normals, out_vertices, out_pixel may be NULL (out_normals needs nmap). */
+int dfa_correspond_projective(const float* vertices, const float* normals, int n, const float* vmap, int vmap_step,
+                              const float* nmap, int nmap_step, int cols, int rows, float fx, float fy, float cx, float cy,
+                              float dist_thresh, float min_cosine, float* out_vertices, float* out_normals,
+                              int32_t* out_pixel, dfa_stream_t stream);
+
 /* ===================================================================================== */
 /* Solver seam — replaces class CombinedSolver (include/dynfu/utils/opt_solver.hpp:19-110, */
 /* src/dynfu/utils/opt_solver.cpp) and the Opt GN/PCG it drives with energy.t            */

@@ -104,6 +104,8 @@ def _declare(L):
     L.orc_tsdf_raycast_points.restype = None
     L.orc_tsdf_vertex_normals.argtypes = [vp, i, i, i, vp, f, vp, i, vp]
     L.orc_tsdf_vertex_normals.restype = None
+    L.orc_correspond_projective.argtypes = [vp, vp, i, vp, i, vp, i, i, i, f, f, f, f, f, f, vp, vp, vp]
+    L.orc_correspond_projective.restype = None
     L.orc_tsdf_raycast_depth.argtypes = [vp, i, i, i, vp, f, vp, vp, f, f, f, f, f, f, vp, i, vp, i, i, i, i]
     L.orc_tsdf_raycast_depth.restype = None
     L.orc_dq_from_euler.argtypes = [f, f, f, f, f, f, vp]
@@ -176,6 +178,22 @@ def tsdf_raycast_points(vol, voxel_size, trunc, cam2vol, Rinv, fx, fy, cx, cy, s
     lib().orc_tsdf_raycast_points(_p(vol), X, Y, Z, _p(vs), trunc, _p(a), _p(ri), fx, fy, cx, cy, step_factor,
                                   delta_factor, _p(pts), pts.strides[0], _p(nrm), nrm.strides[0], cols, rows, threads)
     return pts, nrm
+
+
+def correspond_projective(vertices, normals, vmap, nmap, fx, fy, cx, cy, dist_thresh, min_cosine):
+    """projective association (find_coresp's gates); vmap / nmap: rows x cols x 4 float32; returns (v, n or None, pixel)"""
+    v = np.ascontiguousarray(vertices, np.float32)
+    nr = None if normals is None else np.ascontiguousarray(normals, np.float32)
+    vm = np.ascontiguousarray(vmap, np.float32)
+    nm = None if nmap is None else np.ascontiguousarray(nmap, np.float32)
+    rows, cols = vm.shape[:2]
+    out_v = np.empty((len(v), 3), np.float32)
+    out_n = None if nm is None else np.empty((len(v), 3), np.float32)
+    pix = np.empty(len(v), np.int32)
+    lib().orc_correspond_projective(_p(v), None if nr is None else _p(nr), len(v), _p(vm), vm.strides[0],
+                                    None if nm is None else _p(nm), 0 if nm is None else nm.strides[0], cols, rows, fx, fy,
+                                    cx, cy, dist_thresh, min_cosine, _p(out_v), None if out_n is None else _p(out_n), _p(pix))
+    return out_v, out_n, pix
 
 
 def tsdf_vertex_normals(vol, voxel_size, delta_factor, points):

@@ -190,3 +190,47 @@ int orc_voxel_grid(const float* pts, int n, float leaf, float* out) {
     free(pr);
     return nout;
 }
+
+
+/* projective association of n vertices into a live vertex / normal map: the gates of ComputeIcpHelper::find_coresp
+ * (proj_icp.cu:72-98).  Outputs NaN / -1 where there is no association; normals, nmap, out_n may be NULL. */
+void orc_correspond_projective(const float* verts, const float* normals, int n, const float* vmap, int vmap_step,
+                               const float* nmap, int nmap_step, int cols, int rows, float fx, float fy, float cx, float cy,
+                               float dist_thresh, float min_cosine, float* out_v, float* out_n, int32_t* out_pixel) {
+    const float dist2 = dist_thresh * dist_thresh;
+    union { uint32_t u; float f; } q;
+    q.u = 0x7fc00000u;
+    for (int i = 0; i < n; ++i) {
+        const float sx = verts[3 * i], sy = verts[3 * i + 1], sz = verts[3 * i + 2];
+        float d[3] = {q.f, q.f, q.f}, nd[3] = {q.f, q.f, q.f};
+        int pix = -1;
+        if (sz > 0.f) {
+            const float u = fmaf(fx, sx / sz, cx), w = fmaf(fy, sy / sz, cy);
+            if (u >= 0.f && w >= 0.f && u < (float)cols && w < (float)rows) {
+                const int iu = (int)floorf(u), iw = (int)floorf(w);
+                const float* v = (const float*)((const char*)vmap + (size_t)iw * vmap_step) + 4 * iu;
+                int ok = v[0] == v[0];
+                const float ex = sx - v[0], ey = sy - v[1], ez = sz - v[2];
+                ok = ok && !(fmaf(ez, ez, fmaf(ey, ey, ex * ex)) > dist2); /* the device's dot(): two fused steps */
+                float nn[3] = {q.f, q.f, q.f};
+                if (ok && nmap) {
+                    const float* nv = (const float*)((const char*)nmap + (size_t)iw * nmap_step) + 4 * iu;
+                    nn[0] = nv[0], nn[1] = nv[1], nn[2] = nv[2];
+                    ok = nv[0] == nv[0];
+                    if (ok && normals) {
+                        const float dt = fmaf(normals[3 * i + 2], nn[2], fmaf(normals[3 * i + 1], nn[1], normals[3 * i] * nn[0]));
+                        ok = !(fabsf(dt) < min_cosine);
+                    }
+                }
+                if (ok) {
+                    d[0] = v[0], d[1] = v[1], d[2] = v[2];
+                    nd[0] = nn[0], nd[1] = nn[1], nd[2] = nn[2];
+                    pix = iw * cols + iu;
+                }
+            }
+        }
+        if (out_v) out_v[3 * i] = d[0], out_v[3 * i + 1] = d[1], out_v[3 * i + 2] = d[2];
+        if (out_n) out_n[3 * i] = nd[0], out_n[3 * i + 1] = nd[1], out_n[3 * i + 2] = nd[2];
+        if (out_pixel) out_pixel[i] = pix;
+    }
+}

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 import oracle as O  # noqa: E402
 from dynfu_amd import synth  # noqa: E402
-from gpu_util import dev, host  # noqa: E402
+from gpu_util import bits, dev, host  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -208,3 +208,49 @@ def test_unsupported_vertices_without_nodes(A):
     import torch
     v = torch.zeros((7, 3), device="cuda")
     assert host(A.unsupported_vertices(None, None, 8, v)).tolist() == [1] * 7  # min stays HUGE_VALF (:40,:53)
+
+
+# ------------------------------------------------------------- projective association
+def _live_maps(cfg, frame):
+    fx, fy, cx, cy = synth.intrinsics(cfg)
+    P, Nm = O.points_normals(synth.depth_frame(cfg, frame), fx, fy, cx, cy)
+    return (fx, fy, cx, cy), P, Nm
+
+
+@pytest.mark.parametrize("name,with_normals", [("T1", True), ("T1", False), ("C1", True)])
+def test_correspond_projective_bit_exact(A, name, with_normals):
+    """dfa_correspond_projective vs the oracle's find_coresp gates: the canonical cloud of the synthetic scene against
+    the vertex / normal maps of a later frame, plus vertices behind the camera, outside the image and on the far plane"""
+    cfg = synth.CONFIGS[name]
+    c = synth.canonical(cfg)
+    intr, P, Nm = _live_maps(cfg, 5)
+    extra = np.array([[0, 0, -1], [0, 0, 0], [50, 0, 1], [0, -50, 1], [0.01, 0.01, 2.5], [np.nan, 0, 1]], np.float32)
+    v = np.concatenate([c["verts"], extra]).astype(np.float32)
+    n = np.concatenate([c["normals"], np.tile([[0, 0, -1]], (len(extra), 1))]).astype(np.float32)
+    args = (intr[0], intr[1], intr[2], intr[3], 0.05, 0.7)
+    rv, rn, rp = O.correspond_projective(v, n if with_normals else None, P, Nm, *args)
+    gv, gn, gp = A.correspond_projective(dev(v), dev(n) if with_normals else None, dev(P), dev(Nm), *args)
+    assert np.array_equal(host(gp), rp)
+    assert np.array_equal(bits(host(gv)), bits(rv)) and np.array_equal(bits(host(gn)), bits(rn))
+    matched = rp >= 0
+    assert 0.5 * len(c["verts"]) < matched.sum() < len(v)          # most of the visible surface is associated
+    assert (rp[-6:-2] == -1).all() and rp[-1] == -1                # behind / outside / NaN: no association
+    assert np.isnan(rv[~matched]).all() and np.isfinite(rv[matched]).all()
+    # every association obeys the gates
+    assert (np.linalg.norm(rv[matched] - v[matched], axis=1) <= 0.05 * (1 + 1e-6)).all()
+    if with_normals:
+        assert (np.abs(np.sum(rn[matched] * n[matched], axis=1)) >= 0.7 - 1e-6).all()
+    # without a normal map: vertices only
+    gv2, gn2, gp2 = A.correspond_projective(dev(v), None, dev(P), None, *args)
+    rv2, _, rp2 = O.correspond_projective(v, None, P, None, *args)
+    assert gn2 is None and np.array_equal(host(gp2), rp2) and np.array_equal(bits(host(gv2)), bits(rv2))
+
+
+def test_correspond_projective_errors(A):
+    import torch
+    P = torch.zeros((4, 4, 4), device="cuda")
+    v = torch.zeros((3, 3), device="cuda")
+    with pytest.raises(A.DynfuAmdError):
+        A.correspond_projective(v, None, P, None, 0.0, 1.0, 0.0, 0.0, 0.1, 0.5)  # fx = 0
+    ov, on, pix = A.correspond_projective(torch.zeros((0, 3), device="cuda"), None, P, None, 1.0, 1.0, 0.0, 0.0, 0.1, 0.5)
+    assert ov.shape == (0, 3) and pix.shape == (0,)

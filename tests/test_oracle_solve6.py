@@ -173,3 +173,32 @@ def test_regulariser_alone_keeps_a_rigid_field_and_smooths_a_rough_one(scene):
     rough = _perturbed(c, 3, rot=0.1, trans=0.02)
     out, st = O.solve6(c["node_pos"], rough, c["node_w"], k, c["verts"], c["normals"], empty, empty, intr, **kw)
     assert st["final_cost"] < 0.05 * st["initial_cost"]
+
+
+def test_projective_association_oracle_obeys_its_gates():
+    """orc_correspond_projective (the gates of find_coresp, proj_icp.cu:72-98) on a hand-made map"""
+    fx = fy = 2.0
+    cx = cy = 1.5
+    P = np.full((4, 4, 4), np.nan, np.float32)
+    Nm = np.full((4, 4, 4), np.nan, np.float32)
+    for y in range(4):
+        for x in range(4):
+            P[y, x] = [(x - cx) / fx, (y - cy) / fy, 1.0, 0.0]
+            Nm[y, x] = [0, 0, -1, 0]
+    P[0, 0, 0] = np.nan          # undefined pixel
+    Nm[3, 3] = [1, 0, 0, 0]      # normal at right angles
+    v = np.array([[-0.25, -0.25, 1.0],   # pixel (1, 1): association
+                  [-0.75, -0.75, 1.0],   # pixel (0, 0): undefined
+                  [0.75, 0.75, 1.0],     # pixel (3, 3): normal gate
+                  [-0.25, -0.25, 1.5],   # lands on a pixel 0.5 m away: distance gate
+                  [5.0, 0.0, 1.0],       # outside the image
+                  [0.0, 0.0, -1.0]], np.float32)
+    n = np.tile([[0, 0, -1]], (len(v), 1)).astype(np.float32)
+    ov, on, pix = O.correspond_projective(v, n, P, Nm, fx, fy, cx, cy, 0.1, 0.5)
+    assert pix.tolist() == [1 * 4 + 1, -1, -1, -1, -1, -1]
+    np.testing.assert_array_equal(ov[0], P[1, 1, :3])
+    np.testing.assert_array_equal(on[0], [0, 0, -1])
+    assert np.isnan(ov[1:]).all() and np.isnan(on[1:]).all()
+    # without normals the third vertex is associated too
+    _, _, pix2 = O.correspond_projective(v, None, P, Nm, fx, fy, cx, cy, 0.1, 0.5)
+    assert pix2.tolist() == [5, -1, 15, -1, -1, -1]
