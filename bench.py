@@ -36,9 +36,9 @@ TIMING_SAMPLE = 8  # every 8th timed frame carries the hipEvent brackets of the 
 PMC_TRAFFIC_BYTES = {("C2", "fused_integrate"): 0.5415e9, ("C3", "fused_integrate"): 0.5415e9,
                      # profiles/r01_pmc_northstar.md (FETCH x2 + WRITE per dispatch)
                      ("C3", "s6_assemble"): 0.510e9, ("C3", "s6_pcg_step"): 0.0242e9,
-                     # profiles/r01_pmc_solve.md: (331.4 + 268.4) KiB per pcg_paired_kernel<1024,1,32,1> launch, mean over
+                     # profiles/r01_pmc_solve.md: (338.8 + 274.9) KiB per pcg_paired_kernel<1024,1,32,1> launch, mean over
                      # the five launches of a frame (those that return at entry included)
-                     ("C2", "pcg"): 599.8 * 1024}
+                     ("C2", "pcg"): 613.7 * 1024}
 
 
 def parse():
@@ -492,7 +492,8 @@ def main():
                dtype="f32", data="synthetic",
                config=dict(workload="%s: %d^3 TSDF (4 B voxels), %dx%d depth, %d nodes, k=%d, %d vertices, "
                                     "%d GN iterations (those behind a gradient at the round-off floor are no-ops and return at "
-                                    "entry) x PCG<=256 (tol 1e-6), reference-parity energy (energy.t), "
+                                    "entry) x PCG<=256 (tol 1e-6 per linearisation, never below 1e-12 of the solve's first gradient), "
+                                    "reference-parity energy (energy.t), "
                                     "lambda=200" % (args.config, dim, Wd, Hd, seq.D, seq.k, seq.N, cfg["gn_iters"]),
                            parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus,
                            streams="serial" if args.serial else ("fuse || graph build of frame f+1 || solve of frame f on three "
