@@ -360,3 +360,30 @@ def test_solver_timing_accumulates_pauses_and_resumes(A):
     tm = s.timing()
     assert tm["solves"] == 1 and tm["pcg_launches"] == 2
     s.close()
+
+
+@pytest.mark.parametrize("D,k", [(1500, 8), (2048, 8), (700, 16)])
+def test_rows_wider_than_the_register_slots(A, D, k):
+    """k = 8 / 16 above 1024 (512) nodes: row pairs exceed the 32 (64) register slots of the register-resident PCG —
+    the entries that do not fit are streamed; same translations as the fp64 oracle"""
+    cfg = dict(synth.CONFIGS["T1"], D=D, k=k)
+    c = synth.canonical(cfg)
+    verts = c["verts"][::4].copy()
+    idx = O.knn(c["node_pos"], verts, k, threads=8)
+    d2 = ((verts[:, None, :].astype(np.float64) - c["node_pos"][idx].astype(np.float64)) ** 2).sum(-1)
+    w = np.exp(-d2 / (2 * float(c["node_w"][0]) ** 2)).astype(np.float32)
+    t_true = synth.true_translations(c["node_pos"], 3, k)
+    live = synth.live_vertices(verts, idx, w, t_true)
+    kw = dict(num_iter=2, nonlinear_iter=1, linear_iter=200, lambda_=200.0, pcg_tol=1e-6)
+    s = A.Solver(D, len(verts), k)
+    s.set_problem(dev(c["node_pos"]), dev(c["node_dq"]), dev(c["node_w"]), dev(verts), dev(live))
+    s.solve(_params(A, **kw))
+    st, t = s.stats(), host(s.translations())
+    s.close()
+    assert st["max_row_nnz"] > (16 if D > 1024 else 32), st  # some pair cannot fit
+    t_ref, _, st_ref = O.solve_ref(c["node_pos"], c["node_dq"], c["node_w"], k, verts, live, use_double=True, threads=8,
+                                   tukey_offset=synth.SOLVER["tukey_offset"], psi_data=synth.SOLVER["psi_data"],
+                                   psi_reg=synth.SOLVER["psi_reg"], **kw)
+    assert st["gn_iters"] == 2 and st["pcg_iters"] > 10
+    assert np.abs(t - t_ref).max() <= 3e-5
+    np.testing.assert_allclose(st["final_cost"], st_ref["final_cost"], rtol=2e-3, atol=1e-9)
