@@ -141,6 +141,7 @@ struct dfa_solver {
     std::vector<int> ev_pcg, ev_asm; // indices of the begin events of each bracketed launch
     size_t ev_used;
     int timed_solves = 0;
+    dfa::MbGraphCache mb_graphs;  // HIP graphs of the many-workgroup PCG's launch chunks
     bool just_reset = false;  // the unknowns and the state block were zeroed by set_problem and not touched since
     long long* iters_total = nullptr;  // device: PCG iterations of all solves since enable_timing(1)
     int* host_flag = nullptr;        // pinned int[2]: stop flag of the many-workgroup PCG and the plan's converged flag,
@@ -623,6 +624,7 @@ void dfa_solver_destroy(dfa_solver* s) {
     s->grid.release();
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     if (s->host_flag) (void)hipHostFree(s->host_flag);
+    s->mb_graphs.release();
     delete s;
 }
 
@@ -692,7 +694,7 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
             timing_end(s, ev, st);
             if (ev >= 0) s->ev_asm.push_back(ev);
             ev = s->timing ? timing_begin(s, st) : -1;  // closed behind the solving kernel, before the fallback launch
-            HIP_TRY(dfa::solve_pcg(v, s->state, p->linear_iter, p->pcg_tol, s->host_flag,
+            HIP_TRY(dfa::solve_pcg(v, s->state, p->linear_iter, p->pcg_tol, s->host_flag, &s->mb_graphs,
                                    ev >= 0 ? s->events[ev + 1] : nullptr, st));
             if (ev >= 0) s->ev_pcg.push_back(ev);
         }

@@ -28,6 +28,7 @@
 //     LDS (16 B / node, ds_read_b128 gathers), x / r / p of the thread's own rows in
 //     registers and dot products reduced by wave shuffles in double.
 #include <hip/hip_runtime.h>
+#include <cstring>
 
 #include <algorithm>
 
@@ -1407,16 +1408,72 @@ __global__ __launch_bounds__(256) void pcg_mb_finish_kernel(SolveView s, SolveSt
 // The iteration count is only known on the device.  With a pinned host word the launches go out in chunks (16, 32,
 // 64, ...) and the stop flag is read back between chunks — one stream synchronisation per chunk instead of up to
 // max_iter launches that return at once (3 us each: 0.7 ms per Gauss-Newton iteration at the usual cap of 256).
+void MbGraphCache::release() {
+    for (int i = 0; i < used; ++i)
+        if (e[i].exec) (void)hipGraphExecDestroy(e[i].exec);
+    used = 0;
+    if (capture) (void)hipStreamDestroy(capture), capture = nullptr;
+}
+
+// iterations [it0, it1): from the cache's graph of that range when there is (or can be) one, else launch by launch
+static hipError_t launch_mb_range(const SolveView& s, SolveState* state, int it0, int it1, float pcg_tol,
+                                  MbGraphCache* gc, hipStream_t st) {
+    const int nb = solve_mb_blocks(s.D), nbu = (s.D + 255) / 256;
+    auto direct = [&](hipStream_t q) {
+        for (int it = it0; it < it1; ++it) {
+            pcg_mb_matvec_kernel<<<nb, 256, 0, q>>>(s, state, it, pcg_tol);
+            pcg_mb_update_kernel<<<nbu, 256, 0, q>>>(s, state, it);
+        }
+        return hipGetLastError();
+    };
+    static const bool no_graph = getenv("DFA_MB_NO_GRAPH") != nullptr;  // A/B
+    if (!gc || gc->disabled || no_graph || it1 - it0 < 4) return direct(st);
+    MbGraphCache::Entry* hit = nullptr;
+    for (int i = 0; i < gc->used && !hit; ++i) {
+        MbGraphCache::Entry& c = gc->e[i];
+        // (the plan's own buffers never move; the borrowed pointers of the view change from frame to frame but these
+        // kernels read none of them)
+        if (c.it0 == it0 && c.it1 == it1 && c.tol == pcg_tol && c.state == state && c.view.D == s.D && c.view.ell_vals == s.ell_vals)
+            hit = &c;
+    }
+    if (!hit) {
+        if (gc->used == 8) {  // other problem sizes / pointers: start over
+            for (int i = 0; i < gc->used; ++i)
+                if (gc->e[i].exec) (void)hipGraphExecDestroy(gc->e[i].exec);
+            gc->used = 0;
+        }
+        hipGraph_t g = nullptr;
+        hipGraphExec_t exec = nullptr;
+        bool ok = gc->capture || hipStreamCreateWithFlags(&gc->capture, hipStreamNonBlocking) == hipSuccess;
+        ok      = ok && hipStreamBeginCapture(gc->capture, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            const hipError_t le = direct(gc->capture);
+            const hipError_t ce = hipStreamEndCapture(gc->capture, &g);
+            ok = le == hipSuccess && ce == hipSuccess && g && hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) == hipSuccess;
+            if (g) (void)hipGraphDestroy(g);
+        }
+        if (!ok) {
+            (void)hipGetLastError();  // clear the sticky error of the failed attempt
+            gc->disabled = true;
+            return direct(st);
+        }
+        hit        = &gc->e[gc->used++];
+        hit->it0 = it0, hit->it1 = it1, hit->tol = pcg_tol, hit->view = s, hit->state = state, hit->exec = exec;
+    }
+    return hipGraphLaunch(hit->exec, st);
+}
+
 static hipError_t launch_mb_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag,
-                                hipStream_t st) {
+                                MbGraphCache* gc, hipStream_t st) {
     const int nb = solve_mb_blocks(s.D), nbu = (s.D + 255) / 256;
     pcg_mb_init_kernel<<<nbu, 256, 0, st>>>(s, state);
     int chunk = 16;
     for (int it = 0; it < max_iter;) {
         const int end = host_flag ? std::min(max_iter, it + chunk) : max_iter;
-        for (; it < end; ++it) {
-            pcg_mb_matvec_kernel<<<nb, 256, 0, st>>>(s, state, it, pcg_tol);
-            pcg_mb_update_kernel<<<nbu, 256, 0, st>>>(s, state, it);
+        {
+            const hipError_t e = launch_mb_range(s, state, it, end, pcg_tol, host_flag ? gc : nullptr, st);
+            if (e != hipSuccess) return e;
+            it = end;
         }
         if (host_flag && it < max_iter) {
             // one more matvec launch evaluates the stopping rule on the last update's residual
@@ -1479,8 +1536,8 @@ static void sync_floor_switch() {
     }
 }
 
-static hipError_t route_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag, hipEvent_t& main_done,
-                            hipStream_t st) {
+static hipError_t route_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag, MbGraphCache* gc,
+                            hipEvent_t& main_done, hipStream_t st) {
     // DFA_PCG_VARIANT (read at every call: the tests switch it) selects a kernel for A/B runs:
     // 0 streaming, 1 register-resident with the three coordinates in one workgroup, 2 its 512-thread flavour,
     // 3 many-workgroup, 4 streaming up to 8192 nodes; unset = the default routing below.
@@ -1490,7 +1547,7 @@ static hipError_t route_pcg(const SolveView& s, SolveState* state, int max_iter,
     const bool force_streaming = v2 == 0;
     const int D = s.D;
     hipError_t e;
-    if (v2 == 3) return launch_mb_pcg(s, state, max_iter, pcg_tol, host_flag, st);
+    if (v2 == 3) return launch_mb_pcg(s, state, max_iter, pcg_tol, host_flag, gc, st);
     if (D <= 2048 && !force_streaming) {
         // Register-resident matrix.  512 threads leave 256 VGPRs per lane (64 slots per row pair: k = 8
         // rows fit), 1024 threads 128 VGPRs (32 slots: k = 4).  A pair that does not fit sets
@@ -1517,12 +1574,12 @@ static hipError_t route_pcg(const SolveView& s, SolveState* state, int max_iter,
     const bool keep_streaming = v2 == 4;
     if (keep_streaming && D <= 4096) return launch_streaming_pcg<4, false>(s, state, max_iter, pcg_tol, st);
     if (keep_streaming && D <= 8192) return launch_streaming_pcg<8, false>(s, state, max_iter, pcg_tol, st);
-    return launch_mb_pcg(s, state, max_iter, pcg_tol, host_flag, st);
+    return launch_mb_pcg(s, state, max_iter, pcg_tol, host_flag, gc, st);
 }
 
-hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag, hipEvent_t main_done,
-                     hipStream_t st) {
-    const hipError_t e = route_pcg(s, state, max_iter, pcg_tol, host_flag, main_done, st);
+hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag, MbGraphCache* gc,
+                     hipEvent_t main_done, hipStream_t st) {
+    const hipError_t e = route_pcg(s, state, max_iter, pcg_tol, host_flag, gc, main_done, st);
     if (main_done) (void)hipEventRecord(main_done, st);  // paths without a fallback launch
     return e;
 }

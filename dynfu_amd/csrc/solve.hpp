@@ -91,8 +91,27 @@ __host__ __device__ inline int solve_mb_rows_per_block() { return 16; }  // mult
 __host__ __device__ inline int solve_mb_blocks(int D) { return (D + 15) / 16; }
 // host_flag: pinned host word (may be null); with it, plans above 2048 nodes synchronise with the stream once per
 // chunk of PCG launches to stop launching after convergence
+// The launches of a chunk of many-workgroup PCG iterations, replayed as HIP graphs (one per range of iterations: the
+// iteration number is a kernel argument).  Behind a stream synchronisation the host cannot enqueue two 5 us kernels
+// per iteration fast enough — the GPU idled 4-24 us between launches (profile of C3) — a graph is one host call.
+struct MbGraphCache {
+    struct Entry {
+        int it0 = 0, it1 = 0;
+        float tol = 0.f;
+        SolveView view;
+        const SolveState* state = nullptr;
+        hipGraphExec_t exec = nullptr;
+    };
+    Entry e[8];
+    int used = 0;
+    hipStream_t capture = nullptr;  // capture is not allowed on the legacy default stream
+    bool disabled = false;
+    void release();
+};
+
 // `main_done` (optional) is recorded behind the solving kernel(s), before the fallback launch that usually returns at once
-hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag /* pinned int[2] or null */, hipEvent_t main_done,
+hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag /* pinned int[2] or null */,
+                     MbGraphCache* graphs /* or null */, hipEvent_t main_done,
                      hipStream_t st);
 // books n Gauss-Newton iterations that the host did not launch because the plan had converged (SolveState::converged)
 hipError_t solve_count_noop(SolveState* state, int n, hipStream_t st);
