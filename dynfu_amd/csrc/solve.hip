@@ -1282,7 +1282,9 @@ __global__ __launch_bounds__(256) void pcg_mb_init_kernel(SolveView s, SolveStat
         const float minv = d > FLT_EPSILON ? 1.0f / d : 1.0f;
         const float4 r   = make_float4(s.g[3 * a], s.g[3 * a + 1], s.g[3 * a + 2], 0.f);
         const float4 z   = make_float4(minv * r.x, minv * r.y, minv * r.z, 0.f);
-        s.mb_r[a] = r, s.mb_u[0][a] = z, s.mb_x[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        s.mb_r[a] = r, s.mb_u[0][a] = z, s.mb_x[a] = zero;
+        s.mb_p[a] = s.mb_s[a] = s.mb_t[0][a] = s.mb_t[1][a] = zero;  // (the one-launch form multiplies them by beta_0 = 0)
         rz = fmaf(r.z, z.z, fmaf(r.y, z.y, r.x * z.x));
     }
     rz = wave_sum_all(rz);
@@ -1390,6 +1392,114 @@ __global__ __launch_bounds__(256) void pcg_mb_update_kernel(SolveView s, SolveSt
     }
 }
 
+// ---- Chronopoulos-Gear form: ONE launch per iteration (the two inner products are taken together after the matrix
+// product, so an iteration needs one grid-wide synchronisation; the textbook form above needs two).  As in
+// s6_pcg_step_kernel:  u = M^-1 r, w = A u, m = M^-1 w, t kept by t_i = m_i + beta_i t_(i-1);
+//   p_i = u_i + beta_i p_(i-1);  s_i = w_i + beta_i s_(i-1);  x += alpha_i p_i;  r -= alpha_i s_i;  u_(i+1) = u_i - alpha_i t_i;
+//   w_(i+1) = A u_(i+1) = A u_i - alpha_i (A m_i + beta_i A t_(i-1))  — gathered from the vectors of launch i - 1;
+//   gamma = (r, u), delta = (w, u);  beta_(i+1) = gamma_(i+1) / gamma_i;  alpha_(i+1) = gamma_(i+1) / (delta_(i+1) - beta_(i+1) gamma_(i+1) / alpha_i).
+// launch it = -1: w_0 = A u_0, m_0, gamma_0, delta_0 (u_0 = M^-1 g, x = 0 from pcg_mb_init_kernel).  16 lanes per row.
+// Same iterates as the textbook form in exact arithmetic; the stopping rules are evaluated on gamma = (r, M^-1 r).
+__global__ __launch_bounds__(256) void pcg_mb_step_kernel(SolveView s, SolveState* __restrict__ st, int it, float pcg_tol) {
+    __shared__ float sh[2][4];
+    __shared__ float scal[2];
+    if (st->mb_done) return;
+    const int nb  = solve_mb_blocks(s.D);
+    const int cur = it >= 0 ? (it & 1) : 0, nxt = cur ^ 1;  // u, m: read [cur], write [nxt]; t: read [nxt], write [cur]
+    const float4* ucur  = s.mb_u[cur];
+    const float4* mcur  = s.mb_m[cur];
+    const float4* tprev = s.mb_t[nxt];
+    float alpha = 0.f, beta = 0.f;
+    if (it >= 0) {
+        // the inner products of the launch before: every workgroup adds the partials in the same order
+        float g = 0.f, d = 0.f;
+        for (int i = threadIdx.x; i < nb; i += 256) g += s.mb_gpart[it & 1][i], d += s.mb_dpart[it & 1][i];
+        g = wave_sum_all(g), d = wave_sum_all(d);
+        if ((threadIdx.x & 63) == 0) sh[0][threadIdx.x >> 6] = g, sh[1][threadIdx.x >> 6] = d;
+        __syncthreads();
+        const float gamma = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]), delta = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+        const float floor_ = 1e-12f;
+        const float tol2   = pcg_tol * pcg_tol > floor_ ? pcg_tol * pcg_tol : floor_;
+        float rz0 = gamma, denom = delta;
+        bool stop = !(gamma > 0.f);
+        if (it == 0) {
+            const bool at_floor = st->grad_first > 0.0 && (double)gamma <= (double)floor_ * st->grad_first;
+            stop                = stop || at_floor;  // nothing left to solve
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                st->mb_rz0 = gamma;
+                if (at_floor && st->weights_fresh) st->converged = 1;
+            }
+        } else {
+            rz0   = st->mb_rz0;
+            beta  = gamma / st->mb_gamma_prev[(it + 1) & 1];
+            denom = delta - beta * gamma / st->mb_alpha_prev[(it + 1) & 1];
+            stop  = stop || gamma <= fmaxf(tol2 * rz0, solve_floor(st));
+        }
+        stop = stop || !(denom > 0.f);  // converged, or breakdown: the same decision in every workgroup
+        if (stop) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) st->mb_done = 1;
+            return;
+        }
+        alpha = gamma / denom;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            st->mb_gamma_prev[it & 1] = gamma, st->mb_alpha_prev[it & 1] = alpha;
+            st->mb_iters += 1;
+        }
+    }
+    const int lane16  = threadIdx.x & (MB_LPR - 1);
+    const int a       = (blockIdx.x * 256 + threadIdx.x) / MB_LPR;
+    const bool row_ok = a < s.D;
+    const int cnt     = row_ok ? s.ell_cnt[a] : 0;
+    float au[3] = {0.f, 0.f, 0.f}, am[3] = {0.f, 0.f, 0.f}, at[3] = {0.f, 0.f, 0.f};
+    for (int q = lane16; q < cnt; q += MB_LPR) {
+        const int col   = s.ell_cols[(size_t)q * s.D + a];
+        const float val = s.ell_vals[(size_t)q * s.D + a];
+        const float4 uu = ucur[col];
+        au[0] = fmaf(val, uu.x, au[0]), au[1] = fmaf(val, uu.y, au[1]), au[2] = fmaf(val, uu.z, au[2]);
+        if (it >= 0) {
+            const float4 mm = mcur[col], tt = tprev[col];
+            am[0] = fmaf(val, mm.x, am[0]), am[1] = fmaf(val, mm.y, am[1]), am[2] = fmaf(val, mm.z, am[2]);
+            at[0] = fmaf(val, tt.x, at[0]), at[1] = fmaf(val, tt.y, at[1]), at[2] = fmaf(val, tt.z, at[2]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) au[c] = group16_sum(au[c]), am[c] = group16_sum(am[c]), at[c] = group16_sum(at[c]);
+    float gpart = 0.f, dpart = 0.f;
+    if (row_ok && lane16 == 0) {
+        const float dg   = s.diag[a];
+        const float minv = dg > FLT_EPSILON ? 1.0f / dg : 1.0f;
+        float4 u = ucur[a], r = s.mb_r[a];
+        float w[3] = {au[0], au[1], au[2]};
+        if (it >= 0) {
+            const float4 m = mcur[a], tp = tprev[a], p = s.mb_p[a], sv = s.mb_s[a], wv = s.mb_w[a];
+            float4 x = s.mb_x[a];
+            const float4 tn = make_float4(fmaf(beta, tp.x, m.x), fmaf(beta, tp.y, m.y), fmaf(beta, tp.z, m.z), 0.f);
+            const float4 pn = make_float4(fmaf(beta, p.x, u.x), fmaf(beta, p.y, u.y), fmaf(beta, p.z, u.z), 0.f);
+            const float4 sn = make_float4(fmaf(beta, sv.x, wv.x), fmaf(beta, sv.y, wv.y), fmaf(beta, sv.z, wv.z), 0.f);
+            u = make_float4(fmaf(-alpha, tn.x, u.x), fmaf(-alpha, tn.y, u.y), fmaf(-alpha, tn.z, u.z), 0.f);
+            r = make_float4(fmaf(-alpha, sn.x, r.x), fmaf(-alpha, sn.y, r.y), fmaf(-alpha, sn.z, r.z), 0.f);
+            x.x = fmaf(alpha, pn.x, x.x), x.y = fmaf(alpha, pn.y, x.y), x.z = fmaf(alpha, pn.z, x.z);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) w[c] = au[c] - alpha * (am[c] + beta * at[c]);
+            s.mb_t[cur][a] = tn, s.mb_p[a] = pn, s.mb_s[a] = sn, s.mb_x[a] = x, s.mb_r[a] = r, s.mb_u[nxt][a] = u;
+        }
+        s.mb_w[a]                     = make_float4(w[0], w[1], w[2], 0.f);
+        s.mb_m[it >= 0 ? nxt : 0][a] = make_float4(minv * w[0], minv * w[1], minv * w[2], 0.f);
+        gpart = fmaf(r.z, u.z, fmaf(r.y, u.y, r.x * u.x));
+        dpart = fmaf(w[2], u.z, fmaf(w[1], u.y, w[0] * u.x));
+    }
+    gpart = wave_sum_all(gpart), dpart = wave_sum_all(dpart);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[0][threadIdx.x >> 6] = gpart, sh[1][threadIdx.x >> 6] = dpart;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int slot = it >= 0 ? ((it + 1) & 1) : 0;
+        s.mb_gpart[slot][blockIdx.x] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        s.mb_dpart[slot][blockIdx.x] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    }
+    (void)scal;
+}
+
 // t += delta and the counters the single-workgroup kernels keep
 __global__ __launch_bounds__(256) void pcg_mb_finish_kernel(SolveView s, SolveState* __restrict__ st) {
     if (st->mb_skip) return;
@@ -1415,14 +1525,24 @@ void MbGraphCache::release() {
     if (capture) (void)hipStreamDestroy(capture), capture = nullptr;
 }
 
+// DFA_MB_FORM=2 (A/B): the textbook form, two launches per iteration
+static bool mb_one_launch() {
+    static const bool two = getenv("DFA_MB_FORM") && atoi(getenv("DFA_MB_FORM")) == 2;
+    return !two;
+}
+
 // iterations [it0, it1): from the cache's graph of that range when there is (or can be) one, else launch by launch
 static hipError_t launch_mb_range(const SolveView& s, SolveState* state, int it0, int it1, float pcg_tol,
                                   MbGraphCache* gc, hipStream_t st) {
     const int nb = solve_mb_blocks(s.D), nbu = (s.D + 255) / 256;
     auto direct = [&](hipStream_t q) {
         for (int it = it0; it < it1; ++it) {
-            pcg_mb_matvec_kernel<<<nb, 256, 0, q>>>(s, state, it, pcg_tol);
-            pcg_mb_update_kernel<<<nbu, 256, 0, q>>>(s, state, it);
+            if (mb_one_launch()) {
+                pcg_mb_step_kernel<<<nb, 256, 0, q>>>(s, state, it, pcg_tol);
+            } else {
+                pcg_mb_matvec_kernel<<<nb, 256, 0, q>>>(s, state, it, pcg_tol);
+                pcg_mb_update_kernel<<<nbu, 256, 0, q>>>(s, state, it);
+            }
         }
         return hipGetLastError();
     };
@@ -1467,6 +1587,7 @@ static hipError_t launch_mb_pcg(const SolveView& s, SolveState* state, int max_i
                                 MbGraphCache* gc, hipStream_t st) {
     const int nb = solve_mb_blocks(s.D), nbu = (s.D + 255) / 256;
     pcg_mb_init_kernel<<<nbu, 256, 0, st>>>(s, state);
+    if (mb_one_launch()) pcg_mb_step_kernel<<<nb, 256, 0, st>>>(s, state, -1, pcg_tol);
     int chunk = 16;
     for (int it = 0; it < max_iter;) {
         const int end = host_flag ? std::min(max_iter, it + chunk) : max_iter;
@@ -1474,6 +1595,17 @@ static hipError_t launch_mb_pcg(const SolveView& s, SolveState* state, int max_i
             const hipError_t e = launch_mb_range(s, state, it, end, pcg_tol, host_flag ? gc : nullptr, st);
             if (e != hipSuccess) return e;
             it = end;
+        }
+        if (mb_one_launch() && host_flag && it < max_iter) {
+            // step `it` first evaluates the stopping rule on the residual the chunk left, then iterates
+            pcg_mb_step_kernel<<<nb, 256, 0, st>>>(s, state, it, pcg_tol);
+            hipError_t e = hipMemcpyAsync(host_flag, &state->mb_done, 2 * sizeof(int), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return e;
+            if (*host_flag) break;
+            ++it;
+            chunk *= 2;
+            continue;
         }
         if (host_flag && it < max_iter) {
             // one more matvec launch evaluates the stopping rule on the last update's residual
