@@ -144,7 +144,7 @@ struct dfa_solver {
     dfa::MbGraphCache mb_graphs;  // HIP graphs of the many-workgroup PCG's launch chunks
     bool just_reset = false;  // the unknowns and the state block were zeroed by set_problem and not touched since
     long long* iters_total = nullptr;  // device: PCG iterations of all solves since enable_timing(1)
-    int* host_flag = nullptr;        // pinned int[2]: stop flag of the many-workgroup PCG and the plan's converged flag,
+    int* host_flag = nullptr;        // pinned int[4]: stop flag of the many-workgroup PCG, the plan's converged flag, (skip), iterations;
                                      // read back between launch chunks
 };
 
@@ -605,7 +605,7 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
     if (rc == DFA_OK) rc = plan_alloc(s, &s->state, 1);
     if (rc == DFA_OK) rc = plan_alloc(s, &s->iters_total, 1);
     if (rc == DFA_OK && hipMemset(s->iters_total, 0, sizeof(long long)) != hipSuccess) rc = DFA_ERR_HIP;
-    if (rc == DFA_OK && hipHostMalloc((void**)&s->host_flag, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) s->host_flag = nullptr;
+    if (rc == DFA_OK && hipHostMalloc((void**)&s->host_flag, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) s->host_flag = nullptr;
     if (rc == DFA_OK) rc = plan_alloc(s, &s->cost_partials, (R + 255) / 256 + 1);
     if (rc == DFA_OK) rc = plan_alloc(s, &s->ticket, 64);
     if (rc == DFA_OK && hipMemset(s->ticket, 0, 64 * sizeof(unsigned int)) != hipSuccess)
@@ -677,6 +677,7 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
     const float w_reg_sq  = w_reg_f * w_reg_f;
     if (s->timing) s->timed_solves += 1;
     if (s->host_flag) s->host_flag[0] = s->host_flag[1] = 0;
+    s->mb_graphs.call = 0;
     int not_launched = 0;  // iterations after the host has seen the converged flag (many-workgroup path only)
     for (int outer = 0; outer < p->num_iter; ++outer) {
         // preNonlinearSolve (opt_solver.cpp:135-140): the Huber weights are only observable after

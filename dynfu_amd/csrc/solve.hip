@@ -1557,7 +1557,7 @@ static hipError_t launch_mb_range(const SolveView& s, SolveState* state, int it0
             hit = &c;
     }
     if (!hit) {
-        if (gc->used == 8) {  // other problem sizes / pointers: start over
+        if (gc->used == (int)(sizeof(gc->e) / sizeof(gc->e[0]))) {  // other problem sizes / chunk sizes: start over
             for (int i = 0; i < gc->used; ++i)
                 if (gc->e[i].exec) (void)hipGraphExecDestroy(gc->e[i].exec);
             gc->used = 0;
@@ -1589,6 +1589,8 @@ static hipError_t launch_mb_pcg(const SolveView& s, SolveState* state, int max_i
     pcg_mb_init_kernel<<<nbu, 256, 0, st>>>(s, state);
     if (mb_one_launch()) pcg_mb_step_kernel<<<nb, 256, 0, st>>>(s, state, -1, pcg_tol);
     int chunk = 16;
+    const int ci = gc ? std::min(gc->call++, 63) : 0;
+    if (mb_one_launch() && gc && host_flag && gc->pred[ci] > 0) chunk = std::max(8, (gc->pred[ci] + 4 + 7) & ~7);
     for (int it = 0; it < max_iter;) {
         const int end = host_flag ? std::min(max_iter, it + chunk) : max_iter;
         {
@@ -1599,12 +1601,14 @@ static hipError_t launch_mb_pcg(const SolveView& s, SolveState* state, int max_i
         if (mb_one_launch() && host_flag && it < max_iter) {
             // step `it` first evaluates the stopping rule on the residual the chunk left, then iterates
             pcg_mb_step_kernel<<<nb, 256, 0, st>>>(s, state, it, pcg_tol);
-            hipError_t e = hipMemcpyAsync(host_flag, &state->mb_done, 2 * sizeof(int), hipMemcpyDeviceToHost, st);
+            // mb_done, converged, mb_skip, mb_iters
+            hipError_t e = hipMemcpyAsync(host_flag, &state->mb_done, 4 * sizeof(int), hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) return e;
+            if (gc) gc->pred[ci] = host_flag[3];  // (the total when the flag is set, a lower bound otherwise)
             if (*host_flag) break;
             ++it;
-            chunk *= 2;
+            chunk = 16;  // the prediction fell short: go on in small chunks
             continue;
         }
         if (host_flag && it < max_iter) {

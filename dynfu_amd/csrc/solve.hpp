@@ -102,15 +102,19 @@ struct MbGraphCache {
         const SolveState* state = nullptr;
         hipGraphExec_t exec = nullptr;
     };
-    Entry e[8];
+    Entry e[24];
     int used = 0;
+    // iterations the PCG of Gauss-Newton iteration i took in the solve before (0 = unknown): the first chunk of launches
+    // is sized by it — a sequence changes little from frame to frame — instead of growing 16, 32, 64, ... past the end
+    int pred[64] = {};
+    int call     = 0;  // index of the next PCG inside the current solve (reset by the caller)
     hipStream_t capture = nullptr;  // capture is not allowed on the legacy default stream
     bool disabled = false;
     void release();
 };
 
 // `main_done` (optional) is recorded behind the solving kernel(s), before the fallback launch that usually returns at once
-hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag /* pinned int[2] or null */,
+hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag /* pinned int[4] or null */,
                      MbGraphCache* graphs /* or null */, hipEvent_t main_done,
                      hipStream_t st);
 // books n Gauss-Newton iterations that the host did not launch because the plan had converged (SolveState::converged)
