@@ -566,7 +566,7 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
     A(rw, R * k);
     A(rtau, R);
     A(rb, R * 3);
-    A(re, R * (2 * (size_t)k + 4));
+    A(re, R * (size_t)dfa::solve_rec_words(k));
     A(reg_idx, D * k);
     A(blk_hist, D * dfa::SOLVE_TG_BLOCKS);
     A(node_ptr, D + 1);

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void linearise_kernel(SolveView s, SolveState*
         }
         const float ex = s.rb[3 * r] - sx, ey = s.rb[3 * r + 1] - sy, ez = s.rb[3 * r + 2] - sz;
         // tail of the packed row record (head = k ids + k weights, written once per frame)
-        *(float4*)(s.re + r * (size_t)(2 * s.k + 4) + 2 * s.k) = make_float4(ex, ey, ez, tau);
+        *(float4*)(s.re + r * (size_t)solve_rec_words(s.k) + solve_rec_tail(s.k)) = make_float4(ex, ey, ez, tau);
         c += (double)tau * ((double)ex * ex + (double)ey * ey + (double)ez * ez);
     }
     c = wave_sum_all(c);
@@ -321,7 +321,18 @@ __global__ __launch_bounds__(256) void pack_records_kernel(SolveView s) {
     const size_t R = (size_t)s.N + (size_t)s.D * s.k;
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
-    float* rec = s.re + r * (size_t)(2 * s.k + 4);
+    float* rec = s.re + r * (size_t)solve_rec_words(s.k);
+    if (solve_rec_ids16(s.k)) {  // k / 2 words of 16-bit ids (0xffff = empty slot), then k weights
+        uint16_t* ids = reinterpret_cast<uint16_t*>(rec);
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (j < s.k) {
+                const int n         = s.ridx[r * s.k + j];
+                ids[j]              = n < 0 ? (uint16_t)0xffffu : (uint16_t)n;
+                rec[s.k / 2 + j]    = s.rw[r * s.k + j];
+            }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < K; ++j)
         if (j < s.k) {
@@ -339,10 +350,40 @@ __global__ __launch_bounds__(256) void pack_records_kernel(SolveView s) {
 constexpr int HASH      = 512;
 constexpr int HASH_MASK = HASH - 1;
 
-// one row record = (2k+4) consecutive words written by residual_kernel
+// one row record = solve_rec_words(k) consecutive words (head: pack_records_kernel, tail: linearise_kernel)
 template <int K>
 __device__ __forceinline__ float4 load_record(const SolveView& s, size_t r, int (&idx)[K], float (&w)[K]) {
-    const float* rec = s.re + r * (size_t)(2 * s.k + 4);
+    const float* rec = s.re + r * (size_t)solve_rec_words(s.k);
+    if (s.k == K && (K % 8) == 0) {  // 16-bit ids: K / 8 + K / 4 + 1 aligned 16-byte loads (K = 8: one cache line)
+        const float4* v = (const float4*)rec;
+#pragma unroll
+        for (int q = 0; q < K / 8; ++q) {
+            const float4 i4 = v[q];
+            const uint32_t u[4] = {__float_as_uint(i4.x), __float_as_uint(i4.y), __float_as_uint(i4.z), __float_as_uint(i4.w)};
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int lo = (int)(u[h] & 0xffffu), hi = (int)(u[h] >> 16);
+                idx[8 * q + 2 * h]     = lo == 0xffff ? -1 : lo;
+                idx[8 * q + 2 * h + 1] = hi == 0xffff ? -1 : hi;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < K / 4; ++q) {
+            const float4 w4 = v[K / 8 + q];
+            w[4 * q] = w4.x, w[4 * q + 1] = w4.y, w[4 * q + 2] = w4.z, w[4 * q + 3] = w4.w;
+        }
+        return v[K / 8 + K / 4];
+    }
+    if (solve_rec_ids16(s.k)) {  // (k a multiple of 8 below the kernel's K)
+        const uint16_t* ids = reinterpret_cast<const uint16_t*>(rec);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            idx[j] = j < s.k ? (ids[j] == 0xffffu ? -1 : (int)ids[j]) : -1;
+            w[j]   = j < s.k ? rec[s.k / 2 + j] : 0.f;
+        }
+        const float* tl = rec + solve_rec_tail(s.k);
+        return make_float4(tl[0], tl[1], tl[2], tl[3]);
+    }
     if (s.k == K && (K % 4) == 0) {
         const float4* v = (const float4*)rec;  // (2K+4)*4 bytes is a multiple of 16
 #pragma unroll

@@ -34,6 +34,13 @@ struct SolveState {
 };
 
 // All pointers are device pointers owned by the plan unless marked (borrowed).
+// Words of a packed row record.  k a multiple of 8: the ids are 16-bit (a plan has at most 32 768 nodes), which makes the
+// k = 8 record exactly one 64-byte cache line (80 bytes with 32-bit ids straddle two: every row is gathered by the
+// workgroups of its k nodes).  Other k keep 32-bit ids (k = 4: 48 bytes; 16-bit ids would give 40, off the 16-byte grid).
+__host__ __device__ inline bool solve_rec_ids16(int k) { return k % 8 == 0; }
+__host__ __device__ inline int solve_rec_words(int k) { return solve_rec_ids16(k) ? k + k / 2 + 4 : 2 * k + 4; }
+__host__ __device__ inline int solve_rec_tail(int k) { return solve_rec_words(k) - 4; }  // word offset of (e, tau)
+
 struct SolveView {
     int N, D, k, Dpad, ell_cap;
     // problem (borrowed from the caller)
@@ -47,7 +54,7 @@ struct SolveView {
     float* rw;      // R x k   slot weight
     float* rtau;    // R       robust weight (Tukey) / w_reg^2
     float* rb;      // R x 3   target  (live - canonical | 0)
-    float* re;      // R x (2k+4) packed row records: k node ids, k weights, e = b - sum w t, tau
+    float* re;      // R x solve_rec_words(k) packed row records: k node ids, k weights, e = b - sum w t, tau
     int32_t* reg_idx;  // D x k
     // transpose graph
     int32_t* blk_hist;    // TG_BLOCKS x D  workgroup-private histograms / bases of the counting sort
