@@ -107,12 +107,15 @@ def build_cpp_tests(force=False, verbose=False):
     oracle_dir = os.path.join(root, "oracle")
     built = {}
     for name, needs in (("test_host_dq", []), ("test_host_solver", ["host"]), ("test_host_tsdf", ["host", "oracle"]),
-                        ("test_host_dynfusion", ["host", "oracle"]), ("test_host_icp", ["host"])):
+                        ("test_host_dynfusion", ["host", "oracle"]), ("test_host_icp", ["host"]),
+                        ("test_tsdf_classify", ["oracle", "ieee"])):
         src = os.path.join(tdir, name + ".cpp")
         exe = os.path.join(out, name)
-        deps = [src, os.path.join(tdir, "minitest.hpp"), host]
+        deps = [src, os.path.join(tdir, "minitest.hpp"), host, os.path.join(CSRC, "tsdf_classify.hpp")]
         if force or _stale(exe, deps):
             cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-I" + inc, src, "-o", exe]
+            if "ieee" in needs:  # CPU model of a kernel: same arithmetic contract as the oracle, hardware fma
+                cmd[1:2] = ["-O2", "-march=x86-64-v3", "-ffp-contract=off"]
             if "host" in needs:
                 cmd += ["-L" + HERE, "-ldynfu_amd_host", "-ldynfu_amd", "-Wl,-rpath," + HERE,
                         "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]

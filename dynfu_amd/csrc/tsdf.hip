@@ -3,22 +3,25 @@
 //
 // What they compute is kfusion's src/kfusion/cuda/tsdf_volume.cu + imgproc.cu:233-245
 // (cited per kernel); how they are laid out is MI355X-specific:
-//   * the volume is x-fastest, 4 B / voxel; one lane owns FOUR consecutive x voxels, so a
-//     64-lane wave moves 1 KiB per load / store instruction (global_load/store_dwordx4);
-//   * a 256-thread block = 4 waves = 4 consecutive y rows of one 256-voxel x segment;
-//   * z is cut into chunks (grid.z) so that even a 256^3 volume launches >> 256 workgroups;
-//     inside a chunk the z loop is software-pipelined 4 slices deep (4 KiB in flight per
-//     wave) instead of relying on occupancy alone;
-//   * the reference's running `vc += zstep` (tsdf_volume.cu:64) is kept bit-for-bit: a
-//     chunk that starts at slice z0 replays the z0 additions in registers first (12 VALU
-//     adds per skipped slice, a few % of the chunk's work) rather than using z0*zstep;
-//   * the depth ("dists") image is gathered with plain 2-byte loads: 600 KiB at VGA, it
-//     stays in every XCD's 4 MiB L2 while the volume streams past it.
+//   * the volume is x-fastest, 4 B / voxel; one lane owns one voxel COLUMN and marches it over z, a 256-thread
+//     block covers 64 x 4 columns, z is cut into chunks (grid.z) until >= 4 096 workgroups are in flight;
+//   * the reference's running `vc += zstep` (tsdf_volume.cu:64) is kept bit-for-bit: a chunk that starts at
+//     slice z0 replays the z0 additions in registers first rather than using z0*zstep;
+//   * the sweeps classify runs of 8 voxels of a column at once (tsdf_classify.hpp: skipped / in front of the
+//     surface / per-voxel arithmetic) from one projection and four min-max tiles of the depth image — most of a
+//     volume never sees a division, a gather or a square root, and the fused clear+integrate sweep runs at the
+//     speed of its stores;
+//   * the depth ("dists") image (600 KiB at VGA) and its tile table (19 KiB) stay in L2 / L1 while the volume
+//     streams past them.
 // Every kernel is HBM-bound integer/half work; nothing here is GEMM-shaped, no MFMA.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+#include <map>
+
 #include "device_math.hpp"
 #include "kernels.hpp"
+#include "tsdf_classify.hpp"
 
 namespace dfa {
 
@@ -61,6 +64,7 @@ struct IntegrateArgs {
     Aff3 vol2cam;
     float fx, fy, cx, cy;
     int zchunk;
+    int ablate;  // DEV ONLY (DFA_TSDF_ABLATE): 1 every run SKIP, 2 FULL runs filled like FRONT, 3 no classification at all
 };
 
 // x / z and y / z, correctly rounded.  hipcc expands an fp32 division into
@@ -85,35 +89,40 @@ __device__ __forceinline__ void div_xy_by_z(float x, float y, float z, float& qx
     }
 }
 
-// One voxel of one slice (tsdf_volume.cu:65-91).  `old` is the packed voxel (0 when the clear
-// is fused); returns the packed voxel after the update and sets `changed`.
-template <bool FUSED_CLEAR>
-__device__ __forceinline__ uint32_t integrate_voxel(const IntegrateArgs& a, f3 vc, uint32_t old, bool& changed) {
+// One voxel of one slice, first half (tsdf_volume.cu:65-80): false when the reference leaves the voxel alone, else the
+// truncated signed distance of this frame.
+__device__ __forceinline__ bool voxel_tsdf(const IntegrateArgs& a, f3 vc, float& tsdf) {
     // :74 `vc.z <= 0` is tested first here: the reference tests it after the (side-effect
     // free) projection and texture fetch, the outcome is the same and NaN/inf never form.
-    if (!(vc.z > 0.f)) return old;
+    if (!(vc.z > 0.f)) return false;
     // Projector (device.hpp:40-45): correctly rounded divisions stand in for __fdividef
     float qx, qy;
     div_xy_by_z(vc.x, vc.y, vc.z, qx, qy);
     const float coox = fmaf(a.fx, qx, a.cx);
     const float cooy = fmaf(a.fy, qy, a.cy);
-    if (!(coox >= 0.f && cooy >= 0.f && coox < (float)a.cols && cooy < (float)a.rows)) return old;  // :70
+    if (!(coox >= 0.f && cooy >= 0.f && coox < (float)a.cols && cooy < (float)a.rows)) return false;  // :70
     // :73 point-sampled, un-normalised texture fetch == texel (floor x, floor y); coordinates
     // are non-negative here so the truncating convert is the floor
     const int px         = (int)coox;
     const int py         = (int)cooy;
     const uint16_t* drow = (const uint16_t*)((const char*)a.dists + (size_t)py * a.dists_step);
     const float Dp       = half_bits_to_float(drow[px]);
-    if (Dp == 0.f) return old;                      // :74
+    if (Dp == 0.f) return false;                    // :74
     // Voxels far behind the surface (a third of the volume) leave before the correctly rounded square root: when
     // |vc|^2 exceeds (Dp + trunc)^2 by more than 1e-5 relative, sqrt exceeds Dp + trunc by 5e-6 relative — two orders
     // above the rounding of the three operations below, so the test of :79 fails for certain.
     const float d2  = dot(vc, vc);
     const float lim = Dp + a.trunc;
-    if (d2 > lim * lim * 1.00001f) return old;
+    if (d2 > lim * lim * 1.00001f) return false;
     const float sdf = Dp - sqrtf(d2);               // :77
-    if (!(sdf >= -a.trunc)) return old;             // :79
-    const float tsdf = fminf(1.f, sdf * a.trunc_inv);  // :80
+    if (!(sdf >= -a.trunc)) return false;           // :79
+    tsdf = fminf(1.f, sdf * a.trunc_inv);           // :80
+    return true;
+}
+
+// second half (:82-90): running average with the voxel's previous state (`old` packed; 0 when the clear is fused)
+template <bool FUSED_CLEAR>
+__device__ __forceinline__ uint32_t voxel_update(const IntegrateArgs& a, uint32_t old, float tsdf) {
     int weight_prev;
     float tsdf_prev;
     if (FUSED_CLEAR) {
@@ -125,8 +134,17 @@ __device__ __forceinline__ uint32_t integrate_voxel(const IntegrateArgs& a, f3 v
     }
     const float tsdf_new = fmaf(tsdf_prev, (float)weight_prev, tsdf) / (float)(weight_prev + 1);  // :86
     const int weight_new = min(weight_prev + 1, a.max_weight);                                   // :87
-    changed              = true;
     return pack_tsdf(tsdf_new, weight_new);
+}
+
+// One voxel of one slice (tsdf_volume.cu:65-91).  `old` is the packed voxel (0 when the clear
+// is fused); returns the packed voxel after the update and sets `changed`.
+template <bool FUSED_CLEAR>
+__device__ __forceinline__ uint32_t integrate_voxel(const IntegrateArgs& a, f3 vc, uint32_t old, bool& changed) {
+    float tsdf;
+    if (!voxel_tsdf(a, vc, tsdf)) return old;
+    changed = true;
+    return voxel_update<FUSED_CLEAR>(a, old, tsdf);
 }
 
 template <int VX>
@@ -213,6 +231,119 @@ __global__ __launch_bounds__(256) void integrate_kernel(const IntegrateArgs a) {
             vc[v] = vc[v] + zstep;
         }
         if (changed) cur.store(ptr);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Run-classified sweeps (tsdf_classify.hpp).  Same result as integrate_kernel, voxel for voxel; what changes is the
+// work: per run of U slices a lane projects ONE point (the far end of the run; the near end is the previous run's
+// far end), looks up four min / max tiles of the dists image and knows whether its U voxels are all skipped, all
+// updated with tsdf == 1, or need the reference's per-voxel arithmetic.  At C2 (512^3, U = 8) 83 % of the runs are
+// skipped, 10 % are in front of the surface, 7 % take the per-voxel path; a wave does when one of its lanes does.
+//   * fused clear + integrate: skipped runs store zeros, front runs a constant — the sweep becomes a store stream;
+//   * read + write sweep: skipped runs touch no memory at all.
+// A wave covers WX x (64 / WX) columns, a block 64 x 4.  Measured (tools/tsdf_sweep.py, fused sweep, 512^3 / 1024^3):
+//   per-voxel kernel 0.222 / 1.174 ms; U = 4, WX = 64: 0.157 / 0.883; U = 8, WX = 64: 0.137 / 0.825;
+//   U = 8, WX = 32: 0.117 / 0.721 (128-byte row segments, and lanes that agree more often: 14 % instead of 19 % of
+//   the wave runs hold a lane on the per-voxel path); U = 8, WX = 16: 0.161 / 1.236 (64-byte segments: half cache
+//   lines); the same loop storing zeros only: 0.105 / 0.773.
+constexpr int RUN_U = 8;
+
+__device__ __forceinline__ float rcp_approx(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float half_bits_to_float_u(uint32_t b) { return half_bits_to_float(b); }
+
+// min / max tiles of the dists image: one wave per 8 x 8 tile
+__global__ __launch_bounds__(256) void dists_tiles_kernel(const uint16_t* __restrict__ dists, int dists_step, int cols,
+                                                          int rows, uint32_t* __restrict__ tiles, int tcols, int ntiles) {
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const int lane = threadIdx.x & 63;
+    const int x = (tile % tcols) * 8 + (lane & 7), y = (tile / tcols) * 8 + (lane >> 3);
+    uint32_t lo = 0xffffu, hi = 0u;
+    if (x < cols && y < rows) {
+        const uint16_t* drow = (const uint16_t*)((const char*)dists + (size_t)y * dists_step);
+        lo = hi = tile_value_of_pixel(drow[x]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, 64));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, 64));
+    }
+    if (lane == 0) tiles[tile] = lo | (hi << 16);
+}
+
+template <bool FUSED_CLEAR, int WX, int U>
+__global__ __launch_bounds__(256) void integrate_runs_kernel(const IntegrateArgs a, const RunConsts rc,
+                                                             const uint32_t front_const) {
+    const int lane  = threadIdx.x, wave = threadIdx.y;  // block (64, 4)
+    // the block's 64 x 4 columns, WX x (64 / WX) per wave: waves side by side in x, then stacked in y
+    constexpr int WAVES_X = 64 / WX, WAVE_ROWS = 64 / WX;
+    const int x = blockIdx.x * 64 + (wave % WAVES_X) * WX + (lane % WX);
+    const int y = blockIdx.y * 4 + (wave / WAVES_X) * WAVE_ROWS + lane / WX;
+    if (x >= a.X || y >= a.Y) return;
+    const int z0 = blockIdx.z * a.zchunk;
+    const int z1 = min(z0 + a.zchunk, a.Z);
+
+    const f3 zstep = mk3(a.vol2cam.m[2], a.vol2cam.m[5], a.vol2cam.m[8]) * a.vsz;                  // :58
+    const f3 vx    = mk3((float)x * a.vsx, (float)y * a.vsy, 0.f);                                   // :60
+    f3 vc          = mulR(a.vol2cam, vx) + mk3(a.vol2cam.t[0], a.vol2cam.t[1], a.vol2cam.t[2]);      // :61
+    for (int i = 0; i < z0; ++i) vc = vc + zstep;  // replay :64 up to the chunk's first slice
+
+    const size_t slice = (size_t)a.X * a.Y;
+    uint32_t* ptr      = a.vol + (size_t)x + (size_t)a.X * y + slice * z0;
+    const f3 stepU     = mk3(rc.stepU[0], rc.stepU[1], rc.stepU[2]);
+
+    int z      = z0;
+    RunEnd end = run_end(vc.x, vc.y, vc.z, rc, rcp_approx);
+    for (; z + U <= z1; z += U, ptr += slice * U) {
+        const f3 far     = vc + stepU;
+        int cls          = RUN_SKIP;
+        if (a.ablate != 3) {
+            const RunEnd nxt = run_end(far.x, far.y, far.z, rc, rcp_approx);
+            cls              = classify_run(end, nxt, rc, half_bits_to_float_u);
+            end              = nxt;
+            if (a.ablate == 1) cls = RUN_SKIP;
+            if (a.ablate == 2 && cls == RUN_FULL) cls = RUN_FRONT;
+        }
+        f3 p[U];  // the run's voxel positions by the reference's running addition (:64)
+#pragma unroll
+        for (int u = 0; u < U; ++u) p[u] = vc, vc = vc + zstep;
+        if (FUSED_CLEAR) {
+            uint32_t out[U];
+            const uint32_t fill = cls == RUN_FRONT ? front_const : 0u;
+#pragma unroll
+            for (int u = 0; u < U; ++u) out[u] = fill;
+            if (cls == RUN_FULL) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    bool changed;
+                    out[u] = integrate_voxel<true>(a, p[u], 0u, changed);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) ptr[slice * u] = out[u];
+        } else if (cls != RUN_SKIP) {
+            uint32_t cur[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = ptr[slice * u];
+            if (cls == RUN_FRONT) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) ptr[slice * u] = voxel_update<false>(a, cur[u], 1.0f);
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    bool changed    = false;
+                    const uint32_t v = integrate_voxel<false>(a, p[u], cur[u], changed);
+                    if (changed) ptr[slice * u] = v;
+                }
+            }
+        }
+    }
+    for (; z < z1; ++z, ptr += slice) {  // tail shorter than a run: per voxel
+        bool changed     = FUSED_CLEAR;
+        const uint32_t v = integrate_voxel<FUSED_CLEAR>(a, vc, FUSED_CLEAR ? 0u : *ptr, changed);
+        if (changed) *ptr = v;
+        vc = vc + zstep;
     }
 }
 
@@ -414,6 +545,33 @@ hipError_t launch_tsdf_clear(uint32_t* vol, int X, int Y, int Z, hipStream_t s) 
     return launch_status();
 }
 
+// Scratch for the tile table of one sweep (19 KiB at VGA).  The C ABI's caller owns every buffer it passes and the
+// kernels allocate nothing it can see; this table is internal, so it is cached per stream: work on one stream is
+// ordered, so a sweep never overwrites the table of a sweep still running, whatever the host threads do.  Grows with
+// hipMalloc (hipFree of the old block waits for the device).
+static hipError_t tile_scratch(hipStream_t s, size_t bytes, uint32_t** out) {
+    struct Block {
+        uint32_t* p = nullptr;
+        size_t cap  = 0;
+    };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Block> cache;  // (device, stream): the null stream exists on every device
+    int dev = 0;
+    hipError_t de = hipGetDevice(&dev);
+    if (de != hipSuccess) return de;
+    std::lock_guard<std::mutex> lock(mu);
+    Block& b = cache[std::make_pair(dev, s)];
+    if (b.cap < bytes) {
+        if (b.p) (void)hipFree(b.p);
+        b.p = nullptr, b.cap = 0;
+        hipError_t e = hipMalloc((void**)&b.p, bytes);
+        if (e != hipSuccess) return e;
+        b.cap = bytes;
+    }
+    *out = b.p;
+    return hipSuccess;
+}
+
 // z-chunk heuristic: enough workgroups to fill 256 CUs several times over, while keeping the
 // replayed-additions prologue (z0 adds per chunk) a small fraction of a chunk's work.
 static int pick_zchunk(int X, int Y, int Z, int vx, bool fused_clear) {
@@ -448,6 +606,47 @@ hipError_t launch_tsdf_integrate(bool fused_clear, const uint16_t* dists, int di
     for (int i = 0; i < 9; ++i) a.vol2cam.m[i] = vol2cam[i];
     for (int i = 0; i < 3; ++i) a.vol2cam.t[i] = vol2cam[9 + i];
     a.fx = fx, a.fy = fy, a.cx = cx, a.cy = cy;
+    a.ablate = getenv("DFA_TSDF_ABLATE") ? atoi(getenv("DFA_TSDF_ABLATE")) : 0;
+    // Default: the run-classified sweep.  DFA_TSDF_LEGACY=1 runs the per-voxel sweep (every voxel through the
+    // projection; the round-1 kernel) for A/B timings; DFA_TSDF_WAVE=16 gives a wave a 16 x 4 patch of columns.
+    const bool legacy = getenv("DFA_TSDF_LEGACY") != nullptr;
+    if (!legacy) {
+        const int tcols = (cols + 7) >> TSDF_TILE_SHIFT, trows = (rows + 7) >> TSDF_TILE_SHIFT;
+        uint32_t* tiles = nullptr;
+        hipError_t e    = tile_scratch(s, (size_t)tcols * trows * sizeof(uint32_t), &tiles);
+        if (e != hipSuccess) return e;
+        dists_tiles_kernel<<<(tcols * trows + 3) / 4, 256, 0, s>>>(dists, dists_step, cols, rows, tiles, tcols, tcols * trows);
+        // bound of |component| over every voxel position in camera space: the 8 corners of the volume
+        float extent = 0.f;
+        for (int c = 0; c < 8; ++c) {
+            const float p[3] = {(c & 1) ? a.vsx * X : 0.f, (c & 2) ? a.vsy * Y : 0.f, (c & 4) ? a.vsz * Z : 0.f};
+            for (int r = 0; r < 3; ++r)
+                extent = fmaxf(extent, fabsf(vol2cam[3 * r] * p[0] + vol2cam[3 * r + 1] * p[1] + vol2cam[3 * r + 2] * p[2] + vol2cam[9 + r]));
+        }
+        const float zstep[3] = {vol2cam[2] * a.vsz, vol2cam[5] * a.vsz, vol2cam[8] * a.vsz};
+        if (extent == extent && extent < 1e30f) {  // finite poses only; anything else takes the per-voxel sweep
+            const int run_u = getenv("DFA_TSDF_RUN") ? atoi(getenv("DFA_TSDF_RUN")) : RUN_U;
+            const RunConsts rc = make_run_consts(tiles, cols, rows, fx, fy, cx, cy, trunc_dist, zstep, run_u == 8 ? 8 : 4, extent);
+            const uint32_t front_const = 0x3c00u | ((uint32_t)(max_weight < 1 ? max_weight : 1) << 16);  // (1.0h, min(1, max_weight))
+            // >= 4 096 workgroups for either sweep: the tile look-ups of a run are dependent loads that only occupancy
+            // hides (512^3 fused: 0.147 ms unsplit = 1 024 workgroups, 0.117 ms with z-chunks of 128 slices)
+            a.zchunk = pick_zchunk(X, Y, Z, 1, false);
+            const int wave_x = getenv("DFA_TSDF_WAVE") ? atoi(getenv("DFA_TSDF_WAVE")) : 32;
+            dim3 block(64, 4), grid((X + 63) / 64, (Y + 3) / 4, (Z + a.zchunk - 1) / a.zchunk);
+#define DFA_RUNS(F, W, UU) integrate_runs_kernel<F, W, UU><<<grid, block, 0, s>>>(a, rc, front_const)
+#define DFA_RUNS_W(F, UU) (wave_x == 16 ? DFA_RUNS(F, 16, UU) : wave_x == 32 ? DFA_RUNS(F, 32, UU) : DFA_RUNS(F, 64, UU))
+            if (run_u == 8) {
+                if (fused_clear) DFA_RUNS_W(true, 8);
+                else DFA_RUNS_W(false, 8);
+            } else {
+                if (fused_clear) DFA_RUNS_W(true, 4);
+                else DFA_RUNS_W(false, 4);
+            }
+#undef DFA_RUNS_W
+#undef DFA_RUNS
+            return launch_status();
+        }
+    }
     // One voxel per lane.  Four consecutive voxels per lane (16-byte accesses; DFA_TSDF_VX4=1, the first design) lose
     // everywhere: a lane then walks its four voxels one after the other, each with its own early exits, and a wave
     // waits for its slowest lane four times per slice (fused sweep 0.289 -> 0.229 ms at 512^3, 1.49 -> 1.38 ms at

@@ -119,6 +119,117 @@ def test_fused_clear_integrate_equals_clear_then_integrate(A):
     assert np.array_equal(got, ref)
 
 
+def _odd_dists(cfg, intr, seed):
+    """dists of a synthetic frame with patches of every kind of pixel the reference skips or saturates on:
+    +0, -0, negative, NaN, +inf, the smallest subnormal"""
+    rng = np.random.default_rng(seed)
+    dists = O.compute_dists(synth.depth_frame(cfg, 3, noise_mm=1.0), *intr)
+    H, W = dists.shape
+    vals = np.array([0x0000, 0x8000, 0xC000, 0x7E00, 0x7C00, 0x0001], np.uint16)
+    for _ in range(300):
+        x0, y0 = rng.integers(0, W), rng.integers(0, H)
+        w, h = rng.integers(1, 14), rng.integers(1, 14)
+        dists[y0:y0 + h, x0:x0 + w] = vals[rng.integers(0, len(vals))]
+    return dists
+
+
+@pytest.mark.parametrize("tilt", [0.0, 0.35])
+def test_integrate_bit_exact_with_holes_and_special_halves(A, tilt):
+    # the run classification (csrc/tsdf_classify.hpp) bounds the dists a run can meet by 8x8 tiles: invalid pixels,
+    # NaN and infinities must come out exactly as the per-voxel reference treats them
+    cfg, intr, voxel, trunc, vol2cam, _, _, _ = _scene("T1")
+    dim = cfg["dim"]
+    dists = _odd_dists(cfg, intr, 5)
+    if tilt:
+        R = rot([0.2, 1.0, -0.3], tilt)
+        centre = 0.5 * voxel * dim
+        vol2cam = aff12(R, (vol2cam[9:] + centre) - (R @ centre).astype(np.float32))
+    vol = np.zeros((dim, dim, dim), np.uint32)
+    got, ref, n = _integrate_both(A, vol, dists, voxel, trunc, 64, vol2cam, intr, fused=True)
+    assert n > 0.03 * vol.size
+    assert np.array_equal(got, ref), "%d voxels differ" % int((got != ref).sum())
+    for _ in range(2):
+        got, ref, _ = _integrate_both(A, ref, dists, voxel, trunc, 2, vol2cam, intr)
+        assert np.array_equal(got, ref), "%d voxels differ" % int((got != ref).sum())
+
+
+def test_integrate_close_up_and_camera_plane_through_the_volume(A):
+    # several pixels per voxel (runs spanning many tiles) and runs that cross z = 0
+    cfg, intr, voxel, trunc, _, _, _, depth = _scene("T1")
+    dists = O.compute_dists(depth, *intr)
+    for size, t in ((0.5, (-0.25, -0.25, 0.02)), (3.0, (-1.5, -1.5, -1.0))):
+        dim = 64
+        vx = np.full(3, size / dim, np.float32)
+        R = rot([1.0, 0.5, 0.1], 0.25)
+        v2c = aff12(R, np.array(t, np.float32))
+        vol = np.zeros((dim, dim, dim), np.uint32)
+        got, ref, _ = _integrate_both(A, vol, dists, vx, max(0.04, 2.1 * size / dim), 64, v2c, intr, fused=True)
+        assert np.array_equal(got, ref)
+        got, ref, _ = _integrate_both(A, ref, dists, vx, max(0.04, 2.1 * size / dim), 64, v2c, intr)
+        assert np.array_equal(got, ref)
+
+
+def test_integrate_on_two_streams_with_different_frames(A):
+    # the tile table of a sweep is internal scratch, cached per stream: two sweeps in flight must not share it
+    import torch
+    cfg, intr, voxel, trunc, vol2cam, _, _, _ = _scene("T1")
+    dim = cfg["dim"]
+    d = [O.compute_dists(synth.depth_frame(cfg, f), *intr) for f in (0, 25)]
+    d[1][:, : d[1].shape[1] // 2] = 0
+    refs = []
+    for k in range(2):
+        r = np.zeros((dim, dim, dim), np.uint32)
+        O.tsdf_integrate(r, d[k], voxel, trunc, 64, vol2cam, *intr, threads=8)
+        refs.append(r)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    vols = [torch.empty((dim, dim, dim), dtype=torch.int32, device="cuda") for _ in range(2)]
+    dd = [dev(x) for x in d]
+    torch.cuda.synchronize()
+    for rep in range(8):
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                A.tsdf_clear_integrate(vols[k], dd[k], voxel, trunc, 64, vol2cam, *intr)
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert np.array_equal(host(vols[k], np.uint32), refs[k])
+
+
+def test_run_classified_sweep_equals_per_voxel_sweep_at_512(A):
+    """The default sweep against the per-voxel kernel of round 1 (DFA_TSDF_LEGACY=1 in a child process), C2 volume,
+    tilted camera: same volume, bit for bit, fused and accumulating."""
+    import subprocess, sys, torch
+    cfg, intr, voxel, trunc, vol2cam, _, _, depth = _scene("C2")
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import dynfu_amd as A, oracle as O
+from dynfu_amd import synth
+from gpu_util import aff12, rot, dev
+cfg = synth.CONFIGS["C2"]; intr = synth.intrinsics(cfg)
+voxel, trunc, vol2cam, _, _ = synth.volume_params(cfg)
+dim = cfg["dim"]
+R = rot([0.1, 1.0, 0.2], 0.3); centre = 0.5 * voxel * dim
+v2c = aff12(R, (vol2cam[9:] + centre) - (R @ centre).astype(np.float32))
+dists = dev(O.compute_dists(synth.depth_frame(cfg, 0), *intr))
+v = torch.empty((dim, dim, dim), dtype=torch.int32, device="cuda")
+A.tsdf_clear_integrate(v, dists, voxel, trunc, 64, v2c, *intr)
+A.tsdf_integrate(v, dists, voxel, trunc, 64, v2c, *intr)
+s = v.view(dim, -1).long()
+print("CHK", int(s.sum()), int((s * torch.arange(1, s.shape[1] + 1, device="cuda")).sum() %% (2**61 - 1)), int(((v >> 16) == 2).sum()))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for legacy in (False, True):
+        env = dict(os.environ)
+        env.pop("DFA_TSDF_LEGACY", None)
+        if legacy:
+            env["DFA_TSDF_LEGACY"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("CHK")][0])
+    assert outs[0] == outs[1], outs
+    assert int(outs[0].split()[3]) > 0.02 * cfg["dim"] ** 3
+
+
 @pytest.mark.parametrize("zchunk", ["4", "7", "20", "1000"])
 def test_integrate_independent_of_z_chunking(A, zchunk, monkeypatch):
     # the kernel replays the running `vc += zstep` additions for chunks that start at z0 > 0

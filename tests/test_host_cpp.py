@@ -28,6 +28,12 @@ def test_host_dual_quaternion_known_answers(exes):
     assert "23 tests, 0 failed" in out
 
 
+def test_tsdf_run_classification_model_matches_oracle(exes):
+    """CPU model of the run-classified TSDF sweep (csrc/tsdf_classify.hpp) vs oracle/tsdf_oracle.c, bit for bit."""
+    out = _run(exes["test_tsdf_classify"])
+    assert "6 tests, 0 failed" in out
+
+
 def test_host_library_exports_the_adaptor_classes(exes):
     lib = os.path.join(ROOT, "dynfu_amd", "libdynfu_amd_host.so")
     syms = subprocess.run(["nm", "-DC", lib], capture_output=True, text=True).stdout
