@@ -31,9 +31,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 for wide reads + WRITE_SIZE, corrected as
-# MI355X_MICROARCH.md prescribes) — profiles/r01_pmc_tsdf.md.  Collected offline: PMC needs its own runs.
+# MI355X_MICROARCH.md prescribes) — profiles/r02_pmc_tsdf.md.  Collected offline: PMC needs its own runs.
 TIMING_SAMPLE = 8  # every 8th timed frame carries the hipEvent brackets of the per-kernel report
-PMC_TRAFFIC_BYTES = {("C2", "fused_integrate"): 0.5415e9, ("C3", "fused_integrate"): 0.5415e9,
+PMC_TRAFFIC_BYTES = {# profiles/r02_pmc_tsdf.md: integrate_runs_kernel<true,32,8>, WRITE 524 288 KiB + 2 x FETCH 2 337 KiB (C4: 4 194 304 + 2 x 23 775)
+                     ("C2", "fused_integrate"): 0.5417e9, ("C3", "fused_integrate"): 0.5417e9, ("C4", "fused_integrate"): 4.344e9,
                      # profiles/r01_pmc_northstar.md (FETCH x2 + WRITE per dispatch)
                      ("C3", "s6_assemble"): 0.510e9, ("C3", "s6_pcg_step"): 0.0242e9,
                      # profiles/r01_pmc_solve.md: (338.8 + 274.9) KiB per pcg_paired_kernel<1024,1,32,1> launch, mean over
@@ -50,6 +51,7 @@ def parse():
     ap.add_argument("--fuse-first", action="store_true",
                     help="launch the TSDF sweep at the start of the frame (A/B; default: behind the graph build)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-northstar", action="store_true", help="skip the short north-star-mode measurement of the default run")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded CPU sample")
     ap.add_argument("--serial", action="store_true", help="run fuse and solve on one stream (A/B of the overlap)")
     ap.add_argument("--pipeline", action="store_true",
@@ -249,6 +251,32 @@ def cpu_baseline6(cfg_name, frames, params):
                        % (frames, cfg_name, dim, params.num_iter * params.gn_iter, pcg, threads, os.cpu_count() or 1, dt))
 
 
+def northstar_probe(cfg_name, device, steps=30, warmup=5):
+    """The same frame in north-star mode (6-DoF DQ-blend / projective point-to-plane / ARAP solve), timed
+    on this GPU after the main measurement: a short secondary figure carried in the default bench line."""
+    import torch
+    seq = Sequence6(cfg_name, device, 64)
+    seq.fuse_first = False
+    for f in range(warmup):
+        seq.frame(f)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for f in range(steps):
+        seq.frame(warmup + f)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    st = seq.solver.stats()
+    out = dict(value=round(steps / dt, 2), unit="frames/s", steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 4),
+               workload="%s north-star mode: %d GN iterations x block-Jacobi PCG<=64 (tol 1e-6), 6-DoF twists per node, DQ blend, "
+                        "projective point-to-plane data term against the live depth map, ARAP regulariser; same fuse"
+                        % (cfg_name, seq.gn_total),
+               pcg_iterations_last_frame=st["pcg_iters"], cost_first=st["initial_cost"], cost_last=st["final_cost"],
+               note="parity unpinned (the reference has no such solve); see `python bench.py --mode northstar` for its rooflines")
+    del seq
+    torch.cuda.empty_cache()
+    return out
+
+
 def main_northstar(args, torch, replicas, rank, world, device):
     """bench line of the north-star mode (same contract; the dominant kernel is reported from hipEvent timings
     of the phases of the last frame)."""
@@ -286,7 +314,7 @@ def main_northstar(args, torch, replicas, rank, world, device):
     asm_bytes = seq.N * k * (32 + 4 * k + 8 + k) + nblk * (36 * 4 + 4)
     pcg_bytes_it = nblk * (36 * 4 + 4 + 3 * 24) + 12 * 24.0 * seq.D
     asm_ms, pcg_ms = tm["assemble_ms"] / gn, tm["pcg_ms"] / max(1, its + gn)
-    fuse_entry = dict(kernel="integrate_kernel<FUSED_CLEAR,1> (clear+integrate %d^3)" % dim, bound="hbm",
+    fuse_entry = dict(kernel="integrate_runs_kernel<FUSED_CLEAR,32,8> (clear+integrate %d^3)" % dim, bound="hbm",
                       achieved=round(fuse_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(fuse_gbs / HBM_PEAK_GBS, 4),
                       traffic=PMC_TRAFFIC_BYTES.get((args.config, "fused_integrate")), avg_launch_ms=round(fuse_ms, 4),
                       launches_per_frame=1, algorithmic_bytes_per_launch=fuse_bytes)
@@ -458,10 +486,11 @@ def main():
     pcg_total_ms = tm["pcg_ms"] / frames_timed        # per frame
     pcg_gbs = pcg_bytes / (pcg_total_ms * 1e-3) / 1e9 if pcg_total_ms > 0 else float("nan")
     launches_pf = tm["pcg_launches"] / frames_timed
-    fuse_entry = dict(kernel="integrate_kernel<FUSED_CLEAR,1> (clear+integrate %d^3)" % dim, bound="hbm",
+    fuse_entry = dict(kernel="integrate_runs_kernel<FUSED_CLEAR,32,8> (clear+integrate %d^3, runs of 8 voxels classified "
+                             "against min/max tiles of the depth image)" % dim, bound="hbm",
                       achieved=round(fuse_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(fuse_gbs / HBM_PEAK_GBS, 4),
                       traffic=PMC_TRAFFIC_BYTES.get((args.config, "fused_integrate")),
-                      traffic_source="profiles/r01_pmc_tsdf.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                      traffic_source="profiles/r02_pmc_tsdf.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                       avg_launch_ms=round(fuse_ms, 4), launches_per_frame=1, algorithmic_bytes_per_launch=fuse_bytes)
     split = seq.D <= 2048  # register-resident kernel, one workgroup per coordinate
     pcg_entry = dict(kernel=("pcg_paired_kernel<..,NC=1> (Jacobi PCG, matrix in registers, 3 workgroups = 3 coordinates)" if split
@@ -507,10 +536,13 @@ def main():
                                      frames=len(lat), note="each frame synchronised, measured after the timed region"),
                roofline=dominant, roofline_other=[other],
                solve_kernels_ms_per_frame=dict(pcg=round(pcg_total_ms, 4), assemble=round(tm["assemble_ms"] / frames_timed, 4)))
-    if not args.no_cpu_baseline and world == 1:
+    if world == 1:
         del seq
         torch.cuda.empty_cache()
-        out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_frames)
+        if not args.no_northstar:
+            out["northstar_mode"] = northstar_probe(args.config, device)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_frames)
     print(json.dumps(out), flush=True)
     replicas.shutdown()
 

@@ -50,5 +50,7 @@ def test_bench_line_has_the_contract_fields():
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in rf, key
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    ns = d["northstar_mode"]  # the same frame with the 6-DoF solve, a secondary figure of the default run
+    assert ns["value"] > 30.0 and ns["unit"] == "frames/s" and ns["cost_last"] < ns["cost_first"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
