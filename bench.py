@@ -52,6 +52,7 @@ def parse():
                     help="launch the TSDF sweep at the start of the frame (A/B; default: behind the graph build)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-northstar", action="store_true", help="skip the short north-star-mode measurement of the default run")
+    ap.add_argument("--no-pipelined-probe", action="store_true", help="skip the short pipelined-throughput measurement")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded CPU sample")
     ap.add_argument("--serial", action="store_true", help="run fuse and solve on one stream (A/B of the overlap)")
     ap.add_argument("--pipeline", action="store_true",
@@ -249,6 +250,27 @@ def cpu_baseline6(cfg_name, frames, params):
                        "computePointNormals, k-NN graphs, %d GN x block-Jacobi PCG (%d PCG iterations in total)) by the "
                        "C statement in oracle/solve6_oracle.c (fp64 solve), OpenMP over %d of the host's %d cores; %.1f s"
                        % (frames, cfg_name, dim, params.num_iter * params.gn_iter, pcg, threads, os.cpu_count() or 1, dt))
+
+
+def pipelined_probe(seq, f0, device, steps=100, warmup=10):
+    """Throughput of the same sequence with the graph build of frame f+1 (a function of the canonical vertices and node
+    positions only: k-NN, transposition, record packing) overlapped with the solve of frame f on a third stream and a
+    second solver plan (`--pipeline`).  Every frame does all of its work; only the order across frames changes.  A
+    secondary figure: `value` above is the self-contained frame."""
+    import torch
+    seq.enable_pipeline()
+    for f in range(warmup):
+        seq.frame(f0 + f)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for f in range(steps):
+        seq.frame(f0 + warmup + f)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    t_err = float((seq.solver.translations() - seq.t_true[(f0 + warmup + steps - 1) % seq.n_frames]).abs().max())
+    return dict(value=round(steps / dt, 2), unit="frames/s", steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 4),
+                streams="fuse || graph build of frame f+1 || solve of frame f on three HIP streams, two solver plans",
+                max_abs_translation_error_vs_ground_truth_m=round(t_err, 6))
 
 
 def northstar_probe(cfg_name, device, steps=30, warmup=5):
@@ -537,6 +559,8 @@ def main():
                roofline=dominant, roofline_other=[other],
                solve_kernels_ms_per_frame=dict(pcg=round(pcg_total_ms, 4), assemble=round(tm["assemble_ms"] / frames_timed, 4)))
     if world == 1:
+        if not (args.pipeline or args.serial or args.no_pipelined_probe):
+            out["pipelined"] = pipelined_probe(seq, Wm + K, device)
         del seq
         torch.cuda.empty_cache()
         if not args.no_northstar:

@@ -7,6 +7,8 @@ Tolerances (float32 PCG on the GPU vs float64 oracle):
   * well-posed problems (lambda > 0, N >> D): node translations within 2e-5 m of the float64
     oracle (|t| ~ 1e-2 m, i.e. 2e-3 relative) and final cost within 1e-3 relative.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -387,3 +389,27 @@ def test_rows_wider_than_the_register_slots(A, D, k):
     assert st["gn_iters"] == 2 and st["pcg_iters"] > 10
     assert np.abs(t - t_ref).max() <= 3e-5
     np.testing.assert_allclose(st["final_cost"], st_ref["final_cost"], rtol=2e-3, atol=1e-9)
+
+
+def test_pipelined_sequence_gives_the_same_translations(A):
+    """bench.py --pipeline builds the graphs of frame f+1 on a third stream, into a second plan, while frame f is
+    solved: the node translations of every frame must be those of the frame-by-frame schedule (to the solve's own
+    run-to-run noise: the assembly adds with LDS float atomics, whose order is not fixed; |t| ~ 5e-3 m)."""
+    import sys, torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    dev0 = torch.device("cuda", 0)
+    ref = []
+    seq = bench.Sequence("T1", dev0)
+    for f in range(6):
+        seq.frame(f)
+        torch.cuda.synchronize()
+        ref.append(seq.solver.translations().clone())
+    seq2 = bench.Sequence("T1", dev0)
+    seq2.enable_pipeline()
+    for f in range(6):
+        seq2.frame(f)  # no synchronisation between frames: the streams' events order them
+        got = seq2.solver.translations().clone()
+        torch.cuda.synchronize()
+        assert float((got - ref[f]).abs().max()) <= 5e-7, "frame %d: %g" % (f, float((got - ref[f]).abs().max()))
+    assert float(ref[0].abs().max()) > 1e-3  # the frames do move
