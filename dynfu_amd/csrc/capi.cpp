@@ -7,7 +7,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "../../include/dynfu_amd.h"
@@ -42,6 +45,21 @@ int hip_fail(hipError_t e, const char* what) {
 inline hipStream_t S(dfa_stream_t s) { return (hipStream_t)s; }
 
 bool volume_args_ok(const void* vol, int X, int Y, int Z) { return vol && X > 0 && Y > 0 && Z > 0; }
+
+// Scratch of the entry points that have no plan to keep it in (dfa_knn, dfa_warp_to_live, dfa_correspond,
+// dfa_marching_cubes, dfa_icp_sums ...): one instance per (device, stream), created on first use and kept.  Work on one
+// stream is ordered, so a call never overwrites the scratch of a call still running — whichever host threads and
+// however many streams the caller uses (round 1 kept these per host THREAD: two streams driven by one thread shared
+// them).  Growing frees the old block with hipFree, which waits for the device.
+template <class T>
+T& stream_scratch(hipStream_t s) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, T> table;  // (device, stream): the null stream exists on every device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    return table[std::make_pair(dev, s)];  // std::map nodes never move
+}
 
 // device scratch of one node grid (warp.hip); grows on demand, never shrinks
 struct GridScratch {
@@ -95,7 +113,6 @@ struct PointGridScratch {
         return hipSuccess;
     }
 };
-thread_local PointGridScratch g_thread_point_grid;
 
 // scratch of dfa_marching_cubes (segment offsets + scan partials); grows on demand
 struct McScratch {
@@ -114,11 +131,7 @@ struct McScratch {
         return hipSuccess;
     }
 };
-thread_local McScratch g_thread_mc;
 
-// The standalone entry points (dfa_knn, dfa_warp_to_live) have no plan to keep scratch in:
-// one grid per host thread, reused across calls (stream-ordered use; grows synchronously).
-thread_local GridScratch g_thread_grid;
 
 // exhaustive scan below this many distance evaluations (grid build = 4 small launches)
 bool want_grid(int D, long n_query) { return D >= 64 && (long)D * n_query >= (1L << 22); }
@@ -389,7 +402,6 @@ struct IcpScratch {
         return e;
     }
 };
-thread_local IcpScratch g_thread_icp;
 }  // namespace
 
 int dfa_icp_sums(int depth_variant, const void* curr, int curr_step, const float* ncurr, int ncurr_step, const void* prev,
@@ -402,9 +414,10 @@ int dfa_icp_sums(int depth_variant, const void* curr, int curr_step, const float
     REQUIRE(curr_step >= cols * px && prev_step >= cols * px && ncurr_step >= cols * 16 && nprev_step >= cols * 16,
             "row step smaller than a row");
     REQUIRE(fx != 0.f && fy != 0.f && dist_thres >= 0.f, "bad intrinsics / threshold");
-    HIP_TRY(g_thread_icp.reserve(dfa::icp_partial_floats(cols, rows)));
+    IcpScratch& scratch = stream_scratch<IcpScratch>(S(stream));
+    HIP_TRY(scratch.reserve(dfa::icp_partial_floats(cols, rows)));
     HIP_TRY(dfa::launch_icp_sums(depth_variant != 0, curr, curr_step, ncurr, ncurr_step, prev, prev_step, nprev, nprev_step,
-                                 cols, rows, aff, fx, fy, cx, cy, dist_thres, angle_thres, g_thread_icp.partial, sums27,
+                                 cols, rows, aff, fx, fy, cx, cy, dist_thres, angle_thres, scratch.partial, sums27,
                                  matched, S(stream)));
     return DFA_OK;
 }
@@ -420,9 +433,10 @@ int dfa_marching_cubes(const uint32_t* volume, int X, int Y, int Z, const float 
     REQUIRE((long)X * Y * Z / 64 < (1L << 31), "volume too large");
     const bool vec4  = (X % 4 == 0) && (((uintptr_t)volume & 15) == 0);
     const long nsegs = dfa::mc_segments(X, Y, Z, vec4);
-    HIP_TRY(g_thread_mc.reserve(nsegs));
+    McScratch& scratch = stream_scratch<McScratch>(S(stream));
+    HIP_TRY(scratch.reserve(nsegs));
     HIP_TRY(dfa::launch_marching_cubes(volume, X, Y, Z, cell_size, tri_table, num_verts_table, out_points,
-                                       max_vertices, total_vertices, g_thread_mc.seg_off, g_thread_mc.chunk_sums,
+                                       max_vertices, total_vertices, scratch.seg_off, scratch.chunk_sums,
                                        S(stream)));
     return DFA_OK;
 }
@@ -443,9 +457,13 @@ int dfa_knn(const float* node_pos, const float* node_w, int D, const float* quer
     REQUIRE(!weights || node_w, "weights requested without node_w");
     const dfa::KnnGridView* grid = nullptr;
     if (want_grid(D, n_query)) {
-        HIP_TRY(g_thread_grid.reserve(D));
-        HIP_TRY(dfa::knn_grid_build(g_thread_grid.v, node_pos, D, S(stream)));
-        grid = &g_thread_grid.v;
+        GridScratch& gs = stream_scratch<GridScratch>(S(stream));
+
+        HIP_TRY(gs.reserve(D));
+
+        HIP_TRY(dfa::knn_grid_build(gs.v, node_pos, D, S(stream)));
+
+        grid = &gs.v;
     }
     HIP_TRY(dfa::launch_knn(node_pos, node_w, D, query, n_query, k, idx, weights, grid, S(stream)));
     return DFA_OK;
@@ -459,9 +477,13 @@ int dfa_warp_to_live(const float* node_pos, const float* node_dq, const float* n
     REQUIRE(k >= 1 && k <= DFA_MAX_KNN, "k out of range 1..16");
     const dfa::KnnGridView* grid = nullptr;
     if (want_grid(D, N)) {
-        HIP_TRY(g_thread_grid.reserve(D));
-        HIP_TRY(dfa::knn_grid_build(g_thread_grid.v, node_pos, D, S(stream)));
-        grid = &g_thread_grid.v;
+        GridScratch& gs = stream_scratch<GridScratch>(S(stream));
+
+        HIP_TRY(gs.reserve(D));
+
+        HIP_TRY(dfa::knn_grid_build(gs.v, node_pos, D, S(stream)));
+
+        grid = &gs.v;
     }
     HIP_TRY(dfa::launch_warp_to_live(node_pos, node_dq, node_w, D, k, vertices, normals, N, out_vertices,
                                      out_normals, grid, S(stream)));
@@ -475,9 +497,13 @@ int dfa_calc_dqb(const float* node_pos, const float* node_dq, const float* node_
     REQUIRE(k >= 1 && k <= DFA_MAX_KNN, "k out of range 1..16");
     const dfa::KnnGridView* grid = nullptr;
     if (want_grid(D, n)) {
-        HIP_TRY(g_thread_grid.reserve(D));
-        HIP_TRY(dfa::knn_grid_build(g_thread_grid.v, node_pos, D, S(stream)));
-        grid = &g_thread_grid.v;
+        GridScratch& gs = stream_scratch<GridScratch>(S(stream));
+
+        HIP_TRY(gs.reserve(D));
+
+        HIP_TRY(dfa::knn_grid_build(gs.v, node_pos, D, S(stream)));
+
+        grid = &gs.v;
     }
     HIP_TRY(dfa::launch_dqb_support(node_pos, node_dq, node_w, D, k, points, n, out_dq, nullptr, grid, S(stream)));
     return DFA_OK;
@@ -494,9 +520,13 @@ int dfa_unsupported_vertices(const float* node_pos, const float* node_w, int D, 
     REQUIRE(node_pos && node_w && D > 0, "bad nodes");
     const dfa::KnnGridView* grid = nullptr;
     if (want_grid(D, N)) {
-        HIP_TRY(g_thread_grid.reserve(D));
-        HIP_TRY(dfa::knn_grid_build(g_thread_grid.v, node_pos, D, S(stream)));
-        grid = &g_thread_grid.v;
+        GridScratch& gs = stream_scratch<GridScratch>(S(stream));
+
+        HIP_TRY(gs.reserve(D));
+
+        HIP_TRY(dfa::knn_grid_build(gs.v, node_pos, D, S(stream)));
+
+        grid = &gs.v;
     }
     HIP_TRY(dfa::launch_dqb_support(node_pos, nullptr, node_w, D, k, vertices, N, nullptr, flags, grid, S(stream)));
     return DFA_OK;
@@ -509,13 +539,18 @@ int dfa_correspond(const float* canon_vertices, const float* canon_normals, int 
     REQUIRE(!out_normals || canon_normals, "normals requested without canonical normals");
     const dfa::KnnGridView* grid = nullptr;
     if (n_canon >= 16384 && want_grid(n_canon, n_live)) {  // large cloud: 128^3 point grid
-        HIP_TRY(g_thread_point_grid.reserve(n_canon));
-        HIP_TRY(dfa::point_grid_build(g_thread_point_grid.v, canon_vertices, n_canon, S(stream)));
-        grid = &g_thread_point_grid.v.g;
+        PointGridScratch& pg = stream_scratch<PointGridScratch>(S(stream));
+        HIP_TRY(pg.reserve(n_canon));
+        HIP_TRY(dfa::point_grid_build(pg.v, canon_vertices, n_canon, S(stream)));
+        grid = &pg.v.g;
     } else if (want_grid(n_canon, n_live)) {
-        HIP_TRY(g_thread_grid.reserve(n_canon));
-        HIP_TRY(dfa::knn_grid_build(g_thread_grid.v, canon_vertices, n_canon, S(stream)));
-        grid = &g_thread_grid.v;
+        GridScratch& gs = stream_scratch<GridScratch>(S(stream));
+
+        HIP_TRY(gs.reserve(n_canon));
+
+        HIP_TRY(dfa::knn_grid_build(gs.v, canon_vertices, n_canon, S(stream)));
+
+        grid = &gs.v;
     }
     HIP_TRY(dfa::launch_correspond(canon_vertices, canon_normals, n_canon, live_vertices, n_live, out_vertices,
                                    out_normals, out_index, grid, S(stream)));

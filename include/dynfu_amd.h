@@ -10,7 +10,12 @@
  * Conventions
  *   - all data pointers are DEVICE pointers (hipMalloc / torch CUDA tensors) unless the
  *     parameter is documented as host; the caller owns them, kernels allocate nothing
- *     (same ownership as kfusion::cuda::DeviceMemory, device_memory.cpp:50-113);
+ *     (same ownership as kfusion::cuda::DeviceMemory, device_memory.cpp:50-113).  Entry points
+ *     without a plan keep small internal scratch (search grids, scan partials, the depth tile
+ *     table of the TSDF sweeps) per (device, stream): calls on different streams never share
+ *     it, calls on one stream are ordered by the stream; it grows on demand and is kept;
+ *   - threads: any host thread may call any entry point; two threads must not drive the SAME
+ *     stream or the SAME solver plan at the same time (as with any stream-ordered API);
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is
  *     asynchronous on it.  NOTE the reference's device::integrate ends with
  *     cudaDeviceSynchronize (tsdf_volume.cu:120); the adaptor class syncs where the caller

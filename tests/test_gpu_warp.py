@@ -46,6 +46,29 @@ def test_knn_bit_exact_and_weights(A, D, k, n):
     assert np.all(host(w)[ref < 0] == 0)
 
 
+def test_knn_on_two_streams_from_one_thread(A):
+    # the search grid of dfa_knn is internal scratch kept per (device, stream): two searches in flight on two streams,
+    # driven by ONE host thread, over different node sets must not see each other's grid
+    import torch
+    rng = np.random.default_rng(3)
+    sets = []
+    for i in range(2):
+        D, n = 1500 + 700 * i, 40000
+        nodes = rng.uniform(-1 - i, 1 + i, (D, 3)).astype(np.float32)
+        q = rng.uniform(-1 - i, 1 + i, (n, 3)).astype(np.float32)
+        sets.append((dev(nodes), dev(np.full(D, 0.1, np.float32)), dev(q), O.knn(nodes, q, 4, threads=8)))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    out = [None, None]
+    for rep in range(6):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                out[i] = A.knn(sets[i][0], sets[i][1], sets[i][2], 4)[0]
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert np.array_equal(host(out[i]), sets[i][3])
+
+
 @pytest.mark.parametrize("kind", ["clustered", "planar", "far_queries", "duplicates", "line", "lattice"])
 @pytest.mark.parametrize("k", [4, 8])
 def test_knn_grid_path_is_exact_on_awkward_geometry(A, kind, k):
