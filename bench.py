@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4", "T0", "T1"])
     ap.add_argument("--fuse-first", action="store_true",
                     help="launch the TSDF sweep at the start of the frame (A/B; default: behind the graph build)")
+    ap.add_argument("--fuse-after-build", action="store_true",
+                    help="launch the TSDF sweep behind the graph build (A/B; default up to 2048 nodes: in the shadow of the "
+                         "first PCG, behind the solver's overlap event)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-northstar", action="store_true", help="skip the short north-star-mode measurement of the default run")
     ap.add_argument("--no-pipelined-probe", action="store_true", help="skip the short pipelined-throughput measurement")
@@ -142,11 +145,20 @@ class Sequence:
                 self.solve_pipelined(f)
             else:
                 self.solve(f)
+        elif getattr(self, "ev_overlap", None) is not None:
+            # The volume sweep (all CUs for ~0.13 ms) runs in the shadow of the first PCG (three CUs for ~0.11 ms): the
+            # solver calls back behind its first assembly launch; the callback records an event there, lets the fuse
+            # stream wait for it and enqueues the sweep (dfa_solver_set_overlap_callback).  Launched
+            # behind the graph build instead (--fuse-after-build), the sweep holds every wave slot of the chip while
+            # the first linearisation wants them: that kernel then takes 124 us instead of 22
+            # (profiles/r02a_kernel_stats_bench_c2.csv).  Same work per frame either way.
+            self.build_graph(f)
+            self._overlap_job = (f, timed_events)
+            self.solve(f, graph_built=True)  # calls self._fuse_in_shadow() behind its first assembly launch
         else:
             # The graph build (grid, k-NN, transposition: short kernels that fill the chip) runs alone; the volume
-            # sweep (all CUs for 0.27 ms) starts behind it and overlaps the Gauss-Newton iterations, most of whose
-            # time is the PCG on three CUs.  Same work per frame as launching both at once (--fuse-first), where the
-            # sweep slows the graph build's kernels by ~2x and the chip idles during the PCG.
+            # sweep starts behind it and overlaps the Gauss-Newton iterations.  Same work per frame as launching
+            # both at once (--fuse-first), where the sweep slows the graph build's kernels by ~2x.
             self.build_graph(f)
             self.s_fuse.wait_stream(cur)
             with torch.cuda.stream(self.s_fuse):
@@ -156,9 +168,25 @@ class Sequence:
 
     # ---- software pipeline across frames (--pipeline): two plans; the graphs of frame f+1 (a function of the node
     # positions and the new frame's vertices only) are built on a third stream while frame f is solved
+    def enable_pcg_shadow(self):
+        """fuse in the shadow of the first PCG (plans of <= 2048 nodes: the register-resident PCG on three CUs)"""
+        self.ev_overlap = self.torch.cuda.Event()
+        self.solver.set_overlap_callback(self._fuse_in_shadow)
+
+    def _fuse_in_shadow(self):
+        torch = self.torch
+        f, timed_events = self._overlap_job
+        self.ev_overlap.record()  # on the solve's stream, behind the first assembly
+        self.s_fuse.wait_event(self.ev_overlap)
+        with torch.cuda.stream(self.s_fuse):
+            self.fuse(f, timed_events)
+
     def enable_pipeline(self):
         torch = self.torch
         self.pipelined = True
+        if getattr(self, "ev_overlap", None) is not None:
+            self.solver.set_overlap_callback(None)
+            self.ev_overlap = None
         self.plans = [self.solver, self.A.Solver(self.D, self.N, self.k)]
         self.s_graph = torch.cuda.Stream()
         self.graph_ready = [None, None]   # event: plan i holds the graphs of its next frame
@@ -442,6 +470,9 @@ def main():
         return main_northstar(args, torch, replicas, rank, world, device)
     seq = Sequence(args.config, device)
     seq.fuse_first = args.fuse_first
+    shadow = seq.D <= 2048 and not (args.fuse_first or args.fuse_after_build or args.serial or args.pipeline)
+    if shadow:
+        seq.enable_pcg_shadow()
     if args.pipeline and not args.serial:
         seq.enable_pipeline()
     cfg = seq.cfg
@@ -550,7 +581,9 @@ def main():
                            streams="serial" if args.serial else ("fuse || graph build of frame f+1 || solve of frame f on three "
                                                                  "HIP streams, two solver plans" if args.pipeline else
                                                                  ("fuse || graph build + solve on two HIP streams" if args.fuse_first
-                                                                  else "graph build, then fuse || solve on two HIP streams")),
+                                                                  else ("graph build, then solve on one HIP stream with the fuse on a "
+                                                                        "second one in the shadow of the first PCG" if shadow else
+                                                                        "graph build, then fuse || solve on two HIP streams"))),
                            pcg_iterations_last_frame=st["pcg_iters"], gn_iterations_last_frame=st["gn_iters"],
                            gn_iterations_noop_last_frame=st["gn_noop"],
                            max_abs_translation_error_vs_ground_truth_m=round(t_err, 6)),

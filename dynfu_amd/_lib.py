@@ -20,8 +20,11 @@ SYMBOLS = [
     "dfa_solver_create", "dfa_solver_destroy", "dfa_solver_set_problem", "dfa_solver_solve",
     "dfa_solver_translations", "dfa_solver_node_dq", "dfa_solver_tukey_weights", "dfa_solver_huber_weights",
     "dfa_solver_data_graph", "dfa_solver_reg_graph", "dfa_solver_get_stats", "dfa_solver_enable_timing",
-    "dfa_solver_get_timing", "dfa_solver_warp_to_live",
+    "dfa_solver_get_timing", "dfa_solver_warp_to_live", "dfa_solver_set_overlap_callback",
 ]
+
+
+_OVERLAP_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)  # dfa_overlap_fn
 
 
 class Solve6Params(C.Structure):
@@ -140,6 +143,7 @@ def load():
     L.dfa_solver_warp_to_live.argtypes = [vp, vp, vp, vp, vp]
     L.dfa_solver_get_stats.argtypes = [vp, C.POINTER(_SolveStats), vp]
     L.dfa_solver_enable_timing.argtypes = [vp, i]
+    L.dfa_solver_set_overlap_callback.argtypes = [vp, _OVERLAP_FN, vp]
     L.dfa_solver_get_timing.argtypes = [vp, C.POINTER(_SolveTiming), vp]
     runtimes = set()
     with open("/proc/self/maps") as maps:
@@ -407,6 +411,9 @@ class Solver:
 
     def solve(self, params):
         _check(load().dfa_solver_solve(self._h, C.byref(params), _stream()))
+        err, self._overlap_error = getattr(self, "_overlap_error", None), None
+        if err is not None:
+            raise err
 
     def _view(self, name, shape, dtype):
         """Copy of a plan-owned device array as a torch tensor (zero-copy view, then clone)."""
@@ -454,6 +461,22 @@ class Solver:
     def enable_timing(self, on=True):
         """True / 1 starts a new measurement, 2 resumes a paused one, False / 0 pauses"""
         _check(load().dfa_solver_enable_timing(self._h, int(on)))
+
+    def set_overlap_callback(self, fn):
+        """fn() (or None) is called by every following solve() right after its first assembly launch has been enqueued,
+        before the first PCG launch (dfa_solver_set_overlap_callback): the place to enqueue independent chip-wide work
+        on another stream, behind an event recorded on the current one."""
+        self._overlap_error = None
+        if fn is None:
+            self._overlap_cb = _OVERLAP_FN()
+        else:
+            def trampoline(_user, _stream):
+                try:
+                    fn()
+                except BaseException as e:  # an exception cannot cross the C frame: re-raised by solve()
+                    self._overlap_error = e
+            self._overlap_cb = _OVERLAP_FN(trampoline)  # kept alive with the plan
+        _check(load().dfa_solver_set_overlap_callback(self._h, self._overlap_cb, None))
 
     def timing(self):
         t = _SolveTiming()

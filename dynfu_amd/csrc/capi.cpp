@@ -157,6 +157,8 @@ struct dfa_solver {
     dfa::MbGraphCache mb_graphs;  // HIP graphs of the many-workgroup PCG's launch chunks
     bool just_reset = false;  // the unknowns and the state block were zeroed by set_problem and not touched since
     long long* iters_total = nullptr;  // device: PCG iterations of all solves since enable_timing(1)
+    dfa_overlap_fn overlap_fn = nullptr;  // called behind the first assembly launch of every solve
+    void* overlap_user        = nullptr;
     int* host_flag = nullptr;        // pinned int[4]: stop flag of the many-workgroup PCG, the plan's converged flag, (skip), iterations;
                                      // read back between launch chunks
 };
@@ -714,6 +716,7 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
     if (s->host_flag) s->host_flag[0] = s->host_flag[1] = 0;
     s->mb_graphs.call = 0;
     int not_launched = 0;  // iterations after the host has seen the converged flag (many-workgroup path only)
+    bool overlap_called = s->overlap_fn == nullptr;
     for (int outer = 0; outer < p->num_iter; ++outer) {
         // preNonlinearSolve (opt_solver.cpp:135-140): the Huber weights are only observable after
         // the solve, so they are evaluated for the last outer iteration alone
@@ -729,12 +732,17 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
             HIP_TRY(dfa::solve_assemble(v, s->state, st));
             timing_end(s, ev, st);
             if (ev >= 0) s->ev_asm.push_back(ev);
+            if (!overlap_called) {  // the first PCG starts here: the caller's chip-wide work may run in its shadow
+                s->overlap_fn(s->overlap_user, stream);
+                overlap_called = true;
+            }
             ev = s->timing ? timing_begin(s, st) : -1;  // closed behind the solving kernel, before the fallback launch
             HIP_TRY(dfa::solve_pcg(v, s->state, p->linear_iter, p->pcg_tol, s->host_flag, &s->mb_graphs,
                                    ev >= 0 ? s->events[ev + 1] : nullptr, st));
             if (ev >= 0) s->ev_pcg.push_back(ev);
         }
     }
+    if (!overlap_called) s->overlap_fn(s->overlap_user, stream);  // no iteration ran: the caller's work still goes out
     if (not_launched) HIP_TRY(dfa::solve_count_noop(s->state, not_launched, st));
     // final cost at the solved t; weights re-evaluated only if no iteration ever did
     const bool no_weights = p->num_iter == 0 || p->nonlinear_iter == 0;
@@ -743,6 +751,12 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
                                  p->tukey_offset, p->psi_data, w_reg_sq, st));
     // postSingleSolve -> copyResultToCPUFromFloat3 (opt_solver.cpp:133,270-285), composed once
     HIP_TRY(dfa::solve_writeback(v, s->state, s->timing ? s->iters_total : nullptr, st));
+    return DFA_OK;
+}
+
+int dfa_solver_set_overlap_callback(dfa_solver* s, dfa_overlap_fn fn, void* user) {
+    REQUIRE(s, "null plan");
+    s->overlap_fn = fn, s->overlap_user = user;
     return DFA_OK;
 }
 

@@ -413,3 +413,53 @@ def test_pipelined_sequence_gives_the_same_translations(A):
         torch.cuda.synchronize()
         assert float((got - ref[f]).abs().max()) <= 5e-7, "frame %d: %g" % (f, float((got - ref[f]).abs().max()))
     assert float(ref[0].abs().max()) > 1e-3  # the frames do move
+
+
+def test_overlap_callback_runs_once_per_solve_and_changes_nothing(A):
+    """dfa_solver_set_overlap_callback: called on the calling thread behind the first assembly launch of every solve
+    (also when no iteration runs); work it enqueues on another stream runs beside the PCG; exceptions it raises surface
+    from solve(); the solution is that of a solve without it."""
+    import torch
+    cfg, c, verts, live, _ = _problem("T1")
+    k = cfg["k"]
+    args = (dev(c["node_pos"]), dev(c["node_dq"]), dev(c["node_w"]), dev(verts), dev(live))
+    prm = _params(A, num_iter=3, lambda_=200.0, pcg_tol=1e-6)
+    s = A.Solver(cfg["D"], len(verts), k)
+    s.set_problem(*args)
+    s.solve(prm)
+    t_ref = host(s.translations())
+
+    side = torch.cuda.Stream()
+    calls, ev = [], torch.cuda.Event()
+    vol = torch.empty((64, 64, 64), dtype=torch.int32, device="cuda")
+
+    def cb():
+        calls.append(torch.cuda.current_stream().cuda_stream)
+        ev.record()
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            A.tsdf_clear(vol)  # any independent work
+
+    s.set_overlap_callback(cb)
+    for _ in range(3):
+        s.set_problem(*args)
+        s.solve(prm)
+    torch.cuda.synchronize()
+    assert len(calls) == 3 and int(vol.abs().max()) == 0
+    assert np.abs(host(s.translations()) - t_ref).max() <= 5e-7
+    s.set_problem(*args)
+    s.solve(_params(A, num_iter=0))  # nothing to iterate: still called, once
+    assert len(calls) == 4
+
+    def boom():
+        raise RuntimeError("from the callback")
+
+    s.set_overlap_callback(boom)
+    s.set_problem(*args)
+    with pytest.raises(RuntimeError, match="from the callback"):
+        s.solve(prm)
+    s.set_overlap_callback(None)
+    s.set_problem(*args)
+    s.solve(prm)
+    assert len(calls) == 4 and np.abs(host(s.translations()) - t_ref).max() <= 5e-7
+    s.close()
