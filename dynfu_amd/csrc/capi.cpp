@@ -608,8 +608,7 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
     A(blk_hist, D * dfa::SOLVE_TG_BLOCKS);
     A(node_ptr, D + 1);
     A(node_list, R * k);
-    A(ell_cols, D * s->ell_cap);
-    A(ell_vals, D * s->ell_cap);
+    A(ell, D * s->ell_cap);
     A(ell_cnt, D);
     A(diag, D);
     A(g, D * 3);

@@ -520,8 +520,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
         const int pos    = pos0 + __popcll(m & ((1ull << lane) - 1ull));
         if (valid) {
             if (pos < s.ell_cap) {
-                s.ell_cols[(size_t)pos * s.D + a] = kk;
-                s.ell_vals[(size_t)pos * s.D + a] = vv;
+                s.ell[(size_t)pos * s.D + a] = make_float2(vv, __int_as_float(kk));
             }
             if (kk == a) s.diag[a] = vv, diag = 1.f;
         }
@@ -664,8 +663,9 @@ __global__ __launch_bounds__(NT) void pcg_kernel(SolveView s, SolveState* __rest
         row[i]         = rank < D ? s.pk_perm[rank] : -1;
         rcnt[i]        = row[i] >= 0 ? min(s.ell_cnt[row[i]], 256) : 0;
         for (int q = 0; q < rcnt[i]; ++q) {
-            s.pk_vals[(size_t)q * D + rank] = s.ell_vals[(size_t)q * D + row[i]];
-            s.pk_cols[(size_t)q * D + rank] = (uint16_t)s.ell_cols[(size_t)q * D + row[i]];
+            const float2 e                  = s.ell[(size_t)q * D + row[i]];
+            s.pk_vals[(size_t)q * D + rank] = e.x;
+            s.pk_cols[(size_t)q * D + rank] = (uint16_t)__float_as_int(e.y);
         }
         int m = rcnt[i];
 #pragma unroll
@@ -930,8 +930,9 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
                 const int ent   = isA ? q : E - 1 - q;
                 const int r     = isA ? rA : rB;
                 const bool live = isA ? (q < cntA) : (E - 1 - q < regB);
-                float v         = s.ell_vals[(size_t)ent * D + r];  // unconditional load, masked after
-                int col         = s.ell_cols[(size_t)ent * D + r];
+                const float2 e  = s.ell[(size_t)ent * D + r];  // unconditional 8-byte load, masked after
+                float v         = e.x;
+                int col         = __float_as_int(e.y);
                 if (!live) v = 0.f, col = 0;
                 mval[j][q] = v;
                 packed |= (uint32_t)(col << (NC == 3 ? 4 : 2)) << (16 * h);  // byte offset of p[col] in LDS
@@ -1374,8 +1375,9 @@ __global__ __launch_bounds__(256) void pcg_mb_matvec_kernel(SolveView s, SolveSt
     const bool row_ok = a < s.D;
     const int cnt     = row_ok ? s.ell_cnt[a] : 0;
     for (int q = lane16; q < cnt; q += MB_LPR) {
-        const int col   = s.ell_cols[(size_t)q * s.D + a];
-        const float val = s.ell_vals[(size_t)q * s.D + a];
+        const float2 e  = s.ell[(size_t)q * s.D + a];
+        const int col   = __float_as_int(e.y);
+        const float val = e.x;
         float4 pv       = z[col];
         if (it > 0) {
             const float4 po = pold[col];
@@ -1493,8 +1495,9 @@ __global__ __launch_bounds__(256) void pcg_mb_step_kernel(SolveView s, SolveStat
     const int cnt     = row_ok ? s.ell_cnt[a] : 0;
     float au[3] = {0.f, 0.f, 0.f}, am[3] = {0.f, 0.f, 0.f}, at[3] = {0.f, 0.f, 0.f};
     for (int q = lane16; q < cnt; q += MB_LPR) {
-        const int col   = s.ell_cols[(size_t)q * s.D + a];
-        const float val = s.ell_vals[(size_t)q * s.D + a];
+        const float2 e  = s.ell[(size_t)q * s.D + a];
+        const int col   = __float_as_int(e.y);
+        const float val = e.x;
         const float4 uu = ucur[col];
         au[0] = fmaf(val, uu.x, au[0]), au[1] = fmaf(val, uu.y, au[1]), au[2] = fmaf(val, uu.z, au[2]);
         if (it >= 0) {
@@ -1594,7 +1597,7 @@ static hipError_t launch_mb_range(const SolveView& s, SolveState* state, int it0
         MbGraphCache::Entry& c = gc->e[i];
         // (the plan's own buffers never move; the borrowed pointers of the view change from frame to frame but these
         // kernels read none of them)
-        if (c.it0 == it0 && c.it1 == it1 && c.tol == pcg_tol && c.state == state && c.view.D == s.D && c.view.ell_vals == s.ell_vals)
+        if (c.it0 == it0 && c.it1 == it1 && c.tol == pcg_tol && c.state == state && c.view.D == s.D && c.view.ell == s.ell)
             hit = &c;
     }
     if (!hit) {

@@ -60,9 +60,9 @@ struct SolveView {
     int32_t* blk_hist;    // TG_BLOCKS x D  workgroup-private histograms / bases of the counting sort
     int32_t* node_ptr;    // D + 1
     uint32_t* node_list;  // R x k   flat (row*k + slot) indices grouped by node
-    // normal equations, ELL slot-major: entry q of row a at [q*D + a]
-    int32_t* ell_cols;
-    float* ell_vals;
+    // normal equations, ELL slot-major: entry q of row a at [q*D + a] as ONE 8-byte word (value, column as int bits) —
+    // the register-resident PCG loads its rows in length-sorted order, i.e. scattered: one request per entry, not two
+    float2* ell;
     int32_t* ell_cnt;  // D
     float* diag;       // D
     float* g;          // D x 3   -J^T r
