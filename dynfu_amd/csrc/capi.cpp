@@ -605,7 +605,7 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
     A(rb, R * 3);
     A(re, R * (size_t)dfa::solve_rec_words(k));
     A(reg_idx, D * k);
-    A(blk_hist, D * dfa::SOLVE_TG_BLOCKS);
+    A(blk_hist, D * (dfa::SOLVE_TG_BLOCKS + 1));
     A(node_ptr, D + 1);
     A(node_list, R * k);
     A(ell, D * s->ell_cap);
@@ -689,9 +689,8 @@ int dfa_solver_set_problem(dfa_solver* s, const float* node_pos, const float* no
     if (N > 0) HIP_TRY(dfa::launch_knn(node_pos, node_w, D, canon_vertices, N, s->k, v.ridx, v.rw, grid, st));
     // initializeRegGraph (:74-105): k-NN of every node among the nodes (itself included at distance 0)
     HIP_TRY(dfa::launch_knn(node_pos, node_w, D, node_pos, D, s->k, v.reg_idx, nullptr, grid, st));
-    HIP_TRY(dfa::solve_build_graph(v, st));
-    // resetGPUMemory (:149-202): unknowns start at zero
-    HIP_TRY(dfa::solve_reset(v, s->state, s->ticket, 64, st));
+    // rows + transposition; resetGPUMemory (:149-202): unknowns start at zero (same launch as the row set-up)
+    HIP_TRY(dfa::solve_build_graph(v, s->state, s->ticket, 64, st));
     s->has_problem = true;
     s->just_reset  = true;
     return DFA_OK;
@@ -869,7 +868,7 @@ int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
     A(idx, N * k);
     A(wn, N * k);
     A(reg_idx, D * k);
-    A(blk_hist, D * dfa::SOLVE_TG_BLOCKS);
+    A(blk_hist, D * (dfa::SOLVE_TG_BLOCKS + 1));
     A(node_ptr, D + 1);
     A(node_list, N * k);
     A(rnode_ptr, D + 1);

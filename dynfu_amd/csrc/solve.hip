@@ -40,41 +40,12 @@
 namespace dfa {
 
 // ------------------------------------------------------------------------------------------
-// row construction
-
-// reg rows (opt_solver.cpp:74-105 + energy.t:75-78): row N + n*k + i  <-  {reg_idx[n][i]: -1, n: +1}
-__global__ __launch_bounds__(256) void build_reg_rows_kernel(const int32_t* __restrict__ reg_idx, int D, int k, int N,
-                                                             int32_t* __restrict__ ridx, float* __restrict__ rw,
-                                                             float* __restrict__ rb) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= D * k) return;
-    const int n = e / k;
-    const int m = reg_idx[e];
-    const size_t row = (size_t)N + e;
-    for (int j = 0; j < k; ++j) ridx[row * k + j] = -1, rw[row * k + j] = 0.f;
-    if (m >= 0 && m != n) {
-        // k >= 2 whenever a non-self neighbour exists
-        ridx[row * k + 0] = m, rw[row * k + 0] = -1.f;
-        ridx[row * k + 1] = n, rw[row * k + 1] = +1.f;
-    }
-    rb[row * 3 + 0] = rb[row * 3 + 1] = rb[row * 3 + 2] = 0.f;
-}
-
-// data rows: b = live - canonical (energy.t:55)
-__global__ __launch_bounds__(256) void build_data_rhs_kernel(const float* __restrict__ canon,
-                                                             const float* __restrict__ live, int N,
-                                                             float* __restrict__ rb) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 3 * N) rb[i] = live[i] - canon[i];
-}
-
-// ------------------------------------------------------------------------------------------
 // transpose graph node -> (row, slot).  A counting sort of the R*k slot entries by node id with
 // workgroup-private histograms in LDS: TG_BLOCKS workgroups each own a contiguous chunk of the
 // entries, count into LDS (no global atomics: 1 M device-scope atomics on 2 k counters were
-// the whole cost of the first version), publish their histogram, a single workgroup turns the
-// [block][node] table into node offsets + per-block bases, and the fill pass replays the
-// chunk with an LDS cursor per node.  Deterministic up to the order inside one chunk.
+// the whole cost of the first version), publish their histogram, a thread per node turns the
+// [block][node] table into per-block bases + node totals, and the fill pass (which scans the totals
+// itself) replays the chunk with an LDS cursor per node.  Deterministic up to the order inside one chunk.
 
 constexpr int TG_BLOCKS = SOLVE_TG_BLOCKS;
 
@@ -93,20 +64,39 @@ __global__ __launch_bounds__(1024) void tg_count_kernel(const int32_t* __restric
     for (int i = threadIdx.x; i < D; i += blockDim.x) blk_hist[(size_t)blockIdx.x * D + i] = hist[i];
 }
 
-// one workgroup: node totals -> exclusive scan -> node_ptr; blk_hist becomes per-block bases
-__global__ __launch_bounds__(1024) void tg_scan_kernel(int32_t* __restrict__ blk_hist, int D,
-                                                       int32_t* __restrict__ node_ptr) {
+// per node (one thread each): exclusive prefix over the TG_BLOCKS workgroup counts -> per-block bases RELATIVE to the
+// node's segment, and the node's total in row TG_BLOCKS of the table.  (Round 1 did this and the scan of the totals in
+// one 1024-thread workgroup: two passes of 64 dependent loads per thread, 19 us at C2; now 64 independent loads.)
+__global__ __launch_bounds__(256) void tg_colscan_kernel(int32_t* __restrict__ blk_hist /* [TG_BLOCKS + 1][D] */, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    int h[TG_BLOCKS];
+#pragma unroll
+    for (int b = 0; b < TG_BLOCKS; ++b) h[b] = blk_hist[(size_t)b * D + i];
+    int run = 0;
+#pragma unroll
+    for (int b = 0; b < TG_BLOCKS; ++b) {
+        blk_hist[(size_t)b * D + i] = run;
+        run += h[b];
+    }
+    blk_hist[(size_t)TG_BLOCKS * D + i] = run;
+}
+
+// Every fill workgroup scans the D node totals itself (LDS, a few microseconds) instead of waiting for a scan launch;
+// workgroup 0 publishes node_ptr.
+__global__ __launch_bounds__(1024) void tg_fill_kernel(const int32_t* __restrict__ ridx, size_t total, int D,
+                                                       const int32_t* __restrict__ blk_base /* [TG_BLOCKS + 1][D] */,
+                                                       int32_t* __restrict__ node_ptr, uint32_t* __restrict__ node_list) {
+    extern __shared__ int32_t cursor[];
     __shared__ int32_t wave_tot[16];
-    __shared__ int32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
+    __shared__ int32_t carry_sh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_sh = 0;
+    __syncthreads();
     for (int base = 0; base < D; base += 1024) {
         const int i = base + threadIdx.x;
-        int v       = 0;
-        if (i < D)
-            for (int b = 0; b < TG_BLOCKS; ++b) v += blk_hist[(size_t)b * D + i];
-        int incl = v;
+        const int v = i < D ? blk_base[(size_t)TG_BLOCKS * D + i] : 0;
+        int incl    = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int t = __shfl_up(incl, o, 64);
@@ -114,31 +104,17 @@ __global__ __launch_bounds__(1024) void tg_scan_kernel(int32_t* __restrict__ blk
         }
         if (lane == 63) wave_tot[wave] = incl;
         __syncthreads();
-        int wave_off = 0;
-        for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
-        const int c = carry;
+        int off = carry_sh + incl - v;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
         if (i < D) {
-            int run     = c + wave_off + incl - v;
-            node_ptr[i] = run;
-            for (int b = 0; b < TG_BLOCKS; ++b) {
-                const int h                = blk_hist[(size_t)b * D + i];
-                blk_hist[(size_t)b * D + i] = run;
-                run += h;
-            }
+            cursor[i] = off + blk_base[(size_t)blockIdx.x * D + i];
+            if (blockIdx.x == 0) node_ptr[i] = off;
         }
         __syncthreads();
-        if (threadIdx.x == 1023) carry = c + wave_off + incl;
+        if (threadIdx.x == 1023) carry_sh = off + v;
         __syncthreads();
     }
-    if (threadIdx.x == 0) node_ptr[D] = carry;
-}
-
-__global__ __launch_bounds__(1024) void tg_fill_kernel(const int32_t* __restrict__ ridx, size_t total, int D,
-                                                       const int32_t* __restrict__ blk_base,
-                                                       uint32_t* __restrict__ node_list) {
-    extern __shared__ int32_t cursor[];
-    for (int i = threadIdx.x; i < D; i += blockDim.x) cursor[i] = blk_base[(size_t)blockIdx.x * D + i];
-    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) node_ptr[D] = carry_sh;
     const size_t chunk = (total + TG_BLOCKS - 1) / TG_BLOCKS;
     const size_t beg = chunk * blockIdx.x, end = min(beg + chunk, total);
     for (size_t e = beg + threadIdx.x; e < end; e += blockDim.x) {
@@ -315,30 +291,51 @@ __global__ __launch_bounds__(256) void huber_kernel(SolveView s, float psi_reg) 
     s.huber[i] = h;
 }
 
-// head of the packed row records: k node ids + k weights (constant over a frame)
+// The per-problem row set-up as ONE launch, a thread per row: regularisation rows (opt_solver.cpp:74-105), right-hand
+// sides of the data rows (energy.t:55), packed record heads and the zeroing of the
+// unknowns / state block / tickets (reset_kernel) — four launches of 5-16 us each at C2 in round 1.
 template <int K>
-__global__ __launch_bounds__(256) void pack_records_kernel(SolveView s) {
+__global__ __launch_bounds__(256) void prepare_rows_kernel(SolveView s, SolveState* __restrict__ st,
+                                                           unsigned int* __restrict__ ticket, int nticket) {
     const size_t R = (size_t)s.N + (size_t)s.D * s.k;
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < (size_t)3 * s.D) s.t[r] = 0.f;
+    if (blockIdx.x == 0) {
+        unsigned int* w = (unsigned int*)st;
+        for (int j = threadIdx.x; j < (int)(sizeof(SolveState) / 4); j += blockDim.x) w[j] = 0u;
+        for (int j = threadIdx.x; j < nticket; j += blockDim.x) ticket[j] = 0u;
+    }
     if (r >= R) return;
-    float* rec = s.re + r * (size_t)solve_rec_words(s.k);
-    if (solve_rec_ids16(s.k)) {  // k / 2 words of 16-bit ids (0xffff = empty slot), then k weights
-        uint16_t* ids = reinterpret_cast<uint16_t*>(rec);
+    const int k = s.k;
+    int ids[K];
+    float ws[K];
+    if (r < (size_t)s.N) {  // data row: k-NN + RBF weights already in ridx / rw; b = live - canonical (energy.t:55)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s.rb[3 * r + c] = s.live[3 * r + c] - s.canon[3 * r + c];
 #pragma unroll
         for (int j = 0; j < K; ++j)
-            if (j < s.k) {
-                const int n         = s.ridx[r * s.k + j];
-                ids[j]              = n < 0 ? (uint16_t)0xffffu : (uint16_t)n;
-                rec[s.k / 2 + j]    = s.rw[r * s.k + j];
-            }
+            if (j < k) ids[j] = s.ridx[r * k + j], ws[j] = s.rw[r * k + j];
+    } else {  // regularisation row N + n k + i <- {reg_idx[n][i]: -1, n: +1} (opt_solver.cpp:74-105, energy.t:75-78)
+        const int e = (int)(r - (size_t)s.N), n = e / k, m = s.reg_idx[e];
+#pragma unroll
+        for (int j = 0; j < K; ++j) ids[j] = -1, ws[j] = 0.f;
+        if (m >= 0 && m != n) ids[0] = m, ws[0] = -1.f, ids[1] = n, ws[1] = +1.f;  // k >= 2 whenever a non-self neighbour exists
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (j < k) s.ridx[r * k + j] = ids[j], s.rw[r * k + j] = ws[j];
+        s.rb[3 * r + 0] = s.rb[3 * r + 1] = s.rb[3 * r + 2] = 0.f;
+    }
+    float* rec = s.re + r * (size_t)solve_rec_words(k);
+    if (solve_rec_ids16(k)) {  // k / 2 words of 16-bit ids (0xffff = empty slot), then k weights
+        uint16_t* h = reinterpret_cast<uint16_t*>(rec);
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (j < k) h[j] = ids[j] < 0 ? (uint16_t)0xffffu : (uint16_t)ids[j], rec[k / 2 + j] = ws[j];
         return;
     }
 #pragma unroll
     for (int j = 0; j < K; ++j)
-        if (j < s.k) {
-            rec[j]       = __int_as_float(s.ridx[r * s.k + j]);
-            rec[s.k + j] = s.rw[r * s.k + j];
-        }
+        if (j < k) rec[j] = __int_as_float(ids[j]), rec[k + j] = ws[j];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -350,7 +347,7 @@ __global__ __launch_bounds__(256) void pack_records_kernel(SolveView s) {
 constexpr int HASH      = 512;
 constexpr int HASH_MASK = HASH - 1;
 
-// one row record = solve_rec_words(k) consecutive words (head: pack_records_kernel, tail: linearise_kernel)
+// one row record = solve_rec_words(k) consecutive words (head: prepare_rows_kernel, tail: linearise_kernel)
 template <int K>
 __device__ __forceinline__ float4 load_record(const SolveView& s, size_t r, int (&idx)[K], float (&w)[K]) {
     const float* rec = s.re + r * (size_t)solve_rec_words(s.k);
@@ -1241,23 +1238,20 @@ hipError_t solve_transpose_graph(const int32_t* ridx, size_t total, int D, int32
                                  uint32_t* node_list, hipStream_t st) {
     const size_t lds = sizeof(int32_t) * (size_t)D;
     tg_count_kernel<<<TG_BLOCKS, 1024, lds, st>>>(ridx, total, D, blk_hist);
-    tg_scan_kernel<<<1, 1024, 0, st>>>(blk_hist, D, node_ptr);
-    tg_fill_kernel<<<TG_BLOCKS, 1024, lds, st>>>(ridx, total, D, blk_hist, node_list);
+    tg_colscan_kernel<<<(D + 255) / 256, 256, 0, st>>>(blk_hist, D);
+    tg_fill_kernel<<<TG_BLOCKS, 1024, lds, st>>>(ridx, total, D, blk_hist, node_ptr, node_list);
     return hipGetLastError();
 }
 
-hipError_t solve_build_graph(const SolveView& s, hipStream_t st) {
+hipError_t solve_build_graph(const SolveView& s, SolveState* state, unsigned int* ticket, int nticket, hipStream_t st) {
     const int D = s.D, N = s.N, k = s.k;
     const size_t R = (size_t)N + (size_t)D * k, total = R * k;
-    hipError_t e;
-    build_reg_rows_kernel<<<(D * k + 255) / 256, 256, 0, st>>>(s.reg_idx, D, k, N, s.ridx, s.rw, s.rb);
-    if (N > 0) build_data_rhs_kernel<<<(3 * N + 255) / 256, 256, 0, st>>>(s.canon, s.live, N, s.rb);
-    (void)e;
+    const size_t threads = R > (size_t)3 * D ? R : (size_t)3 * D;
+    KDISPATCH(prepare_rows_kernel, k, <<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(s, state, ticket, nticket));
     const size_t lds = sizeof(int32_t) * (size_t)D;
     tg_count_kernel<<<TG_BLOCKS, 1024, lds, st>>>(s.ridx, total, D, s.blk_hist);
-    tg_scan_kernel<<<1, 1024, 0, st>>>(s.blk_hist, D, s.node_ptr);
-    tg_fill_kernel<<<TG_BLOCKS, 1024, lds, st>>>(s.ridx, total, D, s.blk_hist, s.node_list);
-    KDISPATCH(pack_records_kernel, k, <<<(unsigned)((R + 255) / 256), 256, 0, st>>>(s));
+    tg_colscan_kernel<<<(D + 255) / 256, 256, 0, st>>>(s.blk_hist, D);
+    tg_fill_kernel<<<TG_BLOCKS, 1024, lds, st>>>(s.ridx, total, D, s.blk_hist, s.node_ptr, s.node_list);
     return hipGetLastError();
 }
 

@@ -57,7 +57,7 @@ struct SolveView {
     float* re;      // R x solve_rec_words(k) packed row records: k node ids, k weights, e = b - sum w t, tau
     int32_t* reg_idx;  // D x k
     // transpose graph
-    int32_t* blk_hist;    // TG_BLOCKS x D  workgroup-private histograms / bases of the counting sort
+    int32_t* blk_hist;    // (TG_BLOCKS + 1) x D  workgroup-private histograms / bases of the counting sort, node totals
     int32_t* node_ptr;    // D + 1
     uint32_t* node_list;  // R x k   flat (row*k + slot) indices grouped by node
     // normal equations, ELL slot-major: entry q of row a at [q*D + a] as ONE 8-byte word (value, column as int bits) —
@@ -80,8 +80,10 @@ struct SolveView {
 };
 
 constexpr int SOLVE_TG_BLOCKS = 64;
-hipError_t solve_build_graph(const SolveView& s, hipStream_t st);
-// counting-sort transposition of an (rows x k) node-index array: blk_hist = SOLVE_TG_BLOCKS x D scratch,
+// rows (regularisation rows, right-hand sides, packed record heads), reset of the unknowns / state / tickets, and the
+// node -> rows transposition of the problem in `s`
+hipError_t solve_build_graph(const SolveView& s, SolveState* state, unsigned int* ticket, int nticket, hipStream_t st);
+// counting-sort transposition of an (rows x k) node-index array: blk_hist = (SOLVE_TG_BLOCKS + 1) x D scratch,
 // node_ptr = D + 1, node_list = flat (row * k + slot) indices grouped by node (entries < 0 skipped)
 hipError_t solve_transpose_graph(const int32_t* ridx, size_t total, int D, int32_t* blk_hist, int32_t* node_ptr,
                                  uint32_t* node_list, hipStream_t st);

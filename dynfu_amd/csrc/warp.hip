@@ -187,6 +187,102 @@ __global__ __launch_bounds__(256) void grid_fill_kernel(const float* __restrict_
                                  __int_as_float(i));
 }
 
+// The same grid for a deformation-node set (D <= GRID_ONE_MAX nodes) built by ONE workgroup: bounding box, geometry,
+// cell histogram, exclusive scan and the counting-sort fill all in LDS (the 32^3 counters are 128 KiB) — one launch of
+// ~8 us instead of four (setup 6 + count 5 + scan 13 + fill 5 us and three kernel boundaries at C2, twice per frame in
+// the pipelined schedule).  Same desc / cell_start / sorted as the four-kernel path (order inside a cell is that of the
+// atomics in both: the searches order candidates by (distance, index) themselves).
+constexpr int GRID_ONE_MAX = 8192;
+__global__ __launch_bounds__(1024) void grid_build_one_kernel(const float* __restrict__ node_pos, int D,
+                                                              KnnGridDesc* __restrict__ desc,
+                                                              int32_t* __restrict__ cell_start,
+                                                              float4* __restrict__ sorted) {
+    extern __shared__ int32_t cnt[];  // KNN_GRID_MAX_CELLS counters, then cursors
+    __shared__ float smin[3][16], smax[3][16];
+    __shared__ int32_t wave_tot[16];
+    __shared__ KnnGridDesc gsh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int i = tid; i < D; i += 1024)
+        for (int c = 0; c < 3; ++c) {
+            const float v = node_pos[3 * (size_t)i + c];
+            mn[c] = fminf(mn[c], v), mx[c] = fmaxf(mx[c], v);
+        }
+    for (int c = 0; c < 3; ++c) {
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o, 64));
+            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o, 64));
+        }
+        if (lane == 0) smin[c][wave] = mn[c], smax[c][wave] = mx[c];
+    }
+    for (int i = tid; i < KNN_GRID_MAX_CELLS; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    if (tid == 0) {  // geometry: the arithmetic of grid_setup_kernel
+        float ext[3];
+        for (int c = 0; c < 3; ++c) {
+            float a = smin[c][0], b = smax[c][0];
+            for (int w = 1; w < 16; ++w) a = fminf(a, smin[c][w]), b = fmaxf(b, smax[c][w]);
+            gsh.bmin[c] = a;
+            ext[c]      = fmaxf(b - a, 0.f);
+        }
+        const float emax = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
+        float cs = cbrtf((ext[0] * ext[1] * ext[2]) / (float)D);
+        cs       = fmaxf(cs, emax / (float)KNN_GRID_MAX_DIM);
+        if (!(cs > 0.f)) cs = 1.f;
+        gsh.cs     = cs;
+        gsh.inv_cs = 1.f / cs;
+        for (int c = 0; c < 3; ++c) {
+            const int n = (int)(ext[c] * gsh.inv_cs) + 1;
+            gsh.dim[c]  = min(max(n, 1), KNN_GRID_MAX_DIM);
+        }
+        *desc = gsh;
+    }
+    __syncthreads();
+    const KnnGridDesc g = gsh;
+    for (int i = tid; i < D; i += 1024) {
+        int cx, cy, cz;
+        cell_of(g, mk3(node_pos[3 * (size_t)i], node_pos[3 * (size_t)i + 1], node_pos[3 * (size_t)i + 2]), cx, cy, cz);
+        atomicAdd(&cnt[cx + g.dim[0] * (cy + g.dim[1] * cz)], 1);
+    }
+    __syncthreads();
+    // exclusive scan in cell order: wave w owns cells [2048 w, 2048 (w + 1)), 64 consecutive cells per step (conflict-free)
+    constexpr int PER_WAVE = KNN_GRID_MAX_CELLS / 16, STEPS = PER_WAVE / 64;
+    int carry = 0;
+#pragma unroll 4
+    for (int j = 0; j < STEPS; ++j) {
+        const int idx = wave * PER_WAVE + j * 64 + lane;
+        const int v   = cnt[idx];
+        int incl      = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        cnt[idx] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) wave_tot[wave] = carry;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    for (int j = 0; j < STEPS; ++j) {
+        const int idx   = wave * PER_WAVE + j * 64 + lane;
+        const int start = cnt[idx] + off;
+        cnt[idx]        = start;  // cursor of the fill
+        cell_start[idx] = start;
+    }
+    if (tid == 1023) cell_start[KNN_GRID_MAX_CELLS] = off + carry;
+    __syncthreads();
+    for (int i = tid; i < D; i += 1024) {
+        const float px = node_pos[3 * (size_t)i], py = node_pos[3 * (size_t)i + 1], pz = node_pos[3 * (size_t)i + 2];
+        int cx, cy, cz;
+        cell_of(g, mk3(px, py, pz), cx, cy, cz);
+        const int slot = atomicAdd(&cnt[cx + g.dim[0] * (cy + g.dim[1] * cz)], 1);
+        sorted[slot]   = make_float4(px, py, pz, __int_as_float(i));
+    }
+}
+
 // ---- large point sets (the canonical cloud of dfa_correspond): up to 128^3 cells ----------------
 // Same data structure, built by multi-workgroup kernels: bounding box by per-block partials, the
 // exclusive scan of the cell counts in chunks of PGRID_CHUNK cells (chunk sums, then a scan kernel
@@ -635,6 +731,18 @@ hipError_t point_grid_build(const PointGridView& pg, const float* pts, int n, hi
 }
 
 hipError_t knn_grid_build(const KnnGridView& g, const float* node_pos, int D, hipStream_t s) {
+    static const bool four = getenv("DFA_GRID_FOUR_KERNELS") != nullptr;  // A/B: the four-kernel build
+    if (D <= GRID_ONE_MAX && !four) {
+        constexpr size_t lds = sizeof(int32_t) * KNN_GRID_MAX_CELLS;
+        static bool big_lds = false;  // 128 KiB of dynamic LDS needs the opt-in, once per process
+        if (!big_lds) {
+            hipError_t e = hipFuncSetAttribute((const void*)grid_build_one_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            big_lds = true;
+        }
+        grid_build_one_kernel<<<1, 1024, lds, s>>>(node_pos, D, g.desc, g.cell_start, g.sorted);
+        return hipGetLastError();
+    }
     grid_setup_kernel<<<1, 1024, 0, s>>>(node_pos, D, g.desc, g.cell_count);
     grid_count_kernel<<<(D + 255) / 256, 256, 0, s>>>(node_pos, D, g.desc, g.cell_count, g.node_cell);
     grid_scan_kernel<<<1, 1024, 0, s>>>(g.cell_count, g.cell_start);
