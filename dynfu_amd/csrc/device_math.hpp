@@ -79,6 +79,22 @@ __device__ __forceinline__ float wave_total(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// inclusive prefix sum over the 64 lanes, integers: the same six DPP steps (no LDS crossbar: a __shfl_up chain costs
+// ~60 clocks per step, a DPP add ~8)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_addi(int v) {
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    v = dpp_addi<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_addi<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_addi<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_addi<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_addi<0x142, 0xa>(v);  // row_bcast:15 -> rows 1 and 3
+    v = dpp_addi<0x143, 0xc>(v);  // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
 // 64-lane wave reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -96,12 +96,7 @@ __global__ __launch_bounds__(1024) void tg_fill_kernel(const int32_t* __restrict
     for (int base = 0; base < D; base += 1024) {
         const int i = base + threadIdx.x;
         const int v = i < D ? blk_base[(size_t)TG_BLOCKS * D + i] : 0;
-        int incl    = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
+        const int incl = wave_inclusive_scan(v);
         if (lane == 63) wave_tot[wave] = incl;
         __syncthreads();
         int off = carry_sh + incl - v;

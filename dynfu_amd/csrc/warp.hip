@@ -216,7 +216,6 @@ __global__ __launch_bounds__(1024) void grid_build_one_kernel(const float* __res
         }
         if (lane == 0) smin[c][wave] = mn[c], smax[c][wave] = mx[c];
     }
-    for (int i = tid; i < KNN_GRID_MAX_CELLS; i += 1024) cnt[i] = 0;
     __syncthreads();
     if (tid == 0) {  // geometry: the arithmetic of grid_setup_kernel
         float ext[3];
@@ -240,39 +239,38 @@ __global__ __launch_bounds__(1024) void grid_build_one_kernel(const float* __res
     }
     __syncthreads();
     const KnnGridDesc g = gsh;
+    // only the cells of this grid are cleared, scanned and published (the searches never index beyond dim x dim x dim):
+    // wave w owns PER consecutive cells, 64 per step
+    const int ncells = g.dim[0] * g.dim[1] * g.dim[2];
+    const int PER    = ((ncells + 16 * 64 - 1) / (16 * 64)) * 64;  // <= KNN_GRID_MAX_CELLS / 16
+    for (int j = 0; j < PER; j += 64) cnt[wave * PER + j + lane] = 0;
+    __syncthreads();
     for (int i = tid; i < D; i += 1024) {
         int cx, cy, cz;
         cell_of(g, mk3(node_pos[3 * (size_t)i], node_pos[3 * (size_t)i + 1], node_pos[3 * (size_t)i + 2]), cx, cy, cz);
         atomicAdd(&cnt[cx + g.dim[0] * (cy + g.dim[1] * cz)], 1);
     }
     __syncthreads();
-    // exclusive scan in cell order: wave w owns cells [2048 w, 2048 (w + 1)), 64 consecutive cells per step (conflict-free)
-    constexpr int PER_WAVE = KNN_GRID_MAX_CELLS / 16, STEPS = PER_WAVE / 64;
+    // exclusive scan in cell order
     int carry = 0;
-#pragma unroll 4
-    for (int j = 0; j < STEPS; ++j) {
-        const int idx = wave * PER_WAVE + j * 64 + lane;
-        const int v   = cnt[idx];
-        int incl      = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
-        cnt[idx] = carry + incl - v;
-        carry += __shfl(incl, 63, 64);
+    for (int j = 0; j < PER; j += 64) {
+        const int idx  = wave * PER + j + lane;
+        const int v    = cnt[idx];
+        const int incl = wave_inclusive_scan(v);
+        cnt[idx]       = carry + incl - v;
+        carry += __builtin_amdgcn_readlane(incl, 63);
     }
     if (lane == 0) wave_tot[wave] = carry;
     __syncthreads();
     int off = 0;
     for (int w = 0; w < wave; ++w) off += wave_tot[w];
-    for (int j = 0; j < STEPS; ++j) {
-        const int idx   = wave * PER_WAVE + j * 64 + lane;
+    for (int j = 0; j < PER; j += 64) {
+        const int idx   = wave * PER + j + lane;
         const int start = cnt[idx] + off;
         cnt[idx]        = start;  // cursor of the fill
-        cell_start[idx] = start;
+        if (idx <= ncells) cell_start[idx] = start;
     }
-    if (tid == 1023) cell_start[KNN_GRID_MAX_CELLS] = off + carry;
+    if (tid == 1023 && 16 * PER <= ncells) cell_start[ncells] = off + carry;  // (16 PER == ncells: the end marker)
     __syncthreads();
     for (int i = tid; i < D; i += 1024) {
         const float px = node_pos[3 * (size_t)i], py = node_pos[3 * (size_t)i + 1], pz = node_pos[3 * (size_t)i + 2];
