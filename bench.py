@@ -37,9 +37,9 @@ PMC_TRAFFIC_BYTES = {# profiles/r02_pmc_tsdf.md: integrate_runs_kernel<true,32,8
                      ("C2", "fused_integrate"): 0.5417e9, ("C3", "fused_integrate"): 0.5417e9, ("C4", "fused_integrate"): 4.344e9,
                      # profiles/r01_pmc_northstar.md (FETCH x2 + WRITE per dispatch)
                      ("C3", "s6_assemble"): 0.510e9, ("C3", "s6_pcg_step"): 0.0242e9,
-                     # profiles/r01_pmc_solve.md: (338.8 + 274.9) KiB per pcg_paired_kernel<1024,1,32,1> launch, mean over
+                     # profiles/r02_pmc_solve.md: (340.8 + 276.1) KiB per pcg_paired_kernel<1024,1,32,1> launch, mean over
                      # the five launches of a frame (those that return at entry included)
-                     ("C2", "pcg"): 613.7 * 1024}
+                     ("C2", "pcg"): 616.9 * 1024}
 
 
 def parse():
@@ -550,7 +550,7 @@ def main():
                              else "pcg_mb_* (many-workgroup Jacobi PCG)"), bound="hbm",
                      achieved=round(pcg_gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(pcg_gbs / HBM_PEAK_GBS, 6),
                      traffic=PMC_TRAFFIC_BYTES.get((args.config, "pcg")),
-                     traffic_source="profiles/r01_pmc_solve.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes): "
+                     traffic_source="profiles/r02_pmc_solve.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes): "
                                     "per launch; every workgroup reads the matrix once and keeps it in registers",
                      algorithmic_bytes_per_launch=round(pcg_bytes / max(1e-9, launches_pf), 1),
                      avg_launch_ms=round(pcg_total_ms / max(1e-9, launches_pf), 4),
