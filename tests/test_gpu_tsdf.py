@@ -230,6 +230,43 @@ print("CHK", int(s.sum()), int((s * torch.arange(1, s.shape[1] + 1, device="cuda
     assert int(outs[0].split()[3]) > 0.02 * cfg["dim"] ** 3
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_integrate_random_small_configurations(A, seed):
+    """Randomised sweep over what the run classification depends on: volume dims (1 .. 70 per axis, tails shorter than a
+    run, partial waves), anisotropic voxels, image sizes from 1x1 to partial tiles, focal lengths (a run spanning from a
+    fraction of a pixel to many tiles), poses (camera in front of, inside and behind the volume; any rotation),
+    truncation distances, weights, and depth images with invalid / special pixels.  Fused and accumulating sweeps
+    against the oracle, bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    X, Y, Z = (int(v) for v in rng.integers(1, 71, 3))
+    rows, cols = (int(v) for v in rng.choice([1, 2, 7, 8, 9, 31, 64, 97], 2))
+    focal = float(rng.choice([3.0, 20.0, 80.0, 400.0]))
+    intr = (focal, focal * float(rng.uniform(0.8, 1.2)), cols / 2 - 0.5 + float(rng.uniform(-3, 3)), rows / 2 - 0.5)
+    voxel = rng.uniform(0.01, 0.08, 3).astype(np.float32)
+    trunc = float(rng.uniform(0.03, 0.4))
+    maxw = int(rng.choice([0, 1, 2, 64, 65535]))
+    depth = rng.uniform(300, 4000, (rows, cols)).astype(np.uint16)
+    depth[rng.random(depth.shape) < 0.25] = 0
+    dists = O.compute_dists(depth, *intr)
+    specials = np.array([0x8000, 0xC000, 0x7E00, 0x7C00, 0x0001, 0x03FF], np.uint16)
+    mask = rng.random(dists.shape) < 0.08
+    dists[mask] = specials[rng.integers(0, len(specials), int(mask.sum()))]
+    R = rot(rng.normal(size=3), float(rng.uniform(0, np.pi)))
+    centre = 0.5 * voxel * np.array([X, Y, Z], np.float32)
+    where = rng.choice(["front", "inside", "behind", "far"])
+    offset = {"front": [0.1, -0.1, 1.5], "inside": [0.0, 0.05, 0.1], "behind": [0.0, 0.0, -2.0], "far": [9.0, -7.0, 30.0]}[where]
+    vol2cam = aff12(R, np.array(offset, np.float32) - (R @ centre).astype(np.float32))
+    vol = np.zeros((Z, Y, X), np.uint32)
+    got, ref, _ = _integrate_both(A, vol, dists, voxel, trunc, maxw, vol2cam, intr, fused=True)
+    assert np.array_equal(got, ref), (seed, where, int((got != ref).sum()))
+    junk = rng.integers(0, 2 ** 32, (Z, Y, X), dtype=np.uint64).astype(np.uint32)
+    junk = (junk & 0x003FFFFF) | 0x3000
+    for _ in range(2):
+        got, ref, _ = _integrate_both(A, junk, dists, voxel, trunc, maxw, vol2cam, intr)
+        assert np.array_equal(got, ref), (seed, where, int((got != ref).sum()))
+        junk = ref
+
+
 @pytest.mark.parametrize("zchunk", ["4", "7", "20", "1000"])
 def test_integrate_independent_of_z_chunking(A, zchunk, monkeypatch):
     # the kernel replays the running `vc += zstep` additions for chunks that start at z0 > 0
