@@ -72,7 +72,7 @@ def build(force=False, verbose=False):
 HOST = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(HERE, "libdynfu_amd_host.so")
 HOST_SOURCES = ["device.cpp", "tsdf_volume.cpp", "warp_field.cpp", "opt_solver.cpp", "dyn_fusion.cpp",
-                "marching_cubes.cpp", "imgproc.cpp", "projective_icp.cpp"]
+                "marching_cubes.cpp", "imgproc.cpp", "projective_icp.cpp", "io.cpp"]
 
 
 def build_host(force=False, verbose=False):
@@ -87,7 +87,7 @@ def build_host(force=False, verbose=False):
         deps += [os.path.join(root, f) for f in files]
     if force or _stale(HOST_LIB, deps):
         cmd = [hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + inc] + srcs + \
-              ["-L" + HERE, "-ldynfu_amd", "-Wl,-rpath,$ORIGIN", "-o", HOST_LIB]
+              ["-L" + HERE, "-ldynfu_amd", "-lz", "-Wl,-rpath,$ORIGIN", "-o", HOST_LIB]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -108,7 +108,7 @@ def build_cpp_tests(force=False, verbose=False):
     built = {}
     for name, needs in (("test_host_dq", []), ("test_host_solver", ["host"]), ("test_host_tsdf", ["host", "oracle"]),
                         ("test_host_dynfusion", ["host", "oracle"]), ("test_host_icp", ["host"]),
-                        ("test_tsdf_classify", ["oracle", "ieee"])):
+                        ("test_tsdf_classify", ["oracle", "ieee"]), ("test_host_io", ["host"])):
         src = os.path.join(tdir, name + ".cpp")
         exe = os.path.join(out, name)
         deps = [src, os.path.join(tdir, "minitest.hpp"), host, os.path.join(CSRC, "tsdf_classify.hpp")]
@@ -116,6 +116,8 @@ def build_cpp_tests(force=False, verbose=False):
             cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-I" + inc, src, "-o", exe]
             if "ieee" in needs:  # CPU model of a kernel: same arithmetic contract as the oracle, hardware fma
                 cmd[1:2] = ["-O2", "-march=x86-64-v3", "-ffp-contract=off"]
+            if name == "test_host_io":  # its `sequence` mode drives DynFusion (GPU); the test cases themselves are CPU-only
+                cmd.insert(1, "-DDFA_WITH_DYNFUSION")
             if "host" in needs:
                 cmd += ["-L" + HERE, "-ldynfu_amd_host", "-ldynfu_amd", "-Wl,-rpath," + HERE,
                         "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]

@@ -11,6 +11,7 @@
 #pragma once
 #include <memory>
 
+#include <dfa_host/io.hpp>
 #include <dynfu/utils/frame.hpp>
 #include <dynfu/utils/opt_solver.hpp>
 #include <dynfu/warp_field.hpp>
@@ -69,6 +70,8 @@ public:
     void useMarchingCubes(std::shared_ptr<kfusion::cuda::MarchingCubes> mc) { mc_ = mc; }
     kfusion::cuda::TsdfVolume& tsdf();
     std::shared_ptr<dynfu::Frame> getLiveFrame() { return liveFrame; }
+    // KinFu::getMesh (kinfu.cpp:262): the marching-cubes triangles of the last frame, KinFu::convertToMesh's layout
+    std::shared_ptr<dfa::PolygonMesh> getMesh() { return mesh_; }
     int frameCounter() const { return frame_counter_; }
 
     void init(dfa::PointCloud<dfa::PointXYZ>& canonicalVertices, dfa::PointCloud<dfa::Normal>& canonicalNormals);
@@ -102,7 +105,19 @@ private:
     kfusion::cuda::Depth depth_filtered_;
     std::shared_ptr<kfusion::cuda::TsdfVolume> volume_;
     std::shared_ptr<kfusion::cuda::MarchingCubes> mc_;
+    std::shared_ptr<dfa::PolygonMesh> mesh_;
     int frame_counter_ = 0;
     // vertices of the volume's zero level set as a point cloud (dyn_fusion.cpp:73-88 / :119-134)
     void extractSurface(dfa::PointCloud<dfa::PointXYZ>& vertices, dfa::PointCloud<dfa::Normal>& normals);
 };
+
+// DynFuApp::execute of the reference's demo (src/apps/demo.cpp:68-124) without its windows and command line: every
+// depth PNG of <dir>/depth in lexicographic order is uploaded and handed to DynFusion::operator(); whenever that
+// returns true, <dir>/out/pcl_canonical_to_live<i>.pcd and <dir>/out/<i>_tsdf_mesh.vtk are written (demo.cpp:21-37).
+// <dir>/color must exist and hold at least as many files (the demo reads them for display only; they are not decoded
+// here).  max_frames < 0: all.
+struct SequenceReport {
+    int frames = 0, saved = 0;
+    double dynfu_ms = 0;  // time inside DynFusion::operator() (the demo's SampledScopeTime)
+};
+SequenceReport runSequence(DynFusion& dynfu, const std::string& dir, int max_frames = -1);

@@ -2,6 +2,10 @@
 // (reference: src/dynfu/dyn_fusion.cpp:6-31,147-242).
 #include <dynfu/dyn_fusion.hpp>
 
+#include <algorithm>
+#include <chrono>
+#include <filesystem>
+
 #include <dfa_host/device.hpp>
 
 #include "../../../include/dynfu_amd.h"
@@ -140,6 +144,7 @@ void DynFusion::extractSurface(dfa::PointCloud<dfa::PointXYZ>& vertices, dfa::Po
     std::vector<kfusion::cuda::MarchingCubes::PointType> host;
     if (!triangles.empty()) triangles.download(host);
     for (auto& p : host) vertices.push_back(dfa::PointXYZ(p.x, p.y, p.z));
+    mesh_ = std::make_shared<dfa::PolygonMesh>(dfa::convertToMesh(vertices.points));  // :76 / :122
     if (dynfuParams.mesh_normals && !host.empty()) {  // extension: gradient of the TSDF at the vertices
         dfa::DeviceArray<dfa::Normal> dn;
         mc_->computeNormals(tsdf(), triangles, dn);
@@ -174,4 +179,30 @@ bool DynFusion::operator()(const kfusion::cuda::Depth& depth) {
     warpCanonicalToLiveOpt(camera);                   // :140
     warpfield->update(getCanonicalWarpedToLive());    // :142
     return ++frame_counter_, true;
+}
+
+SequenceReport runSequence(DynFusion& dynfu, const std::string& dir, int max_frames) {
+    const dfa::io::SequenceFiles files = dfa::io::listSequence(dir);  // demo.cpp:39-55
+    if (files.images.size() < files.depths.size())
+        throw dfa::Error(1, "fewer colour images than depth frames in " + dir);  // the demo indexes images[i]
+    const std::string out = dir + "/out";                                      // demo.cpp:58-66
+    std::filesystem::create_directory(out);
+    SequenceReport rep;
+    kfusion::cuda::Depth depth_device;
+    const size_t n = max_frames < 0 ? files.depths.size() : std::min(files.depths.size(), (size_t)max_frames);
+    for (size_t i = 0; i < n; ++i) {
+        const dfa::io::DepthImage depth = dfa::io::readDepthPng(files.depths[i]);  // demo.cpp:81
+        depth_device.upload(depth.data.data(), (size_t)depth.cols * sizeof(uint16_t), depth.rows, depth.cols);  // :90
+        const auto t0        = std::chrono::steady_clock::now();
+        const bool has_image = dynfu(depth_device);  // :94
+        rep.dynfu_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        ++rep.frames;
+        if (has_image) {  // :115-118
+            dfa::io::savePCDFileASCII(out + "/pcl_canonical_to_live" + std::to_string(i) + ".pcd",
+                                      dynfu.getCanonicalWarpedToLive()->getVertices());
+            dfa::io::saveVTKFile(out + "/" + std::to_string(i) + "_tsdf_mesh.vtk", *dynfu.getMesh());
+            ++rep.saved;
+        }
+    }
+    return rep;
 }
