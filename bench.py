@@ -137,7 +137,10 @@ class Sequence:
             self.fuse(f, timed_events)
             self.solve(f)
             return
-        if getattr(self, "pipelined", False) or getattr(self, "fuse_first", False):
+        if getattr(self, "pipelined", False) and self.D <= 2048:
+            # fuse(f) in the shadow of the first PCG of frame f, graph build of frame f + 1 in the shadow of the second
+            self.solve_pipelined(f, timed_events, shadows=True)
+        elif getattr(self, "pipelined", False) or getattr(self, "fuse_first", False):
             self.s_fuse.wait_stream(cur)
             with torch.cuda.stream(self.s_fuse):
                 self.fuse(f, timed_events)
@@ -173,7 +176,9 @@ class Sequence:
         self.ev_overlap = self.torch.cuda.Event()
         self.solver.set_overlap_callback(self._fuse_in_shadow)
 
-    def _fuse_in_shadow(self):
+    def _fuse_in_shadow(self, gn_iteration):
+        if gn_iteration > 0:
+            return
         torch = self.torch
         f, timed_events = self._overlap_job
         self.ev_overlap.record()  # on the solve's stream, behind the first assembly
@@ -188,6 +193,10 @@ class Sequence:
             self.solver.set_overlap_callback(None)
             self.ev_overlap = None
         self.plans = [self.solver, self.A.Solver(self.D, self.N, self.k)]
+        if self.D <= 2048:
+            self.ev_pipe = [torch.cuda.Event(), torch.cuda.Event()]
+            for plan in self.plans:
+                plan.set_overlap_callback(self._pipeline_shadow)
         self.s_graph = torch.cuda.Stream()
         self.graph_ready = [None, None]   # event: plan i holds the graphs of its next frame
         self.plan_free = [None, None]     # event: plan i's last solve (and warp) has finished
@@ -204,18 +213,39 @@ class Sequence:
             ev.record(self.s_graph)
             self.graph_ready[i] = ev
 
-    def solve_pipelined(self, f):
+    def _pipeline_shadow(self, gn_iteration):
+        """overlap callback of the pipelined schedule: the sweep of this frame behind the first assembly launch, the
+        graph build of the next frame behind the second (each then runs beside a PCG on three CUs)"""
+        torch = self.torch
+        f, timed_events = self._pipe_job
+        if gn_iteration in (0, -1):
+            self.ev_pipe[0].record()
+            self.s_fuse.wait_event(self.ev_pipe[0])
+            with torch.cuda.stream(self.s_fuse):
+                self.fuse(f, timed_events)
+        if gn_iteration in (1, -1):
+            self.ev_pipe[1].record()
+            self.s_graph.wait_event(self.ev_pipe[1])
+            self._build_graph(f + 1)
+            self._pipe_built = True
+
+    def solve_pipelined(self, f, timed_events=None, shadows=False):
         torch = self.torch
         cur = torch.cuda.current_stream()
         i = f % 2
         if self.next_graph != f:          # first frame (or a jump in the sequence): no graphs built ahead
             self.s_graph.wait_stream(cur)
             self._build_graph(f)
-        self._build_graph(f + 1)          # runs concurrently with the solve below
+        if not shadows:
+            self._build_graph(f + 1)      # runs concurrently with the solve below
         self.next_graph = f + 1
         cur.wait_event(self.graph_ready[i])
         self.solver = self.plans[i]
+        self._pipe_job, self._pipe_built = (f, timed_events), False
         self.solver.solve(self.params)
+        if shadows and not self._pipe_built:  # a solve with a single Gauss-Newton iteration has no second shadow
+            self.s_graph.wait_stream(cur)
+            self._build_graph(f + 1)
         self.warped, _ = self.solver.warp_to_live(self.normals)
         ev = torch.cuda.Event()
         ev.record(cur)
@@ -297,7 +327,8 @@ def pipelined_probe(seq, f0, device, steps=100, warmup=10):
     dt = time.perf_counter() - t0
     t_err = float((seq.solver.translations() - seq.t_true[(f0 + warmup + steps - 1) % seq.n_frames]).abs().max())
     return dict(value=round(steps / dt, 2), unit="frames/s", steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 4),
-                streams="fuse || graph build of frame f+1 || solve of frame f on three HIP streams, two solver plans",
+                streams="solve of frame f || fuse of frame f (behind its first assembly) || graph build of frame f+1 (behind its "
+                        "second) on three HIP streams, two solver plans",
                 max_abs_translation_error_vs_ground_truth_m=round(t_err, 6))
 
 

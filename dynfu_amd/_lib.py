@@ -24,7 +24,7 @@ SYMBOLS = [
 ]
 
 
-_OVERLAP_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)  # dfa_overlap_fn
+_OVERLAP_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)  # dfa_overlap_fn
 
 
 class Solve6Params(C.Structure):
@@ -463,16 +463,17 @@ class Solver:
         _check(load().dfa_solver_enable_timing(self._h, int(on)))
 
     def set_overlap_callback(self, fn):
-        """fn() (or None) is called by every following solve() right after its first assembly launch has been enqueued,
-        before the first PCG launch (dfa_solver_set_overlap_callback): the place to enqueue independent chip-wide work
-        on another stream, behind an event recorded on the current one."""
+        """fn(gn_iteration) (or None) is called by every following solve() right after the assembly launch of each
+        Gauss-Newton iteration has been enqueued, before that iteration's PCG launch (dfa_solver_set_overlap_callback;
+        -1 when the solve runs no iteration): the place to enqueue independent chip-wide work on another stream, behind
+        an event recorded on the current one."""
         self._overlap_error = None
         if fn is None:
             self._overlap_cb = _OVERLAP_FN()
         else:
-            def trampoline(_user, _stream):
+            def trampoline(_user, _stream, gn_iteration):
                 try:
-                    fn()
+                    fn(gn_iteration)
                 except BaseException as e:  # an exception cannot cross the C frame: re-raised by solve()
                     self._overlap_error = e
             self._overlap_cb = _OVERLAP_FN(trampoline)  # kept alive with the plan

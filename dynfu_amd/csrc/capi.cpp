@@ -714,7 +714,7 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
     if (s->host_flag) s->host_flag[0] = s->host_flag[1] = 0;
     s->mb_graphs.call = 0;
     int not_launched = 0;  // iterations after the host has seen the converged flag (many-workgroup path only)
-    bool overlap_called = s->overlap_fn == nullptr;
+    int gn_launched = 0;  // Gauss-Newton iterations whose assembly has been enqueued
     for (int outer = 0; outer < p->num_iter; ++outer) {
         // preNonlinearSolve (opt_solver.cpp:135-140): the Huber weights are only observable after
         // the solve, so they are evaluated for the last outer iteration alone
@@ -730,17 +730,16 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
             HIP_TRY(dfa::solve_assemble(v, s->state, st));
             timing_end(s, ev, st);
             if (ev >= 0) s->ev_asm.push_back(ev);
-            if (!overlap_called) {  // the first PCG starts here: the caller's chip-wide work may run in its shadow
-                s->overlap_fn(s->overlap_user, stream);
-                overlap_called = true;
-            }
+            // this iteration's PCG starts here: the caller's chip-wide work may run in its shadow
+            if (s->overlap_fn) s->overlap_fn(s->overlap_user, stream, gn_launched);
+            ++gn_launched;
             ev = s->timing ? timing_begin(s, st) : -1;  // closed behind the solving kernel, before the fallback launch
             HIP_TRY(dfa::solve_pcg(v, s->state, p->linear_iter, p->pcg_tol, s->host_flag, &s->mb_graphs,
                                    ev >= 0 ? s->events[ev + 1] : nullptr, st));
             if (ev >= 0) s->ev_pcg.push_back(ev);
         }
     }
-    if (!overlap_called) s->overlap_fn(s->overlap_user, stream);  // no iteration ran: the caller's work still goes out
+    if (s->overlap_fn && gn_launched == 0) s->overlap_fn(s->overlap_user, stream, -1);  // no iteration ran: the caller's work still goes out
     if (not_launched) HIP_TRY(dfa::solve_count_noop(s->state, not_launched, st));
     // final cost at the solved t; weights re-evaluated only if no iteration ever did
     const bool no_weights = p->num_iter == 0 || p->nonlinear_iter == 0;

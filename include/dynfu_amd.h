@@ -317,13 +317,15 @@ int dfa_solver_enable_timing(dfa_solver* s, int enable);
 
 /* Scheduling hook (no reference counterpart).  Up to 2048 nodes the PCG of a solve runs on three CUs and is most of
  * the solve's time; the kernels around it (linearisation, assembly) are short and chip-wide.  A caller with independent
- * chip-wide work of its own — the TSDF sweep of the same frame — wants it in the PCG's shadow, not beside those short
- * kernels (a 512^3 sweep launched at the start of the solve delays the first linearisation by ~0.1 ms).  `fn` (NULL
- * removes it) is called by every following dfa_solver_solve, on the calling thread, right after the first assembly
- * launch has been enqueued on `stream` and before the first PCG launch; with no Gauss-Newton iteration to run it is
- * called before the final cost evaluation.  Typical body: record an event on `solve_stream`, let another stream wait for
- * it, enqueue the independent work there.  The callback must not call into the same plan. */
-typedef void (*dfa_overlap_fn)(void* user, dfa_stream_t solve_stream);
+ * chip-wide work of its own — the TSDF sweep of the same frame, the graph build of the next one — wants it in a PCG's
+ * shadow, not beside those short kernels (a 512^3 sweep launched at the start of the solve delays the first
+ * linearisation by ~0.1 ms).  `fn` (NULL removes it) is called by every following dfa_solver_solve, on the calling
+ * thread, right after the assembly launch of Gauss-Newton iteration `gn_iteration` (0, 1, ... counted over the whole
+ * solve) has been enqueued on `solve_stream` and before that iteration's PCG launch; a solve that runs no iteration
+ * calls it once with gn_iteration = -1 before its final cost evaluation.  Typical body: record an event on
+ * `solve_stream`, let another stream wait for it, enqueue the independent work there.  The callback must not call into
+ * the same plan. */
+typedef void (*dfa_overlap_fn)(void* user, dfa_stream_t solve_stream, int gn_iteration);
 int dfa_solver_set_overlap_callback(dfa_solver* s, dfa_overlap_fn fn, void* user);
 int dfa_solver_get_timing(dfa_solver* s, dfa_solve_timing* host_out, dfa_stream_t stream);
 

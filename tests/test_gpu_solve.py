@@ -416,8 +416,8 @@ def test_pipelined_sequence_gives_the_same_translations(A):
 
 
 def test_overlap_callback_runs_once_per_solve_and_changes_nothing(A):
-    """dfa_solver_set_overlap_callback: called on the calling thread behind the first assembly launch of every solve
-    (also when no iteration runs); work it enqueues on another stream runs beside the PCG; exceptions it raises surface
+    """dfa_solver_set_overlap_callback: called on the calling thread behind the assembly launch of every Gauss-Newton
+    iteration of every solve (once with -1 when no iteration runs); work it enqueues on another stream runs beside the PCG; exceptions it raises surface
     from solve(); the solution is that of a solve without it."""
     import torch
     cfg, c, verts, live, _ = _problem("T1")
@@ -430,10 +430,13 @@ def test_overlap_callback_runs_once_per_solve_and_changes_nothing(A):
     t_ref = host(s.translations())
 
     side = torch.cuda.Stream()
-    calls, ev = [], torch.cuda.Event()
+    calls, seen, ev = [], [], torch.cuda.Event()
     vol = torch.empty((64, 64, 64), dtype=torch.int32, device="cuda")
 
-    def cb():
+    def cb(gn_iteration):
+        seen.append(gn_iteration)
+        if gn_iteration > 0:
+            return
         calls.append(torch.cuda.current_stream().cuda_stream)
         ev.record()
         side.wait_event(ev)
@@ -446,12 +449,13 @@ def test_overlap_callback_runs_once_per_solve_and_changes_nothing(A):
         s.solve(prm)
     torch.cuda.synchronize()
     assert len(calls) == 3 and int(vol.abs().max()) == 0
+    assert seen == [0, 1, 2] * 3  # behind the assembly of every Gauss-Newton iteration (num_iter = 3)
     assert np.abs(host(s.translations()) - t_ref).max() <= 5e-7
     s.set_problem(*args)
-    s.solve(_params(A, num_iter=0))  # nothing to iterate: still called, once
-    assert len(calls) == 4
+    s.solve(_params(A, num_iter=0))  # nothing to iterate: still called, once, with -1
+    assert len(calls) == 4 and seen[-1] == -1
 
-    def boom():
+    def boom(gn_iteration):
         raise RuntimeError("from the callback")
 
     s.set_overlap_callback(boom)
