@@ -71,7 +71,11 @@ public:
     kfusion::cuda::TsdfVolume& tsdf();
     std::shared_ptr<dynfu::Frame> getLiveFrame() { return liveFrame; }
     // KinFu::getMesh (kinfu.cpp:262): the marching-cubes triangles of the last frame, KinFu::convertToMesh's layout
-    std::shared_ptr<dfa::PolygonMesh> getMesh() { return mesh_; }
+    // (built on first use: one small vector per triangle is not something every frame should pay for)
+    std::shared_ptr<dfa::PolygonMesh> getMesh() {
+        if (!mesh_) mesh_ = std::make_shared<dfa::PolygonMesh>(dfa::convertToMesh(mesh_triangles_));
+        return mesh_;
+    }
     int frameCounter() const { return frame_counter_; }
 
     void init(dfa::PointCloud<dfa::PointXYZ>& canonicalVertices, dfa::PointCloud<dfa::Normal>& canonicalNormals);
@@ -106,6 +110,7 @@ private:
     std::shared_ptr<kfusion::cuda::TsdfVolume> volume_;
     std::shared_ptr<kfusion::cuda::MarchingCubes> mc_;
     std::shared_ptr<dfa::PolygonMesh> mesh_;
+    std::vector<dfa::PointXYZ> mesh_triangles_;  // the last frame's marching-cubes output (:76 / :122)
     int frame_counter_ = 0;
     // vertices of the volume's zero level set as a point cloud (dyn_fusion.cpp:73-88 / :119-134)
     void extractSurface(dfa::PointCloud<dfa::PointXYZ>& vertices, dfa::PointCloud<dfa::Normal>& normals);

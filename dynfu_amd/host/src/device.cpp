@@ -1,6 +1,11 @@
 // device.cpp — hipMalloc-backed containers and error translation of the host adaptors.
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
+
 #include <dfa_host/device.hpp>
 #include <dfa_host/types.hpp>
 
@@ -16,12 +21,79 @@ static void hip_check(hipError_t e, const char* where) {
     if (e != hipSuccess) throw Error(DFA_ERR_HIP, std::string(where) + ": " + hipGetErrorString(e));
 }
 
+namespace {
+// The reference's classes allocate per call (a CombinedSolver, its images and every staging array live for one frame);
+// hipMalloc / hipFree cost ~0.1 ms each and hipFree waits for the device.  Blocks are therefore recycled: sizes are
+// rounded up to a power of two and released blocks parked per (device, size), up to 2 GiB per process, beyond which
+// they really are freed.  Safe because the adaptor classes do everything on the default stream (as the reference does):
+// a block released while a kernel still reads it is next touched by its new owner's upload or kernel on that same
+// stream, i.e. behind that kernel; hipMemcpy itself is synchronous.
+struct BlockPool {
+    std::mutex mu;
+    std::map<std::pair<int, size_t>, std::vector<void*>> idle;
+    size_t parked = 0;
+    static size_t round_up(size_t n) {
+        size_t r = 256;
+        while (r < n) r <<= 1;
+        return r;
+    }
+    void* take(size_t bytes, size_t& cap) {
+        cap     = round_up(bytes);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            auto& v = idle[{dev, cap}];
+            if (!v.empty()) {
+                void* p = v.back();
+                v.pop_back();
+                parked -= cap;
+                return p;
+            }
+        }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, cap);
+        if (e != hipSuccess) {  // out of memory with blocks parked: release them and retry once
+            trim();
+            e = hipMalloc(&p, cap);
+        }
+        if (e != hipSuccess) throw dfa::Error(DFA_ERR_HIP, std::string("DeviceMemory::create: ") + hipGetErrorString(e));
+        return p;
+    }
+    void give(void* p, size_t cap) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (parked + cap <= ((size_t)2 << 30)) {
+                idle[{dev, cap}].push_back(p);
+                parked += cap;
+                return;
+            }
+        }
+        (void)hipFree(p);
+    }
+    void trim() {
+        std::lock_guard<std::mutex> lock(mu);
+        for (auto& kv : idle)
+            for (void* p : kv.second) (void)hipFree(p);
+        idle.clear();
+        parked = 0;
+    }
+};
+BlockPool& pool() {
+    static BlockPool* p = new BlockPool();  // never destroyed: blocks may be released after main() returns
+    return *p;
+}
+}  // namespace
+
 void DeviceMemory::create(size_t bytes) {
     if (bytes == size_ && data_) return;
-    void* p = nullptr;
-    if (bytes) hip_check(hipMalloc(&p, bytes), "DeviceMemory::create");
-    data_ = std::shared_ptr<void>(p, [](void* q) {
-        if (q) (void)hipFree(q);
+    void* p    = nullptr;
+    size_t cap = 0;
+    if (bytes) p = pool().take(bytes, cap);
+    data_ = std::shared_ptr<void>(p, [cap](void* q) {
+        if (q) pool().give(q, cap);
     });
     size_ = bytes;
 }

@@ -2,8 +2,12 @@
 // (reference: src/dynfu/dyn_fusion.cpp:6-31,147-242).
 #include <dynfu/dyn_fusion.hpp>
 
+#include <hip/hip_runtime.h>
+
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <filesystem>
 
 #include <dfa_host/device.hpp>
@@ -72,16 +76,37 @@ void DynFusion::addLiveFrame(int frameID, dfa::PointCloud<dfa::PointXYZ>& vertic
     liveFrame = std::make_shared<dynfu::Frame>(frameID, vertices, normals);
 }
 
+namespace {
+// DFA_HOST_PROFILE=1: wall time of the stages of a frame (device synchronised at every mark) on stderr
+struct StageClock {
+    bool on = std::getenv("DFA_HOST_PROFILE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char* what) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[dfa host] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+}  // namespace
+
 void DynFusion::warpCanonicalToLiveOpt(dfa::Affine3f affine) {
     if (!warpfield || !canonicalFrame || !liveFrame)
         throw dfa::Error(DFA_ERR_INVALID, "warpCanonicalToLiveOpt before init / addLiveFrame");
+    StageClock clk;
     CombinedSolver combinedSolver(*warpfield, solverParams, dynfuParams.tukeyOffset, dynfuParams.psi_data,
                                   dynfuParams.lambda, dynfuParams.psi_reg);
+    clk.mark("  CombinedSolver ctor");
     canonicalFrameWarpedToLive = warpfield->warpToLive(canonicalFrame);  // :196
+    clk.mark("  warpToLive");
     auto corresponding         = findCorrespondingFrame(canonicalFrameWarpedToLive->getVertices(),
                                                         canonicalFrameWarpedToLive->getNormals(), liveFrame->getVertices());
+    clk.mark("  findCorrespondingFrame");
     combinedSolver.initializeProblemInstance(corresponding, liveFrame, affine);  // :206
+    clk.mark("  initializeProblemInstance");
     combinedSolver.solveAll();                                                   // :207
+    clk.mark("  solveAll");
 }
 
 std::shared_ptr<dynfu::Frame> DynFusion::findCorrespondingFrame(dfa::PointCloud<dfa::PointXYZ> canonicalVertices,
@@ -143,19 +168,20 @@ void DynFusion::extractSurface(dfa::PointCloud<dfa::PointXYZ>& vertices, dfa::Po
     auto triangles = mc_->run(tsdf(), buffer);  // :73-75 / :119-121
     std::vector<kfusion::cuda::MarchingCubes::PointType> host;
     if (!triangles.empty()) triangles.download(host);
-    for (auto& p : host) vertices.push_back(dfa::PointXYZ(p.x, p.y, p.z));
-    mesh_ = std::make_shared<dfa::PolygonMesh>(dfa::convertToMesh(vertices.points));  // :76 / :122
-    if (dynfuParams.mesh_normals && !host.empty()) {  // extension: gradient of the TSDF at the vertices
+    vertices.points = host;                          // PointType is dfa::PointXYZ: {x, y, z, 1}
+    mesh_triangles_ = std::move(host), mesh_.reset();  // convertToMesh (:76 / :122) on demand: getMesh()
+    const size_t nv = vertices.size();
+    if (dynfuParams.mesh_normals && nv) {  // extension: gradient of the TSDF at the vertices
         dfa::DeviceArray<dfa::Normal> dn;
         mc_->computeNormals(tsdf(), triangles, dn);
         std::vector<dfa::Normal> hn;
         dn.download(hn);
-        for (size_t i = 0; i < host.size(); ++i) normals.push_back(hn[i]);
+        normals.points = std::move(hn);
         return;
     }
     // pcl::copyPointCloud<PointXYZ, Normal> (:87-88 / :133-134) copies the fields the two types share — none:
     // the normals are default-constructed, one per vertex
-    for (size_t i = 0; i < host.size(); ++i) normals.push_back(dfa::Normal());
+    normals.points.assign(nv, dfa::Normal());
 }
 
 bool DynFusion::operator()(const kfusion::cuda::Depth& depth) {
@@ -173,11 +199,17 @@ bool DynFusion::operator()(const kfusion::cuda::Depth& depth) {
         init(vertices, normals);                   // :95
         return ++frame_counter_, false;
     }
+    StageClock clk;
     tsdf().clearAndIntegrate(dists_, camera, p.intr);  // :113-114 as one sweep
+    clk.mark("pre-process + fuse");
     extractSurface(vertices, normals);
+    clk.mark("marching cubes -> host clouds");
     addLiveFrame(frame_counter_, vertices, normals);  // :137
+    clk.mark("addLiveFrame");
     warpCanonicalToLiveOpt(camera);                   // :140
+    clk.mark("warpCanonicalToLiveOpt");
     warpfield->update(getCanonicalWarpedToLive());    // :142
+    clk.mark("warpfield->update");
     return ++frame_counter_, true;
 }
 

@@ -3,15 +3,61 @@
 // dfa_solver_solve).
 #include <dynfu/utils/opt_solver.hpp>
 
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+#include <vector>
+
 #include <dfa_host/device.hpp>
 
 #include "../../../include/dynfu_amd.h"
 
+namespace {
+// The reference constructs a CombinedSolver per frame (dyn_fusion.cpp:193).  A plan is ~40 device allocations, so the
+// plans of destroyed solvers are parked here (at most two) and handed to the next solver whose problem fits.
+struct PlanCache {
+    struct Entry {
+        dfa_solver* plan;
+        int max_D, max_N, k;
+    };
+    std::mutex mu;
+    std::vector<Entry> idle;
+    ~PlanCache() {
+        for (auto& e : idle) dfa_solver_destroy(e.plan);
+    }
+    dfa_solver* take(int D, int N, int k, int& max_D, int& max_N) {
+        std::lock_guard<std::mutex> lock(mu);
+        for (size_t i = 0; i < idle.size(); ++i)
+            if (idle[i].k == k && idle[i].max_D >= D && idle[i].max_N >= N) {
+                const Entry e = idle[i];
+                idle.erase(idle.begin() + (long)i);
+                max_D = e.max_D, max_N = e.max_N;
+                return e.plan;
+            }
+        return nullptr;
+    }
+    void park(dfa_solver* plan, int max_D, int max_N, int k) {
+        if (!plan) return;
+        std::lock_guard<std::mutex> lock(mu);
+        if (idle.size() >= 2) {
+            dfa_solver_destroy(idle.front().plan);
+            idle.erase(idle.begin());
+        }
+        idle.push_back({plan, max_D, max_N, k});
+    }
+};
+PlanCache& plan_cache() {
+    static PlanCache c;
+    return c;
+}
+}  // namespace
+
 struct CombinedSolver::Impl {
     dfa_solver* plan = nullptr;
+    int plan_D = 0, plan_N = 0, plan_k = 0;  // capacity of `plan`
     dfa::DeviceArray<float> node_pos, node_dq, node_w, canon, live, canon_n, live_n;
     int D = 0, N = 0;
-    ~Impl() { dfa_solver_destroy(plan); }
+    ~Impl() { plan_cache().park(plan, plan_D, plan_N, plan_k); }
 };
 
 CombinedSolver::CombinedSolver(Warpfield warpfield, CombinedSolverParameters params, float tukeyOffset_,
@@ -51,8 +97,19 @@ void CombinedSolver::initializeProblemInstance(const std::shared_ptr<dynfu::Fram
     I.D = D, I.N = N;
     I.node_pos.upload(pos), I.node_w.upload(w), I.node_dq.upload(dq);
     I.canon.upload(c), I.live.upload(l), I.canon_n.upload(cnv), I.live_n.upload(lnv);
-    if (I.plan) dfa_solver_destroy(I.plan), I.plan = nullptr;
-    dfa::check(dfa_solver_create(D, N, m_warpfield.getKnn(), &I.plan), "CombinedSolver: dfa_solver_create");
+    const int k = m_warpfield.getKnn();
+    if (I.plan && !(I.plan_k == k && I.plan_D >= D && I.plan_N >= N)) {
+        plan_cache().park(I.plan, I.plan_D, I.plan_N, I.plan_k);
+        I.plan = nullptr;
+    }
+    if (!I.plan) {
+        I.plan   = plan_cache().take(D, N, k, I.plan_D, I.plan_N);
+        I.plan_k = k;
+    }
+    if (!I.plan) {  // headroom: the surface of the next frames has about as many vertices, rarely exactly as many
+        I.plan_D = std::max(D, std::min(D + D / 4 + 16, 32768)), I.plan_N = N + N / 4 + 1024;  // (32768: a plan's node limit)
+        dfa::check(dfa_solver_create(I.plan_D, I.plan_N, k, &I.plan), "CombinedSolver: dfa_solver_create");
+    }
     dfa::check(dfa_solver_set_problem(I.plan, I.node_pos.ptr(), I.node_dq.ptr(), I.node_w.ptr(), D, I.canon.ptr(),
                                       I.canon_n.ptr(), I.live.ptr(), I.live_n.ptr(), N, nullptr),
                "CombinedSolver::initializeProblemInstance");
@@ -64,7 +121,12 @@ void CombinedSolver::solveAll() {
     Impl& I = *impl;
     if (!I.plan) throw dfa::Error(DFA_ERR_INVALID, "solveAll before initializeProblemInstance");
     dfa_solve_params p;
-    p.num_iter       = m_params.numIter;
+    // Opt's CombinedSolverBase::singleSolve (un-vendored; upstream examples/shared/CombinedSolverBase.h) leaves its
+    // outer loop after the first pass when earlyOut is set — as DynFusion and every OptTest set it
+    // (dyn_fusion.cpp:189, opt_optimisation_test.cpp:43): one robust re-weighting, then <= nonLinearIter Gauss-Newton
+    // steps.  DFA_HOST_ALL_OUTER=1 runs all numIter passes (the behaviour of round 1) for comparison.
+    const bool one_pass = m_params.earlyOut && !std::getenv("DFA_HOST_ALL_OUTER");
+    p.num_iter       = one_pass ? std::min(1, m_params.numIter) : m_params.numIter;
     p.nonlinear_iter = m_params.nonLinearIter;
     p.linear_iter    = m_params.linearIter;
     p.tukey_offset   = tukeyOffset;

@@ -269,9 +269,12 @@ int dfa_solver_set_problem(dfa_solver* s, const float* node_pos, const float* no
 
 /* CombinedSolverBase::solveAll() with the hooks of opt_solver.cpp:107-147: per outer
  * iteration Tukey + Huber weights, then Gauss-Newton with a block-Jacobi PCG on the normal
- * equations of energy.t.  Up to 2048 nodes everything is enqueued on `stream` without any host
- * synchronisation; larger problems use a many-workgroup PCG whose launches go out in chunks, and the
- * call waits for `stream` about once per Gauss-Newton iteration to read the stop flag. */
+ * equations of energy.t.  Up to 2048 nodes and 8 Gauss-Newton iterations (num_iter x nonlinear_iter) everything is
+ * enqueued on `stream` without any host synchronisation; with a larger iteration budget (the reference's 24 x 16) the
+ * call reads the plan's `converged` flag back every 4th iteration and stops launching once it is set (the iterations
+ * not launched are booked as no-ops, like those whose kernels return at entry); larger problems use a many-workgroup
+ * PCG whose launches go out in chunks, and the call waits for `stream` about once per Gauss-Newton iteration to read
+ * the stop flag. */
 int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* params, dfa_stream_t stream);
 
 /* Results (device pointers, valid until the next set_problem/solve on this plan):

@@ -135,9 +135,10 @@ static int run_sequence(const char* dir) {
     k.cols = first.cols, k.rows = first.rows;
     k.intr = kfusion::Intr(k.intr.fx * first.cols / 640.f, k.intr.fy * first.rows / 480.f, first.cols / 2 - 0.5f, first.rows / 2 - 0.5f);
     p.intr = k.intr;
-    k.volume_dims = dfa::Vec3i(64, 64, 64);
+    const int dim = std::getenv("DFA_SEQ_DIM") ? std::atoi(std::getenv("DFA_SEQ_DIM")) : 64;
+    k.volume_dims = dfa::Vec3i(dim, dim, dim);
     DynFusion dynfu(p);
-    dynfu.nodeStep = 64;
+    dynfu.nodeStep = dim >= 256 ? 128 : 64;
     const SequenceReport r = runSequence(dynfu, dir);
     std::printf("frames %d saved %d dynfu_ms %.2f nodes %zu canonical_vertices %zu mesh_polygons %zu\n", r.frames, r.saved, r.dynfu_ms,
                 dynfu.getWarpfield()->getNodes().size(), dynfu.getCanonicalWarpedToLive()->getVertices().size(),
