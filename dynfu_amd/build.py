@@ -72,7 +72,7 @@ def build(force=False, verbose=False):
 HOST = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(HERE, "libdynfu_amd_host.so")
 HOST_SOURCES = ["device.cpp", "tsdf_volume.cpp", "warp_field.cpp", "opt_solver.cpp", "dyn_fusion.cpp",
-                "marching_cubes.cpp", "imgproc.cpp", "projective_icp.cpp", "io.cpp"]
+                "marching_cubes.cpp", "imgproc.cpp", "projective_icp.cpp", "io.cpp", "kinfu.cpp"]
 
 
 def build_host(force=False, verbose=False):
@@ -108,7 +108,7 @@ def build_cpp_tests(force=False, verbose=False):
     built = {}
     for name, needs in (("test_host_dq", []), ("test_host_solver", ["host"]), ("test_host_tsdf", ["host", "oracle"]),
                         ("test_host_dynfusion", ["host", "oracle"]), ("test_host_icp", ["host"]),
-                        ("test_tsdf_classify", ["oracle", "ieee"]), ("test_host_io", ["host"])):
+                        ("test_tsdf_classify", ["oracle", "ieee"]), ("test_host_io", ["host"]), ("test_host_kinfu", ["host"])):
         src = os.path.join(tdir, name + ".cpp")
         exe = os.path.join(out, name)
         deps = [src, os.path.join(tdir, "minitest.hpp"), host, os.path.join(CSRC, "tsdf_classify.hpp")]

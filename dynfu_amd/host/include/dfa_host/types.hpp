@@ -86,6 +86,11 @@ struct Intr {
     float fx, fy, cx, cy;
     Intr() : fx(0), fy(0), cx(0), cy(0) {}
     Intr(float fx_, float fy_, float cx_, float cy_) : fx(fx_), fy(fy_), cx(cx_), cy(cy_) {}
+    // intrinsics of pyramid level `level` (src/kfusion/core.cpp: every component divided by 2^level)
+    Intr operator()(int level) const {
+        const float div = (float)(1 << level);
+        return Intr(fx / div, fy / div, cx / div, cy / div);
+    }
 };
 
 // pcl::PointXYZ / pcl::Normal / pcl::PointCloud stand-ins (xyz + pad, 16 bytes like PCL's)

@@ -10,6 +10,7 @@
 // owned kfusion::cuda::TsdfVolume.  Vertices come from the caller (marching cubes is a later row).
 #pragma once
 #include <memory>
+#include <vector>
 
 #include <dfa_host/io.hpp>
 #include <dynfu/utils/frame.hpp>
@@ -32,6 +33,9 @@ struct KinFuParams {
     float bilateral_sigma_depth, bilateral_sigma_spatial;
     int bilateral_kernel_size;
     float icp_truncate_depth_dist;
+    float icp_dist_thres, icp_angle_thres;  // gates of the rigid tracker (kfusion::KinFu)
+    std::vector<int> icp_iter_num;          // iterations per pyramid level, level 0 = full resolution
+    float tsdf_min_camera_movement;
     float tsdf_trunc_dist;
     int tsdf_max_weight;
     float raycast_step_factor, gradient_delta_factor;

@@ -1,0 +1,58 @@
+// kfusion/kinfu.hpp — class kfusion::KinFu, the rigid KinectFusion loop the reference's DynFusion derives from
+// (include/kfusion/kinfu.hpp:24-108, src/kfusion/kinfu.cpp:46-262): per frame
+//   dists -> bilateral filter -> [truncation] -> depth pyramid -> point / normal maps per level
+//   -> projective ICP against the previous frame's model maps (coarse to fine, kinfu.cpp:185-200)
+//   -> pose chain -> clear + integrate -> raycast the model from the new pose -> down-sampled model maps.
+// Every device step is one call of the dynfu_amd C ABI through the adaptor functions of kfusion/cuda/*.hpp; the class
+// itself is host control flow.  Built is the reference's default compile path (point maps; `USE_DEPTH` undefined).
+// Not here: renderImage / the light pose (visualisation) and the colour image argument (never read, kinfu.cpp:140).
+#pragma once
+#include <memory>
+#include <vector>
+
+#include <dfa_host/io.hpp>
+#include <dynfu/dyn_fusion.hpp>  // kfusion::KinFuParams
+#include <kfusion/cuda/imgproc.hpp>
+#include <kfusion/cuda/marching_cubes.hpp>
+#include <kfusion/cuda/projective_icp.hpp>
+#include <kfusion/cuda/tsdf_volume.hpp>
+
+namespace kfusion {
+
+class KinFu {
+public:
+    explicit KinFu(const KinFuParams& params);  // kinfu.cpp:46-67 (volume dims must be a multiple of 32, :47)
+
+    const KinFuParams& params() const { return params_; }
+    KinFuParams& params() { return params_; }
+    cuda::TsdfVolume& tsdf() { return *volume_; }
+    cuda::ProjectiveICP& icp() { return *icp_; }
+    cuda::MarchingCubes& mc() { return *mc_; }
+
+    void reset();                              // :117-126: pose chain back to the identity, volume cleared
+    Affine3f getCameraPose(int time = -1) const;  // :128-134
+    int frameCounter() const { return frame_counter_; }
+
+    // kinfu.cpp:140-234.  false for the first two frames and after a lost track (which resets), true afterwards.
+    bool operator()(const cuda::Depth& depth);
+
+    // marching cubes of the current volume in KinFu::convertToMesh's layout (:236-262)
+    std::shared_ptr<dfa::PolygonMesh> extractMesh();
+
+private:
+    struct Frame {
+        std::vector<cuda::Depth> depth_pyr;
+        std::vector<cuda::Cloud> points_pyr;
+        std::vector<cuda::Normals> normals_pyr;
+    };
+    int frame_counter_ = 0;
+    KinFuParams params_;
+    std::vector<Affine3f> poses_;
+    cuda::Dists dists_;
+    Frame curr_, prev_;
+    std::shared_ptr<cuda::TsdfVolume> volume_;
+    std::shared_ptr<cuda::ProjectiveICP> icp_;
+    std::shared_ptr<cuda::MarchingCubes> mc_;
+};
+
+}  // namespace kfusion

@@ -23,6 +23,8 @@ kfusion::KinFuParams kfusion::KinFuParams::default_params() {  // src/kfusion/ki
     p.volume_pose = Affine3f().translate(Vec3f(-p.volume_size[0] / 2, -p.volume_size[1] / 2, 0.5f));
     p.bilateral_sigma_depth = 0.04f, p.bilateral_sigma_spatial = 4.5f, p.bilateral_kernel_size = 7;
     p.icp_truncate_depth_dist = 0.f;
+    p.icp_dist_thres = 0.1f, p.icp_angle_thres = 30.f * 0.017453293f, p.icp_iter_num = {10, 5, 4, 0};
+    p.tsdf_min_camera_movement = 0.f;
     p.tsdf_trunc_dist = 0.04f, p.tsdf_max_weight = 64;
     p.raycast_step_factor = 0.75f, p.gradient_delta_factor = 0.5f;
     return p;

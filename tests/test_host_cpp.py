@@ -95,7 +95,7 @@ def test_host_library_exports_the_adaptor_classes(exes):
                  "kfusion::cuda::depthBilateralFilter", "kfusion::cuda::computePointNormals",
                  "kfusion::cuda::resizeDepthNormals", "kfusion::cuda::ProjectiveICP::estimateTransform",
                  "dfa::io::readDepthPng", "dfa::io::savePCDFileASCII", "dfa::io::saveVTKFile", "dfa::io::listSequence",
-                 "dfa::convertToMesh", "runSequence"):
+                 "dfa::convertToMesh", "runSequence", "kfusion::KinFu::operator()", "kfusion::KinFu::reset"):
         assert name in syms, name
 
 
@@ -115,6 +115,12 @@ def test_host_tsdf_volume_matches_oracle(exes):
 def test_host_dynfusion_sequence(exes):
     out = _run(exes["test_host_dynfusion"])
     assert "7 tests, 0 failed" in out
+
+
+@pytest.mark.gpu
+def test_host_kinfu_rigid_pipeline(exes):
+    out = _run(exes["test_host_kinfu"])
+    assert "3 tests, 0 failed" in out
 
 
 @pytest.mark.gpu
