@@ -5,7 +5,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if "compute_dists" in r["Kernel_Name"] or "grid_setup" in r["Kernel_Name"]]
 # a frame begins at the grid set-up of its graph build (or the dists kernel, whichever comes first)
-frames = [i for i, r in enumerate(rows) if "grid_setup" in r["Kernel_Name"]]
+frames = [i for i, r in enumerate(rows) if "grid_setup" in r["Kernel_Name"] or "grid_build_one" in r["Kernel_Name"]]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 a, b = frames[-back - 1], frames[-back]
 t0 = int(rows[a]["Start_Timestamp"])
