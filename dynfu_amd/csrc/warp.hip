@@ -413,7 +413,27 @@ __device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32
         margin        = m > 0.f ? m : 0.f;  // negative (outside) or NaN -> 0
     }
     const int rmax = max(g.dim[0], max(g.dim[1], g.dim[2]));
-    for (int r = 0; r < rmax; ++r) {
+    int r_first    = 0;
+    if (!TIGHT) {
+        // Shells 0 and 1 together: the 3 x 3 x 3 block around the query's cell is nine x-rows of cells, and the cells of
+        // an x-row are consecutive in the sorted node array — nine contiguous candidate ranges (18 cell_start loads)
+        // instead of 27 cells (54) walked one by one.  Nearly every query ends here: the stop rule below is that of r = 1.
+        const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dim[2] - 1);
+        const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dim[1] - 1);
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
+        for (int z = z0; z <= z1; ++z)
+            for (int y = y0; y <= y1; ++y) {
+                const int c   = g.dim[0] * (y + g.dim[1] * z);
+                const int beg = cell_start[c + x0], end = cell_start[c + x1 + 1];
+                for (int j = beg; j < end; ++j) {
+                    const float4 n = sorted[j];
+                    best.push(dist2(q, n.x, n.y, n.z), __float_as_int(n.w));
+                }
+            }
+        if (best.d[K - 1] < g.cs * g.cs * 0.9999f) return;  // (r = 1: every node not visited is at least one cell away)
+        r_first = 2;  // (a grid of at most 2 cells per axis has been visited completely: the loop below does not run)
+    }
+    for (int r = r_first; r < rmax; ++r) {
         const int z0 = max(cz - r, 0), z1 = min(cz + r, g.dim[2] - 1);
         const int y0 = max(cy - r, 0), y1 = min(cy + r, g.dim[1] - 1);
         const int x0 = max(cx - r, 0), x1 = min(cx + r, g.dim[0] - 1);
