@@ -10,7 +10,7 @@ _LIB = None
 SYMBOLS = [
     "dfa_last_error", "dfa_version", "dfa_compute_dists", "dfa_tsdf_clear", "dfa_tsdf_integrate",
     "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_tsdf_vertex_normals", "dfa_correspond_projective", "dfa_knn", "dfa_warp_to_live",
-    "dfa_calc_dqb", "dfa_unsupported_vertices", "dfa_icp_sums",
+    "dfa_calc_dqb", "dfa_unsupported_vertices", "dfa_icp_sums", "dfa_repack_points", "dfa_compact_points",
     "dfa_correspond", "dfa_marching_cubes", "dfa_mc_default_tables",
     "dfa_depth_bilateral_filter", "dfa_depth_truncate", "dfa_depth_build_pyramid", "dfa_compute_normals_mask_depth",
     "dfa_resize_depth_normals", "dfa_resize_points_normals",
@@ -131,6 +131,8 @@ def load():
     L.dfa_calc_dqb.argtypes = [vp, vp, vp, i, i, vp, i, vp, vp]
     L.dfa_unsupported_vertices.argtypes = [vp, vp, i, i, vp, i, vp, vp]
     L.dfa_correspond.argtypes = [vp, vp, i, vp, i, vp, vp, vp, vp]
+    L.dfa_repack_points.argtypes = [vp, i, vp, i, i, C.c_float, vp]
+    L.dfa_compact_points.argtypes = [vp, vp, i, vp, vp, vp, vp]
     L.dfa_solver_create.argtypes = [i, i, i, C.POINTER(vp)]
     L.dfa_solver_destroy.argtypes = [vp]
     L.dfa_solver_destroy.restype = None
@@ -363,6 +365,29 @@ def unsupported_vertices(node_pos, node_w, k, verts):
                                            _dev(node_w, torch.float32, "node_w") if D else None, D, k,
                                            _dev(verts, torch.float32, "verts"), verts.shape[0], _dev(flags), _stream()))
     return flags
+
+
+def repack_points(src, dst_stride, pad=1.0):
+    """(n, s) float32 -> (n, dst_stride): xyz of every point, remaining floats = pad (dfa_repack_points)"""
+    torch = _torch()
+    n, s = src.shape
+    dst = torch.empty((n, dst_stride), dtype=torch.float32, device=src.device)
+    _check(load().dfa_repack_points(_dev(src, torch.float32, "src"), s, dst.data_ptr(), dst_stride, n, pad, _stream()))
+    return dst
+
+
+def compact_points(points, flags, want_index=True):
+    """the points with a non-zero flag, in index order (dfa_compact_points) -> (points (m, 3), index (m,) | None)"""
+    torch = _torch()
+    N = flags.shape[0]
+    out = torch.empty((max(N, 1), 3), dtype=torch.float32, device=flags.device)
+    idx = torch.empty((max(N, 1),), dtype=torch.int32, device=flags.device) if want_index else None
+    count = torch.zeros((1,), dtype=torch.int32, device=flags.device)
+    _check(load().dfa_compact_points(_dev(points, torch.float32, "points") if N else None,
+                                     _dev(flags, torch.uint8, "flags") if N else None, N, out.data_ptr(),
+                                     idx.data_ptr() if want_index else None, count.data_ptr(), _stream()))
+    m = int(count.item())
+    return out[:m], (idx[:m] if want_index else None)
 
 
 def correspond(canon_v, canon_n, live_v, want_index=True):

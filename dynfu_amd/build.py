@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libdynfu_amd.so")
-SOURCES = ["tsdf.hip", "warp.hip", "solve.hip", "solve6.hip", "mc.hip", "img.hip", "icp.hip", "capi.cpp"]
+SOURCES = ["tsdf.hip", "warp.hip", "solve.hip", "solve6.hip", "mc.hip", "img.hip", "icp.hip", "points.hip", "capi.cpp"]
 ARCH = "gfx950"
 EXTRA = os.environ.get("DFA_EXTRA_CXXFLAGS", "").split()
 FLAGS = EXTRA + ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function",
@@ -71,7 +71,7 @@ def build(force=False, verbose=False):
 
 HOST = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(HERE, "libdynfu_amd_host.so")
-HOST_SOURCES = ["device.cpp", "tsdf_volume.cpp", "warp_field.cpp", "opt_solver.cpp", "dyn_fusion.cpp",
+HOST_SOURCES = ["device.cpp", "frame.cpp", "tsdf_volume.cpp", "warp_field.cpp", "opt_solver.cpp", "dyn_fusion.cpp",
                 "marching_cubes.cpp", "imgproc.cpp", "projective_icp.cpp", "io.cpp", "kinfu.cpp"]
 
 

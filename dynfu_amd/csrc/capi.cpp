@@ -534,6 +534,42 @@ int dfa_unsupported_vertices(const float* node_pos, const float* node_w, int D, 
     return DFA_OK;
 }
 
+int dfa_repack_points(const float* src, int src_stride, float* dst, int dst_stride, int n, float pad,
+                      dfa_stream_t stream) {
+    REQUIRE(n >= 0 && (n == 0 || (src && dst)), "bad points");
+    REQUIRE(src_stride >= 3 && dst_stride >= 3, "strides are floats per point, >= 3");
+    REQUIRE(src_stride != 4 || ((uintptr_t)src & 15) == 0, "float4 source must be 16-byte aligned");
+    REQUIRE(dst_stride != 4 || ((uintptr_t)dst & 15) == 0, "float4 destination must be 16-byte aligned");
+    HIP_TRY(dfa::launch_repack_points(src, src_stride, dst, dst_stride, n, pad, S(stream)));
+    return DFA_OK;
+}
+
+namespace {
+struct CompactScratch {
+    int32_t* chunks = nullptr;
+    int cap         = 0;
+    hipError_t reserve(int n) {
+        if (n <= cap) return hipSuccess;
+        (void)hipFree(chunks);
+        chunks = nullptr, cap = 0;
+        hipError_t e = hipMalloc((void**)&chunks, sizeof(int32_t) * (size_t)n);
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+};
+}  // namespace
+
+int dfa_compact_points(const float* points, const uint8_t* flags, int N, float* out_points, int32_t* out_index,
+                       int32_t* count, dfa_stream_t stream) {
+    REQUIRE(count, "count is required");
+    REQUIRE(N >= 0 && (N == 0 || flags), "bad flags");
+    REQUIRE(!out_points || points || N == 0, "out_points requested without points");
+    CompactScratch& cs = stream_scratch<CompactScratch>(S(stream));
+    HIP_TRY(cs.reserve(dfa::compact_chunks(N > 0 ? N : 1)));
+    HIP_TRY(dfa::launch_compact_points(points, flags, N, out_points, out_index, count, cs.chunks, S(stream)));
+    return DFA_OK;
+}
+
 int dfa_correspond(const float* canon_vertices, const float* canon_normals, int n_canon, const float* live_vertices,
                    int n_live, float* out_vertices, float* out_normals, int32_t* out_index, dfa_stream_t stream) {
     REQUIRE(canon_vertices && n_canon > 0, "no canonical vertices");
@@ -720,19 +756,24 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
         // preNonlinearSolve (opt_solver.cpp:135-140): the Huber weights are only observable after
         // the solve, so they are evaluated for the last outer iteration alone
         if (outer == p->num_iter - 1) HIP_TRY(dfa::solve_huber(v, p->psi_reg, st));
+        // converged == 2 (gradient at the floor under stale weights) ended the inner iterations of the outer iteration
+        // before only: this one re-weights, and its first linearisation clears the flag on the device
+        if (s->host_flag && s->host_flag[1] == 2) s->host_flag[1] = 0;
+        int gn_in_outer = 0;  // iterations of this outer iteration enqueued (the device's flag is current behind them)
         for (int gn = 0; gn < p->nonlinear_iter; ++gn) {
             // Iteration budgets like the reference's (24 x 16, dyn_fusion.cpp:183-189) are ~380 iterations of which a
             // handful do anything: behind a converged one the kernels return at entry, but 4 launches x 5 us x 380 is
             // still 8 ms of stream time.  Small budgets (<= 8 iterations: bench.py's 5) stay free of any host
-            // synchronisation; larger ones read the sticky `converged` flag back every 4th iteration.
-            if (big_budget && gn_launched >= 4 && gn_launched % 4 == 0 && s->host_flag && !s->host_flag[1] && v.D <= 2048) {
+            // synchronisation; larger ones read the `converged` flag back every 4th iteration.
+            if (big_budget && gn_in_outer >= 4 && gn_in_outer % 4 == 0 && s->host_flag && !s->host_flag[1] && v.D <= 2048) {
                 HIP_TRY(hipMemcpyAsync(&s->host_flag[1], &s->state->converged, sizeof(int), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
             }
-            if (s->host_flag && s->host_flag[1]) {  // t can no longer change: every further iteration is a no-op
-                ++not_launched;
+            if (s->host_flag && s->host_flag[1]) {  // t can no longer change (in this outer iteration, when the flag is
+                ++not_launched;                     // 2): every further iteration is a no-op
                 continue;
             }
+            ++gn_in_outer;
             HIP_TRY(dfa::solve_linearise(v, s->state, s->cost_partials, s->ticket, gn == 0, gn == 0 ? 0 : 1,
                                          p->gn_tol, p->tukey_offset, p->psi_data, w_reg_sq, st));
             int ev = s->timing ? timing_begin(s, st) : -1;

@@ -77,6 +77,12 @@ hipError_t launch_warp_graph(const float* node_pos, const float* node_dq, const 
                              const float* verts, const float* normals, int N, float* out_verts, float* out_normals,
                              hipStream_t s);
 
+// points.hip
+hipError_t launch_repack_points(const float* src, int sstride, float* dst, int dstride, int n, float pad, hipStream_t s);
+int compact_chunks(int n);  // entries of chunk_scratch
+hipError_t launch_compact_points(const float* pts, const uint8_t* flags, int n, float* out_pts, int32_t* out_idx,
+                                 int32_t* count, int32_t* chunk_scratch, hipStream_t s);
+
 // mc.hip
 long mc_segments(int X, int Y, int Z, bool vec4);  // entries of seg_off (+1)
 long mc_scan_chunks(long nsegs);                   // entries of chunk_sums

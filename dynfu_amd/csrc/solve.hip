@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void linearise_kernel(SolveView s, SolveState*
     __shared__ int is_last;
     // after convergence t no longer changes: weights, residual records and cost of this linearisation exist already
     // (mode 2, the solve's closing evaluation, always runs)
-    if (a.mode != 2 && st->converged) return;
+    if (a.mode != 2 && (st->converged == 1 || (st->converged && !a.update_weights))) return;
     const size_t R = (size_t)s.N + (size_t)s.D * s.k;
     double c       = 0.0;
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (size_t)gridDim.x * blockDim.x) {
@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256) void linearise_kernel(SolveView s, SolveState*
         // robust weights evaluated at THIS t: a gradient at the floor now means the whole solve has converged (with
         // stale weights it only ends the current outer iteration: the next one re-weights at the moved t)
         if (a.mode != 2) st->weights_fresh = a.update_weights;
+        if (a.mode != 2 && a.update_weights && st->converged == 2) st->converged = 0;  // a new outer iteration
     }
 }
 
@@ -772,7 +773,7 @@ __global__ __launch_bounds__(NT) void pcg_kernel(SolveView s, SolveState* __rest
         if (st->grad_first == 0.0) st->grad_first = rz0;
         st->pcg_iters += it;
         st->gn_iters += 1;
-        if (skip && st->weights_fresh) st->converged = 1;
+        if (skip) solve_mark_at_floor(st);
     }
 }
 
@@ -840,7 +841,7 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
         if (tid == 0 && blockIdx.x == 0) {
             st->gn_iters += 1;
             st->pcg_fallback = 0;  // nothing left for the streaming kernel launched behind this one
-            if (st->weights_fresh) st->converged = 1;
+            solve_mark_at_floor(st);
         }
         return;
     }
@@ -1344,7 +1345,7 @@ __global__ __launch_bounds__(256) void pcg_mb_matvec_kernel(SolveView s, SolveSt
         stop                = stop || at_floor;  // nothing left to solve
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             st->mb_rz0 = rz_cur;
-            if (at_floor && st->weights_fresh) st->converged = 1;
+            if (at_floor) solve_mark_at_floor(st);
         }
     } else {
         const float rz_prev = sum_partials_mb(s.mb_gpart[(it + 1) & 1], nbu);
@@ -1459,7 +1460,7 @@ __global__ __launch_bounds__(256) void pcg_mb_step_kernel(SolveView s, SolveStat
             stop                = stop || at_floor;  // nothing left to solve
             if (blockIdx.x == 0 && threadIdx.x == 0) {
                 st->mb_rz0 = gamma;
-                if (at_floor && st->weights_fresh) st->converged = 1;
+                if (at_floor) solve_mark_at_floor(st);
             }
         } else {
             rz0   = st->mb_rz0;

@@ -22,9 +22,12 @@ struct SolveState {
     unsigned int split_ticket;  // ... and how many of its three workgroups have finished
     // multi-workgroup PCG: flags and scalars carried from one launch to the next
     int mb_done;
-    int converged;  // sticky for the rest of the solve: the gradient of a linearisation with freshly evaluated robust
+    int converged;  // 1: sticky for the rest of the solve — the gradient of a linearisation with freshly evaluated robust
                     // weights was at the floor.  t can no longer change (re-weighting at the same t gives the same
-                    // system), so every later Gauss-Newton iteration is a no-op and its kernels return at entry;
+                    // system), so every later Gauss-Newton iteration is a no-op and its kernels return at entry.
+                    // 2: the same with STALE weights (an inner iteration of nonlinear_iter > 1): the energy is linear
+                    // least squares while the weights are frozen, so the remaining inner iterations of this outer
+                    // iteration are no-ops; the next re-weighting linearisation clears it.
                     // directly behind mb_done: the many-workgroup path reads both back with one copy
     int mb_skip, mb_iters;
     int weights_fresh;  // the last linearisation re-evaluated the robust weights (at the t it linearised about)
@@ -40,6 +43,12 @@ struct SolveState {
 __host__ __device__ inline bool solve_rec_ids16(int k) { return k % 8 == 0; }
 __host__ __device__ inline int solve_rec_words(int k) { return solve_rec_ids16(k) ? k + k / 2 + 4 : 2 * k + 4; }
 __host__ __device__ inline int solve_rec_tail(int k) { return solve_rec_words(k) - 4; }  // word offset of (e, tau)
+
+// a PCG found its gradient at the round-off floor (see SolveState::converged)
+__device__ __forceinline__ void solve_mark_at_floor(SolveState* st) {
+    if (st->weights_fresh) st->converged = 1;
+    else if (!st->converged) st->converged = 2;
+}
 
 struct SolveView {
     int N, D, k, Dpad, ell_cap;

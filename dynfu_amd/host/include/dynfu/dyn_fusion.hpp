@@ -76,15 +76,18 @@ public:
     std::shared_ptr<dynfu::Frame> getLiveFrame() { return liveFrame; }
     // KinFu::getMesh (kinfu.cpp:262): the marching-cubes triangles of the last frame, KinFu::convertToMesh's layout
     // (built on first use: one small vector per triangle is not something every frame should pay for)
-    std::shared_ptr<dfa::PolygonMesh> getMesh() {
-        if (!mesh_) mesh_ = std::make_shared<dfa::PolygonMesh>(dfa::convertToMesh(mesh_triangles_));
-        return mesh_;
-    }
+    std::shared_ptr<dfa::PolygonMesh> getMesh();
+    // lets go of the mesh getMesh() built (one small vector per triangle: freeing them takes milliseconds, which a
+    // caller may want outside its timed region; the next frame would do it otherwise)
+    void dropMesh() { mesh_.reset(); }
     int frameCounter() const { return frame_counter_; }
 
     void init(dfa::PointCloud<dfa::PointXYZ>& canonicalVertices, dfa::PointCloud<dfa::Normal>& canonicalNormals);
     void initCanonicalFrame(dfa::PointCloud<dfa::PointXYZ>& vertices, dfa::PointCloud<dfa::Normal>& normals);
     void addLiveFrame(int frameID, dfa::PointCloud<dfa::PointXYZ>& vertices, dfa::PointCloud<dfa::Normal>& normals);
+    // the same two steps on frames that may live in HBM (what operator() uses: nothing is staged through the host)
+    void initFromFrame(std::shared_ptr<dynfu::Frame> frame);
+    void addLiveFrame(int frameID, std::shared_ptr<dynfu::Frame> frame);
     void warpCanonicalToLiveOpt(dfa::Affine3f affine);
     std::shared_ptr<dynfu::Frame> getCanonicalWarpedToLive();
 
@@ -92,6 +95,8 @@ public:
     std::shared_ptr<dynfu::Frame> findCorrespondingFrame(dfa::PointCloud<dfa::PointXYZ> canonicalVertices,
                                                          dfa::PointCloud<dfa::Normal> canonicalNormals,
                                                          dfa::PointCloud<dfa::PointXYZ> liveVertices);
+    std::shared_ptr<dynfu::Frame> findCorrespondingFrame(std::shared_ptr<dynfu::Frame> canonical,
+                                                         std::shared_ptr<dynfu::Frame> live);
 
     // dists -> clear -> integrate of operator() (dyn_fusion.cpp:58, :108-115) as one fused sweep
     void fuse(const kfusion::cuda::Depth& depth, kfusion::cuda::TsdfVolume& volume, const dfa::Affine3f& camera_pose);
@@ -114,10 +119,15 @@ private:
     std::shared_ptr<kfusion::cuda::TsdfVolume> volume_;
     std::shared_ptr<kfusion::cuda::MarchingCubes> mc_;
     std::shared_ptr<dfa::PolygonMesh> mesh_;
-    std::vector<dfa::PointXYZ> mesh_triangles_;  // the last frame's marching-cubes output (:76 / :122)
+    // the last frame's marching-cubes output (:76 / :122): in HBM (a view of mc_buffer_, valid until the next frame),
+    // downloaded when getMesh() asks for it
+    dfa::DeviceArray<kfusion::cuda::MarchingCubes::PointType> mc_buffer_, mesh_source_;
+    std::vector<dfa::PointXYZ> mesh_triangles_;
+    bool mesh_downloaded_ = false;
     int frame_counter_ = 0;
-    // vertices of the volume's zero level set as a point cloud (dyn_fusion.cpp:73-88 / :119-134)
-    void extractSurface(dfa::PointCloud<dfa::PointXYZ>& vertices, dfa::PointCloud<dfa::Normal>& normals);
+    void seedNodes(const std::vector<dfa::PointXYZ>& canonicalVertices);
+    // vertices of the volume's zero level set as a point cloud (dyn_fusion.cpp:73-88 / :119-134), device-resident
+    std::shared_ptr<dynfu::Frame> extractSurface(int frame_id);
 };
 
 // DynFuApp::execute of the reference's demo (src/apps/demo.cpp:68-124) without its windows and command line: every
@@ -128,5 +138,6 @@ private:
 struct SequenceReport {
     int frames = 0, saved = 0;
     double dynfu_ms = 0;  // time inside DynFusion::operator() (the demo's SampledScopeTime)
+    std::vector<double> frame_ms;  // ... per frame
 };
 SequenceReport runSequence(DynFusion& dynfu, const std::string& dir, int max_frames = -1);

@@ -45,4 +45,14 @@ private:
     struct DeviceNodes;  // device copies of node positions / weights (positions are immutable)
     std::shared_ptr<DeviceNodes> dev;
     void syncPositions();
+    void syncTransforms();
+
+public:
+    // device copies of the node arrays for the adaptor's own stages (D x 3 positions, D weights, D x 8 transforms as
+    // of the last syncTransforms); nullptr / 0 before init
+    struct DeviceNodeView {
+        const float *pos, *w, *dq;
+        int D;
+    };
+    DeviceNodeView deviceNodes(bool refresh_transforms = true);
 };

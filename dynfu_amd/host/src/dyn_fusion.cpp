@@ -59,6 +59,11 @@ DynFuParams& DynFusion::params() { return dynfuParams; }
 
 void DynFusion::init(dfa::PointCloud<dfa::PointXYZ>& canonicalVertices, dfa::PointCloud<dfa::Normal>& canonicalNormals) {
     initCanonicalFrame(canonicalVertices, canonicalNormals);
+    seedNodes(canonicalVertices.points);
+}
+
+// :147-168 — a node at every nodeStep-th canonical vertex
+void DynFusion::seedNodes(const std::vector<dfa::PointXYZ>& canonicalVertices) {
     std::vector<std::shared_ptr<Node>> seeds;
     const float dg_w = 3 * dynfuParams.epsilon;  // :158
     for (size_t i = 0; i < canonicalVertices.size(); i += (size_t)nodeStep)
@@ -71,6 +76,21 @@ void DynFusion::init(dfa::PointCloud<dfa::PointXYZ>& canonicalVertices, dfa::Poi
 void DynFusion::initCanonicalFrame(dfa::PointCloud<dfa::PointXYZ>& vertices, dfa::PointCloud<dfa::Normal>& normals) {
     canonicalFrame             = std::make_shared<dynfu::Frame>(0, vertices, normals);
     canonicalFrameWarpedToLive = std::make_shared<dynfu::Frame>(0, vertices, normals);
+}
+
+// frame 0 of operator(): the canonical frame is the device-resident marching-cubes cloud; only the seeding reads it
+// on the host (once, through the const accessor: the device arrays stay the master)
+void DynFusion::initFromFrame(std::shared_ptr<dynfu::Frame> frame) {
+    dfa::DeviceArray<float> v3, n3;
+    frame->deviceArrays(v3, n3);
+    canonicalFrame             = frame;
+    canonicalFrameWarpedToLive = dynfu::Frame::fromDevice(0, v3, n3, frame->size());  // a second Frame, as :171-175
+    seedNodes(frame->vertices().points);
+}
+
+void DynFusion::addLiveFrame(int frameID, std::shared_ptr<dynfu::Frame> frame) {
+    (void)frameID;
+    liveFrame = frame;
 }
 
 void DynFusion::addLiveFrame(int frameID, dfa::PointCloud<dfa::PointXYZ>& vertices,
@@ -102,8 +122,7 @@ void DynFusion::warpCanonicalToLiveOpt(dfa::Affine3f affine) {
     clk.mark("  CombinedSolver ctor");
     canonicalFrameWarpedToLive = warpfield->warpToLive(canonicalFrame);  // :196
     clk.mark("  warpToLive");
-    auto corresponding         = findCorrespondingFrame(canonicalFrameWarpedToLive->getVertices(),
-                                                        canonicalFrameWarpedToLive->getNormals(), liveFrame->getVertices());
+    auto corresponding         = findCorrespondingFrame(canonicalFrameWarpedToLive, liveFrame);
     clk.mark("  findCorrespondingFrame");
     combinedSolver.initializeProblemInstance(corresponding, liveFrame, affine);  // :206
     clk.mark("  initializeProblemInstance");
@@ -114,30 +133,21 @@ void DynFusion::warpCanonicalToLiveOpt(dfa::Affine3f affine) {
 std::shared_ptr<dynfu::Frame> DynFusion::findCorrespondingFrame(dfa::PointCloud<dfa::PointXYZ> canonicalVertices,
                                                                 dfa::PointCloud<dfa::Normal> canonicalNormals,
                                                                 dfa::PointCloud<dfa::PointXYZ> liveVertices) {
-    const size_t nc = canonicalVertices.size(), nl = liveVertices.size();
-    dfa::PointCloud<dfa::PointXYZ> outV;
-    dfa::PointCloud<dfa::Normal> outN;
-    if (nl == 0) return std::make_shared<dynfu::Frame>(0, outV, outN);
+    return findCorrespondingFrame(std::make_shared<dynfu::Frame>(0, std::move(canonicalVertices), std::move(canonicalNormals)),
+                                  std::make_shared<dynfu::Frame>(0, std::move(liveVertices), dfa::PointCloud<dfa::Normal>()));
+}
+
+// :212-242 on frames: both clouds are read where they are (HBM for the adaptor's own frames), the result stays there
+std::shared_ptr<dynfu::Frame> DynFusion::findCorrespondingFrame(std::shared_ptr<dynfu::Frame> canonical,
+                                                                std::shared_ptr<dynfu::Frame> live) {
+    const size_t nc = canonical->size(), nl = live->size();
+    if (nl == 0) return std::make_shared<dynfu::Frame>(0, dfa::PointCloud<dfa::PointXYZ>(), dfa::PointCloud<dfa::Normal>());
     if (nc == 0) throw dfa::Error(DFA_ERR_INVALID, "findCorrespondingFrame: empty canonical cloud");
-    std::vector<float> cv(3 * nc), cn(3 * nc), lv(3 * nl);
-    for (size_t i = 0; i < nc; ++i) {
-        cv[3 * i] = canonicalVertices[i].x, cv[3 * i + 1] = canonicalVertices[i].y, cv[3 * i + 2] = canonicalVertices[i].z;
-        const dfa::Normal n = i < canonicalNormals.size() ? canonicalNormals[i] : dfa::Normal();
-        cn[3 * i] = n.normal_x, cn[3 * i + 1] = n.normal_y, cn[3 * i + 2] = n.normal_z;
-    }
-    for (size_t i = 0; i < nl; ++i)
-        lv[3 * i] = liveVertices[i].x, lv[3 * i + 1] = liveVertices[i].y, lv[3 * i + 2] = liveVertices[i].z;
-    dfa::DeviceArray<float> dcv, dcn, dlv, dov(3 * nl), don(3 * nl);
-    dcv.upload(cv), dcn.upload(cn), dlv.upload(lv);
-    dfa::check(dfa_correspond(dcv.ptr(), dcn.ptr(), (int)nc, dlv.ptr(), (int)nl, dov.ptr(), don.ptr(), nullptr, nullptr),
+    const dynfu::Frame::DeviceView c = canonical->device(), l = live->device();
+    dfa::DeviceArray<float> dov(3 * nl), don(3 * nl);
+    dfa::check(dfa_correspond(c.vertices, c.normals, (int)nc, l.vertices, (int)nl, dov.ptr(), don.ptr(), nullptr, nullptr),
                "DynFusion::findCorrespondingFrame");
-    std::vector<float> ov, on;
-    dov.download(ov), don.download(on);
-    for (size_t i = 0; i < nl; ++i) {
-        outV.push_back(dfa::PointXYZ(ov[3 * i], ov[3 * i + 1], ov[3 * i + 2]));
-        outN.push_back(dfa::Normal(on[3 * i], on[3 * i + 1], on[3 * i + 2]));
-    }
-    return std::make_shared<dynfu::Frame>(0, outV, outN);
+    return dynfu::Frame::fromDevice(0, dov, don, nl);
 }
 
 std::shared_ptr<dynfu::Frame> DynFusion::getCanonicalWarpedToLive() { return canonicalFrameWarpedToLive; }
@@ -164,26 +174,39 @@ kfusion::cuda::TsdfVolume& DynFusion::tsdf() {
     return *volume_;
 }
 
-void DynFusion::extractSurface(dfa::PointCloud<dfa::PointXYZ>& vertices, dfa::PointCloud<dfa::Normal>& normals) {
+std::shared_ptr<dynfu::Frame> DynFusion::extractSurface(int frame_id) {
     if (!mc_) mc_ = std::make_shared<kfusion::cuda::MarchingCubes>();
-    dfa::DeviceArray<kfusion::cuda::MarchingCubes::PointType> buffer;
-    auto triangles = mc_->run(tsdf(), buffer);  // :73-75 / :119-121
-    std::vector<kfusion::cuda::MarchingCubes::PointType> host;
-    if (!triangles.empty()) triangles.download(host);
-    vertices.points = host;                          // PointType is dfa::PointXYZ: {x, y, z, 1}
-    mesh_triangles_ = std::move(host), mesh_.reset();  // convertToMesh (:76 / :122) on demand: getMesh()
-    const size_t nv = vertices.size();
-    if (dynfuParams.mesh_normals && nv) {  // extension: gradient of the TSDF at the vertices
+    auto triangles = mc_->run(tsdf(), mc_buffer_);  // :73-75 / :119-121 (one host sync: the vertex count)
+    // convertToMesh (:76 / :122) on demand, in getMesh(): the float4 triangle soup stays in mc_buffer_ until then
+    mesh_source_ = triangles, mesh_.reset(), mesh_triangles_.clear(), mesh_downloaded_ = false;
+    const size_t nv = triangles.size();
+    if (nv == 0) return std::make_shared<dynfu::Frame>(frame_id, dfa::PointCloud<dfa::PointXYZ>(), dfa::PointCloud<dfa::Normal>());
+    // pcl::fromPCLPointCloud2 / copyPointCloud (:80-88): the vertices as a cloud of their own — packed N x 3 in HBM
+    dfa::DeviceArray<float> v3(3 * nv), n3(3 * nv);
+    dfa::check(dfa_repack_points((const float*)triangles.ptr(), 4, v3.ptr(), 3, (int)nv, 0.f, nullptr), "DynFusion: vertices");
+    if (dynfuParams.mesh_normals) {  // extension: gradient of the TSDF at the vertices
         dfa::DeviceArray<dfa::Normal> dn;
         mc_->computeNormals(tsdf(), triangles, dn);
-        std::vector<dfa::Normal> hn;
-        dn.download(hn);
-        normals.points = std::move(hn);
-        return;
+        dfa::check(dfa_repack_points((const float*)dn.ptr(), 4, n3.ptr(), 3, (int)nv, 0.f, nullptr), "DynFusion: normals");
+    } else {
+        // pcl::copyPointCloud<PointXYZ, Normal> (:87-88 / :133-134) copies the fields the two types share — none:
+        // the normals are default-constructed, one per vertex
+        if (hipMemsetAsync(n3.ptr(), 0, 3 * nv * sizeof(float), nullptr) != hipSuccess)
+            throw dfa::Error(DFA_ERR_HIP, "DynFusion::extractSurface: hipMemsetAsync");
     }
-    // pcl::copyPointCloud<PointXYZ, Normal> (:87-88 / :133-134) copies the fields the two types share — none:
-    // the normals are default-constructed, one per vertex
-    normals.points.assign(nv, dfa::Normal());
+    return dynfu::Frame::fromDevice(frame_id, v3, n3, nv);
+}
+
+std::shared_ptr<dfa::PolygonMesh> DynFusion::getMesh() {  // KinFu::getMesh (kinfu.cpp:262)
+    if (!mesh_) {
+        if (!mesh_downloaded_) {
+            mesh_triangles_.clear();
+            if (!mesh_source_.empty()) mesh_source_.download(mesh_triangles_);
+            mesh_downloaded_ = true;
+        }
+        mesh_ = std::make_shared<dfa::PolygonMesh>(dfa::convertToMesh(mesh_triangles_));
+    }
+    return mesh_;
 }
 
 bool DynFusion::operator()(const kfusion::cuda::Depth& depth) {
@@ -193,22 +216,18 @@ bool DynFusion::operator()(const kfusion::cuda::Depth& depth) {
                                         p.bilateral_sigma_depth);                                  // :60-61
     if (p.icp_truncate_depth_dist > 0) kfusion::cuda::depthTruncation(depth_filtered_, p.icp_truncate_depth_dist);  // :64-66
     const dfa::Affine3f camera;  // poses_.back(): the rigid tracker is skipped, the camera stays at the origin (:100-105)
-    dfa::PointCloud<dfa::PointXYZ> vertices;
-    dfa::PointCloud<dfa::Normal> normals;
     if (frame_counter_ == 0) {
         tsdf().integrate(dists_, camera, p.intr);  // :71
-        extractSurface(vertices, normals);
-        init(vertices, normals);                   // :95
+        initFromFrame(extractSurface(0));          // :73-95
         return ++frame_counter_, false;
     }
     StageClock clk;
     tsdf().clearAndIntegrate(dists_, camera, p.intr);  // :113-114 as one sweep
     clk.mark("pre-process + fuse");
-    extractSurface(vertices, normals);
-    clk.mark("marching cubes -> host clouds");
-    addLiveFrame(frame_counter_, vertices, normals);  // :137
-    clk.mark("addLiveFrame");
-    warpCanonicalToLiveOpt(camera);                   // :140
+    auto live = extractSurface(frame_counter_);
+    clk.mark("marching cubes -> live frame");
+    addLiveFrame(frame_counter_, live);  // :137
+    warpCanonicalToLiveOpt(camera);      // :140
     clk.mark("warpCanonicalToLiveOpt");
     warpfield->update(getCanonicalWarpedToLive());    // :142
     clk.mark("warpfield->update");
@@ -229,12 +248,14 @@ SequenceReport runSequence(DynFusion& dynfu, const std::string& dir, int max_fra
         depth_device.upload(depth.data.data(), (size_t)depth.cols * sizeof(uint16_t), depth.rows, depth.cols);  // :90
         const auto t0        = std::chrono::steady_clock::now();
         const bool has_image = dynfu(depth_device);  // :94
-        rep.dynfu_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        rep.frame_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        rep.dynfu_ms += rep.frame_ms.back();
         ++rep.frames;
         if (has_image) {  // :115-118
             dfa::io::savePCDFileASCII(out + "/pcl_canonical_to_live" + std::to_string(i) + ".pcd",
-                                      dynfu.getCanonicalWarpedToLive()->getVertices());
+                                      dynfu.getCanonicalWarpedToLive()->vertices());
             dfa::io::saveVTKFile(out + "/" + std::to_string(i) + "_tsdf_mesh.vtk", *dynfu.getMesh());
+            if (i + 1 < n) dynfu.dropMesh();  // the demo's mesh pointer goes out of scope here, outside the timed call
             ++rep.saved;
         }
     }

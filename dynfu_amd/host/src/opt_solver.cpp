@@ -70,14 +70,9 @@ CombinedSolver::~CombinedSolver() = default;
 void CombinedSolver::initializeProblemInstance(const std::shared_ptr<dynfu::Frame> canonicalFrame,
                                                const std::shared_ptr<dynfu::Frame> liveFrame, dfa::Affine3f /*affine*/) {
     auto nodes = m_warpfield.getNodes();
-    auto& cv = canonicalFrame->getVertices();
-    auto& cn = canonicalFrame->getNormals();
-    auto& lv = liveFrame->getVertices();
-    auto& ln = liveFrame->getNormals();
-    const int D = (int)nodes.size(), N = (int)cv.size();
-    if ((int)lv.size() != N) throw dfa::Error(DFA_ERR_INVALID, "canonical / live vertex counts differ");
-    std::vector<float> pos(3 * (size_t)D), w(D), dq(8 * (size_t)D), c(3 * (size_t)N), l(3 * (size_t)N),
-        cnv(3 * (size_t)N), lnv(3 * (size_t)N);
+    const int D = (int)nodes.size(), N = (int)canonicalFrame->size();
+    if ((int)liveFrame->size() != N) throw dfa::Error(DFA_ERR_INVALID, "canonical / live vertex counts differ");
+    std::vector<float> pos(3 * (size_t)D), w(D), dq(8 * (size_t)D);
     for (int i = 0; i < D; ++i) {
         const dfa::PointXYZ g = nodes[i]->getPosition();
         pos[3 * i] = g.x, pos[3 * i + 1] = g.y, pos[3 * i + 2] = g.z;
@@ -87,16 +82,13 @@ void CombinedSolver::initializeProblemInstance(const std::shared_ptr<dynfu::Fram
         float* o = &dq[8 * (size_t)i];
         o[0] = r.a, o[1] = r.b, o[2] = r.c, o[3] = r.d, o[4] = d.a, o[5] = d.b, o[6] = d.c, o[7] = d.d;
     }
-    for (int i = 0; i < N; ++i) {
-        c[3 * i] = cv[i].x, c[3 * i + 1] = cv[i].y, c[3 * i + 2] = cv[i].z;
-        l[3 * i] = lv[i].x, l[3 * i + 1] = lv[i].y, l[3 * i + 2] = lv[i].z;
-        if (i < (int)cn.size()) cnv[3 * i] = cn[i].normal_x, cnv[3 * i + 1] = cn[i].normal_y, cnv[3 * i + 2] = cn[i].normal_z;
-        if (i < (int)ln.size()) lnv[3 * i] = ln[i].normal_x, lnv[3 * i + 1] = ln[i].normal_y, lnv[3 * i + 2] = ln[i].normal_z;
-    }
     Impl& I = *impl;
     I.D = D, I.N = N;
     I.node_pos.upload(pos), I.node_w.upload(w), I.node_dq.upload(dq);
-    I.canon.upload(c), I.live.upload(l), I.canon_n.upload(cnv), I.live_n.upload(lnv);
+    // the clouds: the frames' own packed device arrays, shared for the life of this solver (frames produced by the
+    // adaptor's stages are already in HBM; frames built from host clouds upload here, as resetGPUMemory does)
+    canonicalFrame->deviceArrays(I.canon, I.canon_n);
+    liveFrame->deviceArrays(I.live, I.live_n);
     const int k = m_warpfield.getKnn();
     if (I.plan && !(I.plan_k == k && I.plan_D >= D && I.plan_N >= N)) {
         plan_cache().park(I.plan, I.plan_D, I.plan_N, I.plan_k);

@@ -45,6 +45,12 @@ void Warpfield::syncPositions() {
     }
 }
 
+Warpfield::DeviceNodeView Warpfield::deviceNodes(bool refresh_transforms) {
+    if (!dev || dev->D == 0) return DeviceNodeView{nullptr, nullptr, nullptr, 0};
+    if (refresh_transforms) syncTransforms();
+    return DeviceNodeView{dev->pos.ptr(), dev->w.ptr(), dev->dq.ptr(), dev->D};
+}
+
 std::vector<size_t> Warpfield::findNeighborsIndex(int numNeighbor, dfa::PointXYZ vertex) {  // :111-122
     std::vector<size_t> out;
     if (!dev || dev->D == 0) return out;
@@ -77,37 +83,30 @@ std::shared_ptr<DualQuaternion<float>> Warpfield::calcDQB(dfa::PointXYZ point) {
     return std::make_shared<DualQuaternion<float>>(sum.normalize());
 }
 
-// :150-171 — bulk warp on the GPU
-std::shared_ptr<dynfu::Frame> Warpfield::warpToLive(std::shared_ptr<dynfu::Frame> canonicalFrame) {
-    auto& verts   = canonicalFrame->getVertices();
-    auto& normals = canonicalFrame->getNormals();
-    const int N   = (int)verts.size();
-    dfa::PointCloud<dfa::PointXYZ> wv;
-    dfa::PointCloud<dfa::Normal> wn;
-    if (N == 0 || !dev || dev->D == 0) return std::make_shared<dynfu::Frame>(0, wv, wn);
-    std::vector<float> hv(3 * (size_t)N), hn(3 * (size_t)N), hdq(8 * nodes.size());
-    for (int i = 0; i < N; ++i) {
-        hv[3 * i] = verts[i].x, hv[3 * i + 1] = verts[i].y, hv[3 * i + 2] = verts[i].z;
-        const dfa::Normal n = i < (int)normals.size() ? normals[i] : dfa::Normal();
-        hn[3 * i] = n.normal_x, hn[3 * i + 1] = n.normal_y, hn[3 * i + 2] = n.normal_z;
-    }
+// the nodes' current transforms dg_se3 as D x 8 floats (real w,x,y,z ; dual w,x,y,z) -> dev->dq
+void Warpfield::syncTransforms() {
+    std::vector<float> hdq(8 * nodes.size());
     for (size_t i = 0; i < nodes.size(); ++i) {
         const auto& dq = *nodes[i]->getTransformation();
         const auto r = dq.getReal(), d = dq.getDual();
         float* o = &hdq[8 * i];
         o[0] = r.a, o[1] = r.b, o[2] = r.c, o[3] = r.d, o[4] = d.a, o[5] = d.b, o[6] = d.c, o[7] = d.d;
     }
-    dfa::DeviceArray<float> dv, dn, ov(3 * (size_t)N), on(3 * (size_t)N);
-    dv.upload(hv), dn.upload(hn), dev->dq.upload(hdq);
-    dfa::check(dfa_warp_to_live(dev->pos.ptr(), dev->dq.ptr(), dev->w.ptr(), dev->D, knn_, dv.ptr(), dn.ptr(), N,
+    if (!hdq.empty()) dev->dq.upload(hdq);
+}
+
+// :150-171 — bulk warp on the GPU; the warped frame stays in HBM until somebody asks for its clouds
+std::shared_ptr<dynfu::Frame> Warpfield::warpToLive(std::shared_ptr<dynfu::Frame> canonicalFrame) {
+    const size_t N = canonicalFrame->size();
+    if (N == 0 || !dev || dev->D == 0)
+        return std::make_shared<dynfu::Frame>(0, dfa::PointCloud<dfa::PointXYZ>(), dfa::PointCloud<dfa::Normal>());
+    const dynfu::Frame::DeviceView in = canonicalFrame->device();
+    syncTransforms();
+    dfa::DeviceArray<float> ov(3 * N), on(3 * N);
+    dfa::check(dfa_warp_to_live(dev->pos.ptr(), dev->dq.ptr(), dev->w.ptr(), dev->D, knn_, in.vertices, in.normals, (int)N,
                                 ov.ptr(), on.ptr(), nullptr),
                "Warpfield::warpToLive");
-    ov.download(hv), on.download(hn);
-    for (int i = 0; i < N; ++i) {
-        wv.push_back(dfa::PointXYZ(hv[3 * i], hv[3 * i + 1], hv[3 * i + 2]));
-        wn.push_back(dfa::Normal(hn[3 * i], hn[3 * i + 1], hn[3 * i + 2]));
-    }
-    return std::make_shared<dynfu::Frame>(0, wv, wn);
+    return dynfu::Frame::fromDevice(0, ov, on, N);
 }
 
 // ------------------------------------------------------------------------------- node insertion
@@ -151,22 +150,28 @@ dfa::PointCloud<dfa::PointXYZ> dfa::voxelGridFilter(const dfa::PointCloud<dfa::P
 
 dfa::PointCloud<dfa::PointXYZ> Warpfield::getUnsupportedVertices(std::shared_ptr<dynfu::Frame> frame) {  // :34-62
     dfa::PointCloud<dfa::PointXYZ> out;
-    auto& verts = frame->getVertices();
-    const int N = (int)verts.size();
+    const size_t N = frame->size();
     if (N == 0) return out;
-    std::vector<float> hv(3 * (size_t)N);
-    for (int i = 0; i < N; ++i) hv[3 * i] = verts[i].x, hv[3 * i + 1] = verts[i].y, hv[3 * i + 2] = verts[i].z;
-    dfa::DeviceArray<float> dv;
-    dfa::DeviceArray<unsigned char> df((size_t)N);
-    dv.upload(hv);
+    const dynfu::Frame::DeviceView in = frame->device();
+    dfa::DeviceArray<unsigned char> flags(N);
+    dfa::DeviceArray<float> picked(3 * N);
+    dfa::DeviceArray<int32_t> count(1);
     const int D = dev ? dev->D : 0;
-    dfa::check(dfa_unsupported_vertices(D ? dev->pos.ptr() : nullptr, D ? dev->w.ptr() : nullptr, D, knn_, dv.ptr(), N,
-                                        df.ptr(), nullptr),
+    dfa::check(dfa_unsupported_vertices(D ? dev->pos.ptr() : nullptr, D ? dev->w.ptr() : nullptr, D, knn_, in.vertices,
+                                        (int)N, flags.ptr(), nullptr),
                "Warpfield::getUnsupportedVertices");
-    std::vector<unsigned char> flags;
-    df.download(flags);
-    for (int i = 0; i < N; ++i)
-        if (flags[i]) out.push_back(verts[i]);
+    // the reference's push_back loop (:42-59) as an order-preserving compaction on the device: only the unsupported
+    // vertices (usually a handful) cross PCIe
+    dfa::check(dfa_compact_points(in.vertices, flags.ptr(), (int)N, picked.ptr(), nullptr, count.ptr(), nullptr),
+               "Warpfield::getUnsupportedVertices (compaction)");
+    std::vector<int32_t> n_host;
+    count.download(n_host);
+    const size_t m = (size_t)n_host[0];
+    if (m == 0) return out;
+    std::vector<float> h(3 * m);
+    picked.DeviceMemory::download(h.data(), h.size() * sizeof(float));
+    out.points.resize(m);
+    for (size_t i = 0; i < m; ++i) out.points[i] = dfa::PointXYZ(h[3 * i], h[3 * i + 1], h[3 * i + 2]);
     return out;
 }
 
@@ -180,16 +185,11 @@ void Warpfield::update(std::shared_ptr<dynfu::Frame> frame) {  // :64-95
     std::vector<float> hq(8 * (size_t)n, 0.f);
     for (int i = 0; i < n; ++i) hq[8 * (size_t)i] = 1.f;
     if (dev && dev->D > 0) {
-        std::vector<float> hp(3 * (size_t)n), hdq(8 * nodes.size());
+        std::vector<float> hp(3 * (size_t)n);
         for (int i = 0; i < n; ++i) hp[3 * i] = seeds[i].x, hp[3 * i + 1] = seeds[i].y, hp[3 * i + 2] = seeds[i].z;
-        for (size_t i = 0; i < nodes.size(); ++i) {
-            const auto& dq = *nodes[i]->getTransformation();
-            const auto r = dq.getReal(), d = dq.getDual();
-            float* o = &hdq[8 * i];
-            o[0] = r.a, o[1] = r.b, o[2] = r.c, o[3] = r.d, o[4] = d.a, o[5] = d.b, o[6] = d.c, o[7] = d.d;
-        }
         dfa::DeviceArray<float> dp, dq_out(8 * (size_t)n);
-        dp.upload(hp), dev->dq.upload(hdq);
+        dp.upload(hp);
+        syncTransforms();
         dfa::check(dfa_calc_dqb(dev->pos.ptr(), dev->dq.ptr(), dev->w.ptr(), dev->D, knn_, dp.ptr(), n, dq_out.ptr(), nullptr),
                    "Warpfield::update (calcDQB)");
         dq_out.download(hq);

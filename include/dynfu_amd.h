@@ -203,6 +203,21 @@ int dfa_calc_dqb(const float* node_pos, const float* node_dq, const float* node_
 int dfa_unsupported_vertices(const float* node_pos, const float* node_w, int D, int k, const float* vertices, int N,
                              uint8_t* flags, dfa_stream_t stream);
 
+/* Point-cloud plumbing between the seams (no arithmetic, bit copies).  The reference moves clouds between its
+ * stages as pcl::PointCloud objects on the host; with the clouds resident in HBM the same two steps are:
+ *
+ * dfa_repack_points — n xyz triples from an array with src_stride floats per point to one with dst_stride floats per
+ *   point (both >= 3); when dst_stride > 3 the remaining floats of every point are set to `pad`.  Converts between the
+ *   float4 {x, y, z, 1} points of dfa_marching_cubes / pcl::PointXYZ (pcl::copyPointCloud, dyn_fusion.cpp:80-88) and the
+ *   packed N x 3 arrays of the warp-field and solver seams.
+ * dfa_compact_points — the points whose flag is non-zero, in ascending index order: the push_back loop of
+ *   Warpfield::getUnsupportedVertices (warp_field.cpp:42-59) over dfa_unsupported_vertices' flags.  out_points
+ *   (capacity N x 3) and out_index (capacity N) may each be NULL; count: device int32, the number of survivors. */
+int dfa_repack_points(const float* src, int src_stride, float* dst, int dst_stride, int n, float pad,
+                      dfa_stream_t stream);
+int dfa_compact_points(const float* points, const uint8_t* flags, int N, float* out_points, int32_t* out_index,
+                       int32_t* count, dfa_stream_t stream);
+
 /* DynFusion::findCorrespondingFrame (src/dynfu/dyn_fusion.cpp:212-242): for each of the
  * n_live live vertices the nearest of the n_canon (warped) canonical vertices — exact 1-NN,
  * ties to the lower index — and the canonical vertex / normal at that index gathered into
@@ -250,7 +265,10 @@ typedef struct {
     int pcg_iters; /* PCG iterations executed in total */
     int max_row_nnz; /* widest row of the assembled normal matrix (blocks) */
     int gn_noop;   /* of gn_iters: iterations behind one whose gradient was at the round-off floor.  The unknown can
-                      no longer change, so their kernels return at entry (same result as running them) */
+                      no longer change — for the rest of the solve when that linearisation had re-evaluated the robust
+                      weights, until the next re-weighting (the end of the outer iteration) otherwise: the energy is
+                      linear least squares while the weights are frozen — so their kernels return at entry (same
+                      result as running them) */
 } dfa_solve_stats;
 
 /* Plan for up to max_D nodes / max_N vertices with k neighbours (1..16). */
@@ -271,8 +289,9 @@ int dfa_solver_set_problem(dfa_solver* s, const float* node_pos, const float* no
  * iteration Tukey + Huber weights, then Gauss-Newton with a block-Jacobi PCG on the normal
  * equations of energy.t.  Up to 2048 nodes and 8 Gauss-Newton iterations (num_iter x nonlinear_iter) everything is
  * enqueued on `stream` without any host synchronisation; with a larger iteration budget (the reference's 24 x 16) the
- * call reads the plan's `converged` flag back every 4th iteration and stops launching once it is set (the iterations
- * not launched are booked as no-ops, like those whose kernels return at entry); larger problems use a many-workgroup
+ * call reads the plan's `converged` flag back every 4th iteration of an outer iteration and stops launching its
+ * remaining (or all remaining) iterations once it is set (the iterations not launched are booked as no-ops, like those
+ * whose kernels return at entry); larger problems use a many-workgroup
  * PCG whose launches go out in chunks, and the call waits for `stream` about once per Gauss-Newton iteration to read
  * the stop flag. */
 int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* params, dfa_stream_t stream);

@@ -251,4 +251,119 @@ TEST(DynFusionTest, MeshNormalsFromTheTsdfGradientFaceTheCamera) {
     }
 }
 
+// dynfu::Frame keeps a host and a device representation coherent lazily (dynfu/utils/frame.hpp)
+TEST(DynFusionTest, FramesStayInHbmUntilSomebodyAsksForTheClouds) {
+    Cloud canon;
+    Normals cn;
+    half_sphere(1000, canon, cn);
+    cn.points.resize(990);  // fewer normals than vertices: the missing ones count as (0, 0, 0)
+    auto host_frame = std::make_shared<dynfu::Frame>(3, canon, cn);
+    ASSERT_TRUE(!host_frame->deviceResident());
+    dfa::DeviceArray<float> v3, n3;
+    host_frame->deviceArrays(v3, n3);
+    ASSERT_EQ(v3.size(), (size_t)3000);
+    auto dev_frame = dynfu::Frame::fromDevice(4, v3, n3, 1000);
+    ASSERT_TRUE(dev_frame->deviceResident());
+    ASSERT_EQ(dev_frame->size(), (size_t)1000);
+    const auto& cv = dev_frame->vertices();  // const view: a download, the device arrays stay the master
+    ASSERT_TRUE(dev_frame->deviceResident());
+    ASSERT_EQ(dev_frame->device().vertices, (const float*)v3.ptr());
+    for (int i : {0, 1, 500, 999}) {
+        ASSERT_EQ(cv[i].x, canon[i].x);
+        ASSERT_EQ(cv[i].y, canon[i].y);
+        ASSERT_EQ(cv[i].z, canon[i].z);
+    }
+    ASSERT_EQ(dev_frame->normals()[989].normal_x, cn[989].normal_x);
+    ASSERT_EQ(dev_frame->normals()[995].normal_x, 0.f);
+    // a mutable reference makes the host clouds the master: what is written through it reaches the device
+    dev_frame->getVertices()[7].x = 42.f;
+    ASSERT_TRUE(!dev_frame->deviceResident());
+    dfa::DeviceArray<float> v3b, n3b;
+    dev_frame->deviceArrays(v3b, n3b);
+    std::vector<float> back;
+    v3b.download(back);
+    ASSERT_EQ(back[21], 42.f);
+    ASSERT_EQ(back[24], canon[8].x);
+    std::vector<float> first;
+    v3.download(first);  // the array handed out before is still the snapshot it was
+    ASSERT_EQ(first[21], canon[7].x);
+    // the bulk stages accept either kind and produce device-resident frames
+    DynFusion df(DynFuParams::defaultParams());
+    df.init(canon, cn);
+    auto warped = df.getWarpfield()->warpToLive(dev_frame);
+    ASSERT_TRUE(warped->deviceResident());
+    ASSERT_EQ(warped->getVertices()[7].x, 42.f);  // identity field
+    ASSERT_TRUE(!warped->deviceResident());
+}
+
+// operator() keeps every cloud in HBM; fed the same clouds through the reference's host-cloud entry points
+// (init / addLiveFrame / warpCanonicalToLiveOpt / update) the warp field comes out the same
+TEST(DynFusionTest, OperatorOnDeviceFramesEqualsTheHostCloudSequence) {
+    const int W = 160, H = 120;
+    auto make = [&](float cz) {
+        std::vector<unsigned short> d((size_t)W * H);
+        const float f = 131.25f, cx = W / 2 - 0.5f, cy = H / 2 - 0.5f, R = 0.5f;
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                float dir[3] = {(x - cx) / f, (y - cy) / f, 1.f};
+                const float n = std::sqrt(dir[0] * dir[0] + dir[1] * dir[1] + 1.f);
+                for (float& v : dir) v /= n;
+                const float b = dir[2] * cz, disc = b * b - (cz * cz - R * R);
+                float z = 2.5f;
+                if (disc > 0) z = (b - std::sqrt(disc)) * dir[2];
+                d[(size_t)y * W + x] = (x < 3 || y < 3 || x >= W - 3 || y >= H - 3) ? 0 : (unsigned short)std::lround(z * 1000.f);
+            }
+        return d;
+    };
+    DynFuParams p = DynFuParams::defaultParams();
+    p.kinfuParams.cols = W, p.kinfuParams.rows = H;
+    p.kinfuParams.intr = kfusion::Intr(131.25f, 131.25f, W / 2 - 0.5f, H / 2 - 0.5f);
+    p.kinfuParams.volume_dims = kfusion::Vec3i::all(64);
+    p.epsilon = 0.02f;  // small support radius: the second and third frame leave vertices unsupported -> nodes inserted
+    DynFusion a(p), b(p);
+    for (DynFusion* d : {&a, &b}) d->solverParams.numIter = 2, d->solverParams.nonLinearIter = 2, d->solverParams.linearIter = 64;
+    const float depths[3] = {1.5f, 1.49f, 1.47f};
+    for (int f = 0; f < 3; ++f) {
+        kfusion::cuda::Depth dm;
+        dm.upload(make(depths[f]), W);
+        ASSERT_TRUE(a(dm) == (f > 0));
+        // b: the clouds of a's frame, downloaded, through the host-cloud interface
+        if (f == 0) {
+            ASSERT_TRUE(a.getCanonicalWarpedToLive()->deviceResident());
+            Cloud v = a.getCanonicalWarpedToLive()->vertices();
+            Normals n = a.getCanonicalWarpedToLive()->normals();
+            b.init(v, n);
+        } else {
+            ASSERT_TRUE(a.getLiveFrame()->deviceResident());
+            Cloud v = a.getLiveFrame()->vertices();
+            Normals n = a.getLiveFrame()->normals();
+            b.addLiveFrame(f, v, n);
+            b.warpCanonicalToLiveOpt(dfa::Affine3f());
+            b.getWarpfield()->update(b.getCanonicalWarpedToLive());
+            ASSERT_TRUE(!b.getLiveFrame()->deviceResident());
+        }
+        auto na = a.getWarpfield()->getNodes(), nb = b.getWarpfield()->getNodes();
+        ASSERT_EQ(na.size(), nb.size());
+        for (size_t i = 0; i < na.size(); ++i) {
+            ASSERT_EQ(na[i]->getPosition().x, nb[i]->getPosition().x);
+            const auto ta = na[i]->getTransformation()->getTranslation(), tb = nb[i]->getTransformation()->getTranslation();
+            // (not bit for bit: the assembly of the normal matrix sums in LDS with float atomics, whose order
+            // differs from run to run; translations here are ~1 cm)
+            for (int c = 0; c < 3; ++c) ASSERT_NEAR(ta[c], tb[c], 2e-5);
+        }
+        if (f > 0) {
+            const auto& wa = a.getCanonicalWarpedToLive()->vertices();
+            const auto& wb = b.getCanonicalWarpedToLive()->vertices();
+            ASSERT_EQ(wa.size(), wb.size());
+            for (size_t i = 0; i < wa.size(); i += 17) ASSERT_NEAR(wa[i].z, wb[i].z, 2e-5);
+        }
+    }
+    ASSERT_TRUE(a.getWarpfield()->getNodes().size() > (a.getCanonicalWarpedToLive()->size() + 127) / 128);  // nodes were inserted
+    // getMesh(): the triangle soup of the last frame, downloaded on demand
+    auto mesh = a.getMesh();
+    ASSERT_EQ(mesh->cloud.size(), a.getLiveFrame()->size());
+    ASSERT_EQ(mesh->polygons.size() * 3, mesh->cloud.size());
+    ASSERT_EQ(mesh->cloud[5].x, a.getLiveFrame()->vertices()[5].x);
+}
+
 int main(int argc, char** argv) { return mt::run_all(argc, argv); }

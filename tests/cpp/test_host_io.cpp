@@ -141,8 +141,13 @@ static int run_sequence(const char* dir) {
     dynfu.nodeStep = dim >= 256 ? 128 : 64;
     const SequenceReport r = runSequence(dynfu, dir);
     std::printf("frames %d saved %d dynfu_ms %.2f nodes %zu canonical_vertices %zu mesh_polygons %zu\n", r.frames, r.saved, r.dynfu_ms,
-                dynfu.getWarpfield()->getNodes().size(), dynfu.getCanonicalWarpedToLive()->getVertices().size(),
+                dynfu.getWarpfield()->getNodes().size(), dynfu.getCanonicalWarpedToLive()->size(),
                 dynfu.getMesh()->polygons.size());
+    if (std::getenv("DFA_SEQ_FRAME_MS")) {  // dev: per-frame time inside operator() (tools/host_sequence_timing.py)
+        std::printf("frame_ms");
+        for (double ms : r.frame_ms) std::printf(" %.3f", ms);
+        std::printf("\n");
+    }
     return 0;
 }
 #endif

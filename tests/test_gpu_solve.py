@@ -338,6 +338,38 @@ def test_iterations_behind_a_converged_one_are_no_ops(A, monkeypatch, variant):
     assert np.abs(out[12][0] - t_true).max() < 1e-4  # the regulariser (lambda = 200) moves the optimum by 5e-5
 
 
+@pytest.mark.parametrize("variant", [None, "3"])
+def test_inner_iterations_behind_a_gradient_at_the_floor_are_no_ops(A, monkeypatch, variant):
+    """Budgets shaped like the reference's (dyn_fusion.cpp:183-189: outer x 16 inner iterations): while the robust weights
+    are frozen the energy is linear least squares, so once an inner iteration finds its gradient at the round-off floor
+    the rest of that outer iteration returns at entry; the next outer iteration re-weights and runs again.  Same
+    translations and cost as a solve whose inner budget ends right there, and as the oracle's."""
+    if variant is not None:
+        monkeypatch.setenv("DFA_PCG_VARIANT", variant)
+    cfg, c, verts, live, t_true = _problem("T1")
+    k = cfg["k"]
+    s = A.Solver(cfg["D"], len(verts), k)
+    out = {}
+    for outer, inner in ((2, 3), (2, 12), (1, 16)):
+        s.set_problem(dev(c["node_pos"]), dev(c["node_dq"]), dev(c["node_w"]), dev(verts), dev(live))
+        s.solve(_params(A, num_iter=outer, nonlinear_iter=inner, linear_iter=256, lambda_=200.0, pcg_tol=1e-6))
+        out[(outer, inner)] = (host(s.translations()).copy(), s.stats())
+    s.close()
+    st = out[(2, 12)][1]
+    assert st["gn_iters"] == 24 and out[(1, 16)][1]["gn_iters"] == 16
+    # each outer iteration: one step that solves, at most two more until the gradient is at the floor, the rest no-ops
+    assert st["gn_noop"] >= 2 * 9, st
+    assert out[(1, 16)][1]["gn_noop"] >= 13
+    # the second outer iteration did run (re-weighted): same result as the (2, 3) budget, which has no room for no-ops
+    assert np.abs(out[(2, 12)][0] - out[(2, 3)][0]).max() < 2e-6
+    np.testing.assert_allclose(out[(2, 3)][1]["final_cost"], st["final_cost"], rtol=1e-4)
+    t_ref, _, st_ref = O.solve_ref(c["node_pos"], c["node_dq"], c["node_w"], k, verts, live, num_iter=2, nonlinear_iter=12,
+                                   linear_iter=256, lambda_=200.0, pcg_tol=1e-6, use_double=True, threads=8,
+                                   tukey_offset=synth.SOLVER["tukey_offset"], psi_data=synth.SOLVER["psi_data"],
+                                   psi_reg=synth.SOLVER["psi_reg"])
+    assert np.abs(out[(2, 12)][0] - t_ref).max() <= 2e-5
+
+
 def test_solver_timing_accumulates_pauses_and_resumes(A):
     """dfa_solver_enable_timing: 1 starts a measurement, 0 pauses it, 2 resumes; dfa_solver_get_timing returns the
     sums over the measured solves (bench.py brackets every 8th frame this way)"""

@@ -277,3 +277,35 @@ def test_correspond_projective_errors(A):
         A.correspond_projective(v, None, P, None, 0.0, 1.0, 0.0, 0.0, 0.1, 0.5)  # fx = 0
     ov, on, pix = A.correspond_projective(torch.zeros((0, 3), device="cuda"), None, P, None, 1.0, 1.0, 0.0, 0.0, 0.1, 0.5)
     assert ov.shape == (0, 3) and pix.shape == (0,)
+
+
+# ---- point-cloud plumbing between the seams (csrc/points.hip): bit copies, checked against numpy
+@pytest.mark.parametrize("n", [0, 1, 63, 4096, 4097, 100003])
+@pytest.mark.parametrize("ss,ds", [(4, 3), (3, 4), (3, 3), (4, 4), (5, 7)])
+def test_repack_points_is_a_bit_copy_of_xyz(A, n, ss, ds):
+    rng = np.random.default_rng(n + ss)
+    src = rng.standard_normal((n, ss)).astype(np.float32)
+    if n:
+        src[0, :3] = [np.nan, -0.0, np.inf]
+    out = host(A.repack_points(dev(src), ds, pad=1.0)) if n else np.zeros((0, ds), np.float32)
+    assert out.shape == (n, ds)
+    assert np.array_equal(bits(out[:, :3]), bits(src[:, :3]))
+    assert np.all(out[:, 3:] == 1.0)
+
+
+@pytest.mark.parametrize("n,density", [(0, 0.5), (1, 1.0), (15, 0.5), (4096, 0.0), (4096, 1.0), (4097, 0.01), (70001, 0.3),
+                                        (1 << 20, 0.001), (3 * (1 << 20) + 5, 0.5)])
+def test_compact_points_keeps_flagged_points_in_index_order(A, n, density):
+    import torch
+    rng = np.random.default_rng(n)
+    pts = rng.standard_normal((n, 3)).astype(np.float32)
+    flags = (rng.random(n) < density).astype(np.uint8) * rng.integers(1, 256, n).astype(np.uint8)  # any non-zero value counts
+    out, idx = A.compact_points(dev(pts) if n else None, dev(flags) if n else torch.zeros(0, dtype=torch.uint8, device="cuda"))
+    want = np.flatnonzero(flags)
+    assert np.array_equal(host(idx), want.astype(np.int32))
+    assert np.array_equal(bits(host(out)), bits(pts[want]))
+    # a flag array that does not start on a 16-byte boundary (the kernel's wide loads must not assume it)
+    if n > 100:
+        f2 = dev(flags)[3:]
+        out2, idx2 = A.compact_points(dev(pts[3:]), f2)
+        assert np.array_equal(host(idx2), np.flatnonzero(flags[3:]).astype(np.int32))

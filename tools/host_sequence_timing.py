@@ -15,6 +15,11 @@ with tempfile.TemporaryDirectory() as d:
     for f in range(n):
         Image.fromarray(synth.depth_frame(cfg, f)).save("%s/depth/frame-%06d.depth.png" % (d, f))
         Image.fromarray(np.zeros((4, 4, 3), np.uint8)).save("%s/color/frame-%06d.color.png" % (d, f))
-    env = dict(os.environ, DFA_SEQ_DIM=str(cfg["dim"]))
+    env = dict(os.environ, DFA_SEQ_DIM=str(cfg["dim"]), DFA_SEQ_FRAME_MS="1")
     r = subprocess.run([exe, "sequence", d], capture_output=True, text=True, env=env)
-    print(r.stdout, r.stderr[-500:])
+    print(r.stdout, r.stderr[-3000:])
+    for line in r.stdout.splitlines():
+        if line.startswith("frame_ms"):
+            ms = [float(v) for v in line.split()[1:]]
+            if len(ms) > 2:
+                print("operator() per frame, frames 2..: median %.2f ms, min %.2f ms" % (float(np.median(ms[2:])), min(ms[2:])))
