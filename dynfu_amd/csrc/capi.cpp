@@ -71,8 +71,11 @@ struct GridScratch {
         v         = dfa::KnnGridView{};
         cap_nodes = 0;
     }
-    hipError_t reserve(int D) {
-        if (D <= cap_nodes) return hipSuccess;
+    hipError_t reserve(int D_needed) {
+        if (D_needed <= cap_nodes) return hipSuccess;
+        // a warp field grows by a few nodes per frame: a quarter of headroom, so that growing (hipFree waits for the
+        // device, and a fresh hipMalloc costs milliseconds) happens a handful of times in a sequence, not every frame
+        const int D = D_needed + D_needed / 4 + 64;
         release();
         hipError_t e;
         if ((e = hipMalloc((void**)&v.desc, sizeof(dfa::KnnGridDesc))) != hipSuccess) return e;
@@ -97,8 +100,9 @@ struct PointGridScratch {
         v          = dfa::PointGridView{};
         cap_points = 0;
     }
-    hipError_t reserve(int n) {
-        if (n <= cap_points) return hipSuccess;
+    hipError_t reserve(int n_needed) {
+        if (n_needed <= cap_points) return hipSuccess;
+        const int n = n_needed + n_needed / 4 + 1024;  // clouds of consecutive frames differ by a few per cent (see GridScratch)
         release();
         hipError_t e;
         const size_t cells = dfa::PGRID_MAX_CELLS;
@@ -548,8 +552,9 @@ namespace {
 struct CompactScratch {
     int32_t* chunks = nullptr;
     int cap         = 0;
-    hipError_t reserve(int n) {
-        if (n <= cap) return hipSuccess;
+    hipError_t reserve(int n_needed) {
+        if (n_needed <= cap) return hipSuccess;
+        const int n = n_needed + n_needed / 4 + 16;
         (void)hipFree(chunks);
         chunks = nullptr, cap = 0;
         hipError_t e = hipMalloc((void**)&chunks, sizeof(int32_t) * (size_t)n);

@@ -64,6 +64,7 @@ struct IntegrateArgs {
     Aff3 vol2cam;
     float fx, fy, cx, cy;
     int zchunk;
+    int nt;      // DFA_TSDF_NT=1 (A/B): non-temporal stores in the fused sweep
     int ablate;  // DEV ONLY (DFA_TSDF_ABLATE): 1 every run SKIP, 2 FULL runs filled like FRONT, 3 no classification at all
 };
 
@@ -320,8 +321,13 @@ __global__ __launch_bounds__(256) void integrate_runs_kernel(const IntegrateArgs
                     out[u] = integrate_voxel<true>(a, p[u], 0u, changed);
                 }
             }
+            if (a.nt) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) ptr[slice * u] = out[u];
+                for (int u = 0; u < U; ++u) __builtin_nontemporal_store(out[u], ptr + slice * u);
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) ptr[slice * u] = out[u];
+            }
         } else if (cls != RUN_SKIP) {
             uint32_t cur[U];
 #pragma unroll
@@ -607,6 +613,7 @@ hipError_t launch_tsdf_integrate(bool fused_clear, const uint16_t* dists, int di
     for (int i = 0; i < 3; ++i) a.vol2cam.t[i] = vol2cam[9 + i];
     a.fx = fx, a.fy = fy, a.cx = cx, a.cy = cy;
     a.ablate = getenv("DFA_TSDF_ABLATE") ? atoi(getenv("DFA_TSDF_ABLATE")) : 0;
+    a.nt     = getenv("DFA_TSDF_NT") ? atoi(getenv("DFA_TSDF_NT")) : 0;
     // Default: the run-classified sweep.  DFA_TSDF_LEGACY=1 runs the per-voxel sweep (every voxel through the
     // projection; the round-1 kernel) for A/B timings; DFA_TSDF_WAVE=16 gives a wave a 16 x 4 patch of columns.
     const bool legacy = getenv("DFA_TSDF_LEGACY") != nullptr;

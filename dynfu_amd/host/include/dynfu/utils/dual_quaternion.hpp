@@ -64,9 +64,12 @@ public:
     }
 
     DualQuaternion(T yaw, T pitch, T roll, T x, T y, T z) {  // :48-67
-        T cy = (T)std::cos(yaw * 0.5), sy = (T)std::sin(yaw * 0.5);
-        T cr = (T)std::cos(roll * 0.5), sr = (T)std::sin(roll * 0.5);
-        T cp = (T)std::cos(pitch * 0.5), sp = (T)std::sin(pitch * 0.5);
+        // (cos 0 = 1 and sin 0 = 0 exactly: the pure translations the solver writes back — one per node and frame,
+        // opt_solver.cpp:281 — skip the six libm calls and give the same bits)
+        const bool no_rotation = yaw == T(0) && pitch == T(0) && roll == T(0);
+        T cy = no_rotation ? T(1) : (T)std::cos(yaw * 0.5), sy = no_rotation ? T(0) : (T)std::sin(yaw * 0.5);
+        T cr = no_rotation ? T(1) : (T)std::cos(roll * 0.5), sr = no_rotation ? T(0) : (T)std::sin(roll * 0.5);
+        T cp = no_rotation ? T(1) : (T)std::cos(pitch * 0.5), sp = no_rotation ? T(0) : (T)std::sin(pitch * 0.5);
         dfa::quaternion<T> rotation(cy * cr * cp + sy * sr * sp, cy * sr * cp - sy * cr * sp,
                                     cy * cr * sp + sy * sr * cp, sy * cr * cp - cy * sr * sp);
         DualQuaternion<T> dq(rotation, dfa::Vec3f(x, y, z));
