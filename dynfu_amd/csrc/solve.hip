@@ -592,22 +592,18 @@ __device__ __forceinline__ float block_sum_f(float v, float* red) {
 // are what matters: the prologue counting-sorts the rows by length (wave-uniform loop bounds with
 // almost no padding) and repacks the ELL image rank-major with 16-bit columns — 6 B per non-zero,
 // fully coalesced — into the plan's workspace.
-template <int NT, int RPT, bool FALLBACK_ONLY>
-__global__ __launch_bounds__(NT) void pcg_kernel(SolveView s, SolveState* __restrict__ st, int max_iter,
-                                                   float pcg_tol) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// The whole workgroup (NT threads, NT * RPT >= D) runs this: the body of pcg_kernel below, and the way out of the
+// register-resident kernel when a row pair does not fit its slots (it used to be a second launch behind every
+// register-resident one, which returned at once in the common case: 5 launches per C2 frame).
+template <int NT, int RPT>
+__device__ __forceinline__ void pcg_stream_body(const SolveView& s, SolveState* __restrict__ st, int max_iter, float pcg_tol,
+                                                char* smem) {
     float4* p_s = (float4*)smem;                                      // D entries
     float* red0 = (float*)(smem + sizeof(float4) * (size_t)s.Dpad);  // 2 x 16 wave partials
     float* red1 = red0 + 16;
     int* hist   = (int*)(red1 + 16);                                  // 260 bins
-    if (st->done) return;
-    if (FALLBACK_ONLY && !st->pcg_fallback) return;  // the register-resident kernel handled it
     const int tid = threadIdx.x;
     const int D   = s.D;
-    if (st->converged) {  // no-op iteration (see SolveState::converged)
-        if (tid == 0) st->gn_iters += 1, st->gn_noop += 1;
-        return;
-    }
 
     // ---- rows sorted by length (descending): rank -> row in s.pk_perm
     for (int i = tid; i < 260; i += NT) hist[i] = 0;
@@ -777,6 +773,18 @@ __global__ __launch_bounds__(NT) void pcg_kernel(SolveView s, SolveState* __rest
     }
 }
 
+template <int NT, int RPT>
+__global__ __launch_bounds__(NT) void pcg_kernel(SolveView s, SolveState* __restrict__ st, int max_iter,
+                                                   float pcg_tol) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (st->done) return;
+    if (st->converged) {  // no-op iteration (see SolveState::converged)
+        if (threadIdx.x == 0) st->gn_iters += 1, st->gn_noop += 1;
+        return;
+    }
+    pcg_stream_body<NT, RPT>(s, st, max_iter, pcg_tol, smem);
+}
+
 // ------------------------------------------------------------------------------------------
 // PCG with the WHOLE matrix in registers (D <= 2 * NT rows).
 //
@@ -814,7 +822,7 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
     if (st->done) return;
     const int tid = threadIdx.x;
     if (st->converged) {  // no-op iteration (see SolveState::converged); booked once, by whoever solves this plan
-        if (tid == 0 && blockIdx.x == 0 && !st->pcg_fallback) st->gn_iters += 1, st->gn_noop += 1;
+        if (tid == 0 && blockIdx.x == 0) st->gn_iters += 1, st->gn_noop += 1;
         return;
     }
     constexpr int R = 2 * P;  // rows per thread
@@ -840,7 +848,6 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
     if (skip) {  // the same decision in every workgroup; the first one books the (empty) iteration
         if (tid == 0 && blockIdx.x == 0) {
             st->gn_iters += 1;
-            st->pcg_fallback = 0;  // nothing left for the streaming kernel launched behind this one
             solve_mark_at_floor(st);
         }
         return;
@@ -886,9 +893,7 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
     __syncthreads();
 
     // ---- this thread's pairs: pair j = rank j*NT + t (long, "A") and rank D-1-j*NT-t (short, "B")
-    int rowA[P], rowB[P], nA[P], nB[P];
-    float mval[P][E];
-    uint32_t mcol[P][E / 2];
+    int rowA[P], rowB[P], nA[P], nB[P], cntA_[P], cntB_[P];
     bool unfit_any = false;
 #pragma unroll
     for (int j = 0; j < P; ++j) {
@@ -897,6 +902,7 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
         rowB[j]      = (ib >= 0 && ib > ia) ? perm[ib] : -1;
         const int cntA = rowA[j] >= 0 ? min(s.ell_cnt[rowA[j]], 256) : 0;
         const int cntB = rowB[j] >= 0 ? min(s.ell_cnt[rowB[j]], 256) : 0;
+        cntA_[j] = cntA, cntB_[j] = cntB;
         int na         = min(cntA, E);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) na = max(na, __shfl_xor(na, o, 64));
@@ -910,6 +916,21 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
         // PCG loop become scalar branches instead of per-lane selects over both accumulators
         nA[j] = __builtin_amdgcn_readfirstlane(na), nB[j] = __builtin_amdgcn_readfirstlane(min((nb + 1) & ~1, capB));
         unfit_any |= cntA > E || cntB > capB;
+    }
+    // A pair that does not fit E slots (k = 8 graphs always, k = 4 hardly ever): the system is streamed from L2 instead,
+    // all three coordinates by the first workgroup — decided from the row lengths alone, before any matrix entry is
+    // loaded, and inside this launch.
+    if (__syncthreads_or(unfit_any)) {
+        if (NC == 3 || blockIdx.x == 0) pcg_stream_body<NT, 2 * P>(s, st, max_iter, pcg_tol, smem);
+        return;
+    }
+    float mval[P][E];
+    uint32_t mcol[P][E / 2];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const int cntA = cntA_[j], cntB = cntB_[j];
+        const int na = nA[j];
+        const int regB = min(cntB, E - na);
         const int rA = rowA[j] >= 0 ? rowA[j] : 0, rB = rowB[j] >= 0 ? rowB[j] : 0;
         // values and columns -> registers for the whole solve (slot q: entry q of A for q < nA, entry
         // E-1-q of B otherwise); two 16-bit columns per register
@@ -934,11 +955,6 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
             if ((q2 & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the loads in flight
         }
     }
-    // a pair that does not fit E slots: leave the system to the streaming kernel launched next
-    const int unfit = __syncthreads_or(unfit_any);
-    if (tid == 0) st->pcg_fallback = unfit;
-    if (unfit) return;
-
     float xA[P][NC], rA_[P][NC], pA[P][NC], xB[P][NC], rB_[P][NC], pB[P][NC], minvA[P], minvB[P];
 #pragma unroll
     for (int j = 0; j < P; ++j) {
@@ -1673,14 +1689,14 @@ static hipError_t allow_big_lds(Kernel* k, bool& done) {
 }
 
 // streaming kernel (matrix re-read from L2 every iteration): 1024 threads, RPT rows per thread
-template <int RPT, bool FALLBACK_ONLY>
+template <int RPT>
 static hipError_t launch_streaming_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol,
                                        hipStream_t st) {
     static bool attr = false;
-    hipError_t e     = allow_big_lds(pcg_kernel<1024, RPT, FALLBACK_ONLY>, attr);
+    hipError_t e     = allow_big_lds(pcg_kernel<1024, RPT>, attr);
     if (e != hipSuccess) return e;
     const size_t shmem = sizeof(float4) * (size_t)s.Dpad + 32 * sizeof(float) + 260 * sizeof(int);
-    pcg_kernel<1024, RPT, FALLBACK_ONLY><<<1, 1024, shmem, st>>>(s, state, max_iter, pcg_tol);
+    pcg_kernel<1024, RPT><<<1, 1024, shmem, st>>>(s, state, max_iter, pcg_tol);
     return hipGetLastError();
 }
 
@@ -1720,9 +1736,8 @@ static hipError_t route_pcg(const SolveView& s, SolveState* state, int max_iter,
     if (v2 == 3) return launch_mb_pcg(s, state, max_iter, pcg_tol, host_flag, gc, st);
     if (D <= 2048 && !force_streaming) {
         // Register-resident matrix.  512 threads leave 256 VGPRs per lane (64 slots per row pair: k = 8
-        // rows fit), 1024 threads 128 VGPRs (32 slots: k = 4).  A pair that does not fit sets
-        // state->pcg_fallback and the streaming kernel launched right behind takes over; otherwise that
-        // launch returns at once.
+        // rows fit), 1024 threads 128 VGPRs (32 slots: k = 4).  A pair that does not fit sends the launch down the
+        // streaming path (pcg_stream_body) instead.
         // The three coordinates are solved by three workgroups (see the kernel); DFA_PCG_VARIANT=1 keeps them in one
         // workgroup with shared CG scalars (A/B and the comparison point of the tests).
         if (D <= 1024 && v2 == 1) e = launch_paired_pcg<512, 1, 64, 3>(s, state, max_iter, pcg_tol, st);
@@ -1731,19 +1746,16 @@ static hipError_t route_pcg(const SolveView& s, SolveState* state, int max_iter,
         else if (v2 == 1) e = launch_paired_pcg<1024, 1, 32, 3>(s, state, max_iter, pcg_tol, st);
         else if (v2 == 5) e = launch_paired_pcg<512, 2, 32, 1>(s, state, max_iter, pcg_tol, st);
         else e = launch_paired_pcg<1024, 1, 32, 1>(s, state, max_iter, pcg_tol, st);
-        if (e != hipSuccess) return e;
-        if (main_done) (void)hipEventRecord(main_done, st), main_done = nullptr;
-        if (D <= 1024) return launch_streaming_pcg<1, true>(s, state, max_iter, pcg_tol, st);
-        return launch_streaming_pcg<2, true>(s, state, max_iter, pcg_tol, st);
+        return e;  // (a system that does not fit the registers is streamed inside the same launch)
     }
-    if (D <= 1024) return launch_streaming_pcg<1, false>(s, state, max_iter, pcg_tol, st);
-    if (D <= 2048) return launch_streaming_pcg<2, false>(s, state, max_iter, pcg_tol, st);
+    if (D <= 1024) return launch_streaming_pcg<1>(s, state, max_iter, pcg_tol, st);
+    if (D <= 2048) return launch_streaming_pcg<2>(s, state, max_iter, pcg_tol, st);
     // Above 2048 nodes the single-workgroup streaming kernel spends ~1 ms per launch sorting and repacking the matrix
     // by itself (measured: 1.2 ms per launch at 8 k nodes for ~12 iterations); the many-workgroup PCG reads the
     // assembled ELL directly.  DFA_PCG_VARIANT=4 keeps the streaming kernel (A/B), possible up to 8192 nodes.
     const bool keep_streaming = v2 == 4;
-    if (keep_streaming && D <= 4096) return launch_streaming_pcg<4, false>(s, state, max_iter, pcg_tol, st);
-    if (keep_streaming && D <= 8192) return launch_streaming_pcg<8, false>(s, state, max_iter, pcg_tol, st);
+    if (keep_streaming && D <= 4096) return launch_streaming_pcg<4>(s, state, max_iter, pcg_tol, st);
+    if (keep_streaming && D <= 8192) return launch_streaming_pcg<8>(s, state, max_iter, pcg_tol, st);
     return launch_mb_pcg(s, state, max_iter, pcg_tol, host_flag, gc, st);
 }
 

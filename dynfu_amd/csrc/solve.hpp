@@ -17,7 +17,7 @@ struct SolveState {
     int pcg_iters;
     int max_row_nnz;
     int overflow;       // a row of the normal matrix did not fit the plan's ELL capacity
-    int pcg_fallback;   // set by the register-resident PCG when a row pair exceeds its slots
+    int pcg_fallback;   // (unused since the streaming path runs inside the register-resident launch; keeps the layout)
     int split_iters;    // per-coordinate PCG: most iterations any coordinate took in the launch in flight
     unsigned int split_ticket;  // ... and how many of its three workgroups have finished
     // multi-workgroup PCG: flags and scalars carried from one launch to the next
