@@ -756,11 +756,12 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
     s->mb_graphs.call = 0;
     int not_launched = 0;  // iterations after the host has seen the converged flag (many-workgroup path only)
     int gn_launched = 0;  // Gauss-Newton iterations whose assembly has been enqueued
+    bool huber_done = false;
     const bool big_budget = (long)p->num_iter * p->nonlinear_iter > 8;
     for (int outer = 0; outer < p->num_iter; ++outer) {
         // preNonlinearSolve (opt_solver.cpp:135-140): the Huber weights are only observable after
         // the solve, so they are evaluated for the last outer iteration alone
-        if (outer == p->num_iter - 1) HIP_TRY(dfa::solve_huber(v, p->psi_reg, st));
+        // (folded into that iteration's first linearisation; a launch of its own only if that one is never enqueued)
         // converged == 2 (gradient at the floor under stale weights) ended the inner iterations of the outer iteration
         // before only: this one re-weights, and its first linearisation clears the flag on the device
         if (s->host_flag && s->host_flag[1] == 2) s->host_flag[1] = 0;
@@ -779,8 +780,10 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
                 continue;
             }
             ++gn_in_outer;
+            const bool with_huber = gn == 0 && outer == p->num_iter - 1;
             HIP_TRY(dfa::solve_linearise(v, s->state, s->cost_partials, s->ticket, gn == 0, gn == 0 ? 0 : 1,
-                                         p->gn_tol, p->tukey_offset, p->psi_data, w_reg_sq, st));
+                                         p->gn_tol, p->tukey_offset, p->psi_data, w_reg_sq, with_huber ? p->psi_reg : 0.f, st));
+            huber_done |= with_huber;
             int ev = s->timing ? timing_begin(s, st) : -1;
             HIP_TRY(dfa::solve_assemble(v, s->state, st));
             timing_end(s, ev, st);
@@ -798,9 +801,9 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
     if (not_launched) HIP_TRY(dfa::solve_count_noop(s->state, not_launched, st));
     // final cost at the solved t; weights re-evaluated only if no iteration ever did
     const bool no_weights = p->num_iter == 0 || p->nonlinear_iter == 0;
-    if (p->num_iter == 0) HIP_TRY(dfa::solve_huber(v, p->psi_reg, st));
+    if (!huber_done) HIP_TRY(dfa::solve_huber(v, p->psi_reg, st));  // no outer iteration, or the host stopped launching before the last
     HIP_TRY(dfa::solve_linearise(v, s->state, s->cost_partials, s->ticket, no_weights ? 1 : 0, 2, 0.f,
-                                 p->tukey_offset, p->psi_data, w_reg_sq, st));
+                                 p->tukey_offset, p->psi_data, w_reg_sq, 0.f, st));
     // postSingleSolve -> copyResultToCPUFromFloat3 (opt_solver.cpp:133,270-285), composed once
     HIP_TRY(dfa::solve_writeback(v, s->state, s->timing ? s->iters_total : nullptr, st));
     return DFA_OK;

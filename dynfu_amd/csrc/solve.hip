@@ -155,10 +155,35 @@ __device__ __forceinline__ float tukey_weight(const SolveView& s, size_t v, floa
     return 0.f;
 }
 
+// Huber weights (opt_solver.cpp:233-268): computed for interface parity, energy.t:70 never uses them
+__device__ __forceinline__ void huber_node(const SolveView& s, int i, float psi_reg) {
+    const DQ dq_i = dq_mul(dq_from_translation(s.t[3 * i], s.t[3 * i + 1], s.t[3 * i + 2]),
+                           dq_load(s.node_dq + 8 * (size_t)i));
+    float h = 0.f;
+    for (int j = 0; j < s.k; ++j) {
+        const int m = s.reg_idx[(size_t)i * s.k + j];
+        if (m < 0) break;
+        const f3 pm   = mk3(s.node_pos[3 * m], s.node_pos[3 * m + 1], s.node_pos[3 * m + 2]);
+        const DQ dq_m = dq_mul(dq_from_translation(s.t[3 * m], s.t[3 * m + 1], s.t[3 * m + 2]),
+                               dq_load(s.node_dq + 8 * (size_t)m));
+        const f3 pa = dq_transform(dq_i, pm), pb = dq_transform(dq_m, pm);
+        const float ex = pa.x - pb.x, ey = pa.y - pb.y, ez = pa.z - pb.z;
+        const float err = sqrtf(ex * ex + ey * ey + ez * ez);
+        h               = fabsf(err) <= psi_reg ? 1.f : psi_reg / fabsf(err);  // last neighbour wins (:263)
+    }
+    s.huber[i] = h;
+}
+__global__ __launch_bounds__(256) void huber_kernel(SolveView s, float psi_reg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < s.D) huber_node(s, i, psi_reg);
+}
+
 struct LineariseArgs {
     int update_weights;  // first linearisation of an outer iteration
     int mode;            // 0 first of outer, 1 later GN iteration, 2 final cost only
     float gn_tol, tukey_offset, psi_data, w_reg_sq;
+    float huber_psi;  // > 0: also evaluate the nodes' Huber weights at the current t (the last outer iteration's
+                      // preNonlinearSolve, opt_solver.cpp:135-140; a launch of its own before)
 };
 
 constexpr int LIN_SHARDS     = 32;    // ticket counters: one device-scope atomic costs ~11 ns when
@@ -171,9 +196,14 @@ __global__ __launch_bounds__(256) void linearise_kernel(SolveView s, SolveState*
                                                         LineariseArgs a) {
     __shared__ double wsum[4];
     __shared__ int is_last;
-    // after convergence t no longer changes: weights, residual records and cost of this linearisation exist already
-    // (mode 2, the solve's closing evaluation, always runs)
-    if (a.mode != 2 && (st->converged == 1 || (st->converged && !a.update_weights))) return;
+    if (a.huber_psi > 0.f)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < s.D; i += gridDim.x * blockDim.x) huber_node(s, i, a.huber_psi);
+    // after convergence t no longer changes: weights, residual records and cost of this linearisation exist already.
+    // That includes the solve's closing evaluation (mode 2) when an iteration ran: the flag is set by a PCG that found
+    // its gradient at the floor and left t where the linearisation before it had evaluated the cost.
+    if (st->converged == 1 || (st->converged && !a.update_weights)) {
+        if (a.mode != 2 || st->have_initial) return;
+    }
     const size_t R = (size_t)s.N + (size_t)s.D * s.k;
     double c       = 0.0;
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (size_t)gridDim.x * blockDim.x) {
@@ -264,27 +294,6 @@ __global__ __launch_bounds__(256) void reset_kernel(float* __restrict__ t, int n
         for (int j = threadIdx.x; j < (int)(sizeof(SolveState) / 4); j += blockDim.x) w[j] = 0u;
         for (int j = threadIdx.x; j < nticket; j += blockDim.x) ticket[j] = 0u;
     }
-}
-
-// Huber weights (opt_solver.cpp:233-268): computed for interface parity, energy.t:70 never uses them
-__global__ __launch_bounds__(256) void huber_kernel(SolveView s, float psi_reg) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= s.D) return;
-    const DQ dq_i = dq_mul(dq_from_translation(s.t[3 * i], s.t[3 * i + 1], s.t[3 * i + 2]),
-                           dq_load(s.node_dq + 8 * (size_t)i));
-    float h = 0.f;
-    for (int j = 0; j < s.k; ++j) {
-        const int m = s.reg_idx[(size_t)i * s.k + j];
-        if (m < 0) break;
-        const f3 pm   = mk3(s.node_pos[3 * m], s.node_pos[3 * m + 1], s.node_pos[3 * m + 2]);
-        const DQ dq_m = dq_mul(dq_from_translation(s.t[3 * m], s.t[3 * m + 1], s.t[3 * m + 2]),
-                               dq_load(s.node_dq + 8 * (size_t)m));
-        const f3 pa = dq_transform(dq_i, pm), pb = dq_transform(dq_m, pm);
-        const float ex = pa.x - pb.x, ey = pa.y - pb.y, ez = pa.z - pb.z;
-        const float err = sqrtf(ex * ex + ey * ey + ez * ez);
-        h               = fabsf(err) <= psi_reg ? 1.f : psi_reg / fabsf(err);  // last neighbour wins (:263)
-    }
-    s.huber[i] = h;
 }
 
 // The per-problem row set-up as ONE launch, a thread per row: regularisation rows (opt_solver.cpp:74-105), right-hand
@@ -1275,9 +1284,9 @@ int solve_residual_blocks(const SolveView& s) {
 
 hipError_t solve_linearise(const SolveView& s, SolveState* state, double* cost_partials, unsigned int* ticket,
                            int update_weights, int mode, float gn_tol, float tukey_offset, float psi_data,
-                           float w_reg_sq, hipStream_t st) {
+                           float w_reg_sq, float huber_psi, hipStream_t st) {
     const int nb = solve_residual_blocks(s);
-    LineariseArgs a{update_weights, mode, gn_tol, tukey_offset, psi_data, w_reg_sq};
+    LineariseArgs a{update_weights, mode, gn_tol, tukey_offset, psi_data, w_reg_sq, huber_psi};
     KDISPATCH(linearise_kernel, s.k, <<<nb, 256, 0, st>>>(s, state, cost_partials, ticket, a));
     return hipGetLastError();
 }

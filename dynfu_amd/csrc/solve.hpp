@@ -100,7 +100,7 @@ int solve_residual_blocks(const SolveView& s);
 // robust weights (optional) + residuals + cost + Gauss-Newton control, one launch
 hipError_t solve_linearise(const SolveView& s, SolveState* state, double* cost_partials, unsigned int* ticket,
                            int update_weights, int mode, float gn_tol, float tukey_offset, float psi_data,
-                           float w_reg_sq, hipStream_t st);
+                           float w_reg_sq, float huber_psi /* > 0: Huber weights too */, hipStream_t st);
 hipError_t solve_huber(const SolveView& s, float psi_reg, hipStream_t st);
 hipError_t solve_reset(const SolveView& s, SolveState* state, unsigned int* ticket, int nticket, hipStream_t st);
 hipError_t solve_assemble(const SolveView& s, SolveState* state, hipStream_t st);
