@@ -782,7 +782,7 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
             ++gn_in_outer;
             const bool with_huber = gn == 0 && outer == p->num_iter - 1;
             HIP_TRY(dfa::solve_linearise(v, s->state, s->cost_partials, s->ticket, gn == 0, gn == 0 ? 0 : 1,
-                                         p->gn_tol, p->tukey_offset, p->psi_data, w_reg_sq, with_huber ? p->psi_reg : 0.f, st));
+                                         p->gn_tol, p->tukey_offset, p->psi_data, w_reg_sq, with_huber ? p->psi_reg : 0.f, nullptr, st));
             huber_done |= with_huber;
             int ev = s->timing ? timing_begin(s, st) : -1;
             HIP_TRY(dfa::solve_assemble(v, s->state, st));
@@ -803,9 +803,8 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
     const bool no_weights = p->num_iter == 0 || p->nonlinear_iter == 0;
     if (!huber_done) HIP_TRY(dfa::solve_huber(v, p->psi_reg, st));  // no outer iteration, or the host stopped launching before the last
     HIP_TRY(dfa::solve_linearise(v, s->state, s->cost_partials, s->ticket, no_weights ? 1 : 0, 2, 0.f,
-                                 p->tukey_offset, p->psi_data, w_reg_sq, 0.f, st));
-    // postSingleSolve -> copyResultToCPUFromFloat3 (opt_solver.cpp:133,270-285), composed once
-    HIP_TRY(dfa::solve_writeback(v, s->state, s->timing ? s->iters_total : nullptr, st));
+                                 p->tukey_offset, p->psi_data, w_reg_sq, 0.f, s->timing ? s->iters_total : nullptr, st));
+    // (postSingleSolve -> copyResultToCPUFromFloat3, opt_solver.cpp:133,270-285: composed once, by that same launch)
     return DFA_OK;
 }
 

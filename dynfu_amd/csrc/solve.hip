@@ -182,6 +182,7 @@ struct LineariseArgs {
     int update_weights;  // first linearisation of an outer iteration
     int mode;            // 0 first of outer, 1 later GN iteration, 2 final cost only
     float gn_tol, tukey_offset, psi_data, w_reg_sq;
+    long long* iters_total;  // mode 2, optional (device): += the solve's PCG iterations
     float huber_psi;  // > 0: also evaluate the nodes' Huber weights at the current t (the last outer iteration's
                       // preNonlinearSolve, opt_solver.cpp:135-140; a launch of its own before)
 };
@@ -198,6 +199,16 @@ __global__ __launch_bounds__(256) void linearise_kernel(SolveView s, SolveState*
     __shared__ int is_last;
     if (a.huber_psi > 0.f)
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < s.D; i += gridDim.x * blockDim.x) huber_node(s, i, a.huber_psi);
+    if (a.mode == 2) {
+        // the closing evaluation also composes the result: dg_se3_i <- DQ(0,0,0,t_i) * dg_se3_i (opt_solver.cpp:270-285,
+        // node.cpp:19-23) — t is final here; a launch of its own before
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < s.D; i += gridDim.x * blockDim.x) {
+            const DQ out = dq_mul(dq_from_translation(s.t[3 * i], s.t[3 * i + 1], s.t[3 * i + 2]),
+                                  dq_load(s.node_dq + 8 * (size_t)i));
+            dq_store(s.node_dq_out + 8 * (size_t)i, out);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0 && a.iters_total) *a.iters_total += st->pcg_iters;
+    }
     // after convergence t no longer changes: weights, residual records and cost of this linearisation exist already.
     // That includes the solve's closing evaluation (mode 2) when an iteration ran: the flag is set by a PCG that found
     // its gradient at the floor and left t where the linearisation before it had evaluated the cost.
@@ -1233,18 +1244,6 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
 }
 
 // ------------------------------------------------------------------------------------------
-// write-back: dg_se3_i <- DQ(0,0,0,t_i) * dg_se3_i  (opt_solver.cpp:270-285, node.cpp:19-23)
-__global__ __launch_bounds__(256) void writeback_kernel(SolveView s, const SolveState* __restrict__ st,
-                                                        long long* __restrict__ iters_total) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0 && iters_total) *iters_total += st->pcg_iters;
-    if (i >= s.D) return;
-    const DQ out = dq_mul(dq_from_translation(s.t[3 * i], s.t[3 * i + 1], s.t[3 * i + 2]),
-                          dq_load(s.node_dq + 8 * (size_t)i));
-    dq_store(s.node_dq_out + 8 * (size_t)i, out);
-}
-
-// ------------------------------------------------------------------------------------------
 // launchers
 
 #define KDISPATCH(kernel, k, ...)                      \
@@ -1284,9 +1283,9 @@ int solve_residual_blocks(const SolveView& s) {
 
 hipError_t solve_linearise(const SolveView& s, SolveState* state, double* cost_partials, unsigned int* ticket,
                            int update_weights, int mode, float gn_tol, float tukey_offset, float psi_data,
-                           float w_reg_sq, float huber_psi, hipStream_t st) {
+                           float w_reg_sq, float huber_psi, long long* iters_total, hipStream_t st) {
     const int nb = solve_residual_blocks(s);
-    LineariseArgs a{update_weights, mode, gn_tol, tukey_offset, psi_data, w_reg_sq, huber_psi};
+    LineariseArgs a{update_weights, mode, gn_tol, tukey_offset, psi_data, w_reg_sq, iters_total, huber_psi};
     KDISPATCH(linearise_kernel, s.k, <<<nb, 256, 0, st>>>(s, state, cost_partials, ticket, a));
     return hipGetLastError();
 }
@@ -1781,9 +1780,5 @@ hipError_t solve_count_noop(SolveState* state, int n, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t solve_writeback(const SolveView& s, const SolveState* state, long long* iters_total, hipStream_t st) {
-    writeback_kernel<<<(s.D + 255) / 256, 256, 0, st>>>(s, state, iters_total);
-    return hipGetLastError();
-}
 
 }  // namespace dfa

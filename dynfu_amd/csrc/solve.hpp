@@ -100,7 +100,8 @@ int solve_residual_blocks(const SolveView& s);
 // robust weights (optional) + residuals + cost + Gauss-Newton control, one launch
 hipError_t solve_linearise(const SolveView& s, SolveState* state, double* cost_partials, unsigned int* ticket,
                            int update_weights, int mode, float gn_tol, float tukey_offset, float psi_data,
-                           float w_reg_sq, float huber_psi /* > 0: Huber weights too */, hipStream_t st);
+                           float w_reg_sq, float huber_psi /* > 0: the nodes' Huber weights too */,
+                           long long* iters_total /* mode 2: += the solve's PCG iterations (optional, device) */, hipStream_t st);
 hipError_t solve_huber(const SolveView& s, float psi_reg, hipStream_t st);
 hipError_t solve_reset(const SolveView& s, SolveState* state, unsigned int* ticket, int nticket, hipStream_t st);
 hipError_t solve_assemble(const SolveView& s, SolveState* state, hipStream_t st);
@@ -137,7 +138,5 @@ hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float 
                      hipStream_t st);
 // books n Gauss-Newton iterations that the host did not launch because the plan had converged (SolveState::converged)
 hipError_t solve_count_noop(SolveState* state, int n, hipStream_t st);
-// also adds the solve's PCG iterations to *iters_total (optional, device)
-hipError_t solve_writeback(const SolveView& s, const SolveState* state, long long* iters_total, hipStream_t st);
 
 }  // namespace dfa
