@@ -33,13 +33,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 for wide reads + WRITE_SIZE, corrected as
 # MI355X_MICROARCH.md prescribes) — profiles/r02_pmc_tsdf.md.  Collected offline: PMC needs its own runs.
 TIMING_SAMPLE = 8  # every 8th timed frame carries the hipEvent brackets of the per-kernel report
-PMC_TRAFFIC_BYTES = {# profiles/r02_pmc_tsdf.md: integrate_runs_kernel<true,32,8>, WRITE 524 288 KiB + 2 x FETCH 2 337 KiB (C4: 4 194 304 + 2 x 23 775)
+PMC_TRAFFIC_BYTES = {# profiles/r02d_pmc_bench_c2.md: integrate_runs_kernel<true,32,8>, WRITE 524 288 KiB + 2 x FETCH 2 368 KiB (C4, profiles/r02_pmc_tsdf.md: 4 194 304 + 2 x 23 775)
                      ("C2", "fused_integrate"): 0.5417e9, ("C3", "fused_integrate"): 0.5417e9, ("C4", "fused_integrate"): 4.344e9,
                      # profiles/r01_pmc_northstar.md (FETCH x2 + WRITE per dispatch)
                      ("C3", "s6_assemble"): 0.510e9, ("C3", "s6_pcg_step"): 0.0242e9,
-                     # profiles/r02_pmc_solve.md: (340.8 + 276.1) KiB per pcg_paired_kernel<1024,1,32,1> launch, mean over
+                     # profiles/r02d_pmc_bench_c2.md: (340.7 + 275.9) KiB per pcg_paired_kernel<1024,1,32,1> launch, mean over
                      # the five launches of a frame (those that return at entry included)
-                     ("C2", "pcg"): 616.9 * 1024}
+                     ("C2", "pcg"): 616.6 * 1024}
 
 
 def parse():
@@ -574,14 +574,14 @@ def main():
                              "against min/max tiles of the depth image)" % dim, bound="hbm",
                       achieved=round(fuse_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(fuse_gbs / HBM_PEAK_GBS, 4),
                       traffic=PMC_TRAFFIC_BYTES.get((args.config, "fused_integrate")),
-                      traffic_source="profiles/r02_pmc_tsdf.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                      traffic_source="profiles/r02d_pmc_bench_c2.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                       avg_launch_ms=round(fuse_ms, 4), launches_per_frame=1, algorithmic_bytes_per_launch=fuse_bytes)
     split = seq.D <= 2048  # register-resident kernel, one workgroup per coordinate
     pcg_entry = dict(kernel=("pcg_paired_kernel<..,NC=1> (Jacobi PCG, matrix in registers, 3 workgroups = 3 coordinates)" if split
                              else "pcg_mb_* (many-workgroup Jacobi PCG)"), bound="hbm",
                      achieved=round(pcg_gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(pcg_gbs / HBM_PEAK_GBS, 6),
                      traffic=PMC_TRAFFIC_BYTES.get((args.config, "pcg")),
-                     traffic_source="profiles/r02_pmc_solve.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes): "
+                     traffic_source="profiles/r02d_pmc_bench_c2.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes): "
                                     "per launch; every workgroup reads the matrix once and keeps it in registers",
                      algorithmic_bytes_per_launch=round(pcg_bytes / max(1e-9, launches_pf), 1),
                      avg_launch_ms=round(pcg_total_ms / max(1e-9, launches_pf), 4),
