@@ -10,7 +10,7 @@ _LIB = None
 SYMBOLS = [
     "dfa_last_error", "dfa_version", "dfa_compute_dists", "dfa_tsdf_clear", "dfa_tsdf_integrate",
     "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_tsdf_vertex_normals", "dfa_correspond_projective", "dfa_knn", "dfa_warp_to_live",
-    "dfa_calc_dqb", "dfa_unsupported_vertices", "dfa_icp_sums", "dfa_repack_points", "dfa_compact_points",
+    "dfa_calc_dqb", "dfa_unsupported_vertices", "dfa_icp_sums", "dfa_repack_points", "dfa_compact_points", "dfa_transform_points",
     "dfa_correspond", "dfa_marching_cubes", "dfa_mc_default_tables",
     "dfa_depth_bilateral_filter", "dfa_depth_truncate", "dfa_depth_build_pyramid", "dfa_compute_normals_mask_depth",
     "dfa_resize_depth_normals", "dfa_resize_points_normals",
@@ -133,6 +133,7 @@ def load():
     L.dfa_correspond.argtypes = [vp, vp, i, vp, i, vp, vp, vp, vp]
     L.dfa_repack_points.argtypes = [vp, i, vp, i, i, C.c_float, vp]
     L.dfa_compact_points.argtypes = [vp, vp, i, vp, vp, vp, vp]
+    L.dfa_transform_points.argtypes = [vp, i, C.POINTER(C.c_float), i, vp, vp]
     L.dfa_solver_create.argtypes = [i, i, i, C.POINTER(vp)]
     L.dfa_solver_destroy.argtypes = [vp]
     L.dfa_solver_destroy.restype = None
@@ -374,6 +375,15 @@ def repack_points(src, dst_stride, pad=1.0):
     dst = torch.empty((n, dst_stride), dtype=torch.float32, device=src.device)
     _check(load().dfa_repack_points(_dev(src, torch.float32, "src"), s, dst.data_ptr(), dst_stride, n, pad, _stream()))
     return dst
+
+
+def transform_points(points, aff12, with_translation=True):
+    """R p (+ t) of (n, 3) points (dfa_transform_points); aff12 = R row-major then t"""
+    torch = _torch()
+    out = torch.empty_like(points)
+    _check(load().dfa_transform_points(_dev(points, torch.float32, "points"), points.shape[0], _farr(aff12, 12),
+                                       1 if with_translation else 0, out.data_ptr(), _stream()))
+    return out
 
 
 def compact_points(points, flags, want_index=True):

@@ -71,7 +71,7 @@ def build(force=False, verbose=False):
 
 HOST = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(HERE, "libdynfu_amd_host.so")
-HOST_SOURCES = ["device.cpp", "frame.cpp", "tsdf_volume.cpp", "warp_field.cpp", "opt_solver.cpp", "dyn_fusion.cpp",
+HOST_SOURCES = ["device.cpp", "frame.cpp", "tsdf_volume.cpp", "warp_field.cpp", "opt_solver.cpp", "northstar_solver.cpp", "dyn_fusion.cpp",
                 "marching_cubes.cpp", "imgproc.cpp", "projective_icp.cpp", "io.cpp", "kinfu.cpp"]
 
 

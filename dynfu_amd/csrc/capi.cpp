@@ -548,6 +548,14 @@ int dfa_repack_points(const float* src, int src_stride, float* dst, int dst_stri
     return DFA_OK;
 }
 
+int dfa_transform_points(const float* points, int n, const float aff[12], int with_translation, float* out,
+                         dfa_stream_t stream) {
+    REQUIRE(n >= 0 && (n == 0 || (points && out)), "bad points");
+    REQUIRE(aff, "null transform");
+    HIP_TRY(dfa::launch_transform_points(points, n, aff, with_translation != 0, out, S(stream)));
+    return DFA_OK;
+}
+
 namespace {
 struct CompactScratch {
     int32_t* chunks = nullptr;

@@ -79,6 +79,7 @@ hipError_t launch_warp_graph(const float* node_pos, const float* node_dq, const 
 
 // points.hip
 hipError_t launch_repack_points(const float* src, int sstride, float* dst, int dstride, int n, float pad, hipStream_t s);
+hipError_t launch_transform_points(const float* in, int n, const float aff[12], bool with_translation, float* out, hipStream_t s);
 int compact_chunks(int n);  // entries of chunk_scratch
 hipError_t launch_compact_points(const float* pts, const uint8_t* flags, int n, float* out_pts, int32_t* out_idx,
                                  int32_t* count, int32_t* chunk_scratch, hipStream_t s);

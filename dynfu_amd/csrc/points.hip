@@ -1,7 +1,8 @@
-// points.hip — point-cloud plumbing between the seams: strided re-packing of xyz triples and order-preserving
-// stream compaction.  The reference does both with host loops over pcl::PointCloud (pcl::copyPointCloud,
-// dyn_fusion.cpp:80-88; the push_back loop of Warpfield::getUnsupportedVertices, warp_field.cpp:42-59); with the
-// clouds resident in HBM they are two small HBM-bound kernels.  No arithmetic: bit copies only.
+// points.hip — point-cloud plumbing between the seams: strided re-packing of xyz triples, order-preserving stream
+// compaction and the affine map of a cloud.  The reference does these with host loops over pcl::PointCloud
+// (pcl::copyPointCloud, dyn_fusion.cpp:80-88; the push_back loop of Warpfield::getUnsupportedVertices,
+// warp_field.cpp:42-59); with the clouds resident in HBM they are small HBM-bound kernels.  Bit copies, except the affine
+// map (three multiply-adds per coordinate in a fixed order).
 #include "kernels.hpp"
 
 namespace dfa {
@@ -31,6 +32,26 @@ __global__ void __launch_bounds__(256) repack_points_kernel(const float* __restr
 hipError_t launch_repack_points(const float* src, int sstride, float* dst, int dstride, int n, float pad, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     repack_points_kernel<<<(n + 255) / 256, 256, 0, s>>>(src, sstride, dst, dstride, n, pad);
+    return hipGetLastError();
+}
+
+// out = R p (+ t): one lane per point, packed n x 3 in and out (in == out allowed).  Plain multiply-adds in a fixed order
+// ((R0 x + R1 y) + R2 z) + t, no contraction: the same bits as the host loop it replaces.
+__global__ void __launch_bounds__(256) transform_points_kernel(const float* __restrict__ in, int n, float r0, float r1, float r2,
+                                                               float r3, float r4, float r5, float r6, float r7, float r8,
+                                                               float tx, float ty, float tz, int with_t, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = in[3 * (size_t)i], y = in[3 * (size_t)i + 1], z = in[3 * (size_t)i + 2];
+    float ox = (r0 * x + r1 * y) + r2 * z, oy = (r3 * x + r4 * y) + r5 * z, oz = (r6 * x + r7 * y) + r8 * z;
+    if (with_t) ox += tx, oy += ty, oz += tz;
+    out[3 * (size_t)i] = ox, out[3 * (size_t)i + 1] = oy, out[3 * (size_t)i + 2] = oz;
+}
+
+hipError_t launch_transform_points(const float* in, int n, const float aff[12], bool with_translation, float* out, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    transform_points_kernel<<<(n + 255) / 256, 256, 0, s>>>(in, n, aff[0], aff[1], aff[2], aff[3], aff[4], aff[5], aff[6], aff[7],
+                                                         aff[8], aff[9], aff[10], aff[11], with_translation ? 1 : 0, out);
     return hipGetLastError();
 }
 

@@ -14,6 +14,7 @@
 
 #include <dfa_host/io.hpp>
 #include <dynfu/utils/frame.hpp>
+#include <dynfu/utils/northstar_solver.hpp>
 #include <dynfu/utils/opt_solver.hpp>
 #include <dynfu/warp_field.hpp>
 #include <kfusion/cuda/imgproc.hpp>
@@ -56,6 +57,13 @@ struct DynFuParams {  // dyn_fusion.hpp:25-42
     // Extension (off = the reference's behaviour: default-constructed normals, dyn_fusion.cpp:80-88): normals of the
     // extracted vertices from the TSDF gradient (MarchingCubes::computeNormals)
     bool mesh_normals = false;
+    // Extension — the north-star mode (BASELINE.json): operator() solves full 6-DoF node transforms
+    // against the live DEPTH FRAME (NorthStarSolver: dual-quaternion blend, projective point-to-plane, ARAP) instead of
+    // the reference's translations against the nearest live marching-cubes vertices.  The canonical cloud (with normals
+    // from the TSDF gradient), the nodes and getCanonicalWarpedToLive() are then in the CAMERA frame (the frame of the
+    // depth maps); getLiveFrame() / getMesh() stay the volume-frame marching-cubes output.
+    bool north_star = false;
+    NorthStarParameters northStarParams;
 };
 
 class DynFusion {
@@ -81,6 +89,10 @@ public:
     // caller may want outside its timed region; the next frame would do it otherwise)
     void dropMesh() { mesh_.reset(); }
     int frameCounter() const { return frame_counter_; }
+    // north-star mode: energy before / after the last frame's solve and the data rows that found an association
+    double northStarInitialCost() const { return ns_initial_cost_; }
+    double northStarFinalCost() const { return ns_final_cost_; }
+    long long northStarValidRows() const { return ns_valid_rows_; }
 
     void init(dfa::PointCloud<dfa::PointXYZ>& canonicalVertices, dfa::PointCloud<dfa::Normal>& canonicalNormals);
     void initCanonicalFrame(dfa::PointCloud<dfa::PointXYZ>& vertices, dfa::PointCloud<dfa::Normal>& normals);
@@ -125,9 +137,14 @@ private:
     std::vector<dfa::PointXYZ> mesh_triangles_;
     bool mesh_downloaded_ = false;
     int frame_counter_ = 0;
+    double ns_initial_cost_ = 0.0, ns_final_cost_ = 0.0;
+    long long ns_valid_rows_ = 0;
     void seedNodes(const std::vector<dfa::PointXYZ>& canonicalVertices);
     // vertices of the volume's zero level set as a point cloud (dyn_fusion.cpp:73-88 / :119-134), device-resident
-    std::shared_ptr<dynfu::Frame> extractSurface(int frame_id);
+    std::shared_ptr<dynfu::Frame> extractSurface(int frame_id, bool with_normals);
+    bool northStarFrame(const kfusion::cuda::Depth& depth);  // operator() in north-star mode
+    kfusion::cuda::Cloud live_points_;
+    kfusion::cuda::Normals live_normals_;
 };
 
 // DynFuApp::execute of the reference's demo (src/apps/demo.cpp:68-124) without its windows and command line: every

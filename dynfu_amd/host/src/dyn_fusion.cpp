@@ -174,7 +174,7 @@ kfusion::cuda::TsdfVolume& DynFusion::tsdf() {
     return *volume_;
 }
 
-std::shared_ptr<dynfu::Frame> DynFusion::extractSurface(int frame_id) {
+std::shared_ptr<dynfu::Frame> DynFusion::extractSurface(int frame_id, bool with_normals) {
     if (!mc_) mc_ = std::make_shared<kfusion::cuda::MarchingCubes>();
     auto triangles = mc_->run(tsdf(), mc_buffer_);  // :73-75 / :119-121 (one host sync: the vertex count)
     // convertToMesh (:76 / :122) on demand, in getMesh(): the float4 triangle soup stays in mc_buffer_ until then
@@ -184,7 +184,7 @@ std::shared_ptr<dynfu::Frame> DynFusion::extractSurface(int frame_id) {
     // pcl::fromPCLPointCloud2 / copyPointCloud (:80-88): the vertices as a cloud of their own — packed N x 3 in HBM
     dfa::DeviceArray<float> v3(3 * nv), n3(3 * nv);
     dfa::check(dfa_repack_points((const float*)triangles.ptr(), 4, v3.ptr(), 3, (int)nv, 0.f, nullptr), "DynFusion: vertices");
-    if (dynfuParams.mesh_normals) {  // extension: gradient of the TSDF at the vertices
+    if (with_normals) {  // extension: gradient of the TSDF at the vertices
         dfa::DeviceArray<dfa::Normal> dn;
         mc_->computeNormals(tsdf(), triangles, dn);
         dfa::check(dfa_repack_points((const float*)dn.ptr(), 4, n3.ptr(), 3, (int)nv, 0.f, nullptr), "DynFusion: normals");
@@ -215,22 +215,63 @@ bool DynFusion::operator()(const kfusion::cuda::Depth& depth) {
     kfusion::cuda::depthBilateralFilter(depth, depth_filtered_, p.bilateral_kernel_size, p.bilateral_sigma_spatial,
                                         p.bilateral_sigma_depth);                                  // :60-61
     if (p.icp_truncate_depth_dist > 0) kfusion::cuda::depthTruncation(depth_filtered_, p.icp_truncate_depth_dist);  // :64-66
+    if (dynfuParams.north_star) return northStarFrame(depth);
     const dfa::Affine3f camera;  // poses_.back(): the rigid tracker is skipped, the camera stays at the origin (:100-105)
     if (frame_counter_ == 0) {
         tsdf().integrate(dists_, camera, p.intr);  // :71
-        initFromFrame(extractSurface(0));          // :73-95
+        initFromFrame(extractSurface(0, dynfuParams.mesh_normals));  // :73-95
         return ++frame_counter_, false;
     }
     StageClock clk;
     tsdf().clearAndIntegrate(dists_, camera, p.intr);  // :113-114 as one sweep
     clk.mark("pre-process + fuse");
-    auto live = extractSurface(frame_counter_);
+    auto live = extractSurface(frame_counter_, dynfuParams.mesh_normals);
     clk.mark("marching cubes -> live frame");
     addLiveFrame(frame_counter_, live);  // :137
     warpCanonicalToLiveOpt(camera);      // :140
     clk.mark("warpCanonicalToLiveOpt");
     warpfield->update(getCanonicalWarpedToLive());    // :142
     clk.mark("warpfield->update");
+    return ++frame_counter_, true;
+}
+
+// The same frame sequence with the north-star solve in the middle: the live side of the solve is the depth frame itself
+// (vertex / normal maps of the filtered depth, as KinFu builds them for its tracker, kinfu.cpp:150-175), so neither the
+// live marching-cubes cloud nor the nearest-neighbour correspondence is on the path; everything the solve sees is in
+// the camera frame.
+bool DynFusion::northStarFrame(const kfusion::cuda::Depth& depth) {
+    const kfusion::KinFuParams& p = dynfuParams.kinfuParams;
+    const dfa::Affine3f camera;  // the camera stays at the origin, as in the reference's operator() (:100-105)
+    if (frame_counter_ == 0) {
+        tsdf().integrate(dists_, camera, p.intr);
+        auto vol_frame = extractSurface(0, true);  // volume frame, normals from the TSDF gradient
+        const size_t n = vol_frame->size();
+        if (n == 0) throw dfa::Error(DFA_ERR_INVALID, "DynFusion (north-star mode): the first frame has no surface");
+        // volume frame -> camera frame: camera_pose^-1 * volume_pose, the inverse of what integrate() applies (tsdf_volume.cpp:83)
+        float aff[12];
+        (camera.inv() * tsdf().getPose()).to12(aff);
+        const dynfu::Frame::DeviceView v = vol_frame->device();
+        dfa::DeviceArray<float> cv(3 * n), cn(3 * n);
+        dfa::check(dfa_transform_points(v.vertices, (int)n, aff, 1, cv.ptr(), nullptr), "DynFusion: canonical vertices to the camera frame");
+        dfa::check(dfa_transform_points(v.normals, (int)n, aff, 0, cn.ptr(), nullptr), "DynFusion: canonical normals to the camera frame");
+        initFromFrame(dynfu::Frame::fromDevice(0, cv, cn, n));
+        return ++frame_counter_, false;
+    }
+    StageClock clk;
+    tsdf().clearAndIntegrate(dists_, camera, p.intr);
+    addLiveFrame(frame_counter_, extractSurface(frame_counter_, dynfuParams.mesh_normals));  // for getLiveFrame() / getMesh()
+    clk.mark("pre-process + fuse + marching cubes");
+    NorthStarSolver solver(*warpfield, dynfuParams.northStarParams, dynfuParams.tukeyOffset, dynfuParams.psi_data,
+                           dynfuParams.lambda, dynfuParams.psi_reg);
+    solver.initializeProblemInstance(canonicalFrame);
+    clk.mark("  initializeProblemInstance");
+    kfusion::cuda::computePointNormals(p.intr, depth_filtered_, live_points_, live_normals_);
+    solver.solveAll(live_points_, live_normals_, p.intr);
+    clk.mark("  solveAll");
+    ns_initial_cost_ = solver.initialCost(), ns_final_cost_ = solver.finalCost(), ns_valid_rows_ = solver.validRows();
+    canonicalFrameWarpedToLive = solver.warpCanonicalToLive();
+    warpfield->update(canonicalFrameWarpedToLive);
+    clk.mark("warp + warpfield->update");
     return ++frame_counter_, true;
 }
 

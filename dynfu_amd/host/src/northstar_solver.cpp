@@ -1,0 +1,153 @@
+// northstar_solver.cpp — NorthStarSolver on the dfa_solver6 plan (see dynfu/utils/northstar_solver.hpp).
+#include <dynfu/utils/northstar_solver.hpp>
+
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include <kfusion/cuda/imgproc.hpp>
+
+#include "../../../include/dynfu_amd.h"
+
+extern void dfa_host_copy_from_device(void*, const void*, size_t);
+
+namespace {
+// a DynFusion constructs its solver per frame (dyn_fusion.cpp:193): plans (~30 device allocations) are parked and handed
+// to the next solver whose problem fits — the same scheme as CombinedSolver's
+struct Plan6Cache {
+    struct Entry {
+        dfa_solver6* plan;
+        int max_D, max_N, k;
+    };
+    std::mutex mu;
+    std::vector<Entry> idle;
+    ~Plan6Cache() {
+        for (auto& e : idle) dfa_solver6_destroy(e.plan);
+    }
+    dfa_solver6* take(int D, int N, int k, int& max_D, int& max_N) {
+        std::lock_guard<std::mutex> lock(mu);
+        for (size_t i = 0; i < idle.size(); ++i)
+            if (idle[i].k == k && idle[i].max_D >= D && idle[i].max_N >= N) {
+                const Entry e = idle[i];
+                idle.erase(idle.begin() + (long)i);
+                max_D = e.max_D, max_N = e.max_N;
+                return e.plan;
+            }
+        return nullptr;
+    }
+    void park(dfa_solver6* plan, int max_D, int max_N, int k) {
+        if (!plan) return;
+        std::lock_guard<std::mutex> lock(mu);
+        if (idle.size() >= 2) {
+            dfa_solver6_destroy(idle.front().plan);
+            idle.erase(idle.begin());
+        }
+        idle.push_back({plan, max_D, max_N, k});
+    }
+};
+Plan6Cache& plan_cache() {
+    static Plan6Cache c;
+    return c;
+}
+}  // namespace
+
+struct NorthStarSolver::Impl {
+    dfa_solver6* plan = nullptr;
+    int plan_D = 0, plan_N = 0, plan_k = 0;
+    dfa::DeviceArray<float> node_pos, node_dq, node_w, canon, canon_n;  // borrowed by the plan until the next set_problem
+    kfusion::cuda::Cloud vmap;
+    kfusion::cuda::Normals nmap;
+    int D = 0, N = 0;
+    ~Impl() { plan_cache().park(plan, plan_D, plan_N, plan_k); }
+};
+
+NorthStarSolver::NorthStarSolver(Warpfield warpfield, NorthStarParameters params, float tukeyOffset_, float psi_data_,
+                                 float lambda_, float psi_reg_)
+    : m_warpfield(warpfield), m_params(params), tukeyOffset(tukeyOffset_), psi_data(psi_data_), lambda(lambda_),
+      psi_reg(psi_reg_), impl(std::make_shared<Impl>()) {}
+NorthStarSolver::~NorthStarSolver() = default;
+
+void NorthStarSolver::initializeProblemInstance(const std::shared_ptr<dynfu::Frame> canonicalFrame) {
+    auto nodes  = m_warpfield.getNodes();
+    const int D = (int)nodes.size(), N = (int)canonicalFrame->size();
+    if (D == 0) throw dfa::Error(DFA_ERR_INVALID, "NorthStarSolver: the warp field has no nodes");
+    std::vector<float> pos(3 * (size_t)D), w(D), dq(8 * (size_t)D);
+    for (int i = 0; i < D; ++i) {
+        const dfa::PointXYZ g = nodes[i]->getPosition();
+        pos[3 * i] = g.x, pos[3 * i + 1] = g.y, pos[3 * i + 2] = g.z;
+        w[i] = nodes[i]->getRadialBasisWeight();
+        const auto& q = *nodes[i]->getTransformation();
+        const auto r = q.getReal(), d = q.getDual();
+        float* o = &dq[8 * (size_t)i];
+        o[0] = r.a, o[1] = r.b, o[2] = r.c, o[3] = r.d, o[4] = d.a, o[5] = d.b, o[6] = d.c, o[7] = d.d;
+    }
+    Impl& I = *impl;
+    I.D = D, I.N = N;
+    I.node_pos.upload(pos), I.node_w.upload(w), I.node_dq.upload(dq);
+    canonicalFrame->deviceArrays(I.canon, I.canon_n);
+    const int k = std::min(m_warpfield.getKnn(), 8);  // a dfa_solver6 plan blends at most 8 nodes (the reference's KNN)
+    if (I.plan && !(I.plan_k == k && I.plan_D >= D && I.plan_N >= N)) {
+        plan_cache().park(I.plan, I.plan_D, I.plan_N, I.plan_k);
+        I.plan = nullptr;
+    }
+    if (!I.plan) {
+        I.plan   = plan_cache().take(D, N, k, I.plan_D, I.plan_N);
+        I.plan_k = k;
+    }
+    if (!I.plan) {
+        I.plan_D = D + D / 4 + 16, I.plan_N = N + N / 4 + 1024;
+        dfa::check(dfa_solver6_create(I.plan_D, I.plan_N, k, &I.plan), "NorthStarSolver: dfa_solver6_create");
+    }
+    dfa::check(dfa_solver6_set_problem(I.plan, I.node_pos.ptr(), I.node_dq.ptr(), I.node_w.ptr(), D, I.canon.ptr(),
+                                       I.canon_n.ptr(), N, nullptr),
+               "NorthStarSolver::initializeProblemInstance");
+}
+
+void NorthStarSolver::solveAll(const kfusion::cuda::Depth& liveDepth, const kfusion::Intr& intr) {
+    Impl& I = *impl;
+    kfusion::cuda::computePointNormals(intr, liveDepth, I.vmap, I.nmap);  // imgproc.cu:187-226
+    solveAll(I.vmap, I.nmap, intr);
+}
+
+void NorthStarSolver::solveAll(const kfusion::cuda::Cloud& vmap, const kfusion::cuda::Normals& nmap, const kfusion::Intr& intr) {
+    Impl& I = *impl;
+    if (!I.plan) throw dfa::Error(DFA_ERR_INVALID, "solveAll before initializeProblemInstance");
+    if (vmap.rows() != nmap.rows() || vmap.cols() != nmap.cols() || vmap.empty())
+        throw dfa::Error(DFA_ERR_INVALID, "NorthStarSolver: vertex / normal maps differ in size or are empty");
+    dfa_solve6_params p;
+    p.num_iter     = m_params.numIter;
+    p.gn_iter      = m_params.gnIter;
+    p.linear_iter  = m_params.linearIter;
+    p.tukey_offset = tukeyOffset;
+    p.psi_data     = psi_data;
+    p.lambda       = lambda;
+    p.psi_reg      = psi_reg;
+    p.dist_thresh  = m_params.distThresh;
+    p.cos_thresh   = m_params.cosThresh;
+    p.damping      = m_params.damping;
+    p.pcg_tol      = m_params.pcgTol;
+    dfa::check(dfa_solver6_solve(I.plan, (const float*)vmap.ptr(), (int)vmap.step(), (const float*)nmap.ptr(), (int)nmap.step(),
+                                 vmap.cols(), vmap.rows(), intr.fx, intr.fy, intr.cx, intr.cy, &p, nullptr),
+               "NorthStarSolver::solveAll");
+    dfa_solve6_stats st;
+    dfa::check(dfa_solver6_get_stats(I.plan, &st, nullptr), "NorthStarSolver::solveAll (stats)");  // synchronises
+    initial_cost_ = st.initial_cost, final_cost_ = st.final_cost, valid_rows_ = st.valid_last, pcg_iters_ = st.pcg_iters;
+    // the solved transforms replace dg_se3 of the shared Nodes (the reference's solver composes a translation onto it,
+    // opt_solver.cpp:270-285; here the unknown IS the transform)
+    std::vector<float> dq(8 * (size_t)I.D);
+    dfa_host_copy_from_device(dq.data(), dfa_solver6_node_dq(I.plan), dq.size() * sizeof(float));
+    auto nodes = m_warpfield.getNodes();
+    for (int i = 0; i < I.D; ++i) {
+        const float* q = &dq[8 * (size_t)i];
+        nodes[i]->setTransformation(std::make_shared<DualQuaternion<float>>(dfa::quaternion<float>(q[0], q[1], q[2], q[3]),
+                                                                            dfa::quaternion<float>(q[4], q[5], q[6], q[7])));
+    }
+}
+
+std::shared_ptr<dynfu::Frame> NorthStarSolver::warpCanonicalToLive() {
+    Impl& I = *impl;
+    if (!I.plan) throw dfa::Error(DFA_ERR_INVALID, "warpCanonicalToLive before initializeProblemInstance");
+    dfa::DeviceArray<float> ov(3 * (size_t)I.N), on(3 * (size_t)I.N);
+    if (I.N) dfa::check(dfa_solver6_warp(I.plan, ov.ptr(), on.ptr(), nullptr), "NorthStarSolver::warpCanonicalToLive");
+    return dynfu::Frame::fromDevice(0, ov, on, (size_t)I.N);
+}

@@ -217,6 +217,11 @@ int dfa_repack_points(const float* src, int src_stride, float* dst, int dst_stri
                       dfa_stream_t stream);
 int dfa_compact_points(const float* points, const uint8_t* flags, int N, float* out_points, int32_t* out_index,
                        int32_t* count, dfa_stream_t stream);
+/* dfa_transform_points — out = R p + t (points) or R p (with_translation = 0: normals) for n packed xyz triples; aff = R
+ * row-major (9) then t (3), the 12 floats of every affine in this header; out may be the input.  cv::Affine3f applied to a
+ * cloud: the volume-frame vertices of marching cubes in the camera frame (TsdfVolume::getPose, tsdf_volume.cpp:83). */
+int dfa_transform_points(const float* points, int n, const float aff[12], int with_translation, float* out,
+                         dfa_stream_t stream);
 
 /* DynFusion::findCorrespondingFrame (src/dynfu/dyn_fusion.cpp:212-242): for each of the
  * n_live live vertices the nearest of the n_canon (warped) canonical vertices — exact 1-NN,

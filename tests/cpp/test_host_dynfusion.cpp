@@ -1,6 +1,8 @@
 // test_host_dynfusion.cpp — DynFusion's warp-field sequence through the host adaptor
 // (reference: src/dynfu/dyn_fusion.cpp:147-242; the reference has no test of its own for it).
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <random>
 
@@ -364,6 +366,91 @@ TEST(DynFusionTest, OperatorOnDeviceFramesEqualsTheHostCloudSequence) {
     ASSERT_EQ(mesh->cloud.size(), a.getLiveFrame()->size());
     ASSERT_EQ(mesh->polygons.size() * 3, mesh->cloud.size());
     ASSERT_EQ(mesh->cloud[5].x, a.getLiveFrame()->vertices()[5].x);
+}
+
+// Extension: DynFuParams::north_star — operator() with the 6-DoF solve against the live depth frame (NorthStarSolver)
+TEST(DynFusionTest, NorthStarModeFollowsTheDepthFrame) {
+    const int W = 320, H = 240;
+    const float f = 262.5f, cx = W / 2 - 0.5f, cy = H / 2 - 0.5f;
+    auto make = [&](float cz) {
+        std::vector<unsigned short> d((size_t)W * H);
+        const float R = 0.5f;
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                float dir[3] = {(x - cx) / f, (y - cy) / f, 1.f};
+                const float n = std::sqrt(dir[0] * dir[0] + dir[1] * dir[1] + 1.f);
+                for (float& v : dir) v /= n;
+                const float b = dir[2] * cz, disc = b * b - (cz * cz - R * R);
+                float z = 0.f;  // only the sphere is observed
+                if (disc > 0) z = (b - std::sqrt(disc)) * dir[2];
+                d[(size_t)y * W + x] = (unsigned short)std::lround(z * 1000.f);
+            }
+        return d;
+    };
+    DynFuParams p = DynFuParams::defaultParams();
+    p.kinfuParams.cols = W, p.kinfuParams.rows = H;
+    p.kinfuParams.intr = kfusion::Intr(f, f, cx, cy);
+    p.kinfuParams.volume_dims = kfusion::Vec3i::all(128);
+    p.epsilon    = 0.05f;
+    p.north_star = true;
+    DynFusion df(p);
+    df.nodeStep = 64;
+    kfusion::cuda::Depth d0, d1, d2;
+    d0.upload(make(1.50f), W);
+    d1.upload(make(1.48f), W);  // the sphere comes 2 cm closer per frame
+    d2.upload(make(1.46f), W);
+    ASSERT_TRUE(df(d0) == false);
+    auto canon = df.getCanonicalWarpedToLive();
+    ASSERT_TRUE(canon->deviceResident());
+    const size_t n_canon = canon->size();
+    ASSERT_TRUE(n_canon > 5000);
+    // the canonical cloud is in the CAMERA frame: on the sphere around (0, 0, 1.5), normals facing the camera
+    {
+        const auto& v  = canon->vertices();
+        const auto& nn = canon->normals();
+        double rad = 0, facing = 0;
+        for (size_t i = 0; i < n_canon; i += 7) {
+            rad += std::sqrt((double)v[i].x * v[i].x + (double)v[i].y * v[i].y + ((double)v[i].z - 1.5) * ((double)v[i].z - 1.5));
+            facing += nn[i].normal_z < 0.f ? 1.0 : 0.0;
+        }
+        const double cnt = (double)((n_canon + 6) / 7);
+        ASSERT_NEAR(rad / cnt, 0.5, 0.02);
+        ASSERT_TRUE(facing / cnt > 0.9);
+    }
+    const size_t n_nodes = df.getWarpfield()->getNodes().size();
+    ASSERT_TRUE(n_nodes > 50);
+    double moved[2] = {0, 0};
+    kfusion::cuda::Depth* frames[2] = {&d1, &d2};
+    for (int fi = 0; fi < 2; ++fi) {
+        ASSERT_TRUE(df(*frames[fi]) == true);
+        ASSERT_TRUE(df.northStarValidRows() > (long long)(n_canon / 2));
+        ASSERT_TRUE(df.northStarFinalCost() < 0.5 * df.northStarInitialCost());
+        // the warped canonical cloud follows the sphere towards the camera
+        const auto& w = df.getCanonicalWarpedToLive()->vertices();
+        const auto& c = canon->vertices();
+        ASSERT_EQ(w.size(), c.size());
+        double dz = 0;
+        for (size_t i = 0; i < w.size(); i += 7) dz += (double)w[i].z - (double)c[i].z;
+        moved[fi] = dz / (double)((w.size() + 6) / 7);
+        if (std::getenv("DFA_TEST_VERBOSE"))
+            std::fprintf(stderr, "north-star frame %d: cost %.4e -> %.4e, valid rows %lld of %zu, mean dz %.4f m, nodes %zu\n", fi + 1,
+                         df.northStarInitialCost(), df.northStarFinalCost(), df.northStarValidRows(), n_canon, moved[fi],
+                         df.getWarpfield()->getNodes().size());
+    }
+    // mean displacement of the cap along z.  The first solve also closes the gap between the marching-cubes surface of
+    // a 128^3 volume (2.3 cm voxels, depth sampled at floor(projection)) and the depth frame's own surface — ~1.3 cm
+    // here — on top of the 2 cm of motion; from then on it is the motion alone: 2 cm per frame.
+    ASSERT_TRUE(moved[0] < -0.02 && moved[0] > -0.045);
+    ASSERT_NEAR(moved[1] - moved[0], -0.02, 0.008);
+    // the nodes carry full transforms now; the solve is regularised towards rigidity: rotations stay small
+    int checked = 0;
+    for (auto& n : df.getWarpfield()->getNodes()) {
+        const auto r = n->getTransformation()->getReal();
+        ASSERT_TRUE(r.a > 0.99f);  // cos(half angle): < 16 degrees
+        ++checked;
+    }
+    ASSERT_TRUE(checked >= (int)n_nodes);
+    ASSERT_TRUE(df.getLiveFrame()->size() > 5000);  // the volume-frame marching-cubes cloud of the last frame
 }
 
 int main(int argc, char** argv) { return mt::run_all(argc, argv); }

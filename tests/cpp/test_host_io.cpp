@@ -137,6 +137,7 @@ static int run_sequence(const char* dir) {
     p.intr = k.intr;
     const int dim = std::getenv("DFA_SEQ_DIM") ? std::atoi(std::getenv("DFA_SEQ_DIM")) : 64;
     k.volume_dims = dfa::Vec3i(dim, dim, dim);
+    if (std::getenv("DFA_SEQ_NORTHSTAR")) p.north_star = true, p.epsilon = 0.05f;  // dev: the 6-DoF mode
     DynFusion dynfu(p);
     dynfu.nodeStep = dim >= 256 ? 128 : 64;
     const SequenceReport r = runSequence(dynfu, dir);

@@ -309,3 +309,19 @@ def test_compact_points_keeps_flagged_points_in_index_order(A, n, density):
         f2 = dev(flags)[3:]
         out2, idx2 = A.compact_points(dev(pts[3:]), f2)
         assert np.array_equal(host(idx2), np.flatnonzero(flags[3:]).astype(np.int32))
+
+
+@pytest.mark.parametrize("n", [1, 257, 100003])
+def test_transform_points_matches_the_host_loop_bit_for_bit(A, n):
+    from gpu_util import rot
+    rng = np.random.default_rng(n)
+    p = rng.standard_normal((n, 3)).astype(np.float32)
+    R = rot([0.3, -1.0, 0.5], 0.7).astype(np.float32)
+    t = np.array([-1.5, -1.5, 0.5], np.float32)
+    aff = np.concatenate([R.reshape(-1), t])
+    for with_t in (True, False):
+        out = host(A.transform_points(dev(p), aff, with_t))
+        ref = np.stack([(R[c, 0] * p[:, 0] + R[c, 1] * p[:, 1]) + R[c, 2] * p[:, 2] for c in range(3)], 1)
+        if with_t:
+            ref = ref + t
+        assert np.array_equal(bits(out), bits(ref.astype(np.float32)))
