@@ -2,9 +2,9 @@
 #include <dynfu/utils/northstar_solver.hpp>
 
 #include <algorithm>
-#include <mutex>
 #include <vector>
 
+#include <dfa_host/plan_cache.hpp>
 #include <kfusion/cuda/imgproc.hpp>
 
 #include "../../../include/dynfu_amd.h"
@@ -12,41 +12,8 @@
 extern void dfa_host_copy_from_device(void*, const void*, size_t);
 
 namespace {
-// a DynFusion constructs its solver per frame (dyn_fusion.cpp:193): plans (~30 device allocations) are parked and handed
-// to the next solver whose problem fits — the same scheme as CombinedSolver's
-struct Plan6Cache {
-    struct Entry {
-        dfa_solver6* plan;
-        int max_D, max_N, k;
-    };
-    std::mutex mu;
-    std::vector<Entry> idle;
-    ~Plan6Cache() {
-        for (auto& e : idle) dfa_solver6_destroy(e.plan);
-    }
-    dfa_solver6* take(int D, int N, int k, int& max_D, int& max_N) {
-        std::lock_guard<std::mutex> lock(mu);
-        for (size_t i = 0; i < idle.size(); ++i)
-            if (idle[i].k == k && idle[i].max_D >= D && idle[i].max_N >= N) {
-                const Entry e = idle[i];
-                idle.erase(idle.begin() + (long)i);
-                max_D = e.max_D, max_N = e.max_N;
-                return e.plan;
-            }
-        return nullptr;
-    }
-    void park(dfa_solver6* plan, int max_D, int max_N, int k) {
-        if (!plan) return;
-        std::lock_guard<std::mutex> lock(mu);
-        if (idle.size() >= 2) {
-            dfa_solver6_destroy(idle.front().plan);
-            idle.erase(idle.begin());
-        }
-        idle.push_back({plan, max_D, max_N, k});
-    }
-};
-Plan6Cache& plan_cache() {
-    static Plan6Cache c;
+dfa::PlanCache<dfa_solver6, dfa_solver6_destroy>& plan_cache() {
+    static dfa::PlanCache<dfa_solver6, dfa_solver6_destroy> c;
     return c;
 }
 }  // namespace

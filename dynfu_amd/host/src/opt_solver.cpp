@@ -5,49 +5,16 @@
 
 #include <algorithm>
 #include <cstdlib>
-#include <mutex>
 #include <vector>
 
 #include <dfa_host/device.hpp>
+#include <dfa_host/plan_cache.hpp>
 
 #include "../../../include/dynfu_amd.h"
 
 namespace {
-// The reference constructs a CombinedSolver per frame (dyn_fusion.cpp:193).  A plan is ~40 device allocations, so the
-// plans of destroyed solvers are parked here (at most two) and handed to the next solver whose problem fits.
-struct PlanCache {
-    struct Entry {
-        dfa_solver* plan;
-        int max_D, max_N, k;
-    };
-    std::mutex mu;
-    std::vector<Entry> idle;
-    ~PlanCache() {
-        for (auto& e : idle) dfa_solver_destroy(e.plan);
-    }
-    dfa_solver* take(int D, int N, int k, int& max_D, int& max_N) {
-        std::lock_guard<std::mutex> lock(mu);
-        for (size_t i = 0; i < idle.size(); ++i)
-            if (idle[i].k == k && idle[i].max_D >= D && idle[i].max_N >= N) {
-                const Entry e = idle[i];
-                idle.erase(idle.begin() + (long)i);
-                max_D = e.max_D, max_N = e.max_N;
-                return e.plan;
-            }
-        return nullptr;
-    }
-    void park(dfa_solver* plan, int max_D, int max_N, int k) {
-        if (!plan) return;
-        std::lock_guard<std::mutex> lock(mu);
-        if (idle.size() >= 2) {
-            dfa_solver_destroy(idle.front().plan);
-            idle.erase(idle.begin());
-        }
-        idle.push_back({plan, max_D, max_N, k});
-    }
-};
-PlanCache& plan_cache() {
-    static PlanCache c;
+dfa::PlanCache<dfa_solver, dfa_solver_destroy>& plan_cache() {
+    static dfa::PlanCache<dfa_solver, dfa_solver_destroy> c;
     return c;
 }
 }  // namespace
