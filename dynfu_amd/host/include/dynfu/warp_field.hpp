@@ -55,4 +55,7 @@ public:
         int D;
     };
     DeviceNodeView deviceNodes(bool refresh_transforms = true);
+    // the same arrays on the host: D x 3 positions, D weights, D x 8 transforms (real w,x,y,z ; dual w,x,y,z) — what
+    // the solver adaptors upload (resetGPUMemory, opt_solver.cpp:149-202)
+    void hostArrays(std::vector<float>& pos, std::vector<float>& w, std::vector<float>& dq);
 };

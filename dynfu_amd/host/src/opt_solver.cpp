@@ -39,16 +39,8 @@ void CombinedSolver::initializeProblemInstance(const std::shared_ptr<dynfu::Fram
     auto nodes = m_warpfield.getNodes();
     const int D = (int)nodes.size(), N = (int)canonicalFrame->size();
     if ((int)liveFrame->size() != N) throw dfa::Error(DFA_ERR_INVALID, "canonical / live vertex counts differ");
-    std::vector<float> pos(3 * (size_t)D), w(D), dq(8 * (size_t)D);
-    for (int i = 0; i < D; ++i) {
-        const dfa::PointXYZ g = nodes[i]->getPosition();
-        pos[3 * i] = g.x, pos[3 * i + 1] = g.y, pos[3 * i + 2] = g.z;
-        w[i] = nodes[i]->getRadialBasisWeight();
-        const auto& q = *nodes[i]->getTransformation();
-        const auto r = q.getReal(), d = q.getDual();
-        float* o = &dq[8 * (size_t)i];
-        o[0] = r.a, o[1] = r.b, o[2] = r.c, o[3] = r.d, o[4] = d.a, o[5] = d.b, o[6] = d.c, o[7] = d.d;
-    }
+    std::vector<float> pos, w, dq;
+    m_warpfield.hostArrays(pos, w, dq);
     Impl& I = *impl;
     I.D = D, I.N = N;
     I.node_pos.upload(pos), I.node_w.upload(w), I.node_dq.upload(dq);

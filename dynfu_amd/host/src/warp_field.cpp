@@ -83,16 +83,31 @@ std::shared_ptr<DualQuaternion<float>> Warpfield::calcDQB(dfa::PointXYZ point) {
     return std::make_shared<DualQuaternion<float>>(sum.normalize());
 }
 
-// the nodes' current transforms dg_se3 as D x 8 floats (real w,x,y,z ; dual w,x,y,z) -> dev->dq
-void Warpfield::syncTransforms() {
-    std::vector<float> hdq(8 * nodes.size());
+static void pack_transforms(const std::vector<std::shared_ptr<Node>>& nodes, std::vector<float>& hdq) {
+    hdq.resize(8 * nodes.size());
     for (size_t i = 0; i < nodes.size(); ++i) {
         const auto& dq = *nodes[i]->getTransformation();
         const auto r = dq.getReal(), d = dq.getDual();
         float* o = &hdq[8 * i];
         o[0] = r.a, o[1] = r.b, o[2] = r.c, o[3] = r.d, o[4] = d.a, o[5] = d.b, o[6] = d.c, o[7] = d.d;
     }
+}
+
+// the nodes' current transforms dg_se3 as D x 8 floats (real w,x,y,z ; dual w,x,y,z) -> dev->dq
+void Warpfield::syncTransforms() {
+    std::vector<float> hdq;
+    pack_transforms(nodes, hdq);
     if (!hdq.empty()) dev->dq.upload(hdq);
+}
+
+void Warpfield::hostArrays(std::vector<float>& pos, std::vector<float>& w, std::vector<float>& dq) {
+    pos.resize(3 * nodes.size()), w.resize(nodes.size());
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        const dfa::PointXYZ g = nodes[i]->getPosition();
+        pos[3 * i] = g.x, pos[3 * i + 1] = g.y, pos[3 * i + 2] = g.z;
+        w[i] = nodes[i]->getRadialBasisWeight();
+    }
+    pack_transforms(nodes, dq);
 }
 
 // :150-171 — bulk warp on the GPU; the warped frame stays in HBM until somebody asks for its clouds
