@@ -167,3 +167,29 @@ def test_png_sequence_through_dynfusion_to_pcd_and_vtk(exes, tmp_path):
     tri = np.array([[int(v) for v in line.split()] for line in vtk[at + 2:at + 2 + npoly]])
     assert (tri[:, 0] == 3).all() and tri[:, 1:].max() == nv - 1
     assert np.array_equal(tri[:3, 1:], [[0, 2, 1], [3, 5, 4], [6, 8, 7]])  # KinFu::convertToMesh's winding
+
+
+@pytest.mark.gpu
+def test_png_sequence_through_dynfusion_in_north_star_mode(exes, tmp_path):
+    """The same loop with DynFuParams::north_star: every frame after the first is solved against its depth map (6-DoF
+    node transforms, NorthStarSolver); the written clouds are the canonical surface warped into the camera frame."""
+    import numpy as np
+    from PIL import Image
+    from dynfu_amd import synth
+    cfg = synth.CONFIGS["T1"]
+    (tmp_path / "depth").mkdir()
+    (tmp_path / "color").mkdir()
+    n = 3
+    for f in range(n):
+        Image.fromarray(synth.depth_frame(cfg, f)).save(tmp_path / "depth" / ("frame-%06d.depth.png" % f))
+        Image.fromarray(np.zeros((4, 4, 3), np.uint8)).save(tmp_path / "color" / ("frame-%06d.color.png" % f))
+    env = dict(os.environ, DFA_SEQ_NORTHSTAR="1", DFA_SEQ_DIM="128")
+    r = subprocess.run([exes["test_host_io"], "sequence", str(tmp_path)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rep = dict(zip(r.stdout.split()[0::2], r.stdout.split()[1::2]))
+    assert int(rep["frames"]) == n and int(rep["saved"]) == n - 1 and int(rep["nodes"]) > 10
+    pcd = (tmp_path / "out" / "pcl_canonical_to_live2.pcd").read_text().splitlines()
+    pts = np.array([[float(v) for v in line.split()] for line in pcd[11:]])
+    assert len(pts) == int(rep["canonical_vertices"]) > 1000 and np.isfinite(pts).all()
+    # camera frame: the sphere of the synthetic scene sits around (0, 0, 1.5), the wall at z = 2.5
+    assert abs(np.median(pts[:, 0])) < 0.3 and abs(np.median(pts[:, 1])) < 0.3 and 0.9 < pts[:, 2].min() < 1.2 and pts[:, 2].max() < 2.7
