@@ -15,7 +15,7 @@ SYMBOLS = [
     "dfa_depth_bilateral_filter", "dfa_depth_truncate", "dfa_depth_build_pyramid", "dfa_compute_normals_mask_depth",
     "dfa_resize_depth_normals", "dfa_resize_points_normals",
     "dfa_compute_points_normals", "dfa_solver6_create", "dfa_solver6_destroy", "dfa_solver6_set_problem",
-    "dfa_solver6_solve", "dfa_solver6_node_dq", "dfa_solver6_warp", "dfa_solver6_get_stats",
+    "dfa_solver6_solve", "dfa_solver6_set_node_transforms", "dfa_solver6_node_dq", "dfa_solver6_warp", "dfa_solver6_get_stats",
     "dfa_solver6_enable_timing", "dfa_solver6_get_timing",
     "dfa_solver_create", "dfa_solver_destroy", "dfa_solver_set_problem", "dfa_solver_solve",
     "dfa_solver_translations", "dfa_solver_node_dq", "dfa_solver_tukey_weights", "dfa_solver_huber_weights",
@@ -118,6 +118,7 @@ def load():
     L.dfa_solver6_destroy.argtypes = [vp]
     L.dfa_solver6_destroy.restype = None
     L.dfa_solver6_set_problem.argtypes = [vp, vp, vp, vp, i, vp, vp, i, vp]
+    L.dfa_solver6_set_node_transforms.argtypes = [vp, vp]
     L.dfa_solver6_solve.argtypes = [vp, vp, i, vp, i, i, i, f, f, f, f, C.POINTER(Solve6Params), vp]
     L.dfa_solver6_node_dq.argtypes = [vp]
     L.dfa_solver6_node_dq.restype = vp
@@ -564,6 +565,11 @@ class Solver6:
         _check(load().dfa_solver6_set_problem(self._h, _dev(node_pos, f32, "node_pos"), _dev(node_dq, f32, "node_dq"),
                                               _dev(node_w, f32, "node_w"), self.D, _dev(canon, f32, "canon"),
                                               _dev(canon_normals, f32, "canon_normals"), self.N, _stream()))
+
+    def set_node_transforms(self, node_dq):
+        """the same graphs, new starting transforms (dfa_solver6_set_node_transforms)"""
+        self._keep = self._keep[:1] + (node_dq,) + self._keep[2:]
+        _check(load().dfa_solver6_set_node_transforms(self._h, _dev(node_dq, _torch().float32, "node_dq")))
 
     def solve(self, vmap, nmap, fx, fy, cx, cy, params):
         f32 = _torch().float32

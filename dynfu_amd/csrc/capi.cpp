@@ -1020,6 +1020,13 @@ int dfa_solver6_set_problem(dfa_solver6* s, const float* node_pos, const float* 
     return DFA_OK;
 }
 
+int dfa_solver6_set_node_transforms(dfa_solver6* s, const float* node_dq) {
+    REQUIRE(s && s->has_problem, "no problem set");
+    REQUIRE(node_dq, "null transforms");
+    s->node_dq = node_dq;
+    return DFA_OK;
+}
+
 int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_step, const float* live_normal_map,
                       int normal_step, int cols, int rows, float fx, float fy, float cx, float cy,
                       const dfa_solve6_params* prm, dfa_stream_t stream) {

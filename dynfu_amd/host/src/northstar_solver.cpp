@@ -2,6 +2,10 @@
 #include <dynfu/utils/northstar_solver.hpp>
 
 #include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include <dfa_host/plan_cache.hpp>
@@ -12,9 +16,33 @@
 extern void dfa_host_copy_from_device(void*, const void*, size_t);
 
 namespace {
-dfa::PlanCache<dfa_solver6, dfa_solver6_destroy>& plan_cache() {
-    static dfa::PlanCache<dfa_solver6, dfa_solver6_destroy> c;
+// What the graphs of a plan were built from.  A DynFusion solves frame after frame over the SAME canonical cloud and —
+// until the field grows — the same nodes: k-NN, transposition and pair lists of the frame before are then still right and
+// only the starting transforms change (dfa_solver6_set_node_transforms).  The arrays are kept alive here: the plan
+// borrows them.
+struct Built {
+    dfa::DeviceArray<float> node_pos, node_w, canon, canon_n;
+    int D = 0, N = 0, k = 0;
+    uint64_t nodes_hash = 0;
+};
+std::mutex g_built_mu;
+std::map<dfa_solver6*, Built> g_built;
+
+void destroy_plan6(dfa_solver6* p) {
+    {
+        std::lock_guard<std::mutex> lock(g_built_mu);
+        g_built.erase(p);
+    }
+    dfa_solver6_destroy(p);
+}
+dfa::PlanCache<dfa_solver6, destroy_plan6>& plan_cache() {
+    static dfa::PlanCache<dfa_solver6, destroy_plan6> c;
     return c;
+}
+uint64_t fnv1a(const std::vector<float>& a, uint64_t h) {
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(a.data());
+    for (size_t i = 0; i < a.size() * sizeof(float); ++i) h = (h ^ p[i]) * 1099511628211ull;
+    return h;
 }
 }  // namespace
 
@@ -42,7 +70,6 @@ void NorthStarSolver::initializeProblemInstance(const std::shared_ptr<dynfu::Fra
     m_warpfield.hostArrays(pos, w, dq);
     Impl& I = *impl;
     I.D = D, I.N = N;
-    I.node_pos.upload(pos), I.node_w.upload(w), I.node_dq.upload(dq);
     canonicalFrame->deviceArrays(I.canon, I.canon_n);
     const int k = std::min(m_warpfield.getKnn(), 8);  // a dfa_solver6 plan blends at most 8 nodes (the reference's KNN)
     if (I.plan && !(I.plan_k == k && I.plan_D >= D && I.plan_N >= N)) {
@@ -57,9 +84,30 @@ void NorthStarSolver::initializeProblemInstance(const std::shared_ptr<dynfu::Fra
         I.plan_D = D + D / 4 + 16, I.plan_N = N + N / 4 + 1024;
         dfa::check(dfa_solver6_create(I.plan_D, I.plan_N, k, &I.plan), "NorthStarSolver: dfa_solver6_create");
     }
+    I.node_dq.upload(dq);
+    const uint64_t nodes_hash = fnv1a(w, fnv1a(pos, 1469598103934665603ull));
+    {
+        std::lock_guard<std::mutex> lock(g_built_mu);
+        auto it = g_built.find(I.plan);
+        if (it != g_built.end() && !std::getenv("DFA_HOST_NO_GRAPH_REUSE")) {
+            const Built& b = it->second;
+            if (b.D == D && b.N == N && b.k == k && b.nodes_hash == nodes_hash && b.canon.ptr() == I.canon.ptr() &&
+                b.canon_n.ptr() == I.canon_n.ptr()) {
+                I.node_pos = b.node_pos, I.node_w = b.node_w;  // shared: the plan reads them
+                dfa::check(dfa_solver6_set_node_transforms(I.plan, I.node_dq.ptr()), "NorthStarSolver: set_node_transforms");
+                return;
+            }
+        }
+    }
+    I.node_pos = dfa::DeviceArray<float>(), I.node_w = dfa::DeviceArray<float>();  // fresh arrays: older ones may be shared
+    I.node_pos.upload(pos), I.node_w.upload(w);
     dfa::check(dfa_solver6_set_problem(I.plan, I.node_pos.ptr(), I.node_dq.ptr(), I.node_w.ptr(), D, I.canon.ptr(),
                                        I.canon_n.ptr(), N, nullptr),
                "NorthStarSolver::initializeProblemInstance");
+    std::lock_guard<std::mutex> lock(g_built_mu);
+    Built& b = g_built[I.plan];
+    b.node_pos = I.node_pos, b.node_w = I.node_w, b.canon = I.canon, b.canon_n = I.canon_n;
+    b.D = D, b.N = N, b.k = k, b.nodes_hash = nodes_hash;
 }
 
 void NorthStarSolver::solveAll(const kfusion::cuda::Depth& liveDepth, const kfusion::Intr& intr) {

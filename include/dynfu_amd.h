@@ -402,6 +402,11 @@ void dfa_solver6_destroy(dfa_solver6* s);
 int dfa_solver6_set_problem(dfa_solver6* s, const float* node_pos, const float* node_dq, const float* node_w, int D,
                             const float* canon_vertices, const float* canon_normals /* may be NULL */, int N,
                             dfa_stream_t stream);
+/* The next frame of a sequence whose canonical cloud and node set have not changed: the graphs of the last
+ * dfa_solver6_set_problem stay, only the transforms the solve starts from are replaced (D x 8, borrowed like the arrays of
+ * set_problem).  What a per-frame caller does instead of rebuilding k-NN, transposition and pair lists (~0.5 ms at 232 k
+ * vertices) when nothing they depend on has moved. */
+int dfa_solver6_set_node_transforms(dfa_solver6* s, const float* node_dq);
 /* live maps: float4 pixels in the camera frame (the canonical cloud and the nodes are in the same
  * frame), NaN where undefined — dfa_compute_points_normals or dfa_tsdf_raycast_points output */
 int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_step, const float* live_normal_map,
