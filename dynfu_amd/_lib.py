@@ -10,7 +10,7 @@ _LIB = None
 SYMBOLS = [
     "dfa_last_error", "dfa_version", "dfa_compute_dists", "dfa_tsdf_clear", "dfa_tsdf_integrate",
     "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_tsdf_vertex_normals", "dfa_correspond_projective", "dfa_knn", "dfa_warp_to_live",
-    "dfa_calc_dqb", "dfa_unsupported_vertices", "dfa_icp_sums", "dfa_repack_points", "dfa_compact_points", "dfa_transform_points",
+    "dfa_calc_dqb", "dfa_unsupported_vertices", "dfa_icp_sums", "dfa_repack_points", "dfa_compact_points", "dfa_transform_points", "dfa_warp_to_live_graph",
     "dfa_correspond", "dfa_marching_cubes", "dfa_mc_default_tables",
     "dfa_depth_bilateral_filter", "dfa_depth_truncate", "dfa_depth_build_pyramid", "dfa_compute_normals_mask_depth",
     "dfa_resize_depth_normals", "dfa_resize_points_normals",
@@ -134,6 +134,7 @@ def load():
     L.dfa_correspond.argtypes = [vp, vp, i, vp, i, vp, vp, vp, vp]
     L.dfa_repack_points.argtypes = [vp, i, vp, i, i, C.c_float, vp]
     L.dfa_compact_points.argtypes = [vp, vp, i, vp, vp, vp, vp]
+    L.dfa_warp_to_live_graph.argtypes = [vp, vp, vp, i, i, vp, vp, vp, i, vp, vp, vp]
     L.dfa_transform_points.argtypes = [vp, i, C.POINTER(C.c_float), i, vp, vp]
     L.dfa_solver_create.argtypes = [i, i, i, C.POINTER(vp)]
     L.dfa_solver_destroy.argtypes = [vp]
@@ -345,6 +346,20 @@ def warp_to_live(node_pos, node_dq, node_w, k, verts, normals=None):
                                    _dev(node_w, torch.float32, "node_w"), node_pos.shape[0], k,
                                    _dev(verts, torch.float32, "verts"), _dev(normals, torch.float32, "normals"),
                                    verts.shape[0], _dev(out_v), _dev(out_n), _stream()))
+    return out_v, out_n
+
+
+def warp_to_live_graph(node_pos, node_dq, node_w, idx, verts, normals=None):
+    """dfa_warp_to_live_graph: the warp of dfa_warp_to_live with the k-NN indices given (idx (N, k) int32)"""
+    torch = _torch()
+    N, k = idx.shape
+    out_v = torch.empty_like(verts)
+    out_n = torch.empty_like(verts) if normals is not None else None
+    f32 = torch.float32
+    _check(load().dfa_warp_to_live_graph(_dev(node_pos, f32, "node_pos"), _dev(node_dq, f32, "node_dq"), _dev(node_w, f32, "node_w"),
+                                         node_pos.shape[0], k, _dev(idx, torch.int32, "idx"), _dev(verts, f32, "verts"),
+                                         _dev(normals, f32, "normals"), N, out_v.data_ptr(),
+                                         out_n.data_ptr() if out_n is not None else None, _stream()))
     return out_v, out_n
 
 

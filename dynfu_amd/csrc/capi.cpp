@@ -496,6 +496,18 @@ int dfa_warp_to_live(const float* node_pos, const float* node_dq, const float* n
     return DFA_OK;
 }
 
+int dfa_warp_to_live_graph(const float* node_pos, const float* node_dq, const float* node_w, int D, int k,
+                           const int32_t* idx, const float* vertices, const float* normals, int N, float* out_vertices,
+                           float* out_normals, dfa_stream_t stream) {
+    REQUIRE(node_pos && node_dq && node_w && D > 0, "no nodes");
+    REQUIRE(N >= 0 && (N == 0 || (vertices && out_vertices && idx)), "bad vertices / graph / output");
+    REQUIRE(k >= 1 && k <= DFA_MAX_KNN, "k out of range 1..16");
+    if (N > 0)
+        HIP_TRY(dfa::launch_warp_graph(node_pos, node_dq, node_w, k, idx, vertices, normals, N, out_vertices, out_normals,
+                                       S(stream)));
+    return DFA_OK;
+}
+
 int dfa_calc_dqb(const float* node_pos, const float* node_dq, const float* node_w, int D, int k, const float* points,
                  int n, float* out_dq, dfa_stream_t stream) {
     REQUIRE(node_pos && node_dq && node_w && D > 0, "no nodes");

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include <dfa_host/device.hpp>
 
@@ -11,6 +12,14 @@
 struct Warpfield::DeviceNodes {
     dfa::DeviceArray<float> pos, w, dq;  // D x 3, D, D x 8
     int D = 0;
+    // neighbours of the cloud warpToLive saw last: every frame of a sequence warps the SAME canonical cloud
+    // (dyn_fusion.cpp:196) and the node set only ever grows, so while the cloud's device array, its size and the node
+    // count are the ones of the call before, the k-NN search of that call still holds (DFA_HOST_NO_GRAPH_REUSE=1: search
+    // every time)
+    dfa::DeviceArray<float> knn_verts;  // (kept alive: its address identifies the cloud)
+    dfa::DeviceArray<int32_t> knn_idx;
+    size_t knn_N = 0;
+    int knn_D = 0, knn_k = 0;
 };
 
 Warpfield::Warpfield()  = default;
@@ -115,9 +124,25 @@ std::shared_ptr<dynfu::Frame> Warpfield::warpToLive(std::shared_ptr<dynfu::Frame
     const size_t N = canonicalFrame->size();
     if (N == 0 || !dev || dev->D == 0)
         return std::make_shared<dynfu::Frame>(0, dfa::PointCloud<dfa::PointXYZ>(), dfa::PointCloud<dfa::Normal>());
-    const dynfu::Frame::DeviceView in = canonicalFrame->device();
     syncTransforms();
     dfa::DeviceArray<float> ov(3 * N), on(3 * N);
+    if (canonicalFrame->deviceResident() && !std::getenv("DFA_HOST_NO_GRAPH_REUSE")) {
+        // a device-resident frame never changes its arrays: their address names the cloud
+        dfa::DeviceArray<float> v3, n3;
+        canonicalFrame->deviceArrays(v3, n3);
+        DeviceNodes& d = *dev;
+        if (!(d.knn_verts.ptr() == v3.ptr() && d.knn_N == N && d.knn_D == d.D && d.knn_k == knn_)) {
+            d.knn_idx = dfa::DeviceArray<int32_t>(N * (size_t)knn_);
+            dfa::check(dfa_knn(d.pos.ptr(), d.w.ptr(), d.D, v3.ptr(), (int)N, knn_, d.knn_idx.ptr(), nullptr, nullptr),
+                       "Warpfield::warpToLive (k-NN)");
+            d.knn_verts = v3, d.knn_N = N, d.knn_D = d.D, d.knn_k = knn_;
+        }
+        dfa::check(dfa_warp_to_live_graph(d.pos.ptr(), d.dq.ptr(), d.w.ptr(), d.D, knn_, d.knn_idx.ptr(), v3.ptr(), n3.ptr(),
+                                          (int)N, ov.ptr(), on.ptr(), nullptr),
+                   "Warpfield::warpToLive");
+        return dynfu::Frame::fromDevice(0, ov, on, N);
+    }
+    const dynfu::Frame::DeviceView in = canonicalFrame->device();
     dfa::check(dfa_warp_to_live(dev->pos.ptr(), dev->dq.ptr(), dev->w.ptr(), dev->D, knn_, in.vertices, in.normals, (int)N,
                                 ov.ptr(), on.ptr(), nullptr),
                "Warpfield::warpToLive");

@@ -193,6 +193,13 @@ int dfa_warp_to_live(const float* node_pos, const float* node_dq, const float* n
                      const float* vertices, const float* normals, int N, float* out_vertices, float* out_normals,
                      dfa_stream_t stream);
 
+/* The same warp with the neighbours given (idx: N x k int32 as dfa_knn returns them, -1 padded): identical output to
+ * dfa_warp_to_live without the search.  For callers that warp the same vertices again while the node set is unchanged
+ * (every frame of a sequence warps the canonical cloud, dyn_fusion.cpp:196). */
+int dfa_warp_to_live_graph(const float* node_pos, const float* node_dq, const float* node_w, int D, int k,
+                           const int32_t* idx, const float* vertices, const float* normals, int N, float* out_vertices,
+                           float* out_normals, dfa_stream_t stream);
+
 /* Warpfield::calcDQB (warp_field.cpp:127-148) at n points: the blended dual quaternion itself, n x 8 floats
  * (Warpfield::update seeds a new node with it, warp_field.cpp:78).  node_dq may be NULL only if out_dq is. */
 int dfa_calc_dqb(const float* node_pos, const float* node_dq, const float* node_w, int D, int k, const float* points,

@@ -125,6 +125,21 @@ def test_warp_to_live_matches_oracle(A, name):
     assert np.array_equal(host(ov), verts)
 
 
+@pytest.mark.parametrize("name", ["T1", "C1"])
+def test_warp_with_a_given_graph_equals_the_warp_that_searches(A, name):
+    cfg = synth.CONFIGS[name]
+    c = synth.canonical(cfg)
+    D, k = cfg["D"], cfg["k"]
+    rng = np.random.default_rng(9)
+    dq = np.stack([O.dq_from_euler(*rng.uniform(-0.2, 0.2, 3), *rng.uniform(-0.05, 0.05, 3)) for _ in range(D)])
+    verts, normals = c["verts"], c["normals"]
+    args = (dev(c["node_pos"]), dev(dq), dev(c["node_w"]))
+    ov, on = A.warp_to_live(*args, k, dev(verts), dev(normals))
+    idx, _ = A.knn(args[0], args[2], dev(verts), k)
+    gv, gn = A.warp_to_live_graph(*args, idx, dev(verts), dev(normals))
+    assert np.array_equal(bits(host(gv)), bits(host(ov))) and np.array_equal(bits(host(gn)), bits(host(on)))
+
+
 def test_warp_empty_and_errors(A):
     import torch
     nodes = torch.zeros((4, 3), device="cuda")
