@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void linearise_kernel(SolveView s, SolveState*
     // That includes the solve's closing evaluation (mode 2) when an iteration ran: the flag is set by a PCG that found
     // its gradient at the floor and left t where the linearisation before it had evaluated the cost.
     if (st->converged == 1 || (st->converged && !a.update_weights)) {
-        if (a.mode != 2 || st->have_initial) return;
+        if (a.mode != 2 || (st->have_initial && !st->cost_stale)) return;
     }
     const size_t R = (size_t)s.N + (size_t)s.D * s.k;
     double c       = 0.0;
@@ -288,6 +288,7 @@ __global__ __launch_bounds__(256) void linearise_kernel(SolveView s, SolveState*
             st->done = 1;
         st->cost       = cost;
         st->final_cost = cost;
+        st->cost_stale = 0;
         // robust weights evaluated at THIS t: a gradient at the floor now means the whole solve has converged (with
         // stale weights it only ends the current outer iteration: the next one re-weights at the moved t)
         if (a.mode != 2) st->weights_fresh = a.update_weights;
@@ -417,7 +418,7 @@ __device__ __forceinline__ float4 load_record(const SolveView& s, size_t r, int 
 }
 
 template <int K>
-__global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* __restrict__ st) {
+__global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* __restrict__ st, int save_base) {
     __shared__ int key[HASH];
     __shared__ float val[HASH];
     __shared__ float gpart[4][3];
@@ -544,7 +545,11 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
         s.ell_cnt[a] = min(total, s.ell_cap);
         if (!has_diag) s.diag[a] = 0.f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) s.g[3 * a + c] = (gpart[0][c] + gpart[1][c]) + (gpart[2][c] + gpart[3][c]);
+        for (int c = 0; c < 3; ++c) {
+            const float gc = (gpart[0][c] + gpart[1][c]) + (gpart[2][c] + gpart[3][c]);
+            s.g[3 * a + c] = gc;
+            if (save_base) s.g_base[3 * a + c] = gc, s.t_base[3 * a + c] = s.t[3 * a + c];
+        }
         // 2048 device-scope atomics on one word cost ~11 ns each: only the (few) blocks that raise
         // the running maximum issue one
         if (total > *(volatile int*)&st->max_row_nnz) atomicMax(&st->max_row_nnz, total);
@@ -1300,8 +1305,31 @@ hipError_t solve_huber(const SolveView& s, float psi_reg, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t solve_assemble(const SolveView& s, SolveState* state, hipStream_t st) {
-    KDISPATCH(assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state));
+hipError_t solve_assemble(const SolveView& s, SolveState* state, int save_base, hipStream_t st) {
+    KDISPATCH(assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base));
+    return hipGetLastError();
+}
+
+// g = g_base - A (t - t_base): a thread per row over the slot-major ELL (entry q of row a at [q * D + a]: coalesced)
+__global__ __launch_bounds__(256) void regradient_kernel(SolveView s, SolveState* __restrict__ st) {
+    if (st->done || st->converged) return;
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a == 0) st->cost_stale = 1, st->weights_fresh = 0;  // (a floor hit now ends this outer iteration only)
+    if (a >= s.D) return;
+    const int cnt = s.ell_cnt[a];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int q = 0; q < cnt; ++q) {
+        const float2 e = s.ell[(size_t)q * s.D + a];
+        const int col  = __float_as_int(e.y);
+        sx = fmaf(e.x, s.t[3 * col] - s.t_base[3 * col], sx);
+        sy = fmaf(e.x, s.t[3 * col + 1] - s.t_base[3 * col + 1], sy);
+        sz = fmaf(e.x, s.t[3 * col + 2] - s.t_base[3 * col + 2], sz);
+    }
+    s.g[3 * a] = s.g_base[3 * a] - sx, s.g[3 * a + 1] = s.g_base[3 * a + 1] - sy, s.g[3 * a + 2] = s.g_base[3 * a + 2] - sz;
+}
+
+hipError_t solve_regradient(const SolveView& s, SolveState* state, hipStream_t st) {
+    regradient_kernel<<<(s.D + 255) / 256, 256, 0, st>>>(s, state);
     return hipGetLastError();
 }
 

@@ -32,6 +32,8 @@ struct SolveState {
     int mb_skip, mb_iters;
     int weights_fresh;  // the last linearisation re-evaluated the robust weights (at the t it linearised about)
     int gn_noop;    // Gauss-Newton iterations that returned at entry this way (counted in gn_iters too)
+    int cost_stale;  // t has moved since the last linearisation evaluated the cost (inner iterations restarted by
+                     // solve_regradient): the closing evaluation must run even when the solve has converged
     float mb_rz0, mb_gamma_prev[2], mb_alpha_prev[2];
     long long prof[8];  // DFA_PCG_PROFILE builds: shader cycles per PCG phase (thread 0)
 };
@@ -75,6 +77,8 @@ struct SolveView {
     int32_t* ell_cnt;  // D
     float* diag;       // D
     float* g;          // D x 3   -J^T r
+    float* g_base;     // D x 3   g at the last full linearisation ...
+    float* t_base;     // D x 3   ... and the t it was taken at (inner iterations: g = g_base - A (t - t_base))
     // workspace of the streaming PCG: rows sorted by length, rank-major repacked matrix
     int32_t* pk_perm;   // D
     float* pk_vals;     // ell_cap x D
@@ -104,7 +108,11 @@ hipError_t solve_linearise(const SolveView& s, SolveState* state, double* cost_p
                            long long* iters_total /* mode 2: += the solve's PCG iterations (optional, device) */, hipStream_t st);
 hipError_t solve_huber(const SolveView& s, float psi_reg, hipStream_t st);
 hipError_t solve_reset(const SolveView& s, SolveState* state, unsigned int* ticket, int nticket, hipStream_t st);
-hipError_t solve_assemble(const SolveView& s, SolveState* state, hipStream_t st);
+hipError_t solve_assemble(const SolveView& s, SolveState* state, int save_base /* g, t -> g_base, t_base */, hipStream_t st);
+// inner Gauss-Newton iteration of an outer iteration whose robust weights are frozen: the energy is linear least squares,
+// so the matrix of the outer iteration's first linearisation still holds and the new right-hand side is
+// g = g_base - A (t - t_base) — one sparse matrix-vector product instead of a linearisation and an assembly
+hipError_t solve_regradient(const SolveView& s, SolveState* state, hipStream_t st);
 int solve_pcg_max_nodes();
 __host__ __device__ inline int solve_mb_rows_per_block() { return 16; }  // multi-workgroup PCG: 16 lanes per row, 256 threads
 __host__ __device__ inline int solve_mb_blocks(int D) { return (D + 15) / 16; }

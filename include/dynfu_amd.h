@@ -301,6 +301,8 @@ int dfa_solver_set_problem(dfa_solver* s, const float* node_pos, const float* no
  * iteration Tukey + Huber weights, then Gauss-Newton with a block-Jacobi PCG on the normal
  * equations of energy.t.  Up to 2048 nodes and 8 Gauss-Newton iterations (num_iter x nonlinear_iter) everything is
  * enqueued on `stream` without any host synchronisation; with a larger iteration budget (the reference's 24 x 16) the
+ * inner iterations (nonlinear_iter > 1: robust weights frozen, so the energy is linear least squares) keep the matrix of
+ * the outer iteration's first linearisation and restart the PCG on g - A (t - t_0) when lambda > 0 and gn_tol = 0; the
  * call reads the plan's `converged` flag back every 4th iteration of an outer iteration and stops launching its
  * remaining (or all remaining) iterations once it is set (the iterations not launched are booked as no-ops, like those
  * whose kernels return at entry); larger problems use a many-workgroup

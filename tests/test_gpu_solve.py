@@ -370,6 +370,31 @@ def test_inner_iterations_behind_a_gradient_at_the_floor_are_no_ops(A, monkeypat
     assert np.abs(out[(2, 12)][0] - t_ref).max() <= 2e-5
 
 
+@pytest.mark.parametrize("name,variant", [("T1", None), ("T1", "3"), ("C1", None)])
+def test_inner_iterations_restart_on_the_true_residual_of_the_same_matrix(A, monkeypatch, name, variant):
+    """While the robust weights are frozen the matrix of an outer iteration's first linearisation holds for its inner
+    iterations, whose right-hand side is g_base - A (t - t_base): same translations and final cost as re-linearising and
+    re-assembling every inner iteration (DFA_NO_REGRADIENT=1), and as the oracle, which does exactly that."""
+    if variant is not None:
+        monkeypatch.setenv("DFA_PCG_VARIANT", variant)
+    cfg, c, verts, live, t_true = _problem(name)
+    k = cfg["k"]
+    s = A.Solver(cfg["D"], len(verts), k)
+    out = {}
+    for long_way in (False, True):
+        if long_way:
+            monkeypatch.setenv("DFA_NO_REGRADIENT", "1")
+        s.set_problem(dev(c["node_pos"]), dev(c["node_dq"]), dev(c["node_w"]), dev(verts), dev(live))
+        s.solve(_params(A, num_iter=2, nonlinear_iter=4, linear_iter=40, lambda_=200.0, pcg_tol=1e-3))  # inexact inner solves
+        out[long_way] = (host(s.translations()).copy(), s.stats())
+    s.close()
+    assert out[False][1]["gn_iters"] == out[True][1]["gn_iters"] == 8
+    assert np.abs(out[False][0] - out[True][0]).max() < 5e-6
+    np.testing.assert_allclose(out[False][1]["final_cost"], out[True][1]["final_cost"], rtol=2e-4)
+    np.testing.assert_allclose(out[False][1]["initial_cost"], out[True][1]["initial_cost"], rtol=1e-6)
+    assert np.abs(out[False][0] - t_true).max() < 2e-4
+
+
 def test_solver_timing_accumulates_pauses_and_resumes(A):
     """dfa_solver_enable_timing: 1 starts a measurement, 0 pauses it, 2 resumes; dfa_solver_get_timing returns the
     sums over the measured solves (bench.py brackets every 8th frame this way)"""
