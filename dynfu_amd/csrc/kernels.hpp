@@ -42,10 +42,10 @@ struct KnnGridView {
     int32_t* node_cell;   // D
     float4* sorted;       // D   (x, y, z, node index bits), grouped by cell
 };
-// The same structure at up to 128^3 cells for large point sets (dfa_correspond's canonical cloud)
-constexpr int PGRID_MAX_DIM     = 128;
+// The same structure at up to 256^3 cells for large point sets (dfa_correspond's canonical cloud)
+constexpr int PGRID_MAX_DIM     = 256;   // (128 up to half a million points: see pgrid_finalize_kernel)
 constexpr int PGRID_MAX_CELLS   = PGRID_MAX_DIM * PGRID_MAX_DIM * PGRID_MAX_DIM;
-constexpr int PGRID_CHUNK       = 8192;  // cells per scan workgroup -> 256 chunks
+constexpr int PGRID_CHUNK       = 8192;  // cells per scan workgroup -> up to 2048 chunks
 constexpr int PGRID_BBOX_BLOCKS = 512;
 struct PointGridView {
     KnnGridView g;           // cell_count: PGRID_MAX_CELLS, cell_start: PGRID_MAX_CELLS + 1

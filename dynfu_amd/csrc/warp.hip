@@ -281,7 +281,7 @@ __global__ __launch_bounds__(1024) void grid_build_one_kernel(const float* __res
     }
 }
 
-// ---- large point sets (the canonical cloud of dfa_correspond): up to 128^3 cells ----------------
+// ---- large point sets (the canonical cloud of dfa_correspond): up to 128^3 cells, 256^3 above 500 k points ----
 // Same data structure, built by multi-workgroup kernels: bounding box by per-block partials, the
 // exclusive scan of the cell counts in chunks of PGRID_CHUNK cells (chunk sums, then a scan kernel
 // that first adds up the sums of the chunks before it).
@@ -327,9 +327,13 @@ __global__ __launch_bounds__(64) void pgrid_finalize_kernel(const float* __restr
         for (int c = 0; c < 3; ++c) desc->bmin[c] = mn[c], ext[c] = fmaxf(mx[c] - mn[c], 0.f);
         const float emax = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
         // points of a surface: the volume rule over-estimates the spacing, so aim below it and let the
-        // 128-cells-per-axis cap decide for thin clouds
-        float cs = 0.7f * cbrtf((ext[0] * ext[1] * ext[2]) / (float)n);
-        cs       = fmaxf(cs, emax / (float)PGRID_MAX_DIM);
+        // cells-per-axis cap decide for thin clouds.  Up to half a million points: 128 cells per axis (2 M cells, 8 MiB of
+        // counters to clear and scan per build).  Above (a 512^3 volume's surface: a million vertices) the search
+        // walks ~70 points per cell at that cap, so the cap doubles and the aim halves: ~20 points per cell, a search
+        // 2.5x shorter for ~40 us more of clearing and scanning.
+        const bool large = n > 500000;
+        float cs = (large ? 0.5f : 0.7f) * cbrtf((ext[0] * ext[1] * ext[2]) / (float)n);
+        cs       = fmaxf(cs, emax / (float)(large ? PGRID_MAX_DIM : 128));
         if (!(cs > 0.f)) cs = 1.f;
         desc->cs = cs, desc->inv_cs = 1.f / cs;
         for (int c = 0; c < 3; ++c) desc->dim[c] = min(max((int)(ext[c] * desc->inv_cs) + 1, 1), PGRID_MAX_DIM);
@@ -364,8 +368,9 @@ __global__ __launch_bounds__(256) void pgrid_scan_kernel(const KnnGridDesc* __re
     __shared__ int sh[4], sh2[4];
     const int nc = pgrid_cells(*desc), base = blockIdx.x * PGRID_CHUNK;
     if (base >= nc) return;
-    // offset of this chunk = sum of the chunk sums before it (at most PGRID_MAX_CELLS / PGRID_CHUNK = 256)
-    int before = (int)threadIdx.x < (int)blockIdx.x ? chunk_sums[threadIdx.x] : 0;
+    // offset of this chunk = sum of the chunk sums before it (at most PGRID_MAX_CELLS / PGRID_CHUNK = 2048)
+    int before = 0;
+    for (int i = (int)threadIdx.x; i < (int)blockIdx.x; i += 256) before += chunk_sums[i];
     for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = before;
     constexpr int PER = PGRID_CHUNK / 256;
@@ -456,7 +461,7 @@ __device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32
         // the grid, hence from the query); stop when the k-th candidate is strictly closer,
         // with a relative margin that absorbs the rounding of the cell assignment
         // (TIGHT: the cell coordinate of a point is rounded with an error ~1e-5 cells at 128 cells per
-        // axis; 1e-3 cells are taken off the bound before the relative margin)
+        // axis, twice that at 256; 1e-3 cells are taken off the bound before the relative margin)
         const float bound = TIGHT ? fmaxf((float)r + margin - 1e-3f, 0.f) * g.cs : (float)r * g.cs;
         if (best.d[K - 1] < bound * bound * 0.9999f) break;
     }
@@ -742,8 +747,9 @@ hipError_t point_grid_build(const PointGridView& pg, const float* pts, int n, hi
     pgrid_finalize_kernel<<<1, 64, 0, s>>>(pg.bbox_partials, bbox_blocks, n, g.desc);
     pgrid_clear_kernel<<<1024, 256, 0, s>>>(g.desc, g.cell_count);
     grid_count_kernel<<<nb, 256, 0, s>>>(pts, n, g.desc, g.cell_count, g.node_cell);
-    pgrid_sum_kernel<<<PGRID_MAX_CELLS / PGRID_CHUNK, 256, 0, s>>>(g.desc, g.cell_count, pg.chunk_sums);
-    pgrid_scan_kernel<<<PGRID_MAX_CELLS / PGRID_CHUNK, 256, 0, s>>>(g.desc, g.cell_count, g.cell_start, pg.chunk_sums);
+    const int chunks = (n > 500000 ? PGRID_MAX_CELLS : 128 * 128 * 128) / PGRID_CHUNK;  // (the cap pgrid_finalize_kernel applies)
+    pgrid_sum_kernel<<<chunks, 256, 0, s>>>(g.desc, g.cell_count, pg.chunk_sums);
+    pgrid_scan_kernel<<<chunks, 256, 0, s>>>(g.desc, g.cell_count, g.cell_start, pg.chunk_sums);
     grid_fill_kernel<<<nb, 256, 0, s>>>(pts, n, g.node_cell, g.cell_count, g.sorted);
     return hipGetLastError();
 }

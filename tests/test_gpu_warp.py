@@ -182,6 +182,27 @@ def test_correspond_bit_exact(A, n_canon, n_live):
         assert np.all((ref[0][:, 0] == ridx[:20000]) | (np.abs(d - dm) <= 1e-12))
 
 
+def test_correspond_a_million_points_against_the_reference_kd_tree(A):
+    """Clouds of more than half a million points switch to the finer grid (up to 256 cells per axis): a million canonical
+    points on the synthetic surface, checked against the reference's own nanoflann KD-tree (oracle/_ref) on 60 000 queries
+    and by the defining property on all of them (no canonical point of a random sample is closer than the one returned)."""
+    cv, cn, lv = _surface_clouds(1 << 20, 300000, 77)
+    ov, on, idx = A.correspond(dev(cv), dev(cn), dev(lv))
+    idx_h, ov_h = host(idx), host(ov)
+    assert np.array_equal(ov_h, cv[idx_h]) and np.array_equal(host(on), cn[idx_h])
+    d_ret = ((lv.astype(np.float64) - ov_h.astype(np.float64)) ** 2).sum(1)
+    rng = np.random.default_rng(1)
+    for _ in range(4):  # random canonical points are never closer than the returned one
+        cand = cv[rng.integers(0, len(cv), len(lv))]
+        assert np.all(((lv.astype(np.float64) - cand.astype(np.float64)) ** 2).sum(1) >= d_ret - 1e-12)
+    ref = O.ref_knn(cv, lv[:60000], 1)
+    if ref is not None:
+        r = ref[0][:, 0]
+        d_ref = ((lv[:60000].astype(np.float64) - cv[r].astype(np.float64)) ** 2).sum(1)
+        assert np.all((r == idx_h[:60000]) | (np.abs(d_ref - d_ret[:60000]) <= 1e-12))
+        assert (r == idx_h[:60000]).mean() > 0.999
+
+
 def test_correspond_duplicates_optional_outputs_and_errors(A):
     import torch
     cv = np.tile(np.array([[0, 0, 1], [0.5, 0, 1], [0, 0, 1]], np.float32), (50, 1))  # every point 50 (or 100) times
