@@ -361,6 +361,36 @@ __global__ __launch_bounds__(256) void pgrid_sum_kernel(const KnnGridDesc* __res
     if (threadIdx.x == 0) chunk_sums[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// exclusive scan of the (at most PGRID_MAX_CELLS / PGRID_CHUNK = 2048) chunk totals, in place, by one workgroup
+__global__ __launch_bounds__(256) void pgrid_chunkscan_kernel(int32_t* __restrict__ chunk_sums, int chunks) {
+    __shared__ int wsum[4];
+    constexpr int PER = (PGRID_MAX_CELLS / PGRID_CHUNK + 255) / 256;
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = (int)threadIdx.x * PER + j;
+        loc[j]      = i < chunks ? chunk_sums[i] : 0;
+        sum += loc[j];
+    }
+    int incl       = sum;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int off = incl - sum;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = (int)threadIdx.x * PER + j;
+        if (i < chunks) chunk_sums[i] = off;
+        off += loc[j];
+    }
+}
+
 __global__ __launch_bounds__(256) void pgrid_scan_kernel(const KnnGridDesc* __restrict__ desc,
                                                          int32_t* __restrict__ cell_count /* in: counts, out: cursors */,
                                                          int32_t* __restrict__ cell_start,
@@ -368,11 +398,8 @@ __global__ __launch_bounds__(256) void pgrid_scan_kernel(const KnnGridDesc* __re
     __shared__ int sh[4], sh2[4];
     const int nc = pgrid_cells(*desc), base = blockIdx.x * PGRID_CHUNK;
     if (base >= nc) return;
-    // offset of this chunk = sum of the chunk sums before it (at most PGRID_MAX_CELLS / PGRID_CHUNK = 2048)
-    int before = 0;
-    for (int i = (int)threadIdx.x; i < (int)blockIdx.x; i += 256) before += chunk_sums[i];
-    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = before;
+    // offset of this chunk: chunk_sums holds the exclusive scan of the chunk totals (pgrid_chunkscan_kernel)
+    if (threadIdx.x < 4) sh[threadIdx.x] = threadIdx.x == 0 ? chunk_sums[blockIdx.x] : 0;
     constexpr int PER = PGRID_CHUNK / 256;
     const int first   = base + threadIdx.x * PER;
     int loc[PER], sum = 0;
@@ -749,6 +776,7 @@ hipError_t point_grid_build(const PointGridView& pg, const float* pts, int n, hi
     grid_count_kernel<<<nb, 256, 0, s>>>(pts, n, g.desc, g.cell_count, g.node_cell);
     const int chunks = (n > 500000 ? PGRID_MAX_CELLS : 128 * 128 * 128) / PGRID_CHUNK;  // (the cap pgrid_finalize_kernel applies)
     pgrid_sum_kernel<<<chunks, 256, 0, s>>>(g.desc, g.cell_count, pg.chunk_sums);
+    pgrid_chunkscan_kernel<<<1, 256, 0, s>>>(pg.chunk_sums, chunks);
     pgrid_scan_kernel<<<chunks, 256, 0, s>>>(g.desc, g.cell_count, g.cell_start, pg.chunk_sums);
     grid_fill_kernel<<<nb, 256, 0, s>>>(pts, n, g.node_cell, g.cell_count, g.sorted);
     return hipGetLastError();
