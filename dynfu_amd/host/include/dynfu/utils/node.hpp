@@ -17,6 +17,10 @@ public:
     void updateTransformation(std::shared_ptr<DualQuaternion<float>> new_dg_se3) {
         dg_se3 = std::make_shared<DualQuaternion<float>>(*new_dg_se3 * *dg_se3);
     }
+    // the same composition from a value (one allocation per call instead of two: a solve updates every node)
+    void updateTransformation(const DualQuaternion<float>& new_dg_se3) {
+        dg_se3 = std::make_shared<DualQuaternion<float>>(new_dg_se3 * *dg_se3);
+    }
     void setTransformation(std::shared_ptr<DualQuaternion<float>> new_dg_se3) { dg_se3 = new_dg_se3; }
     float getRadialBasisWeight() { return dg_w; }
     // exp(-|dg_v - v|^2 / (2 dg_w^2)), double arithmetic (node.cpp:29-36)

@@ -100,7 +100,6 @@ void CombinedSolver::solveAll() {
     }
     auto nodes = m_warpfield.getNodes();
     for (int i = 0; i < I.D; ++i) {
-        auto dq = std::make_shared<DualQuaternion<float>>(0.f, 0.f, 0.f, t[3 * i], t[3 * i + 1], t[3 * i + 2]);
-        nodes[i]->updateTransformation(dq);
+        nodes[i]->updateTransformation(DualQuaternion<float>(0.f, 0.f, 0.f, t[3 * i], t[3 * i + 1], t[3 * i + 2]));
     }
 }
