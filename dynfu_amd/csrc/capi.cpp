@@ -1070,8 +1070,10 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
     REQUIRE(prm->num_iter >= 0 && prm->gn_iter >= 0 && prm->linear_iter >= 0, "negative iteration count");
     REQUIRE(prm->tukey_offset > 0.f && prm->psi_data > 0.f && prm->psi_reg > 0.f, "non-positive robust parameter");
     REQUIRE(prm->damping >= 0.f && prm->lambda >= 0.f, "negative damping / lambda");
+    REQUIRE(prm->pcg_tol_first <= 0.f || (prm->pcg_tol_decay > 0.f && prm->pcg_tol_decay <= 1.f), "forcing decay outside (0, 1]");
     dfa::Solve6Params p{prm->num_iter, prm->gn_iter, prm->linear_iter, prm->tukey_offset, prm->psi_data, prm->lambda,
-                        prm->psi_reg, prm->dist_thresh, prm->cos_thresh, prm->damping, prm->pcg_tol};
+                        prm->psi_reg, prm->dist_thresh, prm->cos_thresh, prm->damping, prm->pcg_tol, prm->pcg_tol_first,
+                        prm->pcg_tol_decay};
     dfa::Solve6Image img{live_vertex_map, live_normal_map, vertex_step, normal_step, cols, rows, fx, fy, cx, cy};
     hipStream_t st = S(stream);
     s->ev_used = 0;
@@ -1090,7 +1092,7 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
             mark();
             HIP_TRY(dfa::s6_linearise(s->v, s->state, img, p, gn == 0, st));
             mark();
-            HIP_TRY(dfa::s6_assemble(s->v, s->state, p, st));
+            HIP_TRY(dfa::s6_assemble(s->v, s->state, p, gn, st));
             mark();
             // the PCG launches of one Gauss-Newton iteration are replayed as a HIP graph; if capture is not possible
             // here (it never is on some stream configurations) the launches are issued one by one — same kernels
@@ -1123,7 +1125,7 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
             }
             if (!replayed) HIP_TRY(dfa::s6_pcg(s->v, s->state, p, st));
             mark();
-            HIP_TRY(dfa::s6_update(s->v, s->state, st));
+            HIP_TRY(dfa::s6_update(s->v, s->state, p.linear_iter, st));
         }
     return DFA_OK;
 }
@@ -1172,6 +1174,13 @@ int dfa_solver6_get_stats(dfa_solver6* s, dfa_solve6_stats* out, dfa_stream_t st
     out->gn_iters = h.gn_iters, out->pcg_iters = h.pcg_iters;
     out->valid_first = (long long)h.valid_first, out->valid_last = (long long)h.valid_last;
     out->max_row_blocks = h.max_row_blocks, out->overflow = h.overflow;
+    static_assert(DFA_SOLVE6_HIST == dfa::S6_HIST, "history length of the C ABI and of the state block");
+    for (int i = 0; i < DFA_SOLVE6_HIST; ++i) {
+        const bool in = i < h.gn_iters;
+        out->cost_hist[i] = in ? h.cost_hist[i] : 0.0;
+        out->pcg_rel_hist[i] = in ? h.pcg_rel_hist[i] : 0.f;
+        out->pcg_it_hist[i] = in ? h.pcg_it_hist[i] : 0;
+    }
     return h.overflow ? fail(DFA_ERR_CAPACITY, "a block row of the normal matrix exceeded the plan's capacity") : DFA_OK;
 }
 

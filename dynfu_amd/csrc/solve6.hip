@@ -341,6 +341,17 @@ __device__ void inv6(const float* M, float* out) {
     }
 }
 
+// bookkeeping of the linearisation that just finished (one thread of the assembly launch): costs, the slot of this
+// Gauss-Newton iteration in the per-iteration history, the stop test of the PCG that follows
+__device__ __forceinline__ void s6_bookkeeping(Solve6State* st, float tol2) {
+    if (!st->have_first) st->initial_cost = st->cost, st->valid_first = st->valid, st->have_first = 1;
+    st->final_cost = st->cost, st->valid_last = st->valid;
+    const int h = st->gn_iters;
+    if (h < S6_HIST) st->cost_hist[h] = st->cost, st->pcg_it_hist[h] = 0, st->pcg_rel_hist[h] = 1.f;
+    st->gn_iters = h + 1;
+    st->tol2 = tol2, st->pcg_last_it = 0;
+}
+
 // Sparsity pattern of block row a (fixed by the graphs of the frame, built once per set_problem):
 // the diagonal first, then every node that shares a vertex with a or is joined to it by a
 // regularisation edge, ascending.
@@ -506,7 +517,7 @@ constexpr int S6_STAGE   = 64;
 constexpr int S6_MAXSLOT = S6_MAXSLOT_PATTERN;  // = plan capacity of a block row
 
 template <int K>
-__global__ __launch_bounds__(256) void s6_assemble_kernel(Solve6View s, Solve6State* st, float wreg2, float damping) {
+__global__ __launch_bounds__(256) void s6_assemble_kernel(Solve6View s, Solve6State* st, float wreg2, float damping, float tol2) {
     __shared__ float4 sl8[S6_STAGE][2];   // l = (lW, lD)
     __shared__ float sfv[S6_STAGE][K];    // f_j
     __shared__ uint8_t sslot[S6_STAGE][K];
@@ -515,11 +526,7 @@ __global__ __launch_bounds__(256) void s6_assemble_kernel(Solve6View s, Solve6St
     __shared__ float g8[4][8];
     __shared__ float diag[36];
     const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
-    if (a == 0 && tid == 0) {  // bookkeeping of the linearisation that just finished
-        if (!st->have_first) st->initial_cost = st->cost, st->valid_first = st->valid, st->have_first = 1;
-        st->final_cost = st->cost, st->valid_last = st->valid;
-        st->gn_iters += 1;
-    }
+    if (a == 0 && tid == 0) s6_bookkeeping(st, tol2);
     const int cnt = s.bcnt[a];
     const int beg = s.node_ptr[a], end = s.node_ptr[a + 1];
     for (int i = tid; i < 4 * S6_MAXSLOT * 16; i += 256) (&acc[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -718,7 +725,7 @@ __device__ __forceinline__ float quads_reduce_scatter(float (&v)[16], int lane) 
 }
 
 template <int K, int S6_RC>
-__global__ __launch_bounds__(256) void s6_assemble2_kernel(Solve6View s, Solve6State* st, float wreg2, float damping) {
+__global__ __launch_bounds__(256) void s6_assemble2_kernel(Solve6View s, Solve6State* st, float wreg2, float damping, float tol2) {
     extern __shared__ __attribute__((aligned(16))) char s6_dyn[];
     float(*sl8)[8]  = reinterpret_cast<float(*)[8]>(s6_dyn);                                      // l = (lW, lD)
     float(*sfv)[K]  = reinterpret_cast<float(*)[K]>(s6_dyn + sizeof(float) * 8 * S6_RC);          // f_j
@@ -729,11 +736,7 @@ __global__ __launch_bounds__(256) void s6_assemble2_kernel(Solve6View s, Solve6S
     __shared__ float diag[36];
     __shared__ int cur[S6_MAXSLOT + 1];
     const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
-    if (a == 0 && tid == 0) {  // bookkeeping of the linearisation that just finished
-        if (!st->have_first) st->initial_cost = st->cost, st->valid_first = st->valid, st->have_first = 1;
-        st->final_cost = st->cost, st->valid_last = st->valid;
-        st->gn_iters += 1;
-    }
+    if (a == 0 && tid == 0) s6_bookkeeping(st, tol2);
     const int cnt = s.bcnt[a];
     const int beg = s.node_ptr[a], len = s.node_ptr[a + 1] - beg;
     const int wave = tid >> 6, lane = tid & 63, g16 = lane >> 2, c4 = lane & 3;
@@ -1013,8 +1016,7 @@ __global__ __launch_bounds__(256) void s6_pcg_init_kernel(Solve6View s, Solve6St
 }
 
 // launch `it` = -1: w_0 = A u_0, m_0, gamma_0, delta_0.   launch it >= 0: iteration `it` as above.
-__global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(Solve6View s, Solve6State* st, int it,
-                                                                              float tol2) {
+__global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(Solve6View s, Solve6State* st, int it) {
     __shared__ float stage[S6_NODES_PER_BLOCK][3][64];
     __shared__ float gd_sh[S6_NODES_PER_BLOCK][2];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1035,6 +1037,7 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(So
     const int done = st->pcg_done;
     float gp[MAXP], dp[MAXP];
     float gamma_prev = 1.f, alpha_prev = 1.f, rz0 = 0.f;
+    const float tol2 = st->tol2;
     if (it >= 0) {
 #pragma unroll
         for (int q = 0; q < MAXP; ++q) {
@@ -1097,7 +1100,11 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(So
         }
         // converged, or breakdown: the same decision in every workgroup
         if (!(gamma > 0.f) || gamma <= tol2 * rz0 || !(denom > 0.f)) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) st->pcg_done = 1;
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                st->pcg_done = 1;
+                const int h = st->gn_iters - 1;
+                if (h >= 0 && h < S6_HIST) st->pcg_rel_hist[h] = gamma > 0.f && rz0 > 0.f ? sqrtf(gamma / rz0) : 0.f;
+            }
             return;
         }
         alpha = gamma / denom;
@@ -1105,6 +1112,9 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(So
             st->gamma_prev[it & 1] = gamma, st->alpha_prev[it & 1] = alpha;
             if (it == 0) st->rz0 = gamma;
             st->pcg_iters += 1;
+            st->pcg_last_it = it + 1;
+            const int h = st->gn_iters - 1;
+            if (h >= 0 && h < S6_HIST) st->pcg_it_hist[h] = it + 1;
         }
     }
     stage[wave][0][lane] = au, stage[wave][1][lane] = am, stage[wave][2][lane] = at;
@@ -1154,8 +1164,20 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(So
 }
 
 // ------------------------------------------------------------------------------------ update
-__global__ __launch_bounds__(256) void s6_update_kernel(Solve6View s) {
+__global__ __launch_bounds__(256) void s6_update_kernel(Solve6View s, Solve6State* st, int linear_iter) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        // a PCG that ran into its iteration cap: its last (r, u) is still in the per-workgroup partials of the last launch
+        const int h = st->gn_iters - 1;
+        if (!st->pcg_done && linear_iter > 0 && st->pcg_last_it == linear_iter) {  // (uniform)
+            const int nb = s6_matvec_blocks(s.D);
+            float g = 0.f;
+            for (int i = threadIdx.x; i < nb; i += 64) g += s.g_part[linear_iter & 1][i];
+            g = wave_sum_all(g);
+            const float rz0 = st->rz0;
+            if (threadIdx.x == 0 && h >= 0 && h < S6_HIST) st->pcg_rel_hist[h] = g > 0.f && rz0 > 0.f ? sqrtf(g / rz0) : 0.f;
+        }
+    }
     if (n >= s.D) return;
     const float* tw = s.x + 6 * (size_t)n;
     const DQ q      = dq_load(s.dq + 8 * (size_t)n);
@@ -1282,10 +1304,17 @@ hipError_t s6_linearise(const Solve6View& s, Solve6State* state, const Solve6Ima
     return hipGetLastError();
 }
 
-hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Params& p, hipStream_t st) {
+hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Params& p, int gn_in_outer, hipStream_t st) {
     const float wreg2 = p.lambda / ((float)s.D * (float)s.k);
+    float eta = p.pcg_tol;
+    if (p.pcg_tol_first > 0.f) {
+        float e = p.pcg_tol_first;
+        for (int i = 0; i < gn_in_outer; ++i) e *= p.pcg_tol_decay;
+        eta = std::max(eta, e);
+    }
+    const float tol2 = eta * eta;
     static const bool lds_form = getenv("DFA_S6_ASSEMBLE") && atoi(getenv("DFA_S6_ASSEMBLE")) == 1;  // A/B: first form
-    if (lds_form) K6DISPATCH(s6_assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, wreg2, p.damping));
+    if (lds_form) K6DISPATCH(s6_assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, wreg2, p.damping, tol2));
     else {
         // rows staged per pass (DFA_S6_RC for A/B): fewer rows = more workgroups per CU, more passes per node; measured
         // best at 320 for k = 4 and k = 8 (192: 0.163 / 0.673 ms at C2 / C3, 320: 0.157 / 0.642, 640: 0.177 / 0.755)
@@ -1300,7 +1329,7 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);                       \
             attr = true;                                                                                          \
         }                                                                                                         \
-        s6_assemble2_kernel<KK, RC><<<s.D, 256, sh, st>>>(s, state, wreg2, p.damping);                            \
+        s6_assemble2_kernel<KK, RC><<<s.D, 256, sh, st>>>(s, state, wreg2, p.damping, tol2);                            \
     } while (0)
         if (s.k <= 4) {
             if (rc <= 320) S6A2(4, 320);
@@ -1317,14 +1346,14 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
 hipError_t s6_pcg(const Solve6View& s, Solve6State* state, const Solve6Params& p, hipStream_t st) {
     const int ub = s6_update_blocks(s.D), mb = s6_matvec_blocks(s.D);
     s6_pcg_init_kernel<<<ub, 256, 0, st>>>(s, state);
-    const float tol2 = p.pcg_tol * p.pcg_tol;
-    // launch -1 forms w_0 = A u_0; launch it >= 0 is iteration it (x_{it+1} is complete when it returns)
-    for (int it = -1; it < p.linear_iter; ++it) s6_pcg_step_kernel<<<mb, 64 * S6_NODES_PER_BLOCK, 0, st>>>(s, state, it, tol2);
+    // launch -1 forms w_0 = A u_0; launch it >= 0 is iteration it (x_{it+1} is complete when it returns); the stop test
+    // reads the tolerance of this Gauss-Newton iteration from the state block (set by the assembly launch)
+    for (int it = -1; it < p.linear_iter; ++it) s6_pcg_step_kernel<<<mb, 64 * S6_NODES_PER_BLOCK, 0, st>>>(s, state, it);
     return hipGetLastError();
 }
 
-hipError_t s6_update(const Solve6View& s, Solve6State*, hipStream_t st) {
-    s6_update_kernel<<<(s.D + 255) / 256, 256, 0, st>>>(s);
+hipError_t s6_update(const Solve6View& s, Solve6State* state, int linear_iter, hipStream_t st) {
+    s6_update_kernel<<<(s.D + 255) / 256, 256, 0, st>>>(s, state, linear_iter);
     return hipGetLastError();
 }
 

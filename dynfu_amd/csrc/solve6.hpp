@@ -9,7 +9,12 @@ namespace dfa {
 struct Solve6Params {
     int num_iter, gn_iter, linear_iter;
     float tukey_offset, psi_data, lambda, psi_reg, dist_thresh, cos_thresh, damping, pcg_tol;
+    // inexact-Newton forcing: Gauss-Newton iteration i of an outer iteration stops its PCG at
+    // max(pcg_tol, pcg_tol_first * pcg_tol_decay^i); pcg_tol_first <= 0: constant pcg_tol
+    float pcg_tol_first, pcg_tol_decay;
 };
+
+constexpr int S6_HIST = 32;  // = DFA_SOLVE6_HIST of include/dynfu_amd.h
 
 // Device-resident scalars of one solve
 struct Solve6State {
@@ -24,6 +29,13 @@ struct Solve6State {
     int pcg_done;        // sticky flag of the PCG in flight
     float rz0;           // (r, u) of its first iteration
     float gamma_prev[2], alpha_prev[2];  // scalars of the previous iteration (ping-pong)
+    float tol2;          // stop test of the PCG in flight: (r, u) <= tol2 (r, u)_0   (set by the assembly launch)
+    int pcg_last_it;     // iterations the PCG in flight has completed
+    // per Gauss-Newton iteration (the first S6_HIST): energy at the linearisation, PCG iterations, relative residual
+    // sqrt((r, u) / (r, u)_0) the PCG stopped at
+    double cost_hist[S6_HIST];
+    float pcg_rel_hist[S6_HIST];
+    int pcg_it_hist[S6_HIST];
 };
 
 struct Solve6Image {  // live vertex / normal maps (borrowed): float4 pixels, NaN where undefined
@@ -91,9 +103,10 @@ hipError_t s6_build_graph(const Solve6View& s, Solve6State* state, const float* 
 hipError_t s6_begin(const Solve6View& s, Solve6State* state, const float* node_dq, hipStream_t st);
 hipError_t s6_linearise(const Solve6View& s, Solve6State* state, const Solve6Image& img, const Solve6Params& p,
                         int update_weights, hipStream_t st);
-hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Params& p, hipStream_t st);
+// gn_in_outer: index of the Gauss-Newton iteration inside its outer iteration (selects the PCG tolerance of the forcing schedule)
+hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Params& p, int gn_in_outer, hipStream_t st);
 hipError_t s6_pcg(const Solve6View& s, Solve6State* state, const Solve6Params& p, hipStream_t st);
-hipError_t s6_update(const Solve6View& s, Solve6State* state, hipStream_t st);
+hipError_t s6_update(const Solve6View& s, Solve6State* state, int linear_iter, hipStream_t st);
 hipError_t s6_warp(const Solve6View& s, const float* dq, float* out_v, float* out_n, hipStream_t st);
 hipError_t launch_points_normals(const uint16_t* depth, int depth_step, int cols, int rows, float fx, float fy, float cx,
                                  float cy, float* points, int points_step, float* normals, int normals_step,

@@ -23,7 +23,11 @@ struct NorthStarParameters {
     float distThresh = 0.1f;   // association gate |p - l| (metres)         (KinFuParams::icp_dist_thres)
     float cosThresh  = 0.5f;   // association gate n_warped . n_live
     float damping    = 1e-4f;  // added to the diagonal of the normal matrix
-    float pcgTol     = 1e-6f;
+    // PCG stop test: relative residual max(pcgTol, pcgTolFirst * pcgTolDecay^i) at Gauss-Newton iteration i of an outer
+    // iteration (inexact Newton: early linearisations are solved loosely); pcgTolFirst <= 0: constant pcgTol
+    float pcgTol      = 1e-3f;
+    float pcgTolFirst = 0.1f;
+    float pcgTolDecay = 0.5f;
 };
 
 class NorthStarSolver {

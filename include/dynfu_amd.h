@@ -395,13 +395,23 @@ typedef struct dfa_solve6_params {
     float cos_thresh;   /* association gate n_warped . n_live                                  */
     float damping;      /* added to the diagonal of the normal matrix                          */
     float pcg_tol;      /* PCG stops when r.z <= pcg_tol^2 (r.z)_0                             */
+    /* Inexact-Newton forcing schedule: Gauss-Newton iteration i (from 0, inside its outer iteration) stops its PCG at
+     * the relative residual max(pcg_tol, pcg_tol_first * pcg_tol_decay^i).  pcg_tol_first <= 0: constant pcg_tol. */
+    float pcg_tol_first, pcg_tol_decay;
 } dfa_solve6_params;
+
+#define DFA_SOLVE6_HIST 32
 
 typedef struct dfa_solve6_stats {
     double initial_cost, final_cost; /* energy at the first / last linearisation */
     int gn_iters, pcg_iters;
     long long valid_first, valid_last; /* data rows with a valid association and non-zero weight */
     int max_row_blocks, overflow;
+    /* per Gauss-Newton iteration (the first DFA_SOLVE6_HIST of the solve): energy at its linearisation, PCG iterations it
+     * ran, and the relative residual sqrt(r.z / (r.z)_0) its PCG stopped at (whether by tolerance or by linear_iter) */
+    double cost_hist[DFA_SOLVE6_HIST];
+    float pcg_rel_hist[DFA_SOLVE6_HIST];
+    int pcg_it_hist[DFA_SOLVE6_HIST];
 } dfa_solve6_stats;
 
 int dfa_solver6_create(int max_D, int max_N, int k /* 1..8 */, dfa_solver6** out);

@@ -201,14 +201,23 @@ typedef struct {
     float cos_thresh;   /* association gate: n_warped . n_live >= cos_thresh       */
     float damping;      /* added to the diagonal of the normal matrix              */
     float pcg_tol;      /* stop when (r.z) <= pcg_tol^2 (r.z)_0                    */
+    /* inexact-Newton forcing schedule: Gauss-Newton iteration i (counted from 0 within its outer iteration) stops
+     * its PCG at max(pcg_tol, pcg_tol_first * pcg_tol_decay^i); pcg_tol_first <= 0 = constant pcg_tol */
+    float pcg_tol_first, pcg_tol_decay;
     int threads;
 } orc6_params;
+
+#define ORC6_HIST 32
 
 typedef struct {
     double initial_cost; /* energy at the first linearisation                      */
     double final_cost;   /* energy at the last linearisation                       */
     int gn_iters, pcg_iters;
     long valid_first, valid_last; /* data rows with a valid association and non-zero weight */
+    /* per Gauss-Newton iteration (the first ORC6_HIST): energy at its linearisation, PCG iterations it ran, and the
+     * relative residual sqrt((r.z) / (r.z)_0) its PCG stopped at */
+    double cost_hist[ORC6_HIST], pcg_rel_hist[ORC6_HIST];
+    int pcg_it_hist[ORC6_HIST];
 } orc6_stats;
 
 /* kfusion::device::computePointNormals (src/kfusion/cuda/imgproc.cu:187-215): float4 vertex and
@@ -230,6 +239,8 @@ void orc6_solve(const float* node_pos, const float* node_dq_in, const float* nod
                 const float* canon_n, int N, const float* vmap, int vmap_step, const float* nmap, int nmap_step, int cols,
                 int rows, float fx, float fy, float cx, float cy, const orc6_params* prm, float* node_dq_out,
                 orc6_stats* stats);
+/* development hook: copy out the normal equations (block CSR) of Gauss-Newton iteration `gn` of the next orc6_solve */
+void orc6_set_dump(int gn, int* row_ptr, int* cols, double* blk, double* g, long cap, long* nblk);
 double orc6_cost(const float* node_pos, const float* node_dq, const float* node_w, int D, int k, const float* canon,
                  const float* canon_n, int N, const float* vmap, int vmap_step, const float* nmap, int nmap_step, int cols,
                  int rows, float fx, float fy, float cx, float cy, const orc6_params* prm, long* nvalid_out);

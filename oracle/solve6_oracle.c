@@ -330,6 +330,18 @@ static double tukey(double err, double offset, double c) { /* opt_solver.cpp:204
 }
 static double huber(double e, double kk) { return e <= kk ? 1.0 : kk / e; } /* opt_solver.cpp:233-268 */
 
+/* development hook (tools/pcg6_experiments.py): the normal equations of Gauss-Newton iteration `gn` of the next
+ * orc6_solve call are copied out as block CSR (row_ptr D + 1, cols / 36 doubles per block up to `cap` blocks, g 6 D) */
+static struct {
+    int gn, *row_ptr, *cols;
+    long cap, *nblk;
+    double *blk, *g;
+} s_dump = {-1, 0, 0, 0, 0, 0, 0};
+void orc6_set_dump(int gn, int* row_ptr, int* cols, double* blk, double* g, long cap, long* nblk) {
+    s_dump.gn = gn, s_dump.row_ptr = row_ptr, s_dump.cols = cols, s_dump.blk = blk, s_dump.g = g, s_dump.cap = cap,
+    s_dump.nblk = nblk;
+}
+
 void orc6_solve(const float* node_pos, const float* node_dq_in, const float* node_w, int D, int k, const float* canon,
                 const float* canon_n, int N, const float* vmap, int vmap_step, const float* nmap, int nmap_step, int cols,
                 int rows, float fx, float fy, float cx, float cy, const orc6_params* prm, float* node_dq_out,
@@ -456,7 +468,12 @@ void orc6_solve(const float* node_pos, const float* node_dq_in, const float* nod
             cost += rcost;
             if (first) stats->initial_cost = cost, stats->valid_first = nvalid, first = 0;
             stats->valid_last = nvalid;
+            const int hist = stats->gn_iters < ORC6_HIST ? stats->gn_iters : -1;
+            if (hist >= 0) stats->cost_hist[hist] = cost, stats->pcg_it_hist[hist] = 0, stats->pcg_rel_hist[hist] = 1.0;
 
+            /* (no PCG iterations asked for — orc6_cost: the energy is all that is wanted — no normal equations either) */
+            if (prm->linear_iter <= 0) memset(x, 0, sizeof(double) * 6 * (size_t)D);
+            else {
             /* ---- assemble H, g */
             for (int n = 0; n < D; ++n) {
                 memset(H[n].blk, 0, sizeof(double) * 36 * (size_t)H[n].ncol);
@@ -506,6 +523,20 @@ void orc6_solve(const float* node_pos, const float* node_dq_in, const float* nod
                 for (int c = 0; c < 6; ++c) Hd[7 * c] += prm->damping;
             }
 
+            if (s_dump.gn == stats->gn_iters && s_dump.row_ptr) {
+                long nb = 0;
+                for (int n = 0; n < D; ++n) {
+                    s_dump.row_ptr[n] = (int)nb;
+                    for (int e = 0; e < H[n].ncol && nb < s_dump.cap; ++e, ++nb) {
+                        s_dump.cols[nb] = H[n].col[e];
+                        memcpy(s_dump.blk + 36 * nb, H[n].blk + 36 * (size_t)e, sizeof(double) * 36);
+                    }
+                }
+                s_dump.row_ptr[D] = (int)nb;
+                *s_dump.nblk      = nb;
+                memcpy(s_dump.g, g, sizeof(double) * 6 * (size_t)D);
+                s_dump.gn = -1;
+            }
             /* ---- block-Jacobi PCG: H x = g */
             memset(x, 0, sizeof(double) * 6 * (size_t)D);
             memcpy(r, g, sizeof(double) * 6 * (size_t)D);
@@ -517,6 +548,13 @@ void orc6_solve(const float* node_pos, const float* node_dq_in, const float* nod
             }
             memcpy(pp, z, sizeof(double) * 6 * (size_t)D);
             const double rz0 = rz;
+            double tol = prm->pcg_tol;
+            if (prm->pcg_tol_first > 0) {
+                double eta = prm->pcg_tol_first;
+                for (int i = 0; i < gn; ++i) eta *= prm->pcg_tol_decay;
+                if (eta > tol) tol = eta;
+            }
+            if (hist >= 0 && !(rz0 > 0)) stats->pcg_rel_hist[hist] = 0.0;
             for (int it = 0; it < prm->linear_iter && rz > 0; ++it) {
                 double pq = 0;
 #pragma omp parallel for schedule(static) num_threads(threads) reduction(+ : pq)
@@ -545,8 +583,10 @@ void orc6_solve(const float* node_pos, const float* node_dq_in, const float* nod
                 ++stats->pcg_iters;
                 const double beta = rz_new / rz;
                 rz                = rz_new;
+                if (hist >= 0) stats->pcg_it_hist[hist] += 1, stats->pcg_rel_hist[hist] = sqrt(rz > 0 ? rz / rz0 : 0.0);
                 for (size_t i = 0; i < 6 * (size_t)D; ++i) pp[i] = z[i] + beta * pp[i];
-                if (rz <= (double)prm->pcg_tol * (double)prm->pcg_tol * rz0) break;
+                if (rz <= tol * tol * rz0) break;
+            }
             }
             /* ---- update */
             for (int n = 0; n < D; ++n) {
