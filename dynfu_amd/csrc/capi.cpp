@@ -983,6 +983,8 @@ int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
     A(rhub, D * k);
     A(bcols, D * cap);
     A(bcnt, D);
+    A(bfu, D);
+    A(rslot, D * cap);
     A(eslot, N * k * k);
     A(pair_list, N * k * k);
     A(pair_ptr, D * (cap + 1));

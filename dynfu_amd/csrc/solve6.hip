@@ -352,6 +352,44 @@ __device__ __forceinline__ void s6_bookkeeping(Solve6State* st, float tol2) {
     st->tol2 = tol2, st->pcg_last_it = 0;
 }
 
+// column c of the inverse of a symmetric positive definite 6x6 (every caller lane factorises for itself: six lanes invert
+// the block in the time of one column); zero if the factorisation fails, as inv6
+__device__ __forceinline__ void inv6_column(const float* M, float* out, int c) {
+    float L[6][6];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            float sm = M[6 * i + j];
+#pragma unroll
+            for (int q = 0; q < j; ++q) sm -= L[i][q] * L[j][q];
+            if (i == j) {
+                ok      = ok && sm > 0.f;
+                L[i][i] = sqrtf(sm);
+            } else {
+                L[i][j] = sm / L[j][j];
+            }
+        }
+    float y[6], x[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float sm = i == c ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 0; q < i; ++q) sm -= L[i][q] * y[q];
+        y[i] = sm / L[i][i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        float sm = y[i];
+#pragma unroll
+        for (int q = i + 1; q < 6; ++q) sm -= L[q][i] * x[q];
+        x[i] = sm / L[i][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) out[6 * i + c] = ok ? x[i] : 0.f;
+}
+
 // Sparsity pattern of block row a (fixed by the graphs of the frame, built once per set_problem):
 // the diagonal first, then every node that shares a vertex with a or is joined to it by a
 // regularisation edge, ascending.
@@ -452,9 +490,18 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
     // ---- the same relation by slot (s6_assemble2_kernel): a stable split of the node's (row, neighbour) pairs by
     // slot.  Counts by LDS atomics, then wave w compacts the lists of slots 1 + w, 5 + w, ... in ascending pair
     // order with ballots: run-to-run identical lists, hence identical sums.
+    // The matrix is symmetric, H_ba = H_ab^T: the assembly computes a block once, in the row of the smaller node index, and
+    // writes it to both rows.  Lists are kept for the "upper" slots only (column > a; the columns ascend, so these are
+    // the slots from `fu` on), the others stay empty.
     __shared__ int pcnt[64], pstart[64];
+    __shared__ int fu_sh;
     if (tid < 64) pcnt[tid] = 0;
+    if (tid < 64) {
+        const uint64_t lower = __ballot(tid >= 1 && tid < stored && cols[tid] < a);
+        if (tid == 0) fu_sh = 1 + __popcll(lower), s.bfu[a] = 1 + __popcll(lower);
+    }
     __syncthreads();  // also: this workgroup's eslot bytes are visible to all of its threads
+    const int fu = fu_sh;
     const int pbeg = s.node_ptr[a], plen = s.node_ptr[a + 1] - pbeg, npairs = plen * k;
     const uint8_t* es = s.eslot + (size_t)pbeg * k;
     // the node's slot bytes are scanned once per slot below: from LDS when they fit the (now idle) sort buffer
@@ -463,7 +510,7 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
     for (int p = tid; p < npairs; p += 256) {
         const int sl = es[p];
         if (in_lds) es_lds[p] = (uint8_t)sl;
-        if (sl >= 1 && sl < stored) atomicAdd(&pcnt[sl], 1);
+        if (sl >= fu && sl < stored) atomicAdd(&pcnt[sl], 1);
     }
     __syncthreads();
     if (tid == 0) {
@@ -489,7 +536,7 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
 #pragma unroll
             for (int i = 0; i < SPW; ++i) {
                 const int q = 1 + wave + 4 * i;
-                if (q < stored) {  // wave-uniform
+                if (q < stored && q >= fu) {  // wave-uniform
                     const bool match  = sl == q;
                     const uint64_t mk = __ballot(match);
                     if (match) s.pair_list[out[i] + __popcll(mk & ((1ull << lane) - 1ull))] = packed;
@@ -498,6 +545,25 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
             }
         }
     }
+}
+
+// slot of node a in the block row of each of its columns (the mirror position of block (a, slot)); 255 = not there
+__global__ __launch_bounds__(256) void s6_rslot_kernel(Solve6View s) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.D * s.cap) return;
+    const int a = i / s.cap, q = i - a * s.cap;
+    int r = 255;
+    if (q < s.bcnt[a]) {
+        const int b = s.bcols[i];
+        if (q == 0) r = 0;
+        else if (b >= 0) {
+            const int32_t* cb = s.bcols + (size_t)b * s.cap;
+            const int nb      = s.bcnt[b];
+            for (int t = 1; t < nb; ++t)
+                if (cb[t] == a) r = t;
+        }
+    }
+    s.rslot[i] = (uint8_t)r;
 }
 
 // Values of block row a.  A data row's 6-vector for neighbour j factors as f_j * M_j l (l: 8 numbers per
@@ -724,42 +790,120 @@ __device__ __forceinline__ float quads_reduce_scatter(float (&v)[16], int lane) 
     return (b2 ? w2[1] : w2[0]) + __shfl_xor(b2 ? w2[0] : w2[1], 4, 64);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+#ifndef DFA_S6_ABLATE
+#define DFA_S6_ABLATE 0  // development builds only (-DDFA_S6_ABLATE=mask): 1 no pair lists, 2 no slot 0, 4 no off-diagonal epilogue
+#endif
+
+// Third form (round 3).  What the second form (a wave walks ONE slot's list, its 16 quads take 16 pairs of it per step
+// and are summed by a 15-shuffle halving exchange per list and pass) spent its time on was not the products but the
+// per-list overhead — ~13 list visits per wave, each with pointer loads, a partly filled last block and the exchange
+// (ablation at C3: pair lists 0.34 of 0.65 ms for 60 FMA-steps' worth of work per wave).  Now:
+//  (1) SYMMETRY: block (a, b) is computed once, by the workgroup of the smaller index, and written to both rows
+//      (H_ba = H_ab^T bit for bit): half the pairs, half the M_a S M_b^T products;
+//  (2) a QUAD PER SLOT: quad g of every wave walks the list of upper slot fu + g (16 lists at a time; the four waves
+//      take interleaved groups of four records of each list), so the 4 lanes of a quad own the slot's 8 x 8 moment (rows
+//      2 c4, 2 c4 + 1: 16 registers) for the whole kernel — no cross-lane reduction at all, the four waves' partial
+//      moments are added through LDS once per node in a fixed order;
+//  (3) two LDS reads per pair instead of five LDS operations per 16: a lane's two l values are neighbours in the staged
+//      row (one 8-byte read), the coefficient rho f_a f_j of every (row, neighbour) is formed once when the rows are
+//      staged, and the quad's lanes hold its next four records (DPP quad broadcast, no cross-lane LDS shuffle);
+//  (4) packed fp32 FMAs (v_pk_fma_f32: both rows of a lane in one instruction);
+//  (5) the regulariser's edges of the node are staged in LDS by the whole workgroup (the six threads of the diagonal
+//      block used to chase them through ~50 dependent global loads), the diagonal block is inverted by six lanes.
+constexpr int S6_REGIN = 24;  // arriving regularisation edges staged in LDS (more: read from global memory)
+
+#ifndef DFA_S6_WAVES
+#define DFA_S6_WAVES 3
+#endif
 template <int K, int S6_RC>
-__global__ __launch_bounds__(256) void s6_assemble2_kernel(Solve6View s, Solve6State* st, float wreg2, float damping, float tol2) {
+__global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6View s, Solve6State* st, float wreg2, float damping, float tol2) {
     extern __shared__ __attribute__((aligned(16))) char s6_dyn[];
     float(*sl8)[8]  = reinterpret_cast<float(*)[8]>(s6_dyn);                                      // l = (lW, lD)
-    float(*sfv)[K]  = reinterpret_cast<float(*)[K]>(s6_dyn + sizeof(float) * 8 * S6_RC);          // f_j
+    float(*scf)[K]  = reinterpret_cast<float(*)[K]>(s6_dyn + sizeof(float) * 8 * S6_RC);          // rho f_own f_j
     float4* sra     = reinterpret_cast<float4*>(s6_dyn + sizeof(float) * (8 + K) * S6_RC);       // rho f_own, rho res f_own, rho f_own^2
-    __shared__ float accS[S6_MAXSLOT][64];
+    // after the passes the rows' area holds the finished moments (64 floats per slot) and M of the column nodes (48 per slot)
+    float(*accS)[64] = reinterpret_cast<float(*)[64]>(s6_dyn);
+    float* smb       = reinterpret_cast<float*>(s6_dyn + sizeof(float) * 64 * S6_MAXSLOT);
+    // (the launcher sizes the dynamic segment for the larger of the two uses)
     __shared__ float part0[4][72];        // slot 0 per wave: 8 x 8 moment + g8
     __shared__ float g8s[8];
     __shared__ float diag[36];
-    __shared__ int cur[S6_MAXSLOT + 1];
+    __shared__ float rout[8][24];         // edges leaving a: neighbour (bits), weight, residual (3), vectors (18)
+    __shared__ float rin[S6_REGIN][24];   // edges arriving at a: source node (bits), weight, residual (3), vectors (18)
     const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
     if (a == 0 && tid == 0) s6_bookkeeping(st, tol2);
-    const int cnt = s.bcnt[a];
+    const int cnt = s.bcnt[a], fu = s.bfu[a];
     const int beg = s.node_ptr[a], len = s.node_ptr[a + 1] - beg;
     const int wave = tid >> 6, lane = tid & 63, g16 = lane >> 2, c4 = lane & 3;
     const int32_t* pptr = s.pair_ptr + (size_t)a * (s.cap + 1);
-    for (int i = tid; i < cnt * 64; i += 256) (&accS[0][0])[i] = 0.f;
-    if (tid <= cnt && tid <= S6_MAXSLOT) cur[tid] = pptr[tid];
-    // Lane (g, c4): pair g of a step, rows c4 and c4 + 4 of its 8 x 8 outer product.  It reads l_c4 and l_(c4+4) from
-    // LDS and gets the other six from its quad by DPP: 4 narrow LDS reads per 16 pairs instead of 5 (two of them
-    // 16 bytes wide) per 8 — the loop was bound by the LDS pipe.
-    auto add_pair = [&](float lo, float hi, float cf, float (&m)[16]) __attribute__((always_inline)) {
+    const int rib = s.rnode_ptr[a], nri = s.rnode_ptr[a + 1] - rib;
+    // ---- the node's regularisation edges (used by the epilogue; loaded first, they fly while the rows are worked on)
+    for (int i = tid; i < k * 24; i += 256) {
+        const int q = i / 24, f = i - 24 * q, e = a * k + q;
+        float v = 0.f;
+        if (f == 0) v = __int_as_float(s.reg_idx[e]);
+        else if (f == 1) v = wreg2 * s.rhub[e];
+        else if (f < 5) v = s.rres[3 * (size_t)e + f - 2];
+        else if (f < 23) v = s.rvec[18 * (size_t)e + f - 5];
+        rout[q][f] = v;
+    }
+    for (int i = tid; i < min(nri, S6_REGIN) * 24; i += 256) {
+        const int q = i / 24, f = i - 24 * q;
+        const unsigned entry = s.rnode_list[rib + q];
+        float v = 0.f;
+        if (f == 0) v = __int_as_float((int)(entry / (unsigned)k));
+        else if (f == 1) v = wreg2 * s.rhub[entry];
+        else if (f < 5) v = s.rres[3 * (size_t)entry + f - 2];
+        else if (f < 23) v = s.rvec[18 * (size_t)entry + f - 5];
+        rin[q][f] = v;
+    }
+    // Lane (g, c4): rows 2 c4 and 2 c4 + 1 of an 8 x 8 outer product.  It reads l[2 c4], l[2 c4 + 1] from LDS (one 8-byte
+    // read) and gets the other six from its quad by DPP.  m[e] = (row 2 c4, row 2 c4 + 1) of column e.
+    auto add_pair = [&](float lo, float hi, float cf, v2f (&m)[8]) __attribute__((always_inline)) {
         float l[8];
-        l[0] = quad_bcast<0>(lo), l[1] = quad_bcast<1>(lo), l[2] = quad_bcast<2>(lo), l[3] = quad_bcast<3>(lo);
-        l[4] = quad_bcast<0>(hi), l[5] = quad_bcast<1>(hi), l[6] = quad_bcast<2>(hi), l[7] = quad_bcast<3>(hi);
-        const float fl = cf * lo, fh = cf * hi;
+        l[0] = quad_bcast<0>(lo), l[1] = quad_bcast<0>(hi), l[2] = quad_bcast<1>(lo), l[3] = quad_bcast<1>(hi);
+        l[4] = quad_bcast<2>(lo), l[5] = quad_bcast<2>(hi), l[6] = quad_bcast<3>(lo), l[7] = quad_bcast<3>(hi);
+        v2f f;
+        f.x = cf * lo, f.y = cf * hi;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = fmaf(fl, l[e], m[e]), m[8 + e] = fmaf(fh, l[e], m[8 + e]);
+        for (int e = 0; e < 8; ++e) {
+            v2f le;
+            le.x = l[e], le.y = l[e];
+            m[e] = __builtin_elementwise_fma(f, le, m[e]);
+        }
     };
-    float own[16], ownG[2] = {0.f, 0.f};  // slot 0 (every row's own neighbour) and -J^T r, this lane's share
+    // ---- upper slots: quad g of round r owns slot fu + 16 r + g; this wave's chunks of 16 records of its list are those at
+    // start + 16 wave + 64 i (lane c4 of the quad holds records 4 c4 .. 4 c4 + 3 of the chunk).  Cursors and moments live
+    // in registers across the passes.
+    constexpr int ROUNDS = (S6_MAXSLOT + 15) / 16;
+    const int nup = cnt > fu ? cnt - fu : 0;
+    v2f mq[ROUNDS][8];
+    int cq[ROUNDS], qend[ROUNDS];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) own[e] = 0.f;
+    for (int r = 0; r < ROUNDS; ++r) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mq[r][e] = v2f{0.f, 0.f};
+        const int q = fu + 16 * r + g16;
+        cq[r] = 0, qend[r] = 0;
+        if (q < cnt) cq[r] = pptr[q] + 16 * wave, qend[r] = pptr[q + 1];
+    }
+    struct Rec4 {
+        uint32_t v[4];
+    };
+    auto load_chunk = [&](int c, int qe, bool on) __attribute__((always_inline)) {
+        Rec4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.v[i] = on && c + 4 * c4 + i < qe ? s.pair_list[c + 4 * c4 + i] : 0xffffffffu;
+        return o;
+    };
+    v2f own[8];
+    float ownG[2] = {0.f, 0.f};  // slot 0 (every row's own neighbour) and -J^T r, this lane's share
+#pragma unroll
+    for (int e = 0; e < 8; ++e) own[e] = v2f{0.f, 0.f};
     for (int r0 = 0; r0 < len; r0 += S6_RC) {
         const int nr = min(S6_RC, len - r0);
-        __syncthreads();  // the pass before is done with the staged rows (first pass: accS / cur are set)
+        __syncthreads();  // the pass before is done with the staged rows
         const size_t e0 = (size_t)(beg + r0);
         {   // every load of the pass is issued before the first LDS store (a thread's ~13 loads fly together)
             constexpr int NL = (S6_RC * 2 + 255) / 256, NF = (S6_RC * K / 4 + 255) / 256, NM = (S6_RC + 255) / 256;
@@ -798,12 +942,12 @@ __global__ __launch_bounds__(256) void s6_assemble2_kernel(Solve6View s, Solve6S
 #pragma unroll
                 for (int q = 0; q < NF; ++q) {
                     const int i = tid + 256 * q;
-                    if (i < nr * (K / 4)) reinterpret_cast<float4*>(&sfv[0][0])[i] = vf[q];
+                    if (i < nr * (K / 4)) reinterpret_cast<float4*>(&scf[0][0])[i] = vf[q];
                 }
             } else {
-                for (int i = tid; i < nr * k; i += 256) {
-                    const int r = i / k, j = i - r * k;
-                    sfv[r][j]   = s.ef[e0 * k + i];
+                for (int i = tid; i < nr * K; i += 256) {
+                    const int r = i / K, j = i - r * K;
+                    scf[r][j]   = j < k ? s.ef[(e0 + r) * k + j] : 0.f;
                 }
             }
 #pragma unroll
@@ -815,81 +959,116 @@ __global__ __launch_bounds__(256) void s6_assemble2_kernel(Solve6View s, Solve6S
                 }
             }
         }
+        // the first chunk of records of this pass flies while the rows settle and slot 0 is worked on
+        Rec4 first[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) first[r] = load_chunk(cq[r], qend[r], 16 * r < nup);
         __syncthreads();
-        // rows without association hold stale numbers (0 * NaN is NaN): zero what the products read
-        for (int i = tid; i < nr; i += 256)
-            if (sra[i].x == 0.f) {
-                for (int j = 0; j < 8; ++j) sl8[i][j] = 0.f;
-                for (int j = 0; j < K; ++j) sfv[i][j] = 0.f;
-            }
-        __syncthreads();
-        // the first block of this wave's first list flies while slot 0 is worked on
-        int q = 1 + wave, c0 = 0, qe = 0;
-        uint32_t mine = 0xffffffffu;
-        if (q < cnt) {
-            qe = pptr[q + 1], c0 = cur[q];
-            if (c0 + lane < qe) mine = s.pair_list[c0 + lane];
+        // f_j -> rho f_own f_j, once per (row, neighbour); rows without association hold stale numbers (0 * NaN is NaN):
+        // zero what the products read
+        for (int i = tid; i < nr * (K / 4); i += 256) {
+            const int r    = i / (K / 4);
+            const float rf = sra[r].x;
+            float4* p      = reinterpret_cast<float4*>(&scf[0][0]) + i;
+            float4 v       = *p;
+            v = rf != 0.f ? make_float4(v.x * rf, v.y * rf, v.z * rf, v.w * rf) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *p = v;
         }
+        for (int i = tid; i < nr * 2; i += 256)
+            if (sra[i >> 1].x == 0.f) reinterpret_cast<float4*>(&sl8[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
         // ---- slot 0: 16 rows per wave and step, the waves interleave
+#if !(DFA_S6_ABLATE & 2)
         for (int rb = 16 * wave; rb < nr; rb += 64) {
+#else
+        for (int rb = 16 * wave; rb < 0; rb += 64) {
+#endif
             const int rr = rb + g16;
             if (rr < nr) {  // (whole quads)
                 const float4 ra = sra[rr];
-                const float lo = sl8[rr][c4], hi = sl8[rr][4 + c4];
-                add_pair(lo, hi, ra.z, own);
-                ownG[0] = fmaf(-ra.y, lo, ownG[0]), ownG[1] = fmaf(-ra.y, hi, ownG[1]);
+                const float2 lh = *reinterpret_cast<const float2*>(&sl8[rr][2 * c4]);
+                add_pair(lh.x, lh.y, ra.z, own);
+                ownG[0] = fmaf(-ra.y, lh.x, ownG[0]), ownG[1] = fmaf(-ra.y, lh.y, ownG[1]);
             }
         }
-        // ---- slots 1 + wave, 5 + wave, ...
-        const unsigned rlim = (unsigned)(r0 + nr);
-        for (; q < cnt; q += 4) {
-            float m[16];
+        // ---- upper slots
+#if !(DFA_S6_ABLATE & 1)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) m[e] = 0.f;
-            // the next list's first block
-            int c0n = 0, qen = 0;
-            uint32_t nmine = 0xffffffffu;
-            if (q + 4 < cnt) {
-                qen = pptr[q + 5], c0n = cur[q + 4];
-                if (c0n + lane < qen) nmine = s.pair_list[c0n + lane];
-            }
-            // 64 pairs per load (lane i holds pair c0 + i; the next block is in flight while this one is used), then
-            // 4 steps of 16 pairs: quad g of step t takes the pair of lane 16 t + g
-            while (c0 < qe) {
-                const uint32_t nxt = c0 + 64 + lane < qe ? s.pair_list[c0 + 64 + lane] : 0xffffffffu;
-                const int nin      = __popcll(__ballot((mine >> 4) < rlim));  // pairs of this block inside the pass: a prefix
-                auto step = [&](const int t, const bool guard) __attribute__((always_inline)) {
-                    const uint32_t pr = (uint32_t)__shfl((int)mine, 16 * t + g16, 64);
-                    if (!guard || 16 * t + g16 < nin) {
-                        const int rr   = (int)(pr >> 4) - r0, j = (int)(pr & 15u);
-                        const float lo = sl8[rr][c4], hi = sl8[rr][4 + c4];
-                        add_pair(lo, hi, sra[rr].x * sfv[rr][j], m);
-                    }
+        for (int r = 0; r < ROUNDS; ++r) {
+            if (16 * r >= nup) break;  // (uniform)
+            int c = cq[r];
+            const int qe = qend[r];
+            bool act  = c < qe;
+            Rec4 mine = first[r];
+            const unsigned rlim = (unsigned)(r0 + nr);
+            while (__any(act)) {
+                const Rec4 nxt = load_chunk(c + 64, qe, act);
+                // a record is in this pass if its row is staged; records of an earlier pass (a chunk that straddled its end)
+                // and of later ones contribute nothing (coefficient 0 on a staged row)
+                auto step = [&](const uint32_t pr) __attribute__((always_inline)) {
+                    const unsigned rr = (pr >> 4) - (unsigned)r0;
+                    const bool in     = act && rr < (unsigned)nr;
+                    const unsigned ri = in ? rr : 0u, j = in ? (pr & 15u) : 0u;
+                    const float2 lh   = *reinterpret_cast<const float2*>(&sl8[ri][2 * c4]);
+                    const float cf    = scf[ri][j];
+                    add_pair(lh.x, lh.y, in ? cf : 0.f, mq[r]);
                 };
-                if (nin == 64) {  // a full block: no tests, the loads of the four steps can overlap
+                // which lanes hold a record of this pass: four steps (the records of one lane of every quad) are skipped
+                // when no quad of the wave has one there
+                bool any_in = false, fin = true;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) step(t, false);
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (16 * t < nin) step(t, true);  // wave-uniform
+                for (int i = 0; i < 4; ++i) {
+                    any_in = any_in || (act && (mine.v[i] >> 4) - (unsigned)r0 < (unsigned)nr);
+                    fin    = fin && (mine.v[i] == 0xffffffffu || (mine.v[i] >> 4) < rlim);
                 }
-                c0 += nin;
-                if (nin < 64) break;
-                mine = nxt;
+                const uint64_t bin = __ballot(any_in);
+#define S6_STEPS(T)                                                                                        \
+    if (bin & (0x1111111111111111ull << T)) {                                                              \
+        step((uint32_t)__float_as_int(quad_bcast<T>(__int_as_float((int)mine.v[0]))));                     \
+        step((uint32_t)__float_as_int(quad_bcast<T>(__int_as_float((int)mine.v[1]))));                     \
+        step((uint32_t)__float_as_int(quad_bcast<T>(__int_as_float((int)mine.v[2]))));                     \
+        step((uint32_t)__float_as_int(quad_bcast<T>(__int_as_float((int)mine.v[3]))));                     \
+    }
+                S6_STEPS(0) S6_STEPS(1) S6_STEPS(2) S6_STEPS(3)
+#undef S6_STEPS
+                // the chunk is finished when none of its records belongs to a later pass (records past the end of the list
+                // read as 0xffffffff: finished)
+                const uint64_t bal  = __ballot(fin);
+                const bool quad_fin = ((bal >> (lane & ~3)) & 0xfull) == 0xfull;
+                if (act && quad_fin) c += 64, mine = nxt;
+                act = act && quad_fin && c < qe;
             }
-            if (lane == 0) cur[q] = c0;
-            const float tot = quads_reduce_scatter(m, lane);  // element g16 of (row c4 | row c4 + 4) of the slot's moment
-            const int row = g16 < 8 ? c4 : c4 + 4, col = g16 & 7;
-            accS[q][8 * row + col] += tot;
-            mine = nmine, c0 = c0n, qe = qen;
+            cq[r] = c;
         }
+#endif
+    }
+    // ---- the four waves' partial moments of the upper slots: added through LDS in wave order
+    __syncthreads();
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const int q = fu + 16 * r + g16;
+                if (q < cnt) {
+                    float* d0 = &accS[q][8 * (2 * c4)];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        d0[e]     = w == 0 ? mq[r][e].x : d0[e] + mq[r][e].x;
+                        d0[8 + e] = w == 0 ? mq[r][e].y : d0[8 + e] + mq[r][e].y;
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
     // slot 0: quads, then waves (fixed order)
     {
-        const float tot = quads_reduce_scatter(own, lane);
-        const int row = g16 < 8 ? c4 : c4 + 4, col = g16 & 7;
-        part0[wave][8 * row + col] = tot;
+        float v[16];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = own[e].x, v[8 + e] = own[e].y;
+        // lane (g, c4) is left with element (row 2 c4 + (g >= 8), column g mod 8)
+        part0[wave][8 * (2 * c4 + (g16 >> 3)) + (g16 & 7)] = quads_reduce_scatter(v, lane);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             ownG[e] += __shfl_xor(ownG[e], 4, 64);
@@ -897,25 +1076,29 @@ __global__ __launch_bounds__(256) void s6_assemble2_kernel(Solve6View s, Solve6S
             ownG[e] += __shfl_xor(ownG[e], 16, 64);
             ownG[e] += __shfl_xor(ownG[e], 32, 64);
         }
-        if (g16 == 0) part0[wave][64 + c4] = ownG[0], part0[wave][68 + c4] = ownG[1];
+        if (g16 == 0) part0[wave][64 + 2 * c4] = ownG[0], part0[wave][64 + 2 * c4 + 1] = ownG[1];
     }
     __syncthreads();
     if (tid < 64 && cnt > 0) accS[0][tid] = (part0[0][tid] + part0[1][tid]) + (part0[2][tid] + part0[3][tid]);
     if (tid >= 64 && tid < 72) g8s[tid - 64] = (part0[0][tid] + part0[1][tid]) + (part0[2][tid] + part0[3][tid]);
-    __syncthreads();
-    // H_ab = M_a S_ab M_b^T, regularisation, output: thread (slot, row) finishes row `row` of the block in `slot`
-    // M of the row's column nodes: staged in the rows' area (the passes are over), 48 floats per slot, coalesced
-    float* smb = reinterpret_cast<float*>(s6_dyn);
-    static_assert((size_t)S6_RC * (8 + K + 4) >= (size_t)S6_MAXSLOT * 48, "the staged rows' area holds the column nodes' M");
+    // H_ab = M_a S_ab M_b^T, regularisation, output: thread (slot, row) finishes row `row` of the block in `slot` — of slot 0
+    // and of the upper slots; an upper block also goes, transposed, to the row of its column.
+    // M of the row's column nodes: 48 floats per slot, coalesced
     for (int i = tid; i < cnt * 48; i += 256) {
         const int slot = i / 48;
         smb[i]         = s.mnode[48 * (size_t)s.bcols[(size_t)a * s.cap + slot] + (i - 48 * slot)];
     }
     __syncthreads();
-    for (int t0 = 0; t0 < cnt * 6; t0 += 256) {
+#if DFA_S6_ABLATE & 4
+    const int nfin = 6;
+#else
+    const int nfin = (1 + nup) * 6;
+#endif
+    for (int t0 = 0; t0 < nfin; t0 += 256) {
         const int t = t0 + tid;
-        if (t < cnt * 6) {
-            const int slot = t / 6, my_row = t - 6 * slot;
+        if (t < nfin) {
+            const int sidx = t / 6, my_row = t - 6 * sidx;
+            const int slot = sidx == 0 ? 0 : fu + sidx - 1;
             const int col  = s.bcols[(size_t)a * s.cap + slot];
             float ma[8];
 #pragma unroll
@@ -942,13 +1125,14 @@ __global__ __launch_bounds__(256) void s6_assemble2_kernel(Solve6View s, Solve6S
             }
             // regularisation edges leaving a (a -> m): rows c of e = T_a g_m - g^_m with vectors (an_c at a, -e_{3+c} at m)
             for (int q = 0; q < k; ++q) {
-                const int e = a * k + q, m = s.reg_idx[e];
+                const float* E = rout[q];
+                const int m    = __float_as_int(E[0]);
                 if (m < 0 || (slot != 0 && col != m)) continue;
-                const float wt = wreg2 * s.rhub[e];
+                const float wt = E[1];
                 for (int cc = 0; cc < 3; ++cc) {
-                    const float* an = s.rvec + 18 * (size_t)e + 6 * cc;
+                    const float* an = E + 5 + 6 * cc;
                     if (slot == 0) {
-                        gacc -= wt * an[my_row] * s.rres[3 * (size_t)e + cc];
+                        gacc -= wt * an[my_row] * E[2 + cc];
 #pragma unroll
                         for (int d = 0; d < 6; ++d) accr[d] += wt * an[my_row] * an[d];
                     } else {
@@ -959,18 +1143,20 @@ __global__ __launch_bounds__(256) void s6_assemble2_kernel(Solve6View s, Solve6S
             // regularisation edges arriving at a (n -> a)
             if (my_row >= 3) {
                 const int cc = my_row - 3;
-                for (int e = s.rnode_ptr[a]; e < s.rnode_ptr[a + 1]; ++e) {
-                    const unsigned entry = s.rnode_list[e];
-                    const int n          = (int)(entry / (unsigned)k);
+                for (int e = 0; e < nri; ++e) {
+                    const bool staged    = e < S6_REGIN;  // (rarely not: more arriving edges than the staged ones)
+                    const float* E       = rin[staged ? e : 0];
+                    const unsigned entry = staged ? 0u : s.rnode_list[rib + e];
+                    const int n          = staged ? __float_as_int(E[0]) : (int)(entry / (unsigned)k);
                     if (slot != 0 && col != n) continue;
-                    const float wt = wreg2 * s.rhub[entry];
+                    const float wt = staged ? E[1] : wreg2 * s.rhub[entry];
                     if (slot == 0) {
-                        gacc += wt * s.rres[3 * (size_t)entry + cc];
+                        gacc += wt * (staged ? E[2 + cc] : s.rres[3 * (size_t)entry + cc]);
                         accr[my_row] += wt;
                     } else {
-                        const float* an = s.rvec + 18 * (size_t)entry + 6 * cc;
 #pragma unroll
-                        for (int d = 0; d < 6; ++d) accr[d] -= wt * an[d];
+                        for (int d = 0; d < 6; ++d)
+                            accr[d] -= wt * (staged ? E[5 + 6 * cc + d] : s.rvec[18 * (size_t)entry + 6 * cc + d]);
                     }
                 }
             }
@@ -983,10 +1169,18 @@ __global__ __launch_bounds__(256) void s6_assemble2_kernel(Solve6View s, Solve6S
             float* out = s.bvals + ((size_t)a * s.cap + slot) * 36 + 6 * my_row;
 #pragma unroll
             for (int d = 0; d < 6; ++d) out[d] = accr[d];
+            if (slot != 0) {  // the mirror block H_ba = H_ab^T: column my_row of it
+                const int rs = s.rslot[(size_t)a * s.cap + slot];
+                if (rs != 255) {
+                    float* out2 = s.bvals + ((size_t)col * s.cap + rs) * 36 + my_row;
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) out2[6 * d] = accr[d];
+                }
+            }
         }
     }
     __syncthreads();
-    if (tid == 0) inv6(diag, s.minv + 36 * (size_t)a);
+    if (tid < 6) inv6_column(diag, s.minv + 36 * (size_t)a, tid);
 }
 
 // -------------------------------------------------------------------------------------- PCG
@@ -1281,6 +1475,7 @@ hipError_t s6_build_graph_impl(const Solve6View& s, Solve6State* state, const fl
     e = solve_transpose_graph(s.reg_idx, (size_t)s.D * s.k, s.D, s.blk_hist, s.rnode_ptr, s.rnode_list, st);
     if (e != hipSuccess) return e;
     s6_pattern_kernel<<<s.D, 256, 0, st>>>(s, state);
+    s6_rslot_kernel<<<(s.D * s.cap + 255) / 256, 256, 0, st>>>(s);
     return hipGetLastError();
 }
 
@@ -1322,7 +1517,7 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
         const int rc = rc_env ? rc_env : 320;
 #define S6A2(KK, RC)                                                                                              \
     do {                                                                                                          \
-        const size_t sh = (size_t)(RC) * (32 + 4 * (KK) + 16);                                                     \
+        const size_t sh = std::max((size_t)(RC) * (32 + 4 * (KK) + 16), (size_t)S6_MAXSLOT * (64 + 48) * 4);        \
         static bool attr = false;                                                                                 \
         if (!attr && sh > 48 * 1024) {                                                                            \
             (void)hipFuncSetAttribute((const void*)s6_assemble2_kernel<KK, RC>,                                   \

@@ -80,6 +80,8 @@ struct Solve6View {
     // normal equations, block ELL
     int32_t* bcols;  // D x cap
     int32_t* bcnt;   // D
+    int32_t* bfu;    // D  first "upper" slot of the row (column > row; slots 1 .. bfu-1 are mirrored from their columns' rows)
+    uint8_t* rslot;  // D x cap  slot of the row's node in the row of each of its columns
     uint8_t* eslot;  // (N k) x k: slot, in the block row of the entry's node, of each neighbour of the entry's vertex
     // the same relation by slot: for node a and slot q >= 1, pair_list[pair_ptr[a (cap+1) + q] .. pair_ptr[.. q+1]) are
     // the (row of a's list << 4 | neighbour) pairs that land in slot q, ascending (slot 0 = every row's own neighbour)
