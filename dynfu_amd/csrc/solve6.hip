@@ -1511,10 +1511,10 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
     static const bool lds_form = getenv("DFA_S6_ASSEMBLE") && atoi(getenv("DFA_S6_ASSEMBLE")) == 1;  // A/B: first form
     if (lds_form) K6DISPATCH(s6_assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, wreg2, p.damping, tol2));
     else {
-        // rows staged per pass (DFA_S6_RC for A/B): fewer rows = more workgroups per CU, more passes per node; measured
-        // best at 320 for k = 4 and k = 8 (192: 0.163 / 0.673 ms at C2 / C3, 320: 0.157 / 0.642, 640: 0.177 / 0.755)
+        // rows staged per pass (DFA_S6_RC for A/B).  Third form, C2 (k = 4) / C3 (k = 8): 192 0.101 / 0.386 ms, 256 0.100 /
+        // 0.358, 320 0.096 / 0.384, 448 0.097 / 0.360 — flat: the passes are no longer what costs
         static const int rc_env = getenv("DFA_S6_RC") ? atoi(getenv("DFA_S6_RC")) : 0;
-        const int rc = rc_env ? rc_env : 320;
+        const int rc = rc_env ? rc_env : (s.k <= 4 ? 320 : 256);
 #define S6A2(KK, RC)                                                                                              \
     do {                                                                                                          \
         const size_t sh = std::max((size_t)(RC) * (32 + 4 * (KK) + 16), (size_t)S6_MAXSLOT * (64 + 48) * 4);        \
@@ -1527,10 +1527,12 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
         s6_assemble2_kernel<KK, RC><<<s.D, 256, sh, st>>>(s, state, wreg2, p.damping, tol2);                            \
     } while (0)
         if (s.k <= 4) {
-            if (rc <= 320) S6A2(4, 320);
+            if (rc <= 256) S6A2(4, 256);
+            else if (rc <= 320) S6A2(4, 320);
             else S6A2(4, 640);
         } else {
-            if (rc <= 320) S6A2(8, 320);
+            if (rc <= 256) S6A2(8, 256);
+            else if (rc <= 320) S6A2(8, 320);
             else S6A2(8, 640);
         }
 #undef S6A2
