@@ -33,6 +33,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 for wide reads + WRITE_SIZE, corrected as
 # MI355X_MICROARCH.md prescribes) — profiles/r02_pmc_tsdf.md.  Collected offline: PMC needs its own runs.
 TIMING_SAMPLE = 8  # every 8th timed frame carries the hipEvent brackets of the per-kernel report
+PMC_TRAFFIC_SOURCE = "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; file and commit beside each figure in bench.py)"
 PMC_TRAFFIC_BYTES = {# profiles/r02d_pmc_bench_c2.md: integrate_runs_kernel<true,32,8>, WRITE 524 288 KiB + 2 x FETCH 2 368 KiB (C4, profiles/r02_pmc_tsdf.md: 4 194 304 + 2 x 23 775)
                      ("C2", "fused_integrate"): 0.5417e9, ("C3", "fused_integrate"): 0.5417e9, ("C4", "fused_integrate"): 4.344e9,
                      # profiles/r01_pmc_northstar.md (FETCH x2 + WRITE per dispatch)
@@ -65,6 +66,9 @@ def parse():
                     help="ref: the reference's translation-only energy (energy.t); northstar: 6-DoF DQ-blend / "
                          "projective point-to-plane / ARAP solve (DESIGN.md 4.5) against the live depth map")
     ap.add_argument("--linear-iter", type=int, default=0, help="PCG iteration cap (default: 256 ref, 64 northstar)")
+    ap.add_argument("--no-adaptive-launch", action="store_true",
+                    help="northstar: enqueue the full PCG launch budget of every Gauss-Newton iteration (A/B of "
+                         "dfa_solve6_params.adaptive_launch)")
     return ap.parse_args()
 
 
@@ -252,19 +256,22 @@ class Sequence:
         self.plan_free[i] = ev
 
 
+NS_PCG = dict(pcg_tol=1e-3, pcg_tol_first=0.1, pcg_tol_decay=0.5, adaptive_launch=1)  # inexact Newton
+
+
 class Sequence6(Sequence):
     """North-star mode: the live input of the solve is the depth frame itself (vertex / normal maps by
     computePointNormals), the unknowns are 6-DoF node twists (dfa_solver6)."""
 
-    def __init__(self, cfg_name, device, linear_iter):
+    def __init__(self, cfg_name, device, linear_iter, pcg=None):
         super().__init__(cfg_name, device)
         A, cfg = self.A, self.cfg
         del self.solver, self.live
         self.solver = A.Solver6(self.D, self.N, self.k)
         gn = cfg["gn_iters"]
         outer = 2 if gn % 2 == 0 else 1
-        self.params = A.Solve6Params(num_iter=outer, gn_iter=gn // outer, linear_iter=linear_iter, pcg_tol=1e-6,
-                                     **self.synth.SOLVER)
+        self.pcg = dict(NS_PCG if pcg is None else pcg)
+        self.params = A.Solve6Params(num_iter=outer, gn_iter=gn // outer, linear_iter=linear_iter, **self.pcg, **self.synth.SOLVER)
         self.gn_total = outer * (gn // outer)
 
     def build_graph(self, f):
@@ -332,9 +339,64 @@ def pipelined_probe(seq, f0, device, steps=100, warmup=10):
                 max_abs_translation_error_vs_ground_truth_m=round(t_err, 6))
 
 
-def northstar_probe(cfg_name, device, steps=30, warmup=5):
+def northstar_rooflines(seq, config, st, tm, fuse_ms):
+    """roofline entries of the north-star kernels from the hipEvent timings of the last timed frame (dfa_solver6_get_timing:
+    events on the solve's stream around every launch group) — the dominant one first.  Algorithmic bytes:
+    linearise reads a vertex (canon 12 + normal 12 + k indices and weights 8 k + the live pixel 32 bytes; the k node
+    transforms come from L2) and writes its row once per neighbour, entry-major (l 32 + f 4 k + weights 8 bytes); the
+    assembly reads every row once per node it touches (the same 40 + 4 k bytes + 4 of the row's list entry) and writes the
+    block matrix (36 floats per block, the upper half computed and mirrored); a PCG iteration reads the matrix (36 floats
+    + a column id per block), three gathered 6-vectors per block and ~12 vectors of 6 D floats."""
+    cfg = seq.cfg
+    dim, Wd, Hd, k = cfg["dim"], cfg["width"], cfg["height"], seq.k
+    V = dim ** 3
+    gn, nblk = max(1, tm["gn_iterations"]), tm["matrix_blocks"]
+    launches = max(1, st["pcg_launches"])
+    fuse_bytes = 4.0 * V + 2.0 * Wd * Hd
+    lin_bytes = seq.N * (24 + 8 * k + 32) + seq.N * k * (40 + 4 * k)
+    asm_bytes = seq.N * k * (44 + 4 * k) + nblk * 36 * 4
+    pcg_bytes = nblk * (36 * 4 + 4 + 3 * 24) + 12 * 24.0 * seq.D
+    asm_ms, lin_ms, pcg_ms = tm["assemble_ms"] / gn, tm["linearise_ms"] / gn, tm["pcg_ms"] / launches
+
+    def entry(kernel, key, ms, nbytes, per_frame, total_ms, **extra):
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else float("nan")
+        src = PMC_TRAFFIC_BYTES.get((config, key))
+        return dict(kernel=kernel, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(gbs / HBM_PEAK_GBS, 4), traffic=src, traffic_source=PMC_TRAFFIC_SOURCE if src else None,
+                    avg_launch_ms=round(ms, 5), launches_per_frame=per_frame, algorithmic_bytes_per_launch=nbytes,
+                    ms_per_frame=round(total_ms, 4), **extra)
+
+    kk = 4 if k <= 4 else 8
+    ents = [
+        entry("s6_assemble2_kernel<%d,%d> (block normal matrix of one Gauss-Newton iteration)" % (kk, 320 if kk == 4 else 256),
+              "s6_assemble", asm_ms, asm_bytes, gn, tm["assemble_ms"],
+              note="a quad of lanes per matrix block walks the block's (row, neighbour) list; bound by LDS latency and the "
+                   "imbalance between lists, not by HBM (DESIGN.md 4.5)"),
+        entry("s6_linearise_kernel<%d> (+ s6_nodes, s6_reg: residuals and row factors of one Gauss-Newton iteration)" % kk,
+              "s6_linearise", lin_ms, lin_bytes, gn, tm["linearise_ms"]),
+        entry("s6_pcg_step_kernel (one Chronopoulos-Gear PCG iteration per launch)", "s6_pcg_step", pcg_ms, pcg_bytes, launches,
+              tm["pcg_ms"], matrix_blocks=nblk,
+              note="launch/latency-bound below ~2k nodes (two dependent memory round trips + the inter-kernel gap); a launch "
+                   "whose PCG has converged costs ~3.5 us, which is why the launch count follows the iteration count"),
+        entry("integrate_runs_kernel<FUSED_CLEAR,32,8> (clear+integrate %d^3)" % dim, "fused_integrate", fuse_ms, fuse_bytes, 1, fuse_ms),
+    ]
+    ents.sort(key=lambda e: -e["ms_per_frame"])
+    return ents
+
+
+def northstar_fields(seq, st):
+    return dict(gn_iterations=st["gn_iters"], pcg_iterations=st["pcg_iters"], pcg_iterations_per_gn=st["pcg_it_hist"],
+                pcg_iteration_cap=seq.params.linear_iter,
+                pcg_relative_residual_per_gn=[round(r, 5) for r in st["pcg_rel_hist"]],
+                pcg_tolerance_schedule="max(%g, %g x %g^i) at Gauss-Newton iteration i of an outer iteration" %
+                                       (seq.pcg["pcg_tol"], seq.pcg["pcg_tol_first"], seq.pcg["pcg_tol_decay"]),
+                pcg_launches=st["pcg_launches"], pcgs_cut_short_by_the_launch_budget=st["pcg_short"],
+                valid_rows=st["valid_last"], cost_per_gn=[float("%.5g" % c) for c in st["cost_hist"]])
+
+
+def northstar_probe(cfg_name, device, steps=30, warmup=8):
     """The same frame in north-star mode (6-DoF DQ-blend / projective point-to-plane / ARAP solve), timed
-    on this GPU after the main measurement: a short secondary figure carried in the default bench line."""
+    on this GPU after the main measurement: a secondary figure of the default bench line, with its own rooflines."""
     import torch
     seq = Sequence6(cfg_name, device, 64)
     seq.fuse_first = False
@@ -346,24 +408,32 @@ def northstar_probe(cfg_name, device, steps=30, warmup=5):
         seq.frame(warmup + f)
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
-    st = seq.solver.stats()
+    # one more frame with hipEvent brackets on the solve's stream (outside the timed region) for the per-kernel figures
+    fuse_events = []
+    seq.solver.enable_timing(True)
+    seq.frame(warmup + steps, False, fuse_events)
+    torch.cuda.synchronize(device)
+    st, tm = seq.solver.stats(), seq.solver.timing()
+    seq.solver.enable_timing(False)
+    fuse_ms = float(np.mean([a.elapsed_time(b) for a, b in fuse_events]))
+    rl = northstar_rooflines(seq, cfg_name, st, tm, fuse_ms)
     out = dict(value=round(steps / dt, 2), unit="frames/s", steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 4),
-               workload="%s north-star mode: %d GN iterations x block-Jacobi PCG<=64 (tol 1e-6), 6-DoF twists per node, DQ blend, "
+               workload="%s north-star mode: %d GN iterations x block-Jacobi PCG (inexact Newton), 6-DoF twists per node, DQ blend, "
                         "projective point-to-plane data term against the live depth map, ARAP regulariser; same fuse"
                         % (cfg_name, seq.gn_total),
-               pcg_iterations_last_frame=st["pcg_iters"], cost_first=st["initial_cost"], cost_last=st["final_cost"],
-               note="parity unpinned (the reference has no such solve); see `python bench.py --mode northstar` for its rooflines")
+               solve=northstar_fields(seq, st), roofline=rl[0], roofline_other=rl[1:],
+               note="parity unpinned (the reference has no such solve): checked against the fp64 statement oracle/solve6_oracle.c")
     del seq
     torch.cuda.empty_cache()
     return out
 
 
 def main_northstar(args, torch, replicas, rank, world, device):
-    """bench line of the north-star mode (same contract; the dominant kernel is reported from hipEvent timings
-    of the phases of the last frame)."""
+    """bench line of the north-star mode (same contract; per-kernel figures from hipEvent timings of the phases of the
+    last timed frame)."""
     n_gpus = world
     lin = args.linear_iter or 64
-    seq = Sequence6(args.config, device, lin)
+    seq = Sequence6(args.config, device, lin, dict(NS_PCG, adaptive_launch=0) if args.no_adaptive_launch else None)
     seq.fuse_first = args.fuse_first
     cfg = seq.cfg
     K, Wm = args.steps, args.warmup
@@ -384,52 +454,22 @@ def main_northstar(args, torch, replicas, rank, world, device):
         replicas.shutdown()
         return
     dim, Wd, Hd = cfg["dim"], cfg["width"], cfg["height"]
-    V = dim ** 3
     fuse_ms = float(np.mean([a.elapsed_time(b) for a, b in fuse_events])) if fuse_events else float("nan")
-    fuse_bytes = 4.0 * V + 2.0 * Wd * Hd
-    fuse_gbs = fuse_bytes / (fuse_ms * 1e-3) / 1e9
-    its, gn, nblk, k = st["pcg_iters"], max(1, tm["gn_iterations"]), tm["matrix_blocks"], seq.k
-    # algorithmic bytes: assembly reads every row once per node it touches (l 32 B + f 4k B + weights 8 B
-    # + slots k B) and writes the block matrix; a PCG iteration reads the matrix (36 floats + a column id per block), three
-    # gathered 6-vectors per block and ~12 vectors of 6 D floats
-    asm_bytes = seq.N * k * (32 + 4 * k + 8 + k) + nblk * (36 * 4 + 4)
-    pcg_bytes_it = nblk * (36 * 4 + 4 + 3 * 24) + 12 * 24.0 * seq.D
-    asm_ms, pcg_ms = tm["assemble_ms"] / gn, tm["pcg_ms"] / max(1, its + gn)
-    fuse_entry = dict(kernel="integrate_runs_kernel<FUSED_CLEAR,32,8> (clear+integrate %d^3)" % dim, bound="hbm",
-                      achieved=round(fuse_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(fuse_gbs / HBM_PEAK_GBS, 4),
-                      traffic=PMC_TRAFFIC_BYTES.get((args.config, "fused_integrate")), avg_launch_ms=round(fuse_ms, 4),
-                      launches_per_frame=1, algorithmic_bytes_per_launch=fuse_bytes)
-    asm_gbs = asm_bytes / (asm_ms * 1e-3) / 1e9
-    asm_entry = dict(kernel="s6_assemble2_kernel<%d,320> (block normal matrix of one Gauss-Newton iteration)" % (4 if k <= 4 else 8),
-                     bound="hbm", achieved=round(asm_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                     frac=round(asm_gbs / HBM_PEAK_GBS, 4), traffic=PMC_TRAFFIC_BYTES.get((args.config, "s6_assemble")),
-                     avg_launch_ms=round(asm_ms, 4), launches_per_frame=gn, algorithmic_bytes_per_launch=asm_bytes,
-                     ms_per_frame=round(tm["assemble_ms"], 3),
-                     note="moments accumulated in registers over per-slot pair lists; LDS-issue / latency-bound (DESIGN.md 4.5)")
-    pcg_gbs = pcg_bytes_it / (pcg_ms * 1e-3) / 1e9
-    pcg_entry = dict(kernel="s6_pcg_step_kernel (one Chronopoulos-Gear PCG iteration per launch)", bound="hbm",
-                     achieved=round(pcg_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(pcg_gbs / HBM_PEAK_GBS, 4),
-                     traffic=PMC_TRAFFIC_BYTES.get((args.config, "s6_pcg_step")), avg_launch_ms=round(pcg_ms, 5),
-                     launches_per_frame=its + gn, algorithmic_bytes_per_launch=pcg_bytes_it, matrix_blocks=nblk,
-                     ms_per_frame=round(tm["pcg_ms"], 3),
-                     note="launch/latency-bound below ~2k nodes (two dependent memory round trips + the inter-kernel gap)")
-    lin_entry = dict(kernel="s6_linearise_kernel", ms_per_frame=round(tm["linearise_ms"], 3), launches_per_frame=gn)
-    cands = sorted([(tm["assemble_ms"], asm_entry), (tm["pcg_ms"], pcg_entry), (fuse_ms, fuse_entry)], key=lambda t: -t[0])
-    dominant, other = cands[0][1], [c[1] for c in cands[1:]] + [lin_entry]
+    rl = northstar_rooflines(seq, args.config, st, tm, fuse_ms)
     out = dict(metric="frames/sec (warp-solve + TSDF fuse), 512^3 vol / 2k nodes / VGA depth",
                value=round(n_gpus * K / dt_max, 2), unit="frames/s", n_gpus=n_gpus, steps=K, warmup=Wm,
                ms_per_step=round(dt_max / K * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="f32", data="synthetic",
                config=dict(workload="%s north-star mode: %d^3 TSDF, %dx%d depth, %d nodes, k=%d, %d vertices, %d GN "
-                                    "iterations x block-Jacobi PCG<=%d (tol 1e-6), 6-DoF DQ-blend / projective "
+                                    "iterations x block-Jacobi PCG<=%d (inexact Newton: %s), 6-DoF DQ-blend / projective "
                                     "point-to-plane / ARAP energy, lambda=200"
-                                    % (args.config, dim, Wd, Hd, seq.D, seq.k, seq.N, seq.gn_total, lin),
+                                    % (args.config, dim, Wd, Hd, seq.D, seq.k, seq.N, seq.gn_total, lin,
+                                       northstar_fields(seq, st)["pcg_tolerance_schedule"]),
                            parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus,
                            streams="serial" if args.serial else ("fuse || graph build + solve on two HIP streams" if args.fuse_first else
                                                                  "graph build, then fuse || solve on two HIP streams"),
-                           pcg_iterations_last_frame=st["pcg_iters"], gn_iterations_last_frame=st["gn_iters"],
-                           valid_rows_last_frame=st["valid_last"], cost_first=st["initial_cost"], cost_last=st["final_cost"]),
-               roofline=dominant, roofline_other=other)
+                           last_frame=northstar_fields(seq, st)),
+               roofline=rl[0], roofline_other=rl[1:])
     if not args.no_cpu_baseline and world == 1:
         params = seq.params
         del seq

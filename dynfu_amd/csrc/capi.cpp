@@ -179,15 +179,16 @@ struct dfa_solver6 {
     bool has_problem;
     // the PCG of one Gauss-Newton iteration (linear_iter + 2 dependent launches) captured as a HIP graph:
     // re-captured when the problem size or the iteration parameters change
-    hipGraphExec_t pcg_graph = nullptr;
+    std::map<int, hipGraphExec_t> pcg_graphs;  // by the number of step launches
+    int last_launches = 0;  // step launches enqueued by the last solve
+    int pred[dfa::S6_HIST] = {};  // adaptive launch budget: iterations each Gauss-Newton iteration needed lately
+    int* mirror = nullptr;  // pinned int[S6_HIST]: PCG iterations of the Gauss-Newton iterations of the solves, kept by the device
     bool graph_disabled = false;
     hipStream_t capture_stream = nullptr;  // capture is not allowed on the legacy default stream
     bool timing = false;  // hipEvent brackets around linearise / assemble / PCG of every Gauss-Newton iteration
     std::vector<hipEvent_t> events;
     size_t ev_used = 0;
     dfa::Solve6View pcg_key_view;
-    int pcg_key_iter = -1;
-    float pcg_key_tol = -1.f;
 };
 
 namespace {
@@ -1010,6 +1011,10 @@ int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
     if (rc == DFA_OK) rc = plan6_alloc(s, &s->raw_w, N * k);
     if (rc == DFA_OK) rc = plan6_alloc(s, &s->raw_reg, D * (k + 1));
     if (rc == DFA_OK) rc = plan6_alloc(s, &s->state, 1);
+    if (rc == DFA_OK && hipHostMalloc((void**)&s->mirror, dfa::S6_HIST * sizeof(int), hipHostMallocDefault) == hipSuccess)
+        std::memset(s->mirror, 0, dfa::S6_HIST * sizeof(int));
+    else
+        s->mirror = nullptr, (void)hipGetLastError();
     if (rc == DFA_OK) {
         hipError_t e = s->grid.reserve(max_D);
         if (e != hipSuccess) rc = hip_fail(e, "hipMalloc (node grid)");
@@ -1024,7 +1029,8 @@ int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
 
 void dfa_solver6_destroy(dfa_solver6* s) {
     if (!s) return;
-    if (s->pcg_graph) (void)hipGraphExecDestroy(s->pcg_graph);
+    for (auto& g : s->pcg_graphs) (void)hipGraphExecDestroy(g.second);
+    if (s->mirror) (void)hipHostFree(s->mirror);
     if (s->capture_stream) (void)hipStreamDestroy(s->capture_stream);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     for (void* p : s->blocks) (void)hipFree(p);
@@ -1080,6 +1086,7 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
     hipStream_t st = S(stream);
     s->ev_used = 0;
     HIP_TRY(dfa::s6_begin(s->v, s->state, s->node_dq, st));
+    s->last_launches = 0;
     for (int outer = 0; outer < p.num_iter; ++outer)
         for (int gn = 0; gn < p.gn_iter; ++gn) {
             auto mark = [&]() {  // 4 events per Gauss-Newton iteration: | linearise | assemble | pcg |
@@ -1096,38 +1103,56 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
             mark();
             HIP_TRY(dfa::s6_assemble(s->v, s->state, p, gn, st));
             mark();
-            // the PCG launches of one Gauss-Newton iteration are replayed as a HIP graph; if capture is not possible
-            // here (it never is on some stream configurations) the launches are issued one by one — same kernels
+            // Launches of this PCG: the caller's cap, or (adaptive_launch) what this Gauss-Newton iteration needed in the
+            // plan's previous solves plus a quarter — the mirror is pinned memory the device writes as it goes; it is read
+            // here without synchronising, so it may be one or two solves old
+            const int gi = outer * p.gn_iter + gn;
+            int launches = p.linear_iter;
+            if (prm->adaptive_launch && s->mirror && gi < dfa::S6_HIST) {
+                // pred: what this iteration needed lately — follows an increase at once, forgets it by one launch per solve
+                const int seen = ((volatile int*)s->mirror)[gi];
+                int& pred      = s->pred[gi];
+                if (seen > 0) pred = std::max(seen, pred - 1);
+                else if (seen < 0) pred = std::max(pred, -2 * seen);  // cut short last time: twice as many
+                if (pred > 0) launches = std::min(p.linear_iter, pred + std::max(2, pred / 4));
+            }
+            // the PCG launches of one Gauss-Newton iteration are replayed as a HIP graph (one per launch count); if capture
+            // is not possible here (it never is on some stream configurations) the launches are issued one by one
             bool replayed = false;
             if (!s->graph_disabled && !getenv("DFA_S6_NO_GRAPH")) {
-                if (!s->pcg_graph || s->pcg_key_iter != p.linear_iter || s->pcg_key_tol != p.pcg_tol ||
-                    std::memcmp(&s->pcg_key_view, &s->v, sizeof(s->v)) != 0) {
-                    if (s->pcg_graph) (void)hipGraphExecDestroy(s->pcg_graph), s->pcg_graph = nullptr;
+                if (std::memcmp(&s->pcg_key_view, &s->v, sizeof(s->v)) != 0) {
+                    for (auto& g : s->pcg_graphs) (void)hipGraphExecDestroy(g.second);
+                    s->pcg_graphs.clear();
+                    s->pcg_key_view = s->v;
+                }
+                auto it = s->pcg_graphs.find(launches);
+                if (it == s->pcg_graphs.end()) {
                     hipGraph_t g = nullptr;
+                    hipGraphExec_t ge = nullptr;
                     bool ok = s->capture_stream || hipStreamCreateWithFlags(&s->capture_stream, hipStreamNonBlocking) == hipSuccess;
                     ok = ok && hipStreamBeginCapture(s->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
                     if (ok) {
-                        const hipError_t le = dfa::s6_pcg(s->v, s->state, p, s->capture_stream);
+                        const hipError_t le = dfa::s6_pcg_n(s->v, s->state, launches, s->capture_stream);
                         const hipError_t ce = hipStreamEndCapture(s->capture_stream, &g);
-                        ok = le == hipSuccess && ce == hipSuccess && g &&
-                             hipGraphInstantiate(&s->pcg_graph, g, nullptr, nullptr, 0) == hipSuccess;
+                        ok = le == hipSuccess && ce == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess;
                         if (g) (void)hipGraphDestroy(g);
                     }
                     if (ok) {
-                        s->pcg_key_view = s->v, s->pcg_key_iter = p.linear_iter, s->pcg_key_tol = p.pcg_tol;
+                        it = s->pcg_graphs.emplace(launches, ge).first;
                     } else {
                         (void)hipGetLastError();  // clear the sticky error of the failed attempt
-                        s->pcg_graph = nullptr, s->graph_disabled = true;
+                        s->graph_disabled = true;
                     }
                 }
-                if (s->pcg_graph) {
-                    HIP_TRY(hipGraphLaunch(s->pcg_graph, st));
+                if (it != s->pcg_graphs.end()) {
+                    HIP_TRY(hipGraphLaunch(it->second, st));
                     replayed = true;
                 }
             }
-            if (!replayed) HIP_TRY(dfa::s6_pcg(s->v, s->state, p, st));
+            if (!replayed) HIP_TRY(dfa::s6_pcg_n(s->v, s->state, launches, st));
+            s->last_launches += launches + 1;
             mark();
-            HIP_TRY(dfa::s6_update(s->v, s->state, p.linear_iter, st));
+            HIP_TRY(dfa::s6_update(s->v, s->state, launches, p.linear_iter, gi < dfa::S6_HIST ? s->mirror : nullptr, st));
         }
     return DFA_OK;
 }
@@ -1176,6 +1201,7 @@ int dfa_solver6_get_stats(dfa_solver6* s, dfa_solve6_stats* out, dfa_stream_t st
     out->gn_iters = h.gn_iters, out->pcg_iters = h.pcg_iters;
     out->valid_first = (long long)h.valid_first, out->valid_last = (long long)h.valid_last;
     out->max_row_blocks = h.max_row_blocks, out->overflow = h.overflow;
+    out->pcg_short = h.pcg_short, out->pcg_launches = s->last_launches;
     static_assert(DFA_SOLVE6_HIST == dfa::S6_HIST, "history length of the C ABI and of the state block");
     for (int i = 0; i < DFA_SOLVE6_HIST; ++i) {
         const bool in = i < h.gn_iters;

@@ -121,11 +121,8 @@ __device__ __forceinline__ f3 blend_normal(const Blend<K>& B, f3 n) {
 }
 
 // ------------------------------------------------------------------------------- per iteration
-__global__ __launch_bounds__(256) void s6_nodes_kernel(Solve6View s, Solve6State* st) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n == 0) st->cost = 0.0, st->valid = 0ull;
-    if (n >= s.D) return;
-    const DQ q = dq_load(s.dq + 8 * (size_t)n);
+// g^_n = T_n(g_n) and M_n of node n at transform q (part of the launch that produced q: s6_begin / s6_update)
+__device__ __forceinline__ void s6_node_now(const Solve6View& s, int n, DQ q) {
     const f3 g = dq_point(q, mk3(s.node_pos[3 * n], s.node_pos[3 * n + 1], s.node_pos[3 * n + 2]));
     s.ghat[3 * n] = g.x, s.ghat[3 * n + 1] = g.y, s.ghat[3 * n + 2] = g.z;
     // M_n (6 x 8): the twist components of node n as dual-quaternion increments (W, Wd).  A data row's
@@ -170,9 +167,17 @@ __device__ __forceinline__ void block_add_cost(double cost, unsigned int nvalid,
     }
 }
 
+__device__ __forceinline__ double s6_reg_edge(const Solve6View& s, int e, float wreg2, float psi_reg, int update_w);
+
+// blocks [0, nlin): the data term, a lane per vertex; blocks from nlin on: the regulariser, a lane per edge
 template <int K>
 __global__ __launch_bounds__(256) void s6_linearise_kernel(Solve6View s, Solve6State* st, Solve6Image img,
-                                                           Solve6Params prm, int update_w) {
+                                                           Solve6Params prm, int update_w, int nlin, float wreg2) {
+    if ((int)blockIdx.x >= nlin) {  // (uniform)
+        const int e = ((int)blockIdx.x - nlin) * 256 + (int)threadIdx.x;
+        block_add_cost(e < s.D * s.k ? s6_reg_edge(s, e, wreg2, prm.psi_reg, update_w) : 0.0, 0u, st);
+        return;
+    }
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     double cost = 0.0;
     unsigned int nvalid = 0;
@@ -256,36 +261,32 @@ __global__ __launch_bounds__(256) void s6_linearise_kernel(Solve6View s, Solve6S
     block_add_cost(cost, nvalid, st);
 }
 
-__global__ __launch_bounds__(256) void s6_reg_kernel(Solve6View s, Solve6State* st, float wreg2, float psi_reg,
-                                                     int update_w) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ double s6_reg_edge(const Solve6View& s, int e, float wreg2, float psi_reg, int update_w) {
     double cost = 0.0;
-    if (e < s.D * s.k) {
-        const int n = e / s.k, m = s.reg_idx[e];
-        float* er = s.rres + 3 * (size_t)e;
-        float* vc = s.rvec + 18 * (size_t)e;
-        float ev[3] = {0.f, 0.f, 0.f}, vec[18];
+    const int n = e / s.k, m = s.reg_idx[e];
+    float* er = s.rres + 3 * (size_t)e;
+    float* vc = s.rvec + 18 * (size_t)e;
+    float ev[3] = {0.f, 0.f, 0.f}, vec[18];
 #pragma unroll
-        for (int i = 0; i < 18; ++i) vec[i] = 0.f;
-        if (m >= 0) {
-            const f3 y   = dq_point(dq_load(s.dq + 8 * (size_t)n), mk3(s.node_pos[3 * m], s.node_pos[3 * m + 1], s.node_pos[3 * m + 2]));
-            const f3 ghm = mk3(s.ghat[3 * m], s.ghat[3 * m + 1], s.ghat[3 * m + 2]);
-            const f3 ghn = mk3(s.ghat[3 * n], s.ghat[3 * n + 1], s.ghat[3 * n + 2]);
-            ev[0] = y.x - ghm.x, ev[1] = y.y - ghm.y, ev[2] = y.z - ghm.z;
-            const float en = sqrtf(ev[0] * ev[0] + ev[1] * ev[1] + ev[2] * ev[2]);
-            if (update_w) s.rhub[e] = en <= psi_reg ? 1.f : psi_reg / en;  // opt_solver.cpp:233-268
-            const float l0 = y.x - ghn.x, l1 = y.y - ghn.y, l2 = y.z - ghn.z;
-            // rows of [ -[l]x | I ]
-            vec[0] = 0.f, vec[1] = l2, vec[2] = -l1, vec[3] = 1.f;
-            vec[6] = -l2, vec[7] = 0.f, vec[8] = l0, vec[10] = 1.f;
-            vec[12] = l1, vec[13] = -l0, vec[14] = 0.f, vec[17] = 1.f;
-            cost = (double)wreg2 * (double)s.rhub[e] * (double)en * (double)en;
-        }
-        er[0] = ev[0], er[1] = ev[1], er[2] = ev[2];
-#pragma unroll
-        for (int i = 0; i < 18; ++i) vc[i] = vec[i];
+    for (int i = 0; i < 18; ++i) vec[i] = 0.f;
+    if (m >= 0) {
+        const f3 y   = dq_point(dq_load(s.dq + 8 * (size_t)n), mk3(s.node_pos[3 * m], s.node_pos[3 * m + 1], s.node_pos[3 * m + 2]));
+        const f3 ghm = mk3(s.ghat[3 * m], s.ghat[3 * m + 1], s.ghat[3 * m + 2]);
+        const f3 ghn = mk3(s.ghat[3 * n], s.ghat[3 * n + 1], s.ghat[3 * n + 2]);
+        ev[0] = y.x - ghm.x, ev[1] = y.y - ghm.y, ev[2] = y.z - ghm.z;
+        const float en = sqrtf(ev[0] * ev[0] + ev[1] * ev[1] + ev[2] * ev[2]);
+        if (update_w) s.rhub[e] = en <= psi_reg ? 1.f : psi_reg / en;  // opt_solver.cpp:233-268
+        const float l0 = y.x - ghn.x, l1 = y.y - ghn.y, l2 = y.z - ghn.z;
+        // rows of [ -[l]x | I ]
+        vec[0] = 0.f, vec[1] = l2, vec[2] = -l1, vec[3] = 1.f;
+        vec[6] = -l2, vec[7] = 0.f, vec[8] = l0, vec[10] = 1.f;
+        vec[12] = l1, vec[13] = -l0, vec[14] = 0.f, vec[17] = 1.f;
+        cost = (double)wreg2 * (double)s.rhub[e] * (double)en * (double)en;
     }
-    block_add_cost(cost, 0u, st);
+    er[0] = ev[0], er[1] = ev[1], er[2] = ev[2];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) vc[i] = vec[i];
+    return cost;
 }
 
 // --------------------------------------------------------------------------------- assembly
@@ -349,12 +350,12 @@ __device__ __forceinline__ void s6_bookkeeping(Solve6State* st, float tol2) {
     const int h = st->gn_iters;
     if (h < S6_HIST) st->cost_hist[h] = st->cost, st->pcg_it_hist[h] = 0, st->pcg_rel_hist[h] = 1.f;
     st->gn_iters = h + 1;
-    st->tol2 = tol2, st->pcg_last_it = 0;
+    st->tol2 = tol2, st->pcg_last_it = 0, st->pcg_done = 0;
 }
 
 // column c of the inverse of a symmetric positive definite 6x6 (every caller lane factorises for itself: six lanes invert
 // the block in the time of one column); zero if the factorisation fails, as inv6
-__device__ __forceinline__ void inv6_column(const float* M, float* out, int c) {
+__device__ __forceinline__ void inv6_column(const float* M, float* out, int c, float (&x)[6]) {
     float L[6][6];
     bool ok = true;
 #pragma unroll
@@ -371,7 +372,7 @@ __device__ __forceinline__ void inv6_column(const float* M, float* out, int c) {
                 L[i][j] = sm / L[j][j];
             }
         }
-    float y[6], x[6];
+    float y[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         float sm = i == c ? 1.f : 0.f;
@@ -387,7 +388,7 @@ __device__ __forceinline__ void inv6_column(const float* M, float* out, int c) {
         x[i] = sm / L[i][i];
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) out[6 * i + c] = ok ? x[i] : 0.f;
+    for (int i = 0; i < 6; ++i) x[i] = ok ? x[i] : 0.f, out[6 * i + c] = x[i];
 }
 
 // Sparsity pattern of block row a (fixed by the graphs of the frame, built once per set_problem):
@@ -829,6 +830,7 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
     __shared__ float part0[4][72];        // slot 0 per wave: 8 x 8 moment + g8
     __shared__ float g8s[8];
     __shared__ float diag[36];
+    __shared__ float gsh[6];              // -J^T W r of the node
     __shared__ float rout[8][24];         // edges leaving a: neighbour (bits), weight, residual (3), vectors (18)
     __shared__ float rin[S6_REGIN][24];   // edges arriving at a: source node (bits), weight, residual (3), vectors (18)
     const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
@@ -1162,7 +1164,7 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
             }
             if (slot == 0) {
                 accr[my_row] += damping;
-                s.g[6 * (size_t)a + my_row] = gacc;
+                s.g[6 * (size_t)a + my_row] = gacc, gsh[my_row] = gacc;
 #pragma unroll
                 for (int d = 0; d < 6; ++d) diag[my_row * 6 + d] = accr[d];
             }
@@ -1180,7 +1182,18 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
         }
     }
     __syncthreads();
-    if (tid < 6) inv6_column(diag, s.minv + 36 * (size_t)a, tid);
+    if (tid < 6) {
+        // column tid of M^-1 (= its row tid: symmetric), and with it the start of the PCG for this node:
+        // x = 0, r = g, u = M^-1 g, p = s = t = 0
+        float col[6];
+        inv6_column(diag, s.minv + 36 * (size_t)a, tid, col);
+        float u = 0.f;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) u += col[d] * gsh[d];
+        const size_t i = 6 * (size_t)a + tid;
+        s.x[i] = 0.f, s.r[i] = gsh[tid], s.u[0][i] = u;
+        s.p[i] = 0.f, s.s[i] = 0.f, s.t[0][i] = 0.f, s.t[1][i] = 0.f;
+    }
 }
 
 // -------------------------------------------------------------------------------------- PCG
@@ -1196,7 +1209,6 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
 // neighbour block next to the block's own 36).  Same iterates as textbook PCG in exact arithmetic.
 __global__ __launch_bounds__(256) void s6_pcg_init_kernel(Solve6View s, Solve6State* st) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (node, component)
-    if (i == 0) st->pcg_done = 0;
     if (i < 6 * s.D) {
         const int n = i / 6, c = i - 6 * n;
         const float* Mi = s.minv + 36 * (size_t)n + 6 * c;
@@ -1358,18 +1370,28 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(So
 }
 
 // ------------------------------------------------------------------------------------ update
-__global__ __launch_bounds__(256) void s6_update_kernel(Solve6View s, Solve6State* st, int linear_iter) {
+__global__ __launch_bounds__(256) void s6_update_kernel(Solve6View s, Solve6State* st, int launched, int linear_iter,
+                                                        int* __restrict__ mirror) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x < 64) {
-        // a PCG that ran into its iteration cap: its last (r, u) is still in the per-workgroup partials of the last launch
-        const int h = st->gn_iters - 1;
-        if (!st->pcg_done && linear_iter > 0 && st->pcg_last_it == linear_iter) {  // (uniform)
+        // a PCG that used every launch it was given: its last (r, u) is still in the per-workgroup partials of the last launch
+        const int h    = st->gn_iters - 1;
+        const bool ran = !st->pcg_done && launched > 0 && st->pcg_last_it == launched;  // (uniform)
+        bool reached   = !ran;
+        if (ran) {
             const int nb = s6_matvec_blocks(s.D);
             float g = 0.f;
-            for (int i = threadIdx.x; i < nb; i += 64) g += s.g_part[linear_iter & 1][i];
+            for (int i = threadIdx.x; i < nb; i += 64) g += s.g_part[launched & 1][i];
             g = wave_sum_all(g);
             const float rz0 = st->rz0;
+            reached         = !(g > st->tol2 * rz0);
             if (threadIdx.x == 0 && h >= 0 && h < S6_HIST) st->pcg_rel_hist[h] = g > 0.f && rz0 > 0.f ? sqrtf(g / rz0) : 0.f;
+        }
+        if (threadIdx.x == 0) {
+            st->cost = 0.0, st->valid = 0ull;  // accumulators of the next linearisation
+            const bool cut = !reached && launched < linear_iter;  // stopped by the plan's prediction, not by the caller's cap
+            if (cut) st->pcg_short += 1;
+            if (mirror && h >= 0 && h < S6_HIST) mirror[h] = cut ? -st->pcg_last_it : st->pcg_last_it;
         }
     }
     if (n >= s.D) return;
@@ -1387,6 +1409,7 @@ __global__ __launch_bounds__(256) void s6_update_kernel(Solve6View s, Solve6Stat
     rn              = qscale(rn, 1.f / sqrtf(qdot(rn, rn)));
     const Quat dn   = qscale(qmul(pureq(t), rn), 0.5f);
     dq_store(s.dq + 8 * (size_t)n, DQ{rn, dn});
+    s6_node_now(s, n, DQ{rn, dn});  // for the next linearisation
 }
 
 template <int K>
@@ -1419,11 +1442,12 @@ __global__ __launch_bounds__(256) void s6_begin_kernel(Solve6View s, Solve6State
         st->cost = 0.0, st->initial_cost = 0.0, st->final_cost = 0.0;
         st->valid = st->valid_first = st->valid_last = 0ull;
         st->have_first = 0, st->gn_iters = 0, st->pcg_iters = 0;  // overflow / max_row_blocks belong to the pattern
-        st->pcg_done = 0, st->rz0 = 0.f;
+        st->pcg_done = 0, st->rz0 = 0.f, st->pcg_short = 0;
     }
     if (i < 8 * s.D) s.dq[i] = node_dq[i];
     if (i < s.N) s.rho[i] = 0.f;
     if (i < s.D * s.k) s.rhub[i] = 1.f;
+    if (i < s.D) s6_node_now(s, i, dq_load(node_dq + 8 * (size_t)i));
 }
 
 // kfusion::device::computePointNormals (src/kfusion/cuda/imgproc.cu:187-215)
@@ -1492,10 +1516,11 @@ hipError_t s6_begin(const Solve6View& s, Solve6State* state, const float* node_d
 
 hipError_t s6_linearise(const Solve6View& s, Solve6State* state, const Solve6Image& img, const Solve6Params& p,
                         int update_weights, hipStream_t st) {
-    s6_nodes_kernel<<<(s.D + 255) / 256, 256, 0, st>>>(s, state);
-    if (s.N > 0) K6DISPATCH(s6_linearise_kernel, s.k, <<<(s.N + 255) / 256, 256, 0, st>>>(s, state, img, p, update_weights));
+    // (g^, M of the nodes and the cleared cost accumulators come from the launch that produced the transforms:
+    // s6_begin / s6_update)
     const float wreg2 = p.lambda / ((float)s.D * (float)s.k);
-    s6_reg_kernel<<<(s.D * s.k + 255) / 256, 256, 0, st>>>(s, state, wreg2, p.psi_reg, update_weights);
+    const int nlin = (s.N + 255) / 256, nreg = (s.D * s.k + 255) / 256;
+    K6DISPATCH(s6_linearise_kernel, s.k, <<<nlin + nreg, 256, 0, st>>>(s, state, img, p, update_weights, nlin, wreg2));
     return hipGetLastError();
 }
 
@@ -1509,8 +1534,10 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
     }
     const float tol2 = eta * eta;
     static const bool lds_form = getenv("DFA_S6_ASSEMBLE") && atoi(getenv("DFA_S6_ASSEMBLE")) == 1;  // A/B: first form
-    if (lds_form) K6DISPATCH(s6_assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, wreg2, p.damping, tol2));
-    else {
+    if (lds_form) {
+        K6DISPATCH(s6_assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, wreg2, p.damping, tol2));
+        s6_pcg_init_kernel<<<s6_update_blocks(s.D), 256, 0, st>>>(s, state);  // (the product's assembly starts the PCG itself)
+    } else {
         // rows staged per pass (DFA_S6_RC for A/B).  Third form, C2 (k = 4) / C3 (k = 8): 192 0.101 / 0.386 ms, 256 0.100 /
         // 0.358, 320 0.096 / 0.384, 448 0.097 / 0.360 — flat: the passes are no longer what costs
         static const int rc_env = getenv("DFA_S6_RC") ? atoi(getenv("DFA_S6_RC")) : 0;
@@ -1541,16 +1568,21 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
 }
 
 hipError_t s6_pcg(const Solve6View& s, Solve6State* state, const Solve6Params& p, hipStream_t st) {
-    const int ub = s6_update_blocks(s.D), mb = s6_matvec_blocks(s.D);
-    s6_pcg_init_kernel<<<ub, 256, 0, st>>>(s, state);
+    const int mb = s6_matvec_blocks(s.D);
     // launch -1 forms w_0 = A u_0; launch it >= 0 is iteration it (x_{it+1} is complete when it returns); the stop test
     // reads the tolerance of this Gauss-Newton iteration from the state block (set by the assembly launch)
     for (int it = -1; it < p.linear_iter; ++it) s6_pcg_step_kernel<<<mb, 64 * S6_NODES_PER_BLOCK, 0, st>>>(s, state, it);
     return hipGetLastError();
 }
 
-hipError_t s6_update(const Solve6View& s, Solve6State* state, int linear_iter, hipStream_t st) {
-    s6_update_kernel<<<(s.D + 255) / 256, 256, 0, st>>>(s, state, linear_iter);
+hipError_t s6_pcg_n(const Solve6View& s, Solve6State* state, int launches, hipStream_t st) {
+    Solve6Params p{};
+    p.linear_iter = launches;
+    return s6_pcg(s, state, p, st);
+}
+
+hipError_t s6_update(const Solve6View& s, Solve6State* state, int launched, int linear_iter, int* mirror, hipStream_t st) {
+    s6_update_kernel<<<(s.D + 255) / 256, 256, 0, st>>>(s, state, launched, linear_iter, mirror);
     return hipGetLastError();
 }
 

@@ -31,6 +31,8 @@ struct Solve6State {
     float gamma_prev[2], alpha_prev[2];  // scalars of the previous iteration (ping-pong)
     float tol2;          // stop test of the PCG in flight: (r, u) <= tol2 (r, u)_0   (set by the assembly launch)
     int pcg_last_it;     // iterations the PCG in flight has completed
+    int pcg_short;       // PCGs of this solve that used every launch enqueued for them — fewer than linear_iter, by the plan's
+                         // prediction — without reaching their tolerance
     // per Gauss-Newton iteration (the first S6_HIST): energy at the linearisation, PCG iterations, relative residual
     // sqrt((r, u) / (r, u)_0) the PCG stopped at
     double cost_hist[S6_HIST];
@@ -108,7 +110,10 @@ hipError_t s6_linearise(const Solve6View& s, Solve6State* state, const Solve6Ima
 // gn_in_outer: index of the Gauss-Newton iteration inside its outer iteration (selects the PCG tolerance of the forcing schedule)
 hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Params& p, int gn_in_outer, hipStream_t st);
 hipError_t s6_pcg(const Solve6View& s, Solve6State* state, const Solve6Params& p, hipStream_t st);
-hipError_t s6_update(const Solve6View& s, Solve6State* state, int linear_iter, hipStream_t st);
+// launched: step launches enqueued for this PCG (<= linear_iter); mirror: pinned host int[S6_HIST] or null — iterations of
+// every PCG of the solve as the device finishes them, negative when the PCG used every launch without converging
+hipError_t s6_update(const Solve6View& s, Solve6State* state, int launched, int linear_iter, int* mirror, hipStream_t st);
+hipError_t s6_pcg_n(const Solve6View& s, Solve6State* state, int launches, hipStream_t st);
 hipError_t s6_warp(const Solve6View& s, const float* dq, float* out_v, float* out_n, hipStream_t st);
 hipError_t launch_points_normals(const uint16_t* depth, int depth_step, int cols, int rows, float fx, float fy, float cx,
                                  float cy, float* points, int points_step, float* normals, int normals_step,

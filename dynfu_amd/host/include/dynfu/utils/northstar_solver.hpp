@@ -28,6 +28,9 @@ struct NorthStarParameters {
     float pcgTol      = 1e-3f;
     float pcgTolFirst = 0.1f;
     float pcgTolDecay = 0.5f;
+    // enqueue only as many PCG launches per Gauss-Newton iteration as the previous frames needed (+ a quarter): see
+    // dfa_solve6_params.adaptive_launch in dynfu_amd.h
+    bool adaptiveLaunch = true;
 };
 
 class NorthStarSolver {

@@ -398,6 +398,14 @@ typedef struct dfa_solve6_params {
     /* Inexact-Newton forcing schedule: Gauss-Newton iteration i (from 0, inside its outer iteration) stops its PCG at
      * the relative residual max(pcg_tol, pcg_tol_first * pcg_tol_decay^i).  pcg_tol_first <= 0: constant pcg_tol. */
     float pcg_tol_first, pcg_tol_decay;
+    /* A PCG iteration is one kernel launch, and a launch whose PCG has already converged still costs ~3.5 us of stream
+     * time.  adaptive_launch != 0: the plan enqueues, for Gauss-Newton iteration i of the solve, only as many launches as
+     * iteration i of its previous solves needed plus a quarter (at least 2 more, at most linear_iter) — read from a
+     * pinned-memory mirror the device keeps, without synchronising.  Results do not change while the prediction holds
+     * (the extra launches of the full budget are no-ops); a PCG that would have needed more is stopped where its launches
+     * end (a truncated PCG: still a descent step), counted in dfa_solve6_stats.pcg_short, and the next solve's budget
+     * for that iteration doubles.  0: always linear_iter launches. */
+    int adaptive_launch;
 } dfa_solve6_params;
 
 #define DFA_SOLVE6_HIST 32
@@ -407,6 +415,9 @@ typedef struct dfa_solve6_stats {
     int gn_iters, pcg_iters;
     long long valid_first, valid_last; /* data rows with a valid association and non-zero weight */
     int max_row_blocks, overflow;
+    int pcg_short;    /* PCGs of this solve cut short by the adaptive launch budget (see dfa_solve6_params.adaptive_launch) */
+    int pcg_launches; /* PCG step launches the last solve enqueued (converged or not; without adaptive_launch:
+                         (linear_iter + 1) per Gauss-Newton iteration) */
     /* per Gauss-Newton iteration (the first DFA_SOLVE6_HIST of the solve): energy at its linearisation, PCG iterations it
      * ran, and the relative residual sqrt(r.z / (r.z)_0) its PCG stopped at (whether by tolerance or by linear_iter) */
     double cost_hist[DFA_SOLVE6_HIST];

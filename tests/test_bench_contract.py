@@ -51,6 +51,12 @@ def test_bench_line_has_the_contract_fields():
         assert key in rf, key
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     ns = d["northstar_mode"]  # the same frame with the 6-DoF solve, a secondary figure of the default run
-    assert ns["value"] > 30.0 and ns["unit"] == "frames/s" and ns["cost_last"] < ns["cost_first"]
+    assert ns["value"] > 30.0 and ns["unit"] == "frames/s"
+    sv = ns["solve"]
+    assert sv["cost_per_gn"][-1] < 0.05 * sv["cost_per_gn"][0] and sv["pcgs_cut_short_by_the_launch_budget"] == 0
+    assert all(0 < n < sv["pcg_iteration_cap"] for n in sv["pcg_iterations_per_gn"])  # every PCG stopped by its tolerance
+    for e in [ns["roofline"]] + ns["roofline_other"]:
+        for key in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms"):
+            assert key in e, key
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0

@@ -159,6 +159,39 @@ def test_forcing_schedule_matches_the_oracle(A, name, frame):
     assert 1e-6 < st5["pcg_rel_hist"][0] < 1.0
 
 
+def test_adaptive_launch_budget(A):
+    """dfa_solve6_params.adaptive_launch: the first solve of a plan enqueues the full budget, later ones what the
+    previous solve needed plus a quarter — same bits while the prediction holds; a prediction that falls short (here: the
+    plan last saw an easy problem) cuts the PCG, says so, and the budget recovers on the next solve."""
+    cfg, c, intr, depth = _scene("T1", 6)
+    P, Nm = A.compute_points_normals(dev(depth), *intr)
+    s = A.Solver6(cfg["D"], len(c["verts"]), cfg["k"])
+    keep = [dev(c["node_pos"]), dev(c["node_dq"]), dev(c["node_w"]), dev(c["verts"]), dev(c["normals"])]
+    s.set_problem(*keep)
+    kw = dict(num_iter=2, gn_iter=3, linear_iter=64, lambda_=200.0, pcg_tol=1e-3, pcg_tol_first=0.1, pcg_tol_decay=0.5)
+    s.solve(P, Nm, *intr, A.Solve6Params(**kw))
+    ref, st_ref = host(s.node_dq()), s.stats()
+    assert st_ref["pcg_launches"] == 6 * 65 and st_ref["pcg_short"] == 0
+    s.solve(P, Nm, *intr, A.Solve6Params(adaptive_launch=1, **kw))
+    st1 = s.stats()  # (the plan had no history before its first adaptive solve saw the mirror of the solve above)
+    s.solve(P, Nm, *intr, A.Solve6Params(adaptive_launch=1, **kw))
+    st2 = s.stats()
+    assert np.array_equal(host(s.node_dq()), ref) and st2["pcg_short"] == 0
+    assert st2["pcg_it_hist"] == st_ref["pcg_it_hist"] and st2["pcg_rel_hist"] == st_ref["pcg_rel_hist"]
+    want = sum(min(64, n + max(2, n // 4)) + 1 for n in st_ref["pcg_it_hist"])
+    assert st1["pcg_launches"] == st2["pcg_launches"] == want < 6 * 65
+    # a much harder solve on the same plan (tight tolerance): the stale prediction cuts its PCGs short, visibly
+    hard = dict(kw, pcg_tol=1e-5, pcg_tol_first=0.0)
+    s.solve(P, Nm, *intr, A.Solve6Params(adaptive_launch=1, **hard))
+    st3 = s.stats()
+    assert st3["pcg_short"] > 0 and st3["pcg_launches"] == want
+    assert all(r > 1e-5 for r in st3["pcg_rel_hist"])
+    s.solve(P, Nm, *intr, A.Solve6Params(adaptive_launch=1, **hard))
+    st4 = s.stats()
+    assert st4["pcg_launches"] > st3["pcg_launches"] and st4["pcg_short"] <= st3["pcg_short"]
+    s.close()
+
+
 def test_c4_solve_properties(A):
     """BASELINE config C4 (8 192 nodes, k = 8, 1 048 576 vertices, 1280 x 720 depth): the fp64 statement needs minutes at
     this size, so the HIP path is checked through properties — the block rows fit the plan, the energy of the

@@ -1,10 +1,7 @@
 cd $GRAFT_REPO_ROOT
-cp dynfu_amd/libdynfu_amd.so /tmp/prod.so
-for v in prod pf2; do
-[ $v = pf2 ] && cp dynfu_amd/libdynfu_amd_pf2.so.bin dynfu_amd/libdynfu_amd.so
-for rc in 256 320 448; do
-DFA_S6_RC=$rc DFA_TAG=$v-rc$rc python tools/ns_assemble_time.py C3 2>&1 | tail -1
-done
-DFA_S6_RC=320 DFA_TAG=$v-rc320 python tools/ns_assemble_time.py C2 2>&1 | tail -1
-done
-cp /tmp/prod.so dynfu_amd/libdynfu_amd.so
+timeout 900 python -m pytest tests/test_gpu_solve6.py -x -q 2>&1 | tail -6
+DFA_S6_ASSEMBLE=1 timeout 900 python -m pytest tests/test_gpu_solve6.py -x -q -k "baseline or matches" 2>&1 | tail -3
+python bench.py --mode northstar --config C2 --no-cpu-baseline | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('C2', d['value'], d['ms_per_step'], d['config']['last_frame']); [print(e['kernel'][:40], e['ms_per_frame'], e['avg_launch_ms'], e['frac']) for e in [d['roofline']]+d['roofline_other']]"
+python bench.py --mode northstar --config C3 --no-cpu-baseline --steps 50 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('C3', d['value'], d['ms_per_step'], d['config']['last_frame']); [print(e['kernel'][:40], e['ms_per_frame'], e['avg_launch_ms'], e['frac']) for e in [d['roofline']]+d['roofline_other']]"
