@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-northstar", action="store_true", help="skip the short north-star-mode measurement of the default run")
     ap.add_argument("--no-pipelined-probe", action="store_true", help="skip the short pipelined-throughput measurement")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip the DynFusion::operator() sequence (the reference's own timed region, C++ adaptor classes)")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded CPU sample")
     ap.add_argument("--serial", action="store_true", help="run fuse and solve on one stream (A/B of the overlap)")
     ap.add_argument("--pipeline", action="store_true",
@@ -479,6 +481,42 @@ def main_northstar(args, torch, replicas, rank, world, device):
     replicas.shutdown()
 
 
+def end_to_end(cfg_name, frames=14, skip=4):
+    """The reference's OWN timed region (src/apps/demo.cpp:90-95: the time inside `(*dynfu)(depth)`, sequence
+    src/dynfu/dyn_fusion.cpp:48-145) through the C++ adaptor classes: DynFusion::operator() — bilateral filter, dists,
+    clear + integrate, marching cubes, warp, correspondence, graph build, solve, node insertion — over the synthetic
+    depth sequence at this configuration's volume and image size, in the reference's mode and with the north-star solve.
+    Run by dynfu_amd/host/build/sequence_bench (a child process: its own HIP context; this process is idle meanwhile);
+    the vertices are whatever marching cubes extracts (~1 M at 512^3), the nodes what the seeding rule and the insertion
+    make of them — NOT the fixed 262 144 / 2 048 of the figure above."""
+    import subprocess
+    import tempfile
+
+    from dynfu_amd import build as B, synth
+    exe = B.SEQ_BENCH
+    if not os.path.exists(exe):
+        return dict(error="dynfu_amd/host/build/sequence_bench is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    cfg = synth.CONFIGS[cfg_name]
+    W, H, dim = cfg["width"], cfg["height"], cfg["dim"]
+    out = dict(unit="ms per frame inside DynFusion::operator() (device synchronised inside the timed call)",
+               sequence="%d synthetic %dx%d depth frames (dynfu_amd/synth.py), %d^3 volume; the first %d frames (seeding, "
+                        "plan and scratch allocation, node insertion settling) are not counted" % (frames, W, H, dim, skip))
+    with tempfile.TemporaryDirectory() as d:
+        raw = os.path.join(d, "frames.u16")
+        np.stack([synth.depth_frame(cfg, f) for f in range(frames)]).astype("<u2").tofile(raw)
+        for mode in ("ref", "northstar"):
+            r = subprocess.run([exe, raw, str(W), str(H), str(frames), str(dim), mode], capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                out[mode] = dict(error=r.stderr[-500:])
+                continue
+            rec = json.loads(r.stdout.strip().splitlines()[-1])
+            ms = sorted(rec.pop("frame_ms")[skip:])
+            rec.update(median_ms=round(ms[len(ms) // 2], 3), p95_ms=round(ms[min(len(ms) - 1, int(0.95 * len(ms)))], 3),
+                       frames_per_s=round(1e3 / ms[len(ms) // 2], 1), frames_measured=len(ms))
+            out[mode] = rec
+    return out
+
+
 def cpu_baseline(cfg_name, frames):
     """The CPU restatement (oracle/, kind "port": NOT Ceres, NOT the reference's CUDA path —
     neither exists for this path in a buildable form) timed on the host cores for `frames`
@@ -676,6 +714,11 @@ def main():
                 out["northstar_mode"] = northstar_probe(args.config, device)
             except Exception as e:  # noqa: BLE001
                 out["northstar_mode"] = dict(error="%s: %s" % (type(e).__name__, e))
+        if not args.no_end_to_end:
+            try:
+                out["end_to_end"] = end_to_end(args.config)
+            except Exception as e:  # noqa: BLE001
+                out["end_to_end"] = dict(error="%s: %s" % (type(e).__name__, e))
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_frames)
     print(json.dumps(out), flush=True)

@@ -96,6 +96,27 @@ def build_host(force=False, verbose=False):
     return HOST_LIB
 
 
+SEQ_BENCH = os.path.join(HERE, "host", "build", "sequence_bench")
+
+
+def build_host_tools(force=False, verbose=False):
+    """dynfu_amd/host/tools/sequence_bench.cpp -> dynfu_amd/host/build/sequence_bench: DynFusion::operator() frame by
+    frame over raw depth frames (bench.py's end_to_end figure)."""
+    host = build_host(force=force, verbose=verbose)
+    src = os.path.join(HOST, "tools", "sequence_bench.cpp")
+    os.makedirs(os.path.dirname(SEQ_BENCH), exist_ok=True)
+    if force or _stale(SEQ_BENCH, [src, host]):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(HOST, "include"), "-I/opt/rocm/include",
+               "-D__HIP_PLATFORM_AMD__", src, "-o", SEQ_BENCH, "-L" + HERE, "-ldynfu_amd_host", "-ldynfu_amd",
+               "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("sequence_bench build failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
+    return SEQ_BENCH
+
+
 def build_cpp_tests(force=False, verbose=False):
     """tests/cpp/*.cpp -> tests/cpp/build/<name> (git-ignored; travels to the GPU box)."""
     host = build_host(force=force, verbose=verbose)

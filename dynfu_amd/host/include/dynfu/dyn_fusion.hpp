@@ -1,7 +1,8 @@
-// dynfu/dyn_fusion.hpp — the non-rigid part of class DynFusion with the reference's interface
-// (include/dynfu/dyn_fusion.hpp:25-90, src/dynfu/dyn_fusion.cpp).  The reference's DynFusion also
-// IS-A kfusion::KinFu (rigid tracker, marching cubes, rendering) — out of scope; here the class
-// holds the per-frame warp-field sequence of dyn_fusion.cpp:147-242 on the dynfu_amd C ABI:
+// dynfu/dyn_fusion.hpp — class DynFusion with the reference's interface (include/dynfu/dyn_fusion.hpp:25-90,
+// src/dynfu/dyn_fusion.cpp).  As in the reference (:45) it IS-A kfusion::KinFu: the volume, the marching-cubes
+// object, the frame counter, the pose chain and the inherited accessors (tsdf(), mc(), icp(), getCameraPose(),
+// KinFu::params()) are the base class's; DynFusion::params() returns the DynFuParams and operator() replaces the
+// rigid loop by the per-frame warp-field sequence of dyn_fusion.cpp:48-242 on the dynfu_amd C ABI:
 //   init                    node seeding, every 128th canonical vertex            (:147-168)
 //   addLiveFrame            store the live cloud                                  (:177-180)
 //   warpCanonicalToLiveOpt  warp -> correspond -> build -> solve -> write-back    (:182-210)
@@ -20,28 +21,7 @@
 #include <kfusion/cuda/imgproc.hpp>
 #include <kfusion/cuda/marching_cubes.hpp>
 #include <kfusion/cuda/tsdf_volume.hpp>
-
-namespace kfusion {
-// the fields of kfusion::KinFuParams (include/kfusion/types.hpp, defaults src/kfusion/kinfu.cpp:10-44) that the
-// non-rigid pipeline reads; the ICP / rendering ones belong to the out-of-scope rigid tracker
-struct KinFuParams {
-    static KinFuParams default_params();
-    int cols, rows;
-    Intr intr;
-    Vec3i volume_dims;
-    Vec3f volume_size;
-    Affine3f volume_pose;
-    float bilateral_sigma_depth, bilateral_sigma_spatial;
-    int bilateral_kernel_size;
-    float icp_truncate_depth_dist;
-    float icp_dist_thres, icp_angle_thres;  // gates of the rigid tracker (kfusion::KinFu)
-    std::vector<int> icp_iter_num;          // iterations per pyramid level, level 0 = full resolution
-    float tsdf_min_camera_movement;
-    float tsdf_trunc_dist;
-    int tsdf_max_weight;
-    float raycast_step_factor, gradient_delta_factor;
-};
-}  // namespace kfusion
+#include <kfusion/kinfu.hpp>
 
 struct DynFuParams {  // dyn_fusion.hpp:25-42
     static DynFuParams defaultParams();  // dyn_fusion.cpp:6-31
@@ -66,7 +46,7 @@ struct DynFuParams {  // dyn_fusion.hpp:25-42
     NorthStarParameters northStarParams;
 };
 
-class DynFusion {
+class DynFusion : public kfusion::KinFu {  // include/dynfu/dyn_fusion.hpp:45
 public:
     explicit DynFusion(const DynFuParams& params);
     ~DynFusion();
@@ -80,7 +60,6 @@ public:
     // params().kinfuParams / the MarchingCubes passed to useMarchingCubes() (default: the library's tables).
     bool operator()(const kfusion::cuda::Depth& depth);
     void useMarchingCubes(std::shared_ptr<kfusion::cuda::MarchingCubes> mc) { mc_ = mc; }
-    kfusion::cuda::TsdfVolume& tsdf();
     std::shared_ptr<dynfu::Frame> getLiveFrame() { return liveFrame; }
     // KinFu::getMesh (kinfu.cpp:262): the marching-cubes triangles of the last frame, KinFu::convertToMesh's layout
     // (built on first use: one small vector per triangle is not something every frame should pay for)
@@ -88,7 +67,6 @@ public:
     // lets go of the mesh getMesh() built (one small vector per triangle: freeing them takes milliseconds, which a
     // caller may want outside its timed region; the next frame would do it otherwise)
     void dropMesh() { mesh_.reset(); }
-    int frameCounter() const { return frame_counter_; }
     // north-star mode: energy before / after the last frame's solve and the data rows that found an association
     double northStarInitialCost() const { return ns_initial_cost_; }
     double northStarFinalCost() const { return ns_final_cost_; }
@@ -126,17 +104,12 @@ private:
     std::shared_ptr<dynfu::Frame> canonicalFrameWarpedToLive;
     std::shared_ptr<dynfu::Frame> liveFrame;
     std::shared_ptr<Warpfield> warpfield;
-    kfusion::cuda::Dists dists_;
-    kfusion::cuda::Depth depth_filtered_;
-    std::shared_ptr<kfusion::cuda::TsdfVolume> volume_;
-    std::shared_ptr<kfusion::cuda::MarchingCubes> mc_;
     std::shared_ptr<dfa::PolygonMesh> mesh_;
     // the last frame's marching-cubes output (:76 / :122): in HBM (a view of mc_buffer_, valid until the next frame),
     // downloaded when getMesh() asks for it
     dfa::DeviceArray<kfusion::cuda::MarchingCubes::PointType> mc_buffer_, mesh_source_;
     std::vector<dfa::PointXYZ> mesh_triangles_;
     bool mesh_downloaded_ = false;
-    int frame_counter_ = 0;
     double ns_initial_cost_ = 0.0, ns_final_cost_ = 0.0;
     long long ns_valid_rows_ = 0;
     void seedNodes(const std::vector<dfa::PointXYZ>& canonicalVertices);

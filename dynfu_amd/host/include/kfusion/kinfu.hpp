@@ -11,13 +11,32 @@
 #include <vector>
 
 #include <dfa_host/io.hpp>
-#include <dynfu/dyn_fusion.hpp>  // kfusion::KinFuParams
 #include <kfusion/cuda/imgproc.hpp>
 #include <kfusion/cuda/marching_cubes.hpp>
 #include <kfusion/cuda/projective_icp.hpp>
 #include <kfusion/cuda/tsdf_volume.hpp>
 
 namespace kfusion {
+
+// kfusion::KinFuParams (include/kfusion/kinfu.hpp:33-61, defaults src/kfusion/kinfu.cpp:10-44) without the light pose
+// (rendering)
+struct KinFuParams {
+    static KinFuParams default_params();
+    int cols, rows;
+    Intr intr;
+    Vec3i volume_dims;
+    Vec3f volume_size;
+    Affine3f volume_pose;
+    float bilateral_sigma_depth, bilateral_sigma_spatial;
+    int bilateral_kernel_size;
+    float icp_truncate_depth_dist;
+    float icp_dist_thres, icp_angle_thres;  // gates of the rigid tracker (kfusion::KinFu)
+    std::vector<int> icp_iter_num;          // iterations per pyramid level, level 0 = full resolution
+    float tsdf_min_camera_movement;
+    float tsdf_trunc_dist;
+    int tsdf_max_weight;
+    float raycast_step_factor, gradient_delta_factor;
+};
 
 class KinFu {
 public:
@@ -39,7 +58,7 @@ public:
     // marching cubes of the current volume in KinFu::convertToMesh's layout (:236-262)
     std::shared_ptr<dfa::PolygonMesh> extractMesh();
 
-private:
+protected:  // as in the reference (kinfu.hpp:88-108): DynFusion derives from this class and drives these directly
     struct Frame {
         std::vector<cuda::Depth> depth_pyr;
         std::vector<cuda::Cloud> points_pyr;

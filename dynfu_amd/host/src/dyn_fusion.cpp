@@ -45,7 +45,7 @@ DynFuParams DynFuParams::defaultParams() {  // dyn_fusion.cpp:6-31
     return p;
 }
 
-DynFusion::DynFusion(const DynFuParams& params) : dynfuParams(params) {
+DynFusion::DynFusion(const DynFuParams& params) : kfusion::KinFu(params.kinfuParams), dynfuParams(params) {  // dyn_fusion.cpp:33
     solverParams.numIter       = 24;  // dyn_fusion.cpp:183-189
     solverParams.nonLinearIter = 16;
     solverParams.linearIter    = 256;
@@ -160,22 +160,7 @@ void DynFusion::fuse(const kfusion::cuda::Depth& depth, kfusion::cuda::TsdfVolum
 
 // ------------------------------------------------------------------------- the per-frame sequence
 
-kfusion::cuda::TsdfVolume& DynFusion::tsdf() {
-    if (!volume_) {  // KinFu::KinFu, src/kfusion/kinfu.cpp:47-58
-        const kfusion::KinFuParams& p = dynfuParams.kinfuParams;
-        volume_ = std::make_shared<kfusion::cuda::TsdfVolume>(p.volume_dims);
-        volume_->setTruncDist(p.tsdf_trunc_dist);
-        volume_->setMaxWeight(p.tsdf_max_weight);
-        volume_->setSize(p.volume_size);
-        volume_->setPose(p.volume_pose);
-        volume_->setRaycastStepFactor(p.raycast_step_factor);
-        volume_->setGradientDeltaFactor(p.gradient_delta_factor);
-    }
-    return *volume_;
-}
-
 std::shared_ptr<dynfu::Frame> DynFusion::extractSurface(int frame_id, bool with_normals) {
-    if (!mc_) mc_ = std::make_shared<kfusion::cuda::MarchingCubes>();
     auto triangles = mc_->run(tsdf(), mc_buffer_);  // :73-75 / :119-121 (one host sync: the vertex count)
     // convertToMesh (:76 / :122) on demand, in getMesh(): the float4 triangle soup stays in mc_buffer_ until then
     mesh_source_ = triangles, mesh_.reset(), mesh_triangles_.clear(), mesh_downloaded_ = false;
@@ -210,7 +195,8 @@ std::shared_ptr<dfa::PolygonMesh> DynFusion::getMesh() {  // KinFu::getMesh (kin
 }
 
 bool DynFusion::operator()(const kfusion::cuda::Depth& depth) {
-    const kfusion::KinFuParams& p = dynfuParams.kinfuParams;
+    const kfusion::KinFuParams& p = params_;                                                       // :51
+    kfusion::cuda::Depth& depth_filtered_ = curr_.depth_pyr[0];
     kfusion::cuda::computeDists(depth, dists_, p.intr);                                            // :58
     kfusion::cuda::depthBilateralFilter(depth, depth_filtered_, p.bilateral_kernel_size, p.bilateral_sigma_spatial,
                                         p.bilateral_sigma_depth);                                  // :60-61
@@ -240,7 +226,8 @@ bool DynFusion::operator()(const kfusion::cuda::Depth& depth) {
 // live marching-cubes cloud nor the nearest-neighbour correspondence is on the path; everything the solve sees is in
 // the camera frame.
 bool DynFusion::northStarFrame(const kfusion::cuda::Depth& depth) {
-    const kfusion::KinFuParams& p = dynfuParams.kinfuParams;
+    const kfusion::KinFuParams& p = params_;
+    kfusion::cuda::Depth& depth_filtered_ = curr_.depth_pyr[0];
     const dfa::Affine3f camera;  // the camera stays at the origin, as in the reference's operator() (:100-105)
     if (frame_counter_ == 0) {
         tsdf().integrate(dists_, camera, p.intr);

@@ -34,7 +34,8 @@ void KinFu::reset() {  // :117-126
 }
 
 Affine3f KinFu::getCameraPose(int time) const {  // :128-134
-    if (time > (int)poses_.size() || time < 0) time = (int)poses_.size() - 1;
+    // (the reference tests `time > size()`, which lets time == size() read one pose past the end: not reproduced)
+    if (time >= (int)poses_.size() || time < 0) time = (int)poses_.size() - 1;
     return poses_[(size_t)time];
 }
 

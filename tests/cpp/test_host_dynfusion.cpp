@@ -54,6 +54,24 @@ TEST(DynFusionTest, FindCorrespondingFrameIsTheNearestCanonicalVertex) {
     }
 }
 
+TEST(DynFusionTest, IsAKinFuAsInTheReference) {
+    // include/dynfu/dyn_fusion.hpp:45 — a caller that holds the object as a kfusion::KinFu keeps compiling and sees the
+    // same volume, parameters and pose chain
+    DynFuParams p = DynFuParams::defaultParams();
+    p.kinfuParams.volume_dims = kfusion::Vec3i::all(64);
+    DynFusion df(p);
+    kfusion::KinFu& base = df;
+    ASSERT_EQ(base.params().volume_dims[0], 64);
+    ASSERT_EQ(base.tsdf().getDims()[2], 64);
+    ASSERT_TRUE(&base.tsdf() == &df.tsdf());
+    ASSERT_EQ(base.frameCounter(), 0);
+    const kfusion::Affine3f pose = base.getCameraPose();
+    ASSERT_EQ(pose.translation()[0], 0.f);
+    ASSERT_EQ(base.getCameraPose(1).translation()[2], base.getCameraPose(-1).translation()[2]);  // past the end: the last pose
+    ASSERT_EQ(df.params().kinfuParams.volume_dims[0], 64);  // DynFusion::params() is the DynFuParams, as :53
+    (void)base.icp(), (void)base.mc();
+}
+
 TEST(DynFusionTest, InitSeedsEvery128thVertex) {
     Cloud canon;
     Normals cn;

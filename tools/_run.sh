@@ -1,7 +1,15 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_solve6.py -x -q 2>&1 | tail -6
-DFA_S6_ASSEMBLE=1 timeout 900 python -m pytest tests/test_gpu_solve6.py -x -q -k "baseline or matches" 2>&1 | tail -3
-python bench.py --mode northstar --config C2 --no-cpu-baseline | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('C2', d['value'], d['ms_per_step'], d['config']['last_frame']); [print(e['kernel'][:40], e['ms_per_frame'], e['avg_launch_ms'], e['frac']) for e in [d['roofline']]+d['roofline_other']]"
-python bench.py --mode northstar --config C3 --no-cpu-baseline --steps 50 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('C3', d['value'], d['ms_per_step'], d['config']['last_frame']); [print(e['kernel'][:40], e['ms_per_frame'], e['avg_launch_ms'], e['frac']) for e in [d['roofline']]+d['roofline_other']]"
+python - <<'PY'
+import json, bench
+r = bench.end_to_end("C2")
+print(json.dumps(r, indent=1))
+PY
+python - <<'PY'
+import numpy as np, subprocess, os
+from dynfu_amd import synth, build as B
+cfg = synth.CONFIGS["C2"]
+np.stack([synth.depth_frame(cfg, f) for f in range(8)]).astype("<u2").tofile("/tmp/f.u16")
+env = dict(os.environ, DFA_HOST_PROFILE="1")
+r = subprocess.run([B.SEQ_BENCH, "/tmp/f.u16", "640", "480", "8", "512", "northstar"], capture_output=True, text=True, env=env)
+print(r.stderr[-2500:])
+PY
