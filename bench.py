@@ -57,6 +57,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-northstar", action="store_true", help="skip the short north-star-mode measurement of the default run")
     ap.add_argument("--no-pipelined-probe", action="store_true", help="skip the short pipelined-throughput measurement")
+    ap.add_argument("--no-live-depth", action="store_true", help="skip the short measurement on the reference's data flow with noisy depth")
+    ap.add_argument("--live", default="targets", choices=["targets", "depth"],
+                    help="targets: index-aligned live vertices canon + sum w t* (SURVEY 8d, the headline workload); depth: the "
+                         "reference's data flow — noisy depth, marching-cubes live cloud, nearest-vertex correspondence "
+                         "(prints the line of that workload alone)")
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the DynFusion::operator() sequence (the reference's own timed region, C++ adaptor classes)")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded CPU sample")
@@ -286,6 +291,85 @@ class Sequence6(Sequence):
         P, Nm = A.compute_points_normals(self.depth[f % self.n_frames], *self.intr)
         self.solver.solve(P, Nm, *self.intr, self.params)
         self.warped, self.warped_n = self.solver.warp()
+
+
+class SequenceLive(Sequence):
+    """Reference mode on the reference's actual DATA FLOW (src/dynfu/dyn_fusion.cpp:119-134, 212-242) instead of the
+    index-aligned zero-residual targets of SURVEY §8(d): the depth frame carries sigma = 1 mm noise, the live cloud is the
+    marching-cubes soup of the frame's fused volume (every s-th vertex, so that the solve keeps this configuration's N
+    rows), each live vertex is paired with its NEAREST canonical vertex (dfa_correspond = findCorrespondingFrame), and
+    that (corresponding canonical, live) pair list is what the solver sees: residuals along the surface, outliers at
+    the silhouette, Tukey weights below one."""
+
+    N_NOISY = 12
+
+    def __init__(self, cfg_name, device):
+        super().__init__(cfg_name, device)
+        A, torch, cfg = self.A, self.torch, self.cfg
+        noisy = [self.synth.depth_frame(cfg, f, noise_mm=1.0) for f in range(self.N_NOISY)]
+        self.depth = torch.from_numpy(np.stack(noisy)).to(device)
+        self.n_frames = self.N_NOISY
+        tri, nv = A.mc_default_tables()
+        self.tri, self.nv = torch.from_numpy(tri).to(device), torch.from_numpy(nv).to(device)
+        # one sizing pass (host synchronisation outside any timed region).  The soup comes out in voxel order (z-major), so
+        # the object's vertices (z < 2 m) precede the background plane's (z = 2.5 m): the live cloud of the solve is a
+        # strided sample of that prefix — the canonical cloud covers the object only (SURVEY 8d), and a plane vertex has
+        # no canonical neighbour within a metre
+        self.fuse(0)
+        _, total = A.marching_cubes(self.vol, self.voxel, self.tri, self.nv, 0)
+        self.mc_total = int(total.item())
+        self.mc_cap = int(self.mc_total * 1.15) + 1024
+        pts, _ = A.marching_cubes(self.vol, self.voxel, self.tri, self.nv, self.mc_cap)
+        on_object = (pts[: self.mc_total, 2] + float(self.vol2cam[11])) < 2.0
+        self.mc_object = int(on_object.sum().item())
+        assert bool(on_object[: self.mc_object].all()), "the object's vertices are not a prefix of the soup"
+        usable = int(0.98 * self.mc_object)  # the count moves a little from frame to frame
+        self.rows = min(self.N, usable)
+        self.stride = max(1, usable // self.rows)
+        self.vol2cam_t = torch.tensor(self.vol2cam[9:12], device=device)
+
+    def frame(self, f, serial=True, timed_events=None):
+        A = self.A
+        self.fuse(f, timed_events)                                                             # dyn_fusion.cpp:58,113-114
+        pts, _ = A.marching_cubes(self.vol, self.voxel, self.tri, self.nv, self.mc_cap)         # :119-121
+        live = (pts[: self.stride * self.rows: self.stride, :3] + self.vol2cam_t).contiguous()  # volume -> camera frame
+        corr_v, _, _ = A.correspond(self.verts, self.normals, live, want_index=False)           # :212-242
+        self.solver.set_problem(self.nodes, self.node_dq, self.node_w, corr_v, live)            # opt_solver.cpp:15-54
+        self.solver.solve(self.params)
+        self.warped, _ = self.solver.warp_to_live(None)
+        self.live_last = live
+
+
+def live_depth_probe(cfg_name, device, steps=30, warmup=5, seq=None):
+    """frames/s of the same configuration on the reference's data flow with noisy depth (SequenceLive), with what the
+    solve went through: PCG iterations, the share of rows the Tukey weight rejects, energies."""
+    import torch
+    seq = seq or SequenceLive(cfg_name, device)
+    for f in range(warmup):
+        seq.frame(f)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for f in range(steps):
+        seq.frame(warmup + f)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    st = seq.solver.stats()
+    tw = seq.solver.tukey_weights()
+    resid = (seq.warped - seq.live_last).norm(dim=1)
+    out = dict(value=round(steps / dt, 2), unit="frames/s", steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 4),
+               workload="%s, reference-parity energy on the reference's data flow: depth with sigma = 1 mm noise -> fused %d^3 "
+                        "volume -> marching cubes (%d vertices, %d of them on the object, every %dth of those kept: %d rows) -> "
+                        "nearest canonical vertex of every live vertex (dfa_correspond, %d canonical vertices) -> graph build "
+                        "(%d nodes, k=%d) -> %d GN x PCG<=256 -> warp; one stream"
+                        % (cfg_name, seq.cfg["dim"], seq.mc_total, seq.mc_object, seq.stride, seq.rows, seq.N, seq.D, seq.k,
+                           seq.cfg["gn_iters"]),
+               pcg_iterations_last_frame=st["pcg_iters"], gn_iterations_last_frame=st["gn_iters"],
+               gn_iterations_noop_last_frame=st["gn_noop"], cost_first=st["initial_cost"], cost_last=st["final_cost"],
+               tukey_rejected_fraction=round(float((tw == 0).float().mean()), 5),
+               tukey_mean_weight=round(float(tw.mean()), 5),
+               residual_after_warp_mm=dict(median=round(float(resid.median()) * 1e3, 3), p95=round(float(resid.quantile(0.95)) * 1e3, 3)),
+               note="secondary figure: SURVEY 8(d)'s index-aligned zero-residual targets are the headline workload")
+    return out
 
 
 def cpu_baseline6(cfg_name, frames, params):
@@ -577,6 +661,19 @@ def main():
 
     if args.mode == "northstar":
         return main_northstar(args, torch, replicas, rank, world, device)
+    if args.live == "depth":
+        seq = SequenceLive(args.config, device)
+        dt_max = replicas.timed_region(lambda: [seq.frame(f) for f in range(args.warmup)], device)  # warm-up, untimed below
+        K = args.steps
+        dt_max = replicas.timed_region(lambda: [seq.frame(args.warmup + f) for f in range(K)], device)
+        if rank == 0:
+            rec = live_depth_probe(args.config, device, steps=min(K, 30), warmup=0, seq=seq)
+            rec.update(metric="frames/sec (warp-solve + TSDF fuse), 512^3 vol / 2k nodes / VGA depth", value=round(world * K / dt_max, 2),
+                       n_gpus=world, steps=K, warmup=args.warmup, ms_per_step=round(dt_max / K * 1e3, 4), higher_is_better=True,
+                       scaling="weak", vs_baseline=None, dtype="f32", data="synthetic", config=dict(workload=rec.pop("workload")))
+            print(json.dumps(rec), flush=True)
+        replicas.shutdown()
+        return
     seq = Sequence(args.config, device)
     seq.fuse_first = args.fuse_first
     shadow = seq.D <= 2048 and not (args.fuse_first or args.fuse_after_build or args.serial or args.pipeline)
@@ -714,6 +811,12 @@ def main():
                 out["northstar_mode"] = northstar_probe(args.config, device)
             except Exception as e:  # noqa: BLE001
                 out["northstar_mode"] = dict(error="%s: %s" % (type(e).__name__, e))
+        if not args.no_live_depth:
+            try:
+                out["live_depth_mode"] = live_depth_probe(args.config, device)
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001
+                out["live_depth_mode"] = dict(error="%s: %s" % (type(e).__name__, e))
         if not args.no_end_to_end:
             try:
                 out["end_to_end"] = end_to_end(args.config)
