@@ -973,10 +973,8 @@ int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
     A(rnode_list, D * k);
     A(dq, D * 8);
     A(ghat, D * 3);
-    A(epos, N * k);
-    A(el, N * k * 8);
-    A(ef, N * k * k);
-    A(em, N * k * 2);
+    A(rec, N * 16);
+    A(rmeta, N * 2);
     A(mnode, D * 48);
     A(rho, N);
     A(rres, D * k * 3);

@@ -231,32 +231,22 @@ __global__ __launch_bounds__(256) void s6_linearise_kernel(Solve6View s, Solve6S
             const Quat lW = Quat{-(U.w + S.w) - np * B.a.w, (U.x + S.x) - np * B.a.x, (U.y + S.y) - np * B.a.y,
                                  (U.z + S.z) - np * B.a.z};
             const float im = 1.f / B.m;
-            // row of the Jacobian for neighbour j: f_j * M_j l with l = (lW, lD); see s6_nodes_kernel.  The row is
-            // written once per neighbour, at the row's position in that node's list (entry-major), so that the
-            // assembly streams each node's rows from contiguous memory instead of chasing vertex indices.
+            // row of the Jacobian for neighbour j: f_j * M_j l with l = (lW, lD); see s6_node_now.  ONE record per vertex —
+            // l, the k scalars f, the robust weight — which the assembly gathers through each node's row list (round 2
+            // wrote the record once per neighbour, at the row's place in that node's list: k times the bytes, and an
+            // index scatter to build per frame)
             float f[K];
 #pragma unroll
             for (int j = 0; j < K; ++j) f[j] = j < k ? wn[j] * B.s[j] * im : 0.f;
-            const float4 l0 = make_float4(lW.w, lW.x, lW.y, lW.z), l1 = make_float4(lD.w, lD.x, lD.y, lD.z);
+            float4* rec = reinterpret_cast<float4*>(s.rec + 16 * (size_t)v);  // one 64-byte line per vertex
+            rec[0] = make_float4(lW.w, lW.x, lW.y, lW.z), rec[1] = make_float4(lD.w, lD.x, lD.y, lD.z);
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-                if (j >= k || idx[j] < 0) continue;
-                const size_t e = s.epos[(size_t)v * k + j];
-                float4* el = reinterpret_cast<float4*>(s.el + 8 * e);
-                el[0] = l0, el[1] = l1;
-#pragma unroll
-                for (int q = 0; q < K; ++q)
-                    if (q < k) s.ef[e * k + q] = f[q];
-            }
+            for (int q = 0; q < K / 4; ++q) rec[2 + q] = make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
             cost   = (double)w_eff * (double)rr * (double)rr;
             nvalid = w_eff > 0.f;
         }
-        const float w_out = ok ? w_eff : 0.f;
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            if (j >= k || idx[j] < 0) continue;
-            *reinterpret_cast<float2*>(s.em + 2 * (size_t)s.epos[(size_t)v * k + j]) = make_float2(w_out, w_out * rr);
-        }
+        const float w_out = ok ? w_eff : 0.f;  // (no association: the stale l / f of the record are never used)
+        *reinterpret_cast<float2*>(s.rmeta + 2 * (size_t)v) = make_float2(w_out, w_out * rr);
     }
     block_add_cost(cost, nvalid, st);
 }
@@ -475,22 +465,10 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
     __shared__ int cols[64];  // the finished column list of this row (searched 8 times per row of the energy)
     if (tid < 64) cols[tid] = tid < stored ? s.bcols[(size_t)a * s.cap + tid] : -1;
     __syncthreads();
-    for (int e = s.node_ptr[a] + tid; e < s.node_ptr[a + 1]; e += 256) {
-        s.epos[s.node_list[e]] = (uint32_t)e;  // where the linearisation writes row (vertex, slot)
-        const unsigned v = s.node_list[e] / (unsigned)k;
-        for (int j = 0; j < k; ++j) {
-            const int b = s.idx[(size_t)v * k + j];
-            int sl      = 255;
-            if (b == a) sl = 0;
-            else if (b >= 0)
-                for (int q = 1; q < stored; ++q)
-                    if (cols[q] == b) sl = q;
-            s.eslot[(size_t)e * k + j] = (uint8_t)sl;
-        }
-    }
-    // ---- the same relation by slot (s6_assemble2_kernel): a stable split of the node's (row, neighbour) pairs by
-    // slot.  Counts by LDS atomics, then wave w compacts the lists of slots 1 + w, 5 + w, ... in ascending pair
-    // order with ballots: run-to-run identical lists, hence identical sums.
+    // ---- the pattern by slot (s6_assemble2_kernel): for every row that touches a and every neighbour of its vertex, the slot
+    // of that neighbour in a's block row; then a stable split of these (row, neighbour) pairs by slot.  Counts by LDS atomics,
+    // then wave w compacts the lists of slots 1 + w, 5 + w, ... in ascending pair order with ballots: run-to-run identical
+    // lists, hence identical sums.
     // The matrix is symmetric, H_ba = H_ab^T: the assembly computes a block once, in the row of the smaller node index, and
     // writes it to both rows.  Lists are kept for the "upper" slots only (column > a; the columns ascend, so these are
     // the slots from `fu` on), the others stay empty.
@@ -501,17 +479,25 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
         const uint64_t lower = __ballot(tid >= 1 && tid < stored && cols[tid] < a);
         if (tid == 0) fu_sh = 1 + __popcll(lower), s.bfu[a] = 1 + __popcll(lower);
     }
-    __syncthreads();  // also: this workgroup's eslot bytes are visible to all of its threads
-    const int fu = fu_sh;
+    __syncthreads();
+    const int fu   = fu_sh;
     const int pbeg = s.node_ptr[a], plen = s.node_ptr[a + 1] - pbeg, npairs = plen * k;
-    const uint8_t* es = s.eslot + (size_t)pbeg * k;
-    // the node's slot bytes are scanned once per slot below: from LDS when they fit the (now idle) sort buffer
-    uint8_t* es_lds      = reinterpret_cast<uint8_t*>(sortbuf);
-    const bool in_lds    = npairs <= (int)sizeof(sortbuf);
-    for (int p = tid; p < npairs; p += 256) {
-        const int sl = es[p];
-        if (in_lds) es_lds[p] = (uint8_t)sl;
-        if (sl >= fu && sl < stored) atomicAdd(&pcnt[sl], 1);
+    // the node's slot bytes live in the (now idle) sort buffer when they fit, else in global scratch
+    uint8_t* es_lds   = reinterpret_cast<uint8_t*>(sortbuf);
+    const bool in_lds = npairs <= (int)sizeof(sortbuf);
+    uint8_t* es       = in_lds ? es_lds : s.eslot + (size_t)pbeg * k;
+    for (int r = tid; r < plen; r += 256) {
+        const unsigned v = s.node_list[pbeg + r] / (unsigned)k;
+        for (int j = 0; j < k; ++j) {
+            const int b = s.idx[(size_t)v * k + j];
+            int sl      = 255;
+            if (b == a) sl = 0;
+            else if (b >= 0)
+                for (int q = 1; q < stored; ++q)
+                    if (cols[q] == b) sl = q;
+            es[(size_t)r * k + j] = (uint8_t)sl;
+            if (sl >= fu && sl < stored) atomicAdd(&pcnt[sl], 1);
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -531,7 +517,7 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
         for (int i = 0; i < SPW; ++i) out[i] = 1 + wave + 4 * i < stored ? pstart[1 + wave + 4 * i] : 0;
         for (int base = 0; base < npairs; base += 64) {
             const int p  = base + lane;
-            const int sl = p < npairs ? (int)(in_lds ? es_lds[p] : es[p]) : 255;
+            const int sl = p < npairs ? (int)es[p] : 255;
             const int r  = p / k;
             const uint32_t packed = ((uint32_t)r << 4) | (uint32_t)(p - r * k);
 #pragma unroll
@@ -568,199 +554,15 @@ __global__ __launch_bounds__(256) void s6_rslot_kernel(Solve6View s) {
 }
 
 // Values of block row a.  A data row's 6-vector for neighbour j factors as f_j * M_j l (l: 8 numbers per
-// vertex, M_j: 6 x 8 per node, s6_nodes_kernel), so the block H_ab = sum_v rho f_a f_b (M_a l)(M_b l)^T is
+// vertex, M_j: 6 x 8 per node, s6_node_now), so the block H_ab = sum_v rho f_a f_b (M_a l)(M_b l)^T is
 // M_a S_ab M_b^T with the 8 x 8 moment S_ab = sum_v (rho f_a f_b) l l^T: the rows that touch node a are read
-// as 8 + k floats instead of 6 k (84 instead of 232 bytes at k = 8, and each row is read by the k workgroups
-// of its nodes), S is accumulated, and M is applied once per block at the end.
-// The rows are staged through LDS 64 at a time (software-pipelined: the loads of the next chunk fly while
-// this one is accumulated).  A wave takes one staged row at a time; lane (j, c) adds rho f_a f_j l_c l[0..7]
-// to row c of the moment in the slot of neighbour j (slot precomputed by s6_pattern_kernel).  The lanes of
-// one instruction hit distinct addresses (distinct neighbours -> distinct slots) and every wave owns a private
-// copy of the moments, so the updates are plain read-add-write: LDS float atomics run at ~0.5 lane / clock
-// on this part.  History at 4 k nodes, k = 8: one lane per row with LDS atomics 3.7 ms (64-way same-address
-// conflicts); every (slot, c) thread scanning every row 2.2 ms (VALU-bound); this layout with ds_add_f32
-// 4.6 ms; private copies 1.0 ms (HBM/L2-bound on 232-byte rows); factored rows: see DESIGN.md.
-constexpr int S6_STAGE   = 64;
+// as 8 + k floats instead of 6 k, S is accumulated, and M is applied once per block at the end.
+// History at 4 k nodes, k = 8 (one Gauss-Newton iteration): one lane per row with LDS atomics 3.7 ms (64-way
+// same-address conflicts); every (slot, c) thread scanning every row 2.2 ms (VALU-bound); per-wave private LDS copies
+// of the moments, rows streamed 1.0 ms, with factored rows 0.81 ms (LDS-bandwidth-bound: 4 KiB read + written per row
+// and wave; the "first form", in the tree until round 3); registers instead of LDS copies 0.65 ms (second form,
+// below); the third form 0.36 ms.
 constexpr int S6_MAXSLOT = S6_MAXSLOT_PATTERN;  // = plan capacity of a block row
-
-template <int K>
-__global__ __launch_bounds__(256) void s6_assemble_kernel(Solve6View s, Solve6State* st, float wreg2, float damping, float tol2) {
-    __shared__ float4 sl8[S6_STAGE][2];   // l = (lW, lD)
-    __shared__ float sfv[S6_STAGE][K];    // f_j
-    __shared__ uint8_t sslot[S6_STAGE][K];
-    __shared__ float4 smeta[S6_STAGE];    // weight, weight * residual, slot of node a in the row
-    __shared__ float4 acc[4][S6_MAXSLOT][16];  // per wave: 8 x 8 moments per slot
-    __shared__ float g8[4][8];
-    __shared__ float diag[36];
-    const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
-    if (a == 0 && tid == 0) s6_bookkeeping(st, tol2);
-    const int cnt = s.bcnt[a];
-    const int beg = s.node_ptr[a], end = s.node_ptr[a + 1];
-    for (int i = tid; i < 4 * S6_MAXSLOT * 16; i += 256) (&acc[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < 32) (&g8[0][0])[tid] = 0.f;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int jl = lane >> 3, c = lane & 7;
-    const bool lane_on = jl < K;
-    // software pipeline registers
-    constexpr int FPT = (S6_STAGE * K + 255) / 256;
-    float pl[2] = {0.f, 0.f}, pf[FPT];
-    uint8_t ps[FPT];
-    float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto fetch = [&](int base) {
-        const int n = min(S6_STAGE, end - base);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {  // S6_STAGE * 8 = 512 floats of l, contiguous from `base`
-            const int i = tid + 256 * q;
-            pl[q] = (i >> 3) < n ? s.el[8 * (size_t)base + i] : 0.f;
-        }
-#pragma unroll
-        for (int q = 0; q < FPT; ++q) {
-            const int i = tid + 256 * q, r = i / K, j = i - r * K;
-            const bool in = r < n && j < k;
-            pf[q] = in ? s.ef[(size_t)(base + r) * k + j] : 0.f;
-            ps[q] = in ? s.eslot[(size_t)(base + r) * k + j] : (uint8_t)255;
-        }
-        if (tid < n) {
-            const float2 m = *reinterpret_cast<const float2*>(s.em + 2 * (size_t)(base + tid));
-            const unsigned entry = s.node_list[base + tid];
-            pm = make_float4(m.x, m.y, __int_as_float((int)(entry % (unsigned)k)), 0.f);
-        }
-    };
-    if (beg < end) fetch(beg);
-    for (int base = beg; base < end; base += S6_STAGE) {
-        const int n = min(S6_STAGE, end - base);
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 2; ++q) (&sl8[0][0].x)[tid + 256 * q] = pl[q];
-#pragma unroll
-        for (int q = 0; q < FPT; ++q) {
-            const int i = tid + 256 * q;
-            if (i < S6_STAGE * K) (&sfv[0][0])[i] = pf[q], (&sslot[0][0])[i] = ps[q];
-        }
-        if (tid < n) smeta[tid] = pm;
-        __syncthreads();
-        if (base + S6_STAGE < end) fetch(base + S6_STAGE);
-        // two rows per step: the staged inputs of both are read together (one LDS latency instead of two); the
-        // read-add-writes stay in row order — row 1's neighbour j' may be row 0's neighbour j (another lane, same
-        // address), and LDS operations of a wave complete in order
-        for (int r = wave; r < n && lane_on; r += 8) {
-            const int r1    = r + 4 < n ? r + 4 : r;
-            const bool has1 = r + 4 < n;
-            const float4 mt0 = smeta[r], mt1 = smeta[r1];
-            const int sl0 = sslot[r][jl], sl1 = sslot[r1][jl];
-            const bool v0 = mt0.x != 0.f && sl0 < cnt, v1 = has1 && mt1.x != 0.f && sl1 < cnt;
-            const int own0 = __float_as_int(mt0.z), own1 = __float_as_int(mt1.z);
-            const float fa0 = sfv[r][own0], fa1 = sfv[r1][own1];
-            const float lc0 = (&sl8[r][0].x)[c], lc1 = (&sl8[r1][0].x)[c];
-            const float4 a0 = sl8[r][0], a1 = sl8[r][1], b0 = sl8[r1][0], b1 = sl8[r1][1];
-            const float fac0 = mt0.x * fa0 * sfv[r][jl] * lc0, fac1 = mt1.x * fa1 * sfv[r1][jl] * lc1;
-            if (v0) {
-                float4* dst = &acc[wave][sl0][2 * c];
-                float4 d0 = dst[0], d1 = dst[1];
-                d0.x += fac0 * a0.x, d0.y += fac0 * a0.y, d0.z += fac0 * a0.z, d0.w += fac0 * a0.w;
-                d1.x += fac0 * a1.x, d1.y += fac0 * a1.y, d1.z += fac0 * a1.z, d1.w += fac0 * a1.w;
-                dst[0] = d0, dst[1] = d1;
-                if (jl == own0) g8[wave][c] -= mt0.y * fa0 * lc0;
-            }
-            if (v1) {
-                float4* dst = &acc[wave][sl1][2 * c];
-                float4 d0 = dst[0], d1 = dst[1];
-                d0.x += fac1 * b0.x, d0.y += fac1 * b0.y, d0.z += fac1 * b0.z, d0.w += fac1 * b0.w;
-                d1.x += fac1 * b1.x, d1.y += fac1 * b1.y, d1.z += fac1 * b1.z, d1.w += fac1 * b1.w;
-                dst[0] = d0, dst[1] = d1;
-                if (jl == own1) g8[wave][c] -= mt1.y * fa1 * lc1;
-            }
-        }
-    }
-    __syncthreads();
-    // sum the four private copies into copy 0
-    for (int i = tid; i < cnt * 16; i += 256) {
-        float4* p0 = &acc[0][0][0] + i;
-        const float4 b = (&acc[1][0][0])[i], cc = (&acc[2][0][0])[i], dd = (&acc[3][0][0])[i];
-        float4 t = *p0;
-        t.x = (t.x + b.x) + (cc.x + dd.x), t.y = (t.y + b.y) + (cc.y + dd.y);
-        t.z = (t.z + b.z) + (cc.z + dd.z), t.w = (t.w + b.w) + (cc.w + dd.w);
-        *p0 = t;
-    }
-    if (tid < 8) g8[0][tid] = (g8[0][tid] + g8[1][tid]) + (g8[2][tid] + g8[3][tid]);
-    __syncthreads();
-    // H_ab = M_a S_ab M_b^T, regularisation, output: thread (slot, row) finishes row `row` of the block in `slot`
-    for (int t0 = 0; t0 < cnt * 6; t0 += 256) {
-        const int t = t0 + tid;
-        if (t < cnt * 6) {
-            const int slot = t / 6, my_row = t - 6 * slot;
-            const int col  = s.bcols[(size_t)a * s.cap + slot];
-            float ma[8];
-#pragma unroll
-            for (int p = 0; p < 8; ++p) ma[p] = s.mnode[48 * (size_t)a + 8 * my_row + p];
-            float vq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // row my_row of M_a S
-            const float* S0 = &acc[0][slot][0].x;
-#pragma unroll
-            for (int p = 0; p < 8; ++p)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) vq[q] += ma[p] * S0[8 * p + q];
-            float accr[6];
-#pragma unroll
-            for (int d = 0; d < 6; ++d) {
-                const float* mb = s.mnode + 48 * (size_t)col + 8 * d;
-                float h = 0.f;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) h += vq[q] * mb[q];
-                accr[d] = h;
-            }
-            float gacc = 0.f;
-            if (slot == 0) {
-#pragma unroll
-                for (int p = 0; p < 8; ++p) gacc += ma[p] * g8[0][p];
-            }
-            // regularisation edges leaving a (a -> m): rows c of e = T_a g_m - g^_m with vectors (an_c at a, -e_{3+c} at m)
-            for (int q = 0; q < k; ++q) {
-                const int e = a * k + q, m = s.reg_idx[e];
-                if (m < 0 || (slot != 0 && col != m)) continue;
-                const float wt = wreg2 * s.rhub[e];
-                for (int cc = 0; cc < 3; ++cc) {
-                    const float* an = s.rvec + 18 * (size_t)e + 6 * cc;
-                    if (slot == 0) {
-                        gacc -= wt * an[my_row] * s.rres[3 * (size_t)e + cc];
-#pragma unroll
-                        for (int d = 0; d < 6; ++d) accr[d] += wt * an[my_row] * an[d];
-                    } else {
-                        accr[3 + cc] -= wt * an[my_row];
-                    }
-                }
-            }
-            // regularisation edges arriving at a (n -> a)
-            if (my_row >= 3) {
-                const int cc = my_row - 3;
-                for (int e = s.rnode_ptr[a]; e < s.rnode_ptr[a + 1]; ++e) {
-                    const unsigned entry = s.rnode_list[e];
-                    const int n          = (int)(entry / (unsigned)k);
-                    if (slot != 0 && col != n) continue;
-                    const float wt = wreg2 * s.rhub[entry];
-                    if (slot == 0) {
-                        gacc += wt * s.rres[3 * (size_t)entry + cc];
-                        accr[my_row] += wt;
-                    } else {
-                        const float* an = s.rvec + 18 * (size_t)entry + 6 * cc;
-#pragma unroll
-                        for (int d = 0; d < 6; ++d) accr[d] -= wt * an[d];
-                    }
-                }
-            }
-            if (slot == 0) {
-                accr[my_row] += damping;
-                s.g[6 * (size_t)a + my_row] = gacc;
-#pragma unroll
-                for (int d = 0; d < 6; ++d) diag[my_row * 6 + d] = accr[d];
-            }
-            float* out = s.bvals + ((size_t)a * s.cap + slot) * 36 + 6 * my_row;
-#pragma unroll
-            for (int d = 0; d < 6; ++d) out[d] = accr[d];
-        }
-    }
-    __syncthreads();
-    if (tid == 0) inv6(diag, s.minv + 36 * (size_t)a);
-}
 
 // Second form of the assembly: the moments are accumulated in REGISTERS, slot by slot.
 //
@@ -903,61 +705,51 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
     float ownG[2] = {0.f, 0.f};  // slot 0 (every row's own neighbour) and -J^T r, this lane's share
 #pragma unroll
     for (int e = 0; e < 8; ++e) own[e] = v2f{0.f, 0.f};
+    constexpr int RS4 = 2 + K / 4 + 1, NCH = (S6_RC * RS4 + 255) / 256;  // 16-byte chunks of a record; chunks per thread and pass
+    uint32_t ent[NCH];  // (vertex k + slot) of the rows whose chunks this thread loads
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        const int r = (tid + 256 * q) / RS4;
+        ent[q]      = r < min(S6_RC, len) ? s.node_list[beg + r] : 0u;
+    }
     for (int r0 = 0; r0 < len; r0 += S6_RC) {
         const int nr = min(S6_RC, len - r0);
         __syncthreads();  // the pass before is done with the staged rows
         const size_t e0 = (size_t)(beg + r0);
-        {   // every load of the pass is issued before the first LDS store (a thread's ~13 loads fly together)
-            constexpr int NL = (S6_RC * 2 + 255) / 256, NF = (S6_RC * K / 4 + 255) / 256, NM = (S6_RC + 255) / 256;
-            float4 vl[NL], vf[NF];
-            float2 vm[NM];
-            float vfa[NM];
-            const float4* gl = reinterpret_cast<const float4*>(s.el + 8 * e0);  // 32 bytes per row
-            const bool wide  = k == K;  // f rows are K floats: 16-byte loads (el / ef rows start 16-byte aligned)
-            const float4* gf = reinterpret_cast<const float4*>(s.ef + e0 * k);
+        {   // The rows of the pass: one record per vertex (s6_linearise), gathered through the node's row list; RS4 chunks per
+            // row — l (2 x 16 bytes), f (K / 4 x 16 bytes) from the vertex's 64-byte line, (weight, weight x residual) from
+            // the small per-vertex array — one chunk per thread and step, the chunks of a row on neighbouring lanes.  The list entries of this pass were loaded
+            // during the pass before; all of a thread's row loads are issued before the first LDS store.
+            float4 val[NCH];
 #pragma unroll
-            for (int q = 0; q < NL; ++q) {
-                const int i = tid + 256 * q;
-                vl[q]       = i < nr * 2 ? gl[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int q = 0; q < NF; ++q) {
-                const int i = tid + 256 * q;
-                vf[q]       = wide && i < nr * (K / 4) ? gf[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int q = 0; q < NM; ++q) {
-                const int i = tid + 256 * q;
-                vm[q] = make_float2(0.f, 0.f), vfa[q] = 0.f;
-                if (i < nr) {
-                    vm[q]         = *reinterpret_cast<const float2*>(s.em + 2 * (e0 + i));
-                    const int own_j = (int)(s.node_list[e0 + i] % (unsigned)k);
-                    vfa[q]        = s.ef[(e0 + i) * k + own_j];
+            for (int q = 0; q < NCH; ++q) {
+                const int i = tid + 256 * q, r = i / RS4, c = i - RS4 * r;
+                val[q]      = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < nr) {
+                    const size_t v = ent[q] / (unsigned)k;
+                    if (c < RS4 - 1) val[q] = reinterpret_cast<const float4*>(s.rec + 16 * v)[c];
+                    else {
+                        const float2 m = *reinterpret_cast<const float2*>(s.rmeta + 2 * v);
+                        val[q]         = make_float4(m.x, m.y, 0.f, 0.f);
+                    }
                 }
             }
 #pragma unroll
-            for (int q = 0; q < NL; ++q) {
-                const int i = tid + 256 * q;
-                if (i < nr * 2) reinterpret_cast<float4*>(&sl8[0][0])[i] = vl[q];
-            }
-            if (wide) {
-#pragma unroll
-                for (int q = 0; q < NF; ++q) {
-                    const int i = tid + 256 * q;
-                    if (i < nr * (K / 4)) reinterpret_cast<float4*>(&scf[0][0])[i] = vf[q];
-                }
-            } else {
-                for (int i = tid; i < nr * K; i += 256) {
-                    const int r = i / K, j = i - r * K;
-                    scf[r][j]   = j < k ? s.ef[(e0 + r) * k + j] : 0.f;
+            for (int q = 0; q < NCH; ++q) {
+                const int i = tid + 256 * q, r = i / RS4, c = i - RS4 * r;
+                if (r < nr) {
+                    if (c < 2) reinterpret_cast<float4*>(&sl8[r][0])[c] = val[q];
+                    else if (c < 2 + K / 4) reinterpret_cast<float4*>(&scf[r][0])[c - 2] = val[q];
+                    else sra[r] = make_float4(val[q].x, val[q].y, __int_as_float((int)(ent[q] % (unsigned)k)), 0.f);
                 }
             }
+            // the next pass's list entries (consumed after the barriers that end this pass)
+            if (r0 + S6_RC < len) {
+                const int nn = min(S6_RC, len - r0 - S6_RC);
 #pragma unroll
-            for (int q = 0; q < NM; ++q) {
-                const int i = tid + 256 * q;
-                if (i < nr) {
-                    const float rf = vm[q].x * vfa[q];
-                    sra[i] = vm[q].x != 0.f ? make_float4(rf, vm[q].y * vfa[q], rf * vfa[q], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int q = 0; q < NCH; ++q) {
+                    const int r = (tid + 256 * q) / RS4;
+                    ent[q]      = r < nn ? s.node_list[e0 + S6_RC + r] : 0u;
                 }
             }
         }
@@ -965,6 +757,14 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
         Rec4 first[ROUNDS];
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) first[r] = load_chunk(cq[r], qend[r], 16 * r < nup);
+        __syncthreads();
+        // per row: (weight, weight x residual, own slot) -> (rho f_own, rho res f_own, rho f_own^2)
+        for (int i = tid; i < nr; i += 256) {
+            const float4 m  = sra[i];
+            const float fo  = scf[i][__float_as_int(m.z)];
+            const float rf  = m.x * fo;
+            sra[i] = m.x != 0.f ? make_float4(rf, m.y * fo, rf * fo, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         __syncthreads();
         // f_j -> rho f_own f_j, once per (row, neighbour); rows without association hold stale numbers (0 * NaN is NaN):
         // zero what the products read
@@ -1207,20 +1007,6 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
 // The matrix product of launch i needs u_{i+1} of OTHER nodes, which their waves are only computing in
 // the same launch: the gather rebuilds it from u_i, m_i, t_{i-1} and the two scalars (18 floats per
 // neighbour block next to the block's own 36).  Same iterates as textbook PCG in exact arithmetic.
-__global__ __launch_bounds__(256) void s6_pcg_init_kernel(Solve6View s, Solve6State* st) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (node, component)
-    if (i < 6 * s.D) {
-        const int n = i / 6, c = i - 6 * n;
-        const float* Mi = s.minv + 36 * (size_t)n + 6 * c;
-        const float* gn = s.g + 6 * (size_t)n;
-        float u = 0.f;
-#pragma unroll
-        for (int d = 0; d < 6; ++d) u += Mi[d] * gn[d];
-        s.x[i] = 0.f, s.r[i] = gn[c], s.u[0][i] = u;
-        s.p[i] = 0.f, s.s[i] = 0.f, s.t[0][i] = 0.f, s.t[1][i] = 0.f;
-    }
-}
-
 // launch `it` = -1: w_0 = A u_0, m_0, gamma_0, delta_0.   launch it >= 0: iteration `it` as above.
 __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(Solve6View s, Solve6State* st, int it) {
     __shared__ float stage[S6_NODES_PER_BLOCK][3][64];
@@ -1533,11 +1319,7 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
         eta = std::max(eta, e);
     }
     const float tol2 = eta * eta;
-    static const bool lds_form = getenv("DFA_S6_ASSEMBLE") && atoi(getenv("DFA_S6_ASSEMBLE")) == 1;  // A/B: first form
-    if (lds_form) {
-        K6DISPATCH(s6_assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, wreg2, p.damping, tol2));
-        s6_pcg_init_kernel<<<s6_update_blocks(s.D), 256, 0, st>>>(s, state);  // (the product's assembly starts the PCG itself)
-    } else {
+    {
         // rows staged per pass (DFA_S6_RC for A/B).  Third form, C2 (k = 4) / C3 (k = 8): 192 0.101 / 0.386 ms, 256 0.100 /
         // 0.358, 320 0.096 / 0.384, 448 0.097 / 0.360 — flat: the passes are no longer what costs
         static const int rc_env = getenv("DFA_S6_RC") ? atoi(getenv("DFA_S6_RC")) : 0;

@@ -68,12 +68,11 @@ struct Solve6View {
     float* dq;    // D x 8  current node transforms
     float* ghat;  // D x 3  current node positions T_i(g_i)
     // linearisation
-    // rows of the data term, ENTRY-major (position of (vertex, slot) in its node's list, `epos`): the row's
-    // 6-vector for neighbour j is f_j M_j l with the per-vertex functional l = (lW, lD)
-    uint32_t* epos;  // N x k   (vertex, slot) -> entry
-    float* el;       // (N k) x 8
-    float* ef;       // (N k) x k   f_j = w~_j s_j / |a|^2 of all k neighbours of the entry's vertex
-    float* em;       // (N k) x 2   robust weight (0 = no association), weight * residual
+    // rows of the data term, one record per VERTEX: the row's 6-vector for neighbour j is f_j M_j l with the per-vertex
+    // functional l = (lW, lD).  rec[v] = { l[8], f[8] } (f_j = w~_j s_j / |a|^2): one 64-byte line; rmeta[v] = { robust
+    // weight (0 = no association), weight * residual }
+    float* rec;    // N x 16
+    float* rmeta;  // N x 2
     float* mnode;  // D x 6 x 8  M_n: twist components of node n as (W, Wd) increments
     float* rho;   // N           Tukey weight (frozen between re-weightings)
     float* rres;  // D x k x 3   regularisation residuals
@@ -84,7 +83,7 @@ struct Solve6View {
     int32_t* bcnt;   // D
     int32_t* bfu;    // D  first "upper" slot of the row (column > row; slots 1 .. bfu-1 are mirrored from their columns' rows)
     uint8_t* rslot;  // D x cap  slot of the row's node in the row of each of its columns
-    uint8_t* eslot;  // (N k) x k: slot, in the block row of the entry's node, of each neighbour of the entry's vertex
+    uint8_t* eslot;  // (N k) x k scratch of s6_pattern (nodes whose slot bytes do not fit its LDS buffer)
     // the same relation by slot: for node a and slot q >= 1, pair_list[pair_ptr[a (cap+1) + q] .. pair_ptr[.. q+1]) are
     // the (row of a's list << 4 | neighbour) pairs that land in slot q, ascending (slot 0 = every row's own neighbour)
     uint32_t* pair_list;  // (N k) x k
