@@ -30,17 +30,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-# HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 for wide reads + WRITE_SIZE, corrected as
-# MI355X_MICROARCH.md prescribes) — profiles/r02_pmc_tsdf.md.  Collected offline: PMC needs its own runs.
+LDS_GATHER_PEAK_GBS = 921.6  # 3 CUs x 128 B/clk x 2.4 GHz: the LDS read rate of the three CUs the reference-mode PCG runs on
 TIMING_SAMPLE = 8  # every 8th timed frame carries the hipEvent brackets of the per-kernel report
-PMC_TRAFFIC_SOURCE = "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; file and commit beside each figure in bench.py)"
-PMC_TRAFFIC_BYTES = {# profiles/r02d_pmc_bench_c2.md: integrate_runs_kernel<true,32,8>, WRITE 524 288 KiB + 2 x FETCH 2 368 KiB (C4, profiles/r02_pmc_tsdf.md: 4 194 304 + 2 x 23 775)
-                     ("C2", "fused_integrate"): 0.5417e9, ("C3", "fused_integrate"): 0.5417e9, ("C4", "fused_integrate"): 4.344e9,
-                     # profiles/r01_pmc_northstar.md (FETCH x2 + WRITE per dispatch)
-                     ("C3", "s6_assemble"): 0.510e9, ("C3", "s6_pcg_step"): 0.0242e9,
-                     # profiles/r02d_pmc_bench_c2.md: (340.7 + 275.9) KiB per pcg_paired_kernel<1024,1,32,1> launch, mean over
-                     # the five launches of a frame (those that return at entry included)
-                     ("C2", "pcg"): 616.6 * 1024}
+# HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x 2 for wide read streams + WRITE_SIZE, corrected as
+# MI355X_MICROARCH.md prescribes).  Collected offline — PMC needs its own runs — so every figure names the tracked file it
+# was read from and the commit that file was measured at: a figure older than the kernel it describes is visible as such.
+PMC_TRAFFIC = {
+    # (config, kernel key): (bytes per launch, profile file, commit of the measured tree)
+    ("C2", "fused_integrate"): (0.5417e9, "profiles/r03a_pmc_c2.md", "683a341"),   # WRITE 524 288 KiB + 2 x FETCH 2 340 KiB
+    ("C3", "fused_integrate"): (0.5414e9, "profiles/r03a_pmc_ns_c3.md", "683a341"),
+    ("C4", "fused_integrate"): (4.344e9, "profiles/r02_pmc_tsdf.md", "round 2"),   # 4 194 304 + 2 x 23 775 KiB
+    ("C2", "pcg"): (616.6 * 1024, "profiles/r02d_pmc_bench_c2.md", "round 2"),      # pcg_paired_kernel<1024,1,32,1>: FETCH 340.7 + WRITE 275.9 KiB
+    # north-star kernels: FETCH + WRITE, uncorrected, for the gather-heavy PCG step; 2 x FETCH + WRITE for the assembly and
+    # the linearisation
+    ("C2", "s6_assemble"): (84.08e6, "profiles/r03a_pmc_ns_c2.md", "683a341"),
+    ("C2", "s6_linearise"): (115.2e6, "profiles/r03a_pmc_ns_c2.md", "683a341"),
+    ("C2", "s6_pcg_step"): (2.534e6, "profiles/r03a_pmc_ns_c2.md", "683a341"),
+    ("C3", "s6_assemble"): (427.6e6, "profiles/r03a_pmc_ns_c3.md", "683a341"),
+    ("C3", "s6_linearise"): (504.8e6, "profiles/r03a_pmc_ns_c3.md", "683a341"),
+    ("C3", "s6_pcg_step"): (7.334e6, "profiles/r03a_pmc_ns_c3.md", "683a341"),
+}
+PMC_TRAFFIC_BYTES = {k: v[0] for k, v in PMC_TRAFFIC.items()}
+
+
+def traffic_source(config, key):
+    t = PMC_TRAFFIC.get((config, key))
+    return "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes) measured at commit %s" % (t[1], t[2]) if t else None
 
 
 def parse():
@@ -448,7 +463,7 @@ def northstar_rooflines(seq, config, st, tm, fuse_ms):
         gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else float("nan")
         src = PMC_TRAFFIC_BYTES.get((config, key))
         return dict(kernel=kernel, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(gbs / HBM_PEAK_GBS, 4), traffic=src, traffic_source=PMC_TRAFFIC_SOURCE if src else None,
+                    frac=round(gbs / HBM_PEAK_GBS, 4), traffic=src, traffic_source=traffic_source(config, key),
                     avg_launch_ms=round(ms, 5), launches_per_frame=per_frame, algorithmic_bytes_per_launch=nbytes,
                     ms_per_frame=round(total_ms, 4), **extra)
 
@@ -749,29 +764,33 @@ def main():
                              "against min/max tiles of the depth image)" % dim, bound="hbm",
                       achieved=round(fuse_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(fuse_gbs / HBM_PEAK_GBS, 4),
                       traffic=PMC_TRAFFIC_BYTES.get((args.config, "fused_integrate")),
-                      traffic_source="profiles/r02d_pmc_bench_c2.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                      traffic_source=traffic_source(args.config, "fused_integrate"),
                       avg_launch_ms=round(fuse_ms, 4), launches_per_frame=1, algorithmic_bytes_per_launch=fuse_bytes)
     split = seq.D <= 2048  # register-resident kernel, one workgroup per coordinate
-    pcg_entry = dict(kernel=("pcg_paired_kernel<..,NC=1> (Jacobi PCG, matrix in registers, 3 workgroups = 3 coordinates)" if split
-                             else "pcg_mb_* (many-workgroup Jacobi PCG)"), bound="hbm",
-                     achieved=round(pcg_gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(pcg_gbs / HBM_PEAK_GBS, 6),
-                     traffic=PMC_TRAFFIC_BYTES.get((args.config, "pcg")),
-                     traffic_source="profiles/r02d_pmc_bench_c2.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes): "
-                                    "per launch; every workgroup reads the matrix once and keeps it in registers",
-                     algorithmic_bytes_per_launch=round(pcg_bytes / max(1e-9, launches_pf), 1),
-                     avg_launch_ms=round(pcg_total_ms / max(1e-9, launches_pf), 4),
-                     launches_per_frame=round(launches_pf, 2), pcg_iterations_per_frame=round(its, 1), matrix_nnz=nnz,
-                     algorithmic_bytes_per_frame=round(pcg_bytes, 1), frames_measured=frames_timed)
+    pcg_common = dict(traffic=PMC_TRAFFIC_BYTES.get((args.config, "pcg")), traffic_source=traffic_source(args.config, "pcg"),
+                      algorithmic_bytes_per_launch=round(pcg_bytes / max(1e-9, launches_pf), 1),
+                      avg_launch_ms=round(pcg_total_ms / max(1e-9, launches_pf), 4),
+                      launches_per_frame=round(launches_pf, 2), pcg_iterations_per_frame=round(its, 1), matrix_nnz=nnz,
+                      algorithmic_bytes_per_frame=round(pcg_bytes, 1), frames_measured=frames_timed)
     if split:
-        # what bounds it: the gather of p from LDS, 4 B per non-zero and coordinate, on three CUs
+        # What bounds it is the gather of p from LDS — 4 B per non-zero and coordinate, on the three CUs the three
+        # workgroups occupy — not HBM: the matrix is read once per launch and stays in registers (traffic above: 1/16 of
+        # the algorithmic bytes).  The HBM figures stay in the entry because the contract's metric is HBM-based.
         lds_bytes = 12.0 * nnz * its
-        pcg_entry["lds_gather"] = dict(bytes_per_frame=lds_bytes, peak_gbs=921.6,
-                                       achieved_gbs=round(lds_bytes / (pcg_total_ms * 1e-3) / 1e9, 1) if pcg_total_ms > 0 else None,
-                                       note="3 CUs x 128 B/clk (ds_read_b32, conflict-free) x 2.4 GHz; random 4-byte gathers "
-                                            "measure ~6.5 clk per wave instruction against 2 (bank conflicts)")
+        lds_gbs = lds_bytes / (pcg_total_ms * 1e-3) / 1e9 if pcg_total_ms > 0 else float("nan")
+        pcg_entry = dict(kernel="pcg_paired_kernel<..,NC=1> (Jacobi PCG, matrix in registers, 3 workgroups = 3 coordinates)",
+                         bound="lds-gather", achieved=round(lds_gbs, 1), peak=LDS_GATHER_PEAK_GBS, unit="GB/s",
+                         frac=round(lds_gbs / LDS_GATHER_PEAK_GBS, 4),
+                         peak_is="3 CUs x 128 B/clk (ds_read_b32, conflict-free) x 2.4 GHz; random 4-byte gathers of 32 lanes into 32 "
+                                 "banks measure ~6.5-7.4 clk per wave instruction against 2 (tools/microbench_lds_gather.hip)",
+                         lds_gather_bytes_per_frame=lds_bytes, hbm_achieved_gbs=round(pcg_gbs, 2),
+                         hbm_frac=round(pcg_gbs / HBM_PEAK_GBS, 6), **pcg_common)
         pcg_entry["note"] = ("register/LDS-resident and synchronisation-bound by design: one workgroup per coordinate, %d "
-                             "barrier-separated iterations per frame; the ceiling is the LDS gather rate of a CU, the HBM fraction "
-                             "is shown because the contract asks for it" % round(its))
+                             "barrier-separated iterations per frame, 253 of 256 CUs idle while it runs (the fuse fills them); "
+                             "hbm_frac is the contract's HBM view of the same kernel" % round(its))
+    else:
+        pcg_entry = dict(kernel="pcg_mb_* (many-workgroup Jacobi PCG)", bound="hbm", achieved=round(pcg_gbs, 2), peak=HBM_PEAK_GBS,
+                         unit="GB/s", frac=round(pcg_gbs / HBM_PEAK_GBS, 6), **pcg_common)
     dominant, other = (pcg_entry, fuse_entry) if pcg_total_ms > fuse_ms else (fuse_entry, pcg_entry)
 
     out = dict(metric="frames/sec (warp-solve + TSDF fuse), 512^3 vol / 2k nodes / VGA depth",

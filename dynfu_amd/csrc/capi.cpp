@@ -781,6 +781,7 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
     int gn_launched = 0;  // Gauss-Newton iterations whose assembly has been enqueued
     bool huber_done = false;
     const bool big_budget = (long)p->num_iter * p->nonlinear_iter > 8;
+    const bool no_regradient = getenv("DFA_NO_REGRADIENT") != nullptr;  // (A/B; read per solve: the tests switch it)
     for (int outer = 0; outer < p->num_iter; ++outer) {
         // preNonlinearSolve (opt_solver.cpp:135-140): the Huber weights are only observable after
         // the solve, so they are evaluated for the last outer iteration alone
@@ -811,9 +812,11 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
             // round-off in its null space, which CG then amplifies (a re-linearised gradient is J^T of something and has
             // none; measured: two of the eight OptTest scenes leave their 1e-3 tolerance): the long way as well.
             // DFA_NO_REGRADIENT=1: the long way always (A/B).
-            const bool no_regradient = getenv("DFA_NO_REGRADIENT") != nullptr;  // (read per call: the tests switch it)
             if (gn > 0 && p->gn_tol == 0.f && p->lambda > 0.f && !no_regradient) {
+                int evg = s->timing ? timing_begin(s, st) : -1;  // booked with the assemblies: it stands in for one
                 HIP_TRY(dfa::solve_regradient(v, s->state, st));
+                timing_end(s, evg, st);
+                if (evg >= 0) s->ev_asm.push_back(evg);
                 if (s->overlap_fn) s->overlap_fn(s->overlap_user, stream, gn_launched);
                 ++gn_launched;
                 int evr = s->timing ? timing_begin(s, st) : -1;

@@ -1,6 +1,9 @@
 // kernels.hpp — host-callable launchers of the gfx950 kernels (internal; the public surface
 // is include/dynfu_amd.h).
 #pragma once
+#include <map>
+#include <mutex>
+#include <utility>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -112,5 +115,22 @@ hipError_t launch_icp_sums(bool depth_variant, const void* curr, int curr_step, 
                            const void* prev, int prev_step, const float* nprev, int nprev_step, int cols, int rows,
                            const float aff[12], float fx, float fy, float cx, float cy, float dist_thres, float angle_thres,
                            float* partial, float* sums27, unsigned int* matched, hipStream_t s);
+
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is an attribute of a kernel ON A DEVICE: the opt-in to more than 48 KiB of
+// dynamic LDS is made once per (device, kernel), under a lock (the C ABI serves several devices and host threads)
+inline hipError_t allow_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, int> done;
+    int dev      = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    int& have = done[std::make_pair(dev, kernel)];
+    if (have >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
 
 }  // namespace dfa

@@ -35,6 +35,7 @@
 #include <float.h>
 
 #include "dq_device.hpp"
+#include "kernels.hpp"
 #include "solve.hpp"
 
 namespace dfa {
@@ -1717,19 +1718,15 @@ static hipError_t launch_mb_pcg(const SolveView& s, SolveState* state, int max_i
 int solve_pcg_max_nodes() { return 32768; }  // bounded by the transposition's LDS histogram (4 B x D)
 
 template <class Kernel>
-static hipError_t allow_big_lds(Kernel* k, bool& done) {
-    if (done) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-    done         = e == hipSuccess;
-    return e;
+static hipError_t allow_big_lds(Kernel* k) {
+    return allow_dynamic_lds((const void*)k, 160 * 1024 - 1024);  // once per (device, kernel)
 }
 
 // streaming kernel (matrix re-read from L2 every iteration): 1024 threads, RPT rows per thread
 template <int RPT>
 static hipError_t launch_streaming_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol,
                                        hipStream_t st) {
-    static bool attr = false;
-    hipError_t e     = allow_big_lds(pcg_kernel<1024, RPT>, attr);
+    hipError_t e = allow_big_lds(pcg_kernel<1024, RPT>);
     if (e != hipSuccess) return e;
     const size_t shmem = sizeof(float4) * (size_t)s.Dpad + 32 * sizeof(float) + 260 * sizeof(int);
     pcg_kernel<1024, RPT><<<1, 1024, shmem, st>>>(s, state, max_iter, pcg_tol);
@@ -1741,8 +1738,7 @@ static hipError_t launch_streaming_pcg(const SolveView& s, SolveState* state, in
 template <int NT, int P, int E, int NC>
 static hipError_t launch_paired_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol,
                                     hipStream_t st) {
-    static bool attr = false;
-    hipError_t e     = allow_big_lds(pcg_paired_kernel<NT, P, E, NC>, attr);
+    hipError_t e = allow_big_lds(pcg_paired_kernel<NT, P, E, NC>);
     if (e != hipSuccess) return e;
     const size_t sh = sizeof(float4) * (size_t)s.Dpad + 32 * sizeof(float) + sizeof(int) * (260 + (size_t)s.Dpad);
     pcg_paired_kernel<NT, P, E, NC><<<NC == 1 ? 3 : 1, NT, sh, st>>>(s, state, max_iter, pcg_tol);

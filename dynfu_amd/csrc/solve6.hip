@@ -1327,11 +1327,9 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
 #define S6A2(KK, RC)                                                                                              \
     do {                                                                                                          \
         const size_t sh = std::max((size_t)(RC) * (32 + 4 * (KK) + 16), (size_t)S6_MAXSLOT * (64 + 48) * 4);        \
-        static bool attr = false;                                                                                 \
-        if (!attr && sh > 48 * 1024) {                                                                            \
-            (void)hipFuncSetAttribute((const void*)s6_assemble2_kernel<KK, RC>,                                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);                       \
-            attr = true;                                                                                          \
+        if (sh > 48 * 1024) {                                                                                     \
+            const hipError_t ae = allow_dynamic_lds((const void*)s6_assemble2_kernel<KK, RC>, (int)sh);             \
+            if (ae != hipSuccess) return ae;                                                                      \
         }                                                                                                         \
         s6_assemble2_kernel<KK, RC><<<s.D, 256, sh, st>>>(s, state, wreg2, p.damping, tol2);                            \
     } while (0)

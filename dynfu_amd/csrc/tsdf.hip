@@ -51,6 +51,23 @@ __global__ __launch_bounds__(256) void clear_kernel(uint4* __restrict__ vol4, si
     if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0u;
 }
 
+// The store pattern of the fused sweep's zero fill (a lane per voxel column, a wave stores one 256-byte x-row segment per
+// slice and marches over z): measured faster than the grid-stride 16-byte stores above at 512^3 and 1024^3 (DESIGN.md
+// 4.1), so clear() uses it for volumes with whole 64-voxel rows.
+__global__ __launch_bounds__(256) void clear_columns_kernel(uint32_t* __restrict__ vol, int X, int Y, int Z, int zchunk) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= X || y >= Y) return;
+    const int z0 = blockIdx.z * zchunk, z1 = min(Z, z0 + zchunk);
+    const size_t slice = (size_t)X * Y;
+    uint32_t* p        = vol + (size_t)z0 * slice + (size_t)y * X + x;
+    int z              = z0;
+    for (; z + 8 <= z1; z += 8, p += 8 * slice) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u * slice] = 0u;
+    }
+    for (; z < z1; ++z, p += slice) *p = 0u;
+}
+
 // ------------------------------------------------------------------------------------------
 // integrate — tsdf_volume.cu:43-96
 struct IntegrateArgs {
@@ -65,7 +82,7 @@ struct IntegrateArgs {
     float fx, fy, cx, cy;
     int zchunk;
     int nt;      // DFA_TSDF_NT=1 (A/B): non-temporal stores in the fused sweep
-    int ablate;  // DEV ONLY (DFA_TSDF_ABLATE): 1 every run SKIP, 2 FULL runs filled like FRONT, 3 no classification at all
+    int ablate;  // -DDFA_DEV_ABLATE builds only (DFA_TSDF_ABLATE): 1 every run SKIP, 2 FULL runs filled like FRONT, 3 no classification
 };
 
 // x / z and y / z, correctly rounded.  hipcc expands an fp32 division into
@@ -263,7 +280,8 @@ __global__ __launch_bounds__(256) void dists_tiles_kernel(const uint16_t* __rest
     uint32_t lo = 0xffffu, hi = 0u;
     if (x < cols && y < rows) {
         const uint16_t* drow = (const uint16_t*)((const char*)dists + (size_t)y * dists_step);
-        lo = hi = tile_value_of_pixel(drow[x]);
+        const uint32_t t = tile_bounds_of_pixel(drow[x]);
+        lo = t & 0xffffu, hi = t >> 16;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -299,6 +317,7 @@ __global__ __launch_bounds__(256) void integrate_runs_kernel(const IntegrateArgs
     for (; z + U <= z1; z += U, ptr += slice * U) {
         const f3 far     = vc + stepU;
         int cls          = RUN_SKIP;
+#ifdef DFA_DEV_ABLATE
         if (a.ablate != 3) {
             const RunEnd nxt = run_end(far.x, far.y, far.z, rc, rcp_approx);
             cls              = classify_run(end, nxt, rc, half_bits_to_float_u);
@@ -306,6 +325,13 @@ __global__ __launch_bounds__(256) void integrate_runs_kernel(const IntegrateArgs
             if (a.ablate == 1) cls = RUN_SKIP;
             if (a.ablate == 2 && cls == RUN_FULL) cls = RUN_FRONT;
         }
+#else
+        {
+            const RunEnd nxt = run_end(far.x, far.y, far.z, rc, rcp_approx);
+            cls              = classify_run(end, nxt, rc, half_bits_to_float_u);
+            end              = nxt;
+        }
+#endif
         f3 p[U];  // the run's voxel positions by the reference's running addition (:64)
 #pragma unroll
         for (int u = 0; u < U; ++u) p[u] = vc, vc = vc + zstep;
@@ -531,8 +557,17 @@ hipError_t launch_compute_dists(const uint16_t* depth, int depth_step, uint16_t*
     return launch_status();
 }
 
+static int pick_zchunk(int X, int Y, int Z, int vx, bool fused_clear);
+
 hipError_t launch_tsdf_clear(uint32_t* vol, int X, int Y, int Z, hipStream_t s) {
     const size_t n = (size_t)X * Y * Z;
+    static const bool linear = getenv("DFA_TSDF_CLEAR_LINEAR") != nullptr;  // A/B: the grid-stride 16-byte stores
+    if (!linear && X % 64 == 0 && Z >= 32 && (((uintptr_t)vol & 255) == 0)) {
+        const int zchunk = pick_zchunk(X, Y, Z, 1, true);
+        dim3 block(64, 4), grid(X / 64, (Y + 3) / 4, (Z + zchunk - 1) / zchunk);
+        clear_columns_kernel<<<grid, block, 0, s>>>(vol, X, Y, Z, zchunk);
+        return launch_status();
+    }
     // head/tail so the 16-byte stores are aligned whatever pointer the caller passes
     size_t head = ((16 - ((uintptr_t)vol & 15)) & 15) / 4;
     if (head > n) head = n;
@@ -612,7 +647,11 @@ hipError_t launch_tsdf_integrate(bool fused_clear, const uint16_t* dists, int di
     for (int i = 0; i < 9; ++i) a.vol2cam.m[i] = vol2cam[i];
     for (int i = 0; i < 3; ++i) a.vol2cam.t[i] = vol2cam[9 + i];
     a.fx = fx, a.fy = fy, a.cx = cx, a.cy = cy;
+#ifdef DFA_DEV_ABLATE  // development builds only (-DDFA_DEV_ABLATE): values 1 / 2 write WRONG volumes by design
     a.ablate = getenv("DFA_TSDF_ABLATE") ? atoi(getenv("DFA_TSDF_ABLATE")) : 0;
+#else
+    a.ablate = 0;
+#endif
     a.nt     = getenv("DFA_TSDF_NT") ? atoi(getenv("DFA_TSDF_NT")) : 0;
     // Default: the run-classified sweep.  DFA_TSDF_LEGACY=1 runs the per-voxel sweep (every voxel through the
     // projection; the round-1 kernel) for A/B timings; DFA_TSDF_WAVE=16 gives a wave a 16 x 4 patch of columns.

@@ -35,12 +35,20 @@ namespace dfa {
 constexpr int TSDF_TILE_SHIFT = 3;  // 8 x 8 pixel tiles
 enum { RUN_SKIP = 0, RUN_FRONT = 1, RUN_FULL = 2 };
 
-// One tile of the dists image: low 16 bits = smallest, high 16 bits = largest fp16 bit pattern of its VALID pixels,
-// where an invalid pixel (the reference skips it whatever the voxel: +-0, negative, NaN) counts as 0 in both.
-// Non-negative fp16 values order like their bit patterns.
-DFA_HD uint32_t tile_value_of_pixel(uint32_t half_bits) {
-    const bool valid = (half_bits & 0x8000u) == 0u && half_bits != 0u && (half_bits & 0x7fffu) <= 0x7c00u;
-    return valid ? half_bits : 0u;
+// One tile of the dists image: low 16 bits = a lower bound, high 16 bits = an upper bound (fp16 bit patterns; non-negative
+// fp16 values order like their bit patterns) of what its pixels can contribute.  Per pixel (lo, hi):
+//   valid (positive, finite or +inf)          (bits, bits)
+//   the reference skips it whatever the voxel (0, 0)        +-0 (tsdf_volume.cu:74 `Dp == 0`), NaN and -inf (sdf is NaN / -inf:
+//                                                           :79 fails)
+//   negative and finite                       (0, +inf)     NOT skipped by :74 — a voxel nearer to the camera than
+//                                                           trunc - |Dp| passes :79 — so a run that can meet one is never
+//                                                           called SKIP (upper bound +inf) nor FRONT (lower bound 0):
+//                                                           it takes the per-voxel path.  compute_dists never produces
+//                                                           one; a caller's own dists image may.
+DFA_HD uint32_t tile_bounds_of_pixel(uint32_t half_bits) {
+    const uint32_t mag = half_bits & 0x7fffu;
+    if ((half_bits & 0x8000u) == 0u) return mag != 0u && mag <= 0x7c00u ? (half_bits | (half_bits << 16)) : 0u;
+    return mag != 0u && mag < 0x7c00u ? (0x7c00u << 16) : 0u;
 }
 
 struct RunConsts {

@@ -336,7 +336,10 @@ __global__ __launch_bounds__(64) void pgrid_finalize_kernel(const float* __restr
         cs       = fmaxf(cs, emax / (float)(large ? PGRID_MAX_DIM : 128));
         if (!(cs > 0.f)) cs = 1.f;
         desc->cs = cs, desc->inv_cs = 1.f / cs;
-        for (int c = 0; c < 3; ++c) desc->dim[c] = min(max((int)(ext[c] * desc->inv_cs) + 1, 1), PGRID_MAX_DIM);
+        // clamped with the SAME cap the cell size was derived from (and the host's chunk count assumes, point_grid_build):
+        // dim[0] dim[1] dim[2] <= cap^3 whatever the rounding of ext / cs does
+        const int cap = large ? PGRID_MAX_DIM : 128;
+        for (int c = 0; c < 3; ++c) desc->dim[c] = min(max((int)(ext[c] * desc->inv_cs) + 1, 1), cap);
     }
 }
 
@@ -786,12 +789,9 @@ hipError_t knn_grid_build(const KnnGridView& g, const float* node_pos, int D, hi
     static const bool four = getenv("DFA_GRID_FOUR_KERNELS") != nullptr;  // A/B: the four-kernel build
     if (D <= GRID_ONE_MAX && !four) {
         constexpr size_t lds = sizeof(int32_t) * KNN_GRID_MAX_CELLS;
-        static bool big_lds = false;  // 128 KiB of dynamic LDS needs the opt-in, once per process
-        if (!big_lds) {
-            hipError_t e = hipFuncSetAttribute((const void*)grid_build_one_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            big_lds = true;
-        }
+        // 128 KiB of dynamic LDS needs the opt-in, once per device
+        hipError_t e = allow_dynamic_lds((const void*)grid_build_one_kernel, (int)lds);
+        if (e != hipSuccess) return e;
         grid_build_one_kernel<<<1, 1024, lds, s>>>(node_pos, D, g.desc, g.cell_start, g.sorted);
         return hipGetLastError();
     }

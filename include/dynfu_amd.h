@@ -307,7 +307,9 @@ int dfa_solver_set_problem(dfa_solver* s, const float* node_pos, const float* no
  * remaining (or all remaining) iterations once it is set (the iterations not launched are booked as no-ops, like those
  * whose kernels return at entry); larger problems use a many-workgroup
  * PCG whose launches go out in chunks, and the call waits for `stream` about once per Gauss-Newton iteration to read
- * the stop flag. */
+ * the stop flag.  Only the first case (<= 2048 nodes and <= 8 Gauss-Newton iterations) is therefore asynchronous and
+ * capturable into a caller's HIP graph; in the others the call blocks the calling thread (hipStreamSynchronize on
+ * `stream`) between its launches, also between two invocations of the overlap callback. */
 int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* params, dfa_stream_t stream);
 
 /* Results (device pointers, valid until the next set_problem/solve on this plan):

@@ -56,8 +56,8 @@ std::vector<uint32_t> build_tiles(const Scene& s) {
             uint32_t lo = 0xffffu, hi = 0u;
             for (int y = ty * T; y < std::min(s.rows, ty * T + T); ++y)
                 for (int x = tx * T; x < std::min(s.cols, tx * T + T); ++x) {
-                    const uint32_t v = dfa::tile_value_of_pixel(s.dists[(size_t)y * s.cols + x]);
-                    lo = std::min(lo, v), hi = std::max(hi, v);
+                    const uint32_t v = dfa::tile_bounds_of_pixel(s.dists[(size_t)y * s.cols + x]);
+                    lo = std::min(lo, v & 0xffffu), hi = std::max(hi, v >> 16);
                 }
             tiles[(size_t)ty * tc + tx] = lo | (hi << 16);
         }
@@ -257,10 +257,10 @@ TEST(TsdfClassify, CameraInsideTheVolume) {
 TEST(TsdfClassify, HolesAndSpecialHalves) {
     Scene s = make_scene(320, 240, 262.5f, 5);
     std::mt19937 rng(11);
-    std::uniform_int_distribution<int> px(0, s.cols - 1), py(0, s.rows - 1), kind(0, 5);
-    for (int i = 0; i < 400; ++i) {  // patches of invalid / odd values: 0, -0, negative, NaN, +inf, subnormal
+    std::uniform_int_distribution<int> px(0, s.cols - 1), py(0, s.rows - 1), kind(0, 8);
+    for (int i = 0; i < 400; ++i) {  // patches of invalid / odd values: 0, -0, -2, NaN, +inf, subnormal, -subnormal, -0.01, -inf
         const int x0 = px(rng), y0 = py(rng), w = 1 + px(rng) % 12, h = 1 + py(rng) % 12;
-        static const uint16_t vals[6] = {0x0000, 0x8000, 0xc000, 0x7e00, 0x7c00, 0x0001};
+        static const uint16_t vals[9] = {0x0000, 0x8000, 0xc000, 0x7e00, 0x7c00, 0x0001, 0x8001, 0xa11f, 0xfc00};
         const uint16_t val            = vals[kind(rng)];
         for (int y = y0; y < std::min(s.rows, y0 + h); ++y)
             for (int x = x0; x < std::min(s.cols, x0 + w); ++x) s.dists[(size_t)y * s.cols + x] = val;
@@ -270,6 +270,12 @@ TEST(TsdfClassify, HolesAndSpecialHalves) {
     rotate(v, -0.2f, 0.4f, 0.1f);
     check(s, v, 128, 8);
     check(s, v, 128, 4);
+    // a volume that starts AT the camera with a thick band: voxels within trunc - |Dp| of the camera see the small
+    // negative pixels (the reference only skips Dp == 0, tsdf_volume.cu:74)
+    Volume n = make_volume(64, 0.6f, -0.3f, -0.3f, 0.01f);
+    n.trunc  = 0.1f;
+    check(s, n, 64, 8);
+    check(s, n, 64, 4);
 }
 
 TEST(TsdfClassify, RaggedDimsOddImageSmallWeights) {

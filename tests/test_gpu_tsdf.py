@@ -125,7 +125,7 @@ def _odd_dists(cfg, intr, seed):
     rng = np.random.default_rng(seed)
     dists = O.compute_dists(synth.depth_frame(cfg, 3, noise_mm=1.0), *intr)
     H, W = dists.shape
-    vals = np.array([0x0000, 0x8000, 0xC000, 0x7E00, 0x7C00, 0x0001], np.uint16)
+    vals = np.array([0x0000, 0x8000, 0xC000, 0x7E00, 0x7C00, 0x0001, 0x8001, 0xA11F, 0xFC00], np.uint16)  # .. -tiny, -0.01, -inf
     for _ in range(300):
         x0, y0 = rng.integers(0, W), rng.integers(0, H)
         w, h = rng.integers(1, 14), rng.integers(1, 14)
@@ -248,7 +248,7 @@ def test_integrate_random_small_configurations(A, seed):
     depth = rng.uniform(300, 4000, (rows, cols)).astype(np.uint16)
     depth[rng.random(depth.shape) < 0.25] = 0
     dists = O.compute_dists(depth, *intr)
-    specials = np.array([0x8000, 0xC000, 0x7E00, 0x7C00, 0x0001, 0x03FF], np.uint16)
+    specials = np.array([0x8000, 0xC000, 0x7E00, 0x7C00, 0x0001, 0x03FF, 0x8001, 0xA11F, 0xFC00], np.uint16)
     mask = rng.random(dists.shape) < 0.08
     dists[mask] = specials[rng.integers(0, len(specials), int(mask.sum()))]
     R = rot(rng.normal(size=3), float(rng.uniform(0, np.pi)))

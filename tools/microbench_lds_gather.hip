@@ -19,7 +19,7 @@ __global__ __launch_bounds__(NT) void gather_kernel(const uint16_t* __restrict__
     uint32_t off[NG];
     for (int q = 0; q < NG; ++q) {
         const int col = cols[q * NT + threadIdx.x];
-        off[q]        = WIDTH == 4 ? (uint32_t)(col * R + (threadIdx.x % R)) * 4u : (uint32_t)col * 16u;
+        off[q]        = WIDTH == 4 ? (uint32_t)(col * R + (threadIdx.x % R)) * 4u : (uint32_t)col * (uint32_t)WIDTH;
     }
     __syncthreads();
     float acc          = 0.f;
@@ -32,6 +32,10 @@ __global__ __launch_bounds__(NT) void gather_kernel(const uint16_t* __restrict__
             if (WIDTH == 4) {
                 acc += *(const float*)(smem + o0) + *(const float*)(smem + o1) + *(const float*)(smem + o2) +
                        *(const float*)(smem + o3);
+            } else if (WIDTH == 8) {  // 8-byte elements (value + pad): ds_read_b64 banks on (a / 4) mod 64
+                const float2 a = *(const float2*)(smem + o0), b = *(const float2*)(smem + o1), c = *(const float2*)(smem + o2),
+                             d = *(const float2*)(smem + o3);
+                acc += a.x + a.y + b.x + b.y + c.x + c.y + d.x + d.y;
             } else {
                 const float4 a = *(const float4*)(smem + o0), b = *(const float4*)(smem + o1),
                              c = *(const float4*)(smem + o2), d = *(const float4*)(smem + o3);
@@ -133,6 +137,8 @@ int main() {
     run<4, 4>("b32 random, 4 copies", d_cols, out, cyc, D);
     run<8, 4>("b32 random, 8 copies", d_cols, out, cyc, D);
     run<16, 4>("b32 random, 16 copies", d_cols, out, cyc, D);
+    run<1, 8>("b64 consecutive lanes", d_lin, out, cyc, D);
+    run<1, 8>("b64 random (8-byte elements)", d_cols, out, cyc, D);
     run<1, 16>("b128 consecutive lanes", d_lin, out, cyc, D);
     run<1, 16>("b128 random", d_cols, out, cyc, D);
     float* gp;
