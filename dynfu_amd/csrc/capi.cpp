@@ -968,6 +968,13 @@ int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
     if (rc == DFA_OK) rc = plan6_alloc(s, &s->v.field, (count))
     A(idx, N * k);
     A(wn, N * k);
+    A(idx_nat, N * k);
+    A(near, N);
+    A(vptr, D + 1);
+    A(vlist, N);
+    A(vperm, N);
+    A(canon_own, N * 3);
+    A(canon_n_own, N * 3);
     A(reg_idx, D * k);
     A(blk_hist, D * (dfa::SOLVE_TG_BLOCKS + 1));
     A(node_ptr, D + 1);
@@ -1047,17 +1054,18 @@ int dfa_solver6_set_problem(dfa_solver6* s, const float* node_pos, const float* 
     if (D > s->max_D || N > s->max_N) return fail(DFA_ERR_CAPACITY, "problem larger than the plan");
     dfa::Solve6View& v = s->v;
     v.N = N, v.D = D, v.k = s->k;
-    v.node_pos = node_pos, v.node_w = node_w, v.canon = canon_vertices, v.canon_n = canon_normals;
+    // (the solver reads its own, sorted copies of the vertices: s6_build_graph)
+    v.node_pos = node_pos, v.node_w = node_w, v.canon = v.canon_own, v.canon_n = canon_normals ? v.canon_n_own : nullptr;
     s->node_dq = node_dq;
     const dfa::KnnGridView* grid = nullptr;
     if (want_grid(D, N)) {
         HIP_TRY(dfa::knn_grid_build(s->grid.v, node_pos, D, S(stream)));
         grid = &s->grid.v;
     }
-    HIP_TRY(dfa::launch_knn(node_pos, node_w, D, canon_vertices, N, s->k, v.idx, s->raw_w, grid, S(stream)));
+    HIP_TRY(dfa::launch_knn(node_pos, node_w, D, canon_vertices, N, s->k, v.idx_nat, s->raw_w, grid, S(stream)));
     const int kreg = s->k + 1;
     HIP_TRY(dfa::launch_knn(node_pos, node_w, D, node_pos, D, kreg, s->raw_reg, nullptr, grid, S(stream)));
-    HIP_TRY(dfa::s6_build_graph(v, s->state, s->raw_w, s->raw_reg, kreg, S(stream)));
+    HIP_TRY(dfa::s6_build_graph(v, s->state, canon_vertices, canon_normals, s->raw_w, s->raw_reg, kreg, S(stream)));
     s->has_problem = true;
     return DFA_OK;
 }

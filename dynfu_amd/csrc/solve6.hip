@@ -55,13 +55,65 @@ __device__ __forceinline__ f3 dq_point(DQ q, f3 c) {
 }
 
 // ------------------------------------------------------------------------------------ graphs
-__global__ __launch_bounds__(256) void s6_normalise_kernel(const float* __restrict__ raw_w, int N, int k,
-                                                           float* __restrict__ wn) {
+// nearest node of every vertex (the key of the vertex sort)
+__global__ __launch_bounds__(256) void s6_near_kernel(const int32_t* __restrict__ idx_nat, int N, int k, int32_t* __restrict__ near) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= N) return;
-    float sum = 0.f;
-    for (int j = 0; j < k; ++j) sum += raw_w[(size_t)v * k + j];
-    for (int j = 0; j < k; ++j) wn[(size_t)v * k + j] = sum > 0.f ? raw_w[(size_t)v * k + j] / sum : 0.f;
+    if (v < N) near[v] = idx_nat[(size_t)v * k];
+}
+
+constexpr int S6_SORT_MAX = 4096;
+
+// bitonic sort of n <= S6_SORT_MAX keys in LDS by one 256-thread workgroup (buf holds the next power of two, padded with
+// 0xffffffff)
+__device__ __forceinline__ void s6_sort_lds(uint32_t* buf, int n2, int tid) {
+    for (int size = 2; size <= n2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < n2 / 2; i += 256) {
+                const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint32_t x = buf[lo], y = buf[hi];
+                if ((x > y) == up) buf[lo] = y, buf[hi] = x;
+            }
+            __syncthreads();
+        }
+}
+
+// One workgroup per node: its vertices (grouped by the transposition in whatever order the atomics landed) sorted by
+// index — a reproducible order — and gathered into the solver's arrays at their sorted positions, the radial basis
+// weights normalised on the way (weight of node.cpp:29-36 divided by the row sum).
+__global__ __launch_bounds__(256) void s6_permute_kernel(Solve6View s, const float* __restrict__ canon_user,
+                                                         const float* __restrict__ canon_n_user,
+                                                         const float* __restrict__ raw_w) {
+    __shared__ uint32_t sortbuf[S6_SORT_MAX];
+    const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
+    const int beg = s.vptr[a], len = s.vptr[a + 1] - beg;
+    const bool sorted = len <= S6_SORT_MAX;
+    if (sorted && len > 1) {
+        int n2 = 1;
+        while (n2 < len) n2 <<= 1;
+        for (int i = tid; i < n2; i += 256) sortbuf[i] = i < len ? s.vlist[beg + i] : 0xffffffffu;
+        __syncthreads();
+        s6_sort_lds(sortbuf, n2, tid);
+    } else if (sorted && len == 1 && tid == 0) {
+        sortbuf[0] = s.vlist[beg];
+    }
+    __syncthreads();
+    for (int i = tid; i < len; i += 256) {
+        const uint32_t v = sorted ? sortbuf[i] : s.vlist[beg + i];
+        const size_t p   = (size_t)(beg + i);
+        s.vperm[p]       = v;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s.canon_own[3 * p + c] = canon_user[3 * (size_t)v + c];
+        if (canon_n_user)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s.canon_n_own[3 * p + c] = canon_n_user[3 * (size_t)v + c];
+        float sum = 0.f;
+        for (int j = 0; j < k; ++j) sum += raw_w[(size_t)v * k + j];
+        for (int j = 0; j < k; ++j) {
+            s.idx[p * k + j] = s.idx_nat[(size_t)v * k + j];
+            s.wn[p * k + j]  = sum > 0.f ? raw_w[(size_t)v * k + j] / sum : 0.f;
+        }
+    }
 }
 
 // k nearest OTHER nodes from a (k + 1)-NN list of the nodes among themselves
@@ -384,7 +436,6 @@ __device__ __forceinline__ void inv6_column(const float* M, float* out, int c, f
 // Sparsity pattern of block row a (fixed by the graphs of the frame, built once per set_problem):
 // the diagonal first, then every node that shares a vertex with a or is joined to it by a
 // regularisation edge, ascending.
-constexpr int S6_SORT_MAX = 4096;
 constexpr int S6_MAXSLOT_PATTERN = 48;  // = S6_MAXSLOT (declared below), the plan capacity of a block row
 
 __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6State* st) {
@@ -403,16 +454,7 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
             while (n2 < len) n2 <<= 1;
             for (int i = tid; i < n2; i += 256) sortbuf[i] = i < len ? s.node_list[beg + i] : 0xffffffffu;
             __syncthreads();
-            for (int size = 2; size <= n2; size <<= 1)
-                for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                    for (int i = tid; i < n2 / 2; i += 256) {
-                        const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
-                        const bool up = (lo & size) == 0;
-                        const uint32_t x = sortbuf[lo], y = sortbuf[hi];
-                        if ((x > y) == up) sortbuf[lo] = y, sortbuf[hi] = x;
-                    }
-                    __syncthreads();
-                }
+            s6_sort_lds(sortbuf, n2, tid);
             for (int i = tid; i < len; i += 256) s.node_list[beg + i] = sortbuf[i];
         }
         if (tid == 0) {  // the few regularisation edges arriving at a: insertion sort
@@ -726,7 +768,7 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
                 const int i = tid + 256 * q, r = i / RS4, c = i - RS4 * r;
                 val[q]      = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < nr) {
-                    const size_t v = ent[q] / (unsigned)k;
+                    const size_t v = k == K ? ent[q] / (unsigned)K : ent[q] / (unsigned)k;  // (K: a shift)
                     if (c < RS4 - 1) val[q] = reinterpret_cast<const float4*>(s.rec + 16 * v)[c];
                     else {
                         const float2 m = *reinterpret_cast<const float2*>(s.rmeta + 2 * v);
@@ -740,7 +782,7 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
                 if (r < nr) {
                     if (c < 2) reinterpret_cast<float4*>(&sl8[r][0])[c] = val[q];
                     else if (c < 2 + K / 4) reinterpret_cast<float4*>(&scf[r][0])[c - 2] = val[q];
-                    else sra[r] = make_float4(val[q].x, val[q].y, __int_as_float((int)(ent[q] % (unsigned)k)), 0.f);
+                    else sra[r] = make_float4(val[q].x, val[q].y, __int_as_float((int)(k == K ? ent[q] % (unsigned)K : ent[q] % (unsigned)k)), 0.f);
                 }
             }
             // the next pass's list entries (consumed after the barriers that end this pass)
@@ -1024,7 +1066,7 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(So
     // products A u, A m, A t are gathered separately and w = A u - alpha (A m + beta A t) is formed at
     // the end, so round (2) does not wait for the scalars either.
     constexpr int MAXIT = 5;  // 10 slots per pass, plan capacity 48
-    constexpr int MAXP  = 16; // partials per lane: 64 x 16 = 1024 workgroups = 8192 nodes
+    constexpr int MAXP  = 16; // partials per lane held in registers: 64 x 16 = 1024 workgroups = 8192 nodes (more: a loop)
     const int nb   = s6_matvec_blocks(s.D);
     const int done = st->pcg_done;
     float gp[MAXP], dp[MAXP];
@@ -1037,6 +1079,8 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(So
             gp[q] = i < nb ? s.g_part[it & 1][i] : 0.f;
             dp[q] = i < nb ? s.d_part[it & 1][i] : 0.f;
         }
+        // more than 64 MAXP workgroups (8 192 nodes): the rest in a loop, into the last register (same order in every wave)
+        for (int i = lane + 64 * MAXP; i < nb; i += 64) gp[MAXP - 1] += s.g_part[it & 1][i], dp[MAXP - 1] += s.d_part[it & 1][i];
         if (it > 0) gamma_prev = st->gamma_prev[(it + 1) & 1], alpha_prev = st->alpha_prev[(it + 1) & 1], rz0 = st->rz0;
     }
     const int ss = lane / 6, c = lane - 6 * ss;
@@ -1214,11 +1258,12 @@ __global__ __launch_bounds__(256) void s6_warp_kernel(Solve6View s, const float*
     blend<K>(dq, idx, wn, s.k, B);
     const f3 c = mk3(s.canon[3 * (size_t)v], s.canon[3 * (size_t)v + 1], s.canon[3 * (size_t)v + 2]);
     const f3 p = B.m > 0.f ? blend_point<K>(B, c) : c;
-    out_v[3 * (size_t)v] = p.x, out_v[3 * (size_t)v + 1] = p.y, out_v[3 * (size_t)v + 2] = p.z;
+    const size_t o = s.vperm[v];  // the caller's index of the solver's vertex v
+    out_v[3 * o] = p.x, out_v[3 * o + 1] = p.y, out_v[3 * o + 2] = p.z;
     if (out_n && s.canon_n) {
         const f3 n0 = mk3(s.canon_n[3 * (size_t)v], s.canon_n[3 * (size_t)v + 1], s.canon_n[3 * (size_t)v + 2]);
         const f3 n  = B.m > 0.f ? blend_normal<K>(B, n0) : n0;
-        out_n[3 * (size_t)v] = n.x, out_n[3 * (size_t)v + 1] = n.y, out_n[3 * (size_t)v + 2] = n.z;
+        out_n[3 * o] = n.x, out_n[3 * o + 1] = n.y, out_n[3 * o + 2] = n.z;
     }
 }
 
@@ -1275,23 +1320,25 @@ namespace {
 __global__ void s6_pattern_reset_kernel(Solve6State* st) { st->overflow = 0, st->max_row_blocks = 0; }
 }  // namespace
 
-hipError_t s6_build_graph_impl(const Solve6View& s, Solve6State* state, const float* raw_w, const int32_t* raw_reg, int kreg,
-                               hipStream_t st) {
+hipError_t s6_build_graph(const Solve6View& s, Solve6State* state, const float* canon_user, const float* canon_n_user,
+                          const float* raw_w, const int32_t* raw_reg, int kreg, hipStream_t st) {
     s6_pattern_reset_kernel<<<1, 1, 0, st>>>(state);
-    if (s.N > 0) s6_normalise_kernel<<<(s.N + 255) / 256, 256, 0, st>>>(raw_w, s.N, s.k, s.wn);
+    hipError_t e = hipSuccess;
+    if (s.N > 0) {
+        // the solver's vertex order: by nearest node (counting sort), by index inside a node
+        s6_near_kernel<<<(s.N + 255) / 256, 256, 0, st>>>(s.idx_nat, s.N, s.k, s.near);
+        e = solve_transpose_graph(s.near, (size_t)s.N, s.D, s.blk_hist, s.vptr, s.vlist, st);
+        if (e != hipSuccess) return e;
+        s6_permute_kernel<<<s.D, 256, 0, st>>>(s, canon_user, canon_n_user, raw_w);
+    }
     s6_reg_graph_kernel<<<(s.D + 255) / 256, 256, 0, st>>>(raw_reg, s.D, kreg, s.k, s.reg_idx);
-    hipError_t e = solve_transpose_graph(s.idx, (size_t)s.N * s.k, s.D, s.blk_hist, s.node_ptr, s.node_list, st);
+    e = solve_transpose_graph(s.idx, (size_t)s.N * s.k, s.D, s.blk_hist, s.node_ptr, s.node_list, st);
     if (e != hipSuccess) return e;
     e = solve_transpose_graph(s.reg_idx, (size_t)s.D * s.k, s.D, s.blk_hist, s.rnode_ptr, s.rnode_list, st);
     if (e != hipSuccess) return e;
     s6_pattern_kernel<<<s.D, 256, 0, st>>>(s, state);
     s6_rslot_kernel<<<(s.D * s.cap + 255) / 256, 256, 0, st>>>(s);
     return hipGetLastError();
-}
-
-hipError_t s6_build_graph(const Solve6View& s, Solve6State* state, const float* raw_w, const int32_t* raw_reg, int kreg,
-                          hipStream_t st) {
-    return s6_build_graph_impl(s, state, raw_w, raw_reg, kreg, st);
 }
 
 hipError_t s6_begin(const Solve6View& s, Solve6State* state, const float* node_dq, hipStream_t st) {

@@ -53,9 +53,19 @@ struct Solve6View {
     // problem (borrowed)
     const float* node_pos;  // D x 3
     const float* node_w;    // D
-    const float* canon;     // N x 3
+    const float* canon;     // N x 3          canonical vertices / normals in the solver's order (own copies, see below)
     const float* canon_n;   // N x 3 or null
-    // graphs
+    // The solver works on its own copy of the vertices, SORTED BY NEAREST NODE (s6_build_graph): lanes of a wave then
+    // share their nodes' transforms and neighbouring pixels, the rows a node's workgroup gathers lie in a few runs
+    // instead of all over the cloud.  vperm maps the solver's order back to the caller's (s6_warp scatters through it).
+    int32_t* idx_nat;   // N x k  nearest nodes, caller's vertex order (k-NN output)
+    int32_t* near;      // N      nearest node of every vertex
+    int32_t* vptr;      // D + 1  first sorted position of every node's vertices
+    uint32_t* vlist;    // N      vertices grouped by nearest node (scratch of the sort)
+    uint32_t* vperm;    // N      sorted position -> caller's vertex
+    float* canon_own;   // N x 3  (= canon below)
+    float* canon_n_own; // N x 3  (= canon_n below, when the caller gave normals)
+    // graphs (sorted order from here on)
     int32_t* idx;       // N x k  nearest nodes
     float* wn;          // N x k  normalised radial basis weights
     int32_t* reg_idx;   // D x k  nearest OTHER nodes
@@ -101,8 +111,10 @@ constexpr int S6_NODES_PER_BLOCK = 8;  // matvec: one wave per node, 512 threads
 __host__ __device__ inline int s6_matvec_blocks(int D) { return (D + S6_NODES_PER_BLOCK - 1) / S6_NODES_PER_BLOCK; }
 __host__ __device__ inline int s6_update_blocks(int D) { return (6 * D + 255) / 256; }
 
-hipError_t s6_build_graph(const Solve6View& s, Solve6State* state, const float* raw_w /* N x k */,
-                          const int32_t* raw_reg /* D x (k+1) */, int kreg, hipStream_t st);
+// canon_user / canon_n_user: the caller's vertices (and normals or null) in the caller's order; raw_w and s.idx_nat hold
+// the k-NN pass's output for them
+hipError_t s6_build_graph(const Solve6View& s, Solve6State* state, const float* canon_user, const float* canon_n_user,
+                          const float* raw_w /* N x k */, const int32_t* raw_reg /* D x (k+1) */, int kreg, hipStream_t st);
 hipError_t s6_begin(const Solve6View& s, Solve6State* state, const float* node_dq, hipStream_t st);
 hipError_t s6_linearise(const Solve6View& s, Solve6State* state, const Solve6Image& img, const Solve6Params& p,
                         int update_weights, hipStream_t st);

@@ -43,7 +43,7 @@ def _scene(name, frame):
     return cfg, c, intr, depth
 
 
-def _solve_both(A, cfg, c, intr, depth, node_dq, **kw):
+def _solve_both(A, cfg, c, intr, depth, node_dq, threads=8, **kw):
     k = cfg["k"]
     P, Nm = A.compute_points_normals(dev(depth), *intr)
     s = A.Solver6(cfg["D"], len(c["verts"]), k)
@@ -54,7 +54,7 @@ def _solve_both(A, cfg, c, intr, depth, node_dq, **kw):
     dq = host(s.node_dq())
     wv, wn_ = s.warp()
     dq_ref, st_ref = O.solve6(c["node_pos"], node_dq, c["node_w"], k, c["verts"], c["normals"], host(P), host(Nm), intr,
-                              threads=8, **kw)
+                              threads=threads, **kw)
     return s, dq, st, host(wv), host(wn_), dq_ref, st_ref
 
 
@@ -157,6 +157,27 @@ def test_forcing_schedule_matches_the_oracle(A, name, frame):
                           threads=_threads(), num_iter=1, gn_iter=1, linear_iter=5, lambda_=200.0, pcg_tol=1e-6)
     assert st5["pcg_it_hist"] == [5] and st5["pcg_rel_hist"][0] == pytest.approx(st5_ref["pcg_rel_hist"][0], rel=0.02)
     assert 1e-6 < st5["pcg_rel_hist"][0] < 1.0
+
+
+def test_more_than_8192_nodes_matches_the_oracle(A):
+    """9 216 nodes (k = 4, 1 179 648 vertices): the PCG's scalars are sums of one partial per workgroup of 8 nodes, of
+    which a lane keeps 16 in registers — beyond 8 192 nodes the rest is summed in a loop (a round-2 build dropped them:
+    the adaptor's 512^3 sequence, 8 469 nodes, ran on slightly wrong step lengths)."""
+    cfg = dict(synth.CONFIGS["C2"], D=9216)
+    c = synth.canonical(cfg)
+    intr = synth.intrinsics(cfg)
+    depth = synth.depth_frame(cfg, 5)
+    kw = dict(num_iter=1, gn_iter=2, linear_iter=25, lambda_=200.0)
+    s, dq, st, wv, wn_, dq_ref, st_ref = _solve_both(A, cfg, c, intr, depth, c["node_dq"], threads=_threads(), **kw)
+    assert st["overflow"] == 0 and st["pcg_it_hist"] == st_ref["pcg_it_hist"] == [25, 25]
+    assert np.allclose(st["pcg_rel_hist"], st_ref["pcg_rel_hist"], rtol=0.05)
+    assert st["final_cost"] == pytest.approx(st_ref["final_cost"], rel=1e-3)
+    sample = np.arange(0, len(c["verts"]), 37)
+    idx, wn, _ = O.graph6(c["node_pos"], c["node_w"], cfg["k"], c["verts"][sample], threads=_threads())
+    p_ref, _ = O.warp6(dq_ref, idx, wn, c["verts"][sample])
+    d = np.linalg.norm(wv[sample] - p_ref, axis=1)
+    assert d.mean() < 5e-5 and d.max() < 1e-3
+    s.close()
 
 
 def test_adaptive_launch_budget(A):
