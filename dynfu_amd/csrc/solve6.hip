@@ -748,16 +748,25 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
 #pragma unroll
     for (int e = 0; e < 8; ++e) own[e] = v2f{0.f, 0.f};
     constexpr int RS4 = 2 + K / 4 + 1, NCH = (S6_RC * RS4 + 255) / 256;  // 16-byte chunks of a record; chunks per thread and pass
-    uint32_t ent[NCH];  // (vertex k + slot) of the rows whose chunks this thread loads
+    constexpr int EPT = (S6_RC + 255) / 256;
+    __shared__ uint32_t sent[2][S6_RC];  // (vertex k + slot) of the rows of this pass / the next one
 #pragma unroll
-    for (int q = 0; q < NCH; ++q) {
-        const int r = (tid + 256 * q) / RS4;
-        ent[q]      = r < min(S6_RC, len) ? s.node_list[beg + r] : 0u;
+    for (int q = 0; q < EPT; ++q) {
+        const int r = tid + 256 * q;
+        if (r < min(S6_RC, len)) sent[0][r] = s.node_list[beg + r];
     }
-    for (int r0 = 0; r0 < len; r0 += S6_RC) {
+    int pass = 0;
+    for (int r0 = 0; r0 < len; r0 += S6_RC, pass ^= 1) {
         const int nr = min(S6_RC, len - r0);
-        __syncthreads();  // the pass before is done with the staged rows
+        __syncthreads();  // the pass before is done with the staged rows (and has stored this pass's list entries)
         const size_t e0 = (size_t)(beg + r0);
+        // the next pass's list entries: loaded now, parked in LDS at the end of this pass (one register meanwhile)
+        uint32_t nxt_ent[EPT];
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int r = tid + 256 * q;
+            nxt_ent[q]  = r0 + S6_RC + r < len ? s.node_list[e0 + S6_RC + r] : 0u;
+        }
         {   // The rows of the pass: one record per vertex (s6_linearise), gathered through the node's row list; RS4 chunks per
             // row — l (2 x 16 bytes), f (K / 4 x 16 bytes) from the vertex's 64-byte line, (weight, weight x residual) from
             // the small per-vertex array — one chunk per thread and step, the chunks of a row on neighbouring lanes.  The list entries of this pass were loaded
@@ -768,7 +777,8 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
                 const int i = tid + 256 * q, r = i / RS4, c = i - RS4 * r;
                 val[q]      = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < nr) {
-                    const size_t v = k == K ? ent[q] / (unsigned)K : ent[q] / (unsigned)k;  // (K: a shift)
+                    const uint32_t en = sent[pass][r];
+                    const size_t v    = k == K ? en / (unsigned)K : en / (unsigned)k;  // (K: a shift)
                     if (c < RS4 - 1) val[q] = reinterpret_cast<const float4*>(s.rec + 16 * v)[c];
                     else {
                         const float2 m = *reinterpret_cast<const float2*>(s.rmeta + 2 * v);
@@ -782,23 +792,15 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
                 if (r < nr) {
                     if (c < 2) reinterpret_cast<float4*>(&sl8[r][0])[c] = val[q];
                     else if (c < 2 + K / 4) reinterpret_cast<float4*>(&scf[r][0])[c - 2] = val[q];
-                    else sra[r] = make_float4(val[q].x, val[q].y, __int_as_float((int)(k == K ? ent[q] % (unsigned)K : ent[q] % (unsigned)k)), 0.f);
-                }
-            }
-            // the next pass's list entries (consumed after the barriers that end this pass)
-            if (r0 + S6_RC < len) {
-                const int nn = min(S6_RC, len - r0 - S6_RC);
-#pragma unroll
-                for (int q = 0; q < NCH; ++q) {
-                    const int r = (tid + 256 * q) / RS4;
-                    ent[q]      = r < nn ? s.node_list[e0 + S6_RC + r] : 0u;
+                    else {
+                        const uint32_t en = sent[pass][r];
+                        sra[r] = make_float4(val[q].x, val[q].y, __int_as_float((int)(k == K ? en % (unsigned)K : en % (unsigned)k)), 0.f);
+                    }
                 }
             }
         }
         // the first chunk of records of this pass flies while the rows settle and slot 0 is worked on
-        Rec4 first[ROUNDS];
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) first[r] = load_chunk(cq[r], qend[r], 16 * r < nup);
+        const Rec4 first0 = load_chunk(cq[0], qend[0], nup > 0);  // (rounds 1, 2 — rows of more than 16 upper blocks — load theirs when they start)
         __syncthreads();
         // per row: (weight, weight x residual, own slot) -> (rho f_own, rho res f_own, rho f_own^2)
         for (int i = tid; i < nr; i += 256) {
@@ -843,7 +845,7 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
             int c = cq[r];
             const int qe = qend[r];
             bool act  = c < qe;
-            Rec4 mine = first[r];
+            Rec4 mine = r == 0 ? first0 : load_chunk(c, qe, c < qe);
             const unsigned rlim = (unsigned)(r0 + nr);
             while (__any(act)) {
                 const Rec4 nxt = load_chunk(c + 64, qe, act);
@@ -885,6 +887,11 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
             cq[r] = c;
         }
 #endif
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int r = tid + 256 * q;
+            if (r < S6_RC) sent[pass ^ 1][r] = nxt_ent[q];
+        }
     }
     // ---- the four waves' partial moments of the upper slots: added through LDS in wave order
     __syncthreads();
@@ -1385,7 +1392,8 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
             else if (rc <= 320) S6A2(4, 320);
             else S6A2(4, 640);
         } else {
-            if (rc <= 256) S6A2(8, 256);
+            if (rc <= 192) S6A2(8, 192);
+            else if (rc <= 256) S6A2(8, 256);
             else if (rc <= 320) S6A2(8, 320);
             else S6A2(8, 640);
         }

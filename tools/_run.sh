@@ -1,6 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python - <<'PY'
-import json, bench
-r = bench.end_to_end("C2")
-print({k: (v.get('median_ms'), v.get('frames_per_s'), v.get('nodes_last'), v.get('cost_first'), v.get('cost_last')) for k, v in r.items() if isinstance(v, dict)})
-PY
+for rc in 192 256 320; do DFA_S6_RC=$rc DFA_TAG=rc$rc python tools/ns_assemble_time.py C3 2>&1 | tail -1; done
+DFA_TAG=k4 python tools/ns_assemble_time.py C2 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_gpu_solve6.py -x -q 2>&1 | tail -3
