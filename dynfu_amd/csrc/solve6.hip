@@ -81,6 +81,7 @@ __device__ __forceinline__ void s6_sort_lds(uint32_t* buf, int n2, int tid) {
 // One workgroup per node: its vertices (grouped by the transposition in whatever order the atomics landed) sorted by
 // index — a reproducible order — and gathered into the solver's arrays at their sorted positions, the radial basis
 // weights normalised on the way (weight of node.cpp:29-36 divided by the row sum).
+template <int K>
 __global__ __launch_bounds__(256) void s6_permute_kernel(Solve6View s, const float* __restrict__ canon_user,
                                                          const float* __restrict__ canon_n_user,
                                                          const float* __restrict__ raw_w) {
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(256) void s6_permute_kernel(Solve6View s, const flo
         sortbuf[0] = s.vlist[beg];
     }
     __syncthreads();
+    const bool wide = k == K;  // rows of K entries: 16-byte loads and stores
     for (int i = tid; i < len; i += 256) {
         const uint32_t v = sorted ? sortbuf[i] : s.vlist[beg + i];
         const size_t p   = (size_t)(beg + i);
@@ -107,11 +109,33 @@ __global__ __launch_bounds__(256) void s6_permute_kernel(Solve6View s, const flo
         if (canon_n_user)
 #pragma unroll
             for (int c = 0; c < 3; ++c) s.canon_n_own[3 * p + c] = canon_n_user[3 * (size_t)v + c];
+        float w[K];
+        int32_t id[K];
+        if (wide) {
+#pragma unroll
+            for (int q = 0; q < K / 4; ++q) {
+                const float4 w4 = reinterpret_cast<const float4*>(raw_w + (size_t)v * K)[q];
+                const int4 i4   = reinterpret_cast<const int4*>(s.idx_nat + (size_t)v * K)[q];
+                w[4 * q] = w4.x, w[4 * q + 1] = w4.y, w[4 * q + 2] = w4.z, w[4 * q + 3] = w4.w;
+                id[4 * q] = i4.x, id[4 * q + 1] = i4.y, id[4 * q + 2] = i4.z, id[4 * q + 3] = i4.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < K; ++j) w[j] = j < k ? raw_w[(size_t)v * k + j] : 0.f, id[j] = j < k ? s.idx_nat[(size_t)v * k + j] : -1;
+        }
         float sum = 0.f;
-        for (int j = 0; j < k; ++j) sum += raw_w[(size_t)v * k + j];
-        for (int j = 0; j < k; ++j) {
-            s.idx[p * k + j] = s.idx_nat[(size_t)v * k + j];
-            s.wn[p * k + j]  = sum > 0.f ? raw_w[(size_t)v * k + j] / sum : 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) sum += j < k ? w[j] : 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) w[j] = sum > 0.f ? w[j] / sum : 0.f;
+        if (wide) {
+#pragma unroll
+            for (int q = 0; q < K / 4; ++q) {
+                reinterpret_cast<float4*>(s.wn + p * K)[q] = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+                reinterpret_cast<int4*>(s.idx + p * K)[q]  = make_int4(id[4 * q], id[4 * q + 1], id[4 * q + 2], id[4 * q + 3]);
+            }
+        } else {
+            for (int j = 0; j < k; ++j) s.idx[p * k + j] = id[j], s.wn[p * k + j] = w[j];
         }
     }
 }
@@ -534,9 +558,15 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
             const int b = s.idx[(size_t)v * k + j];
             int sl      = 255;
             if (b == a) sl = 0;
-            else if (b >= 0)
-                for (int q = 1; q < stored; ++q)
-                    if (cols[q] == b) sl = q;
+            else if (b >= 0) {  // the columns of slots 1 .. stored - 1 ascend: binary search
+                int lo = 1, hi = stored - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (cols[mid] < b) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (lo < stored && cols[lo] == b) sl = lo;
+            }
             es[(size_t)r * k + j] = (uint8_t)sl;
             if (sl >= fu && sl < stored) atomicAdd(&pcnt[sl], 1);
         }
@@ -1336,7 +1366,7 @@ hipError_t s6_build_graph(const Solve6View& s, Solve6State* state, const float* 
         s6_near_kernel<<<(s.N + 255) / 256, 256, 0, st>>>(s.idx_nat, s.N, s.k, s.near);
         e = solve_transpose_graph(s.near, (size_t)s.N, s.D, s.blk_hist, s.vptr, s.vlist, st);
         if (e != hipSuccess) return e;
-        s6_permute_kernel<<<s.D, 256, 0, st>>>(s, canon_user, canon_n_user, raw_w);
+        K6DISPATCH(s6_permute_kernel, s.k, <<<s.D, 256, 0, st>>>(s, canon_user, canon_n_user, raw_w));
     }
     s6_reg_graph_kernel<<<(s.D + 255) / 256, 256, 0, st>>>(raw_reg, s.D, kreg, s.k, s.reg_idx);
     e = solve_transpose_graph(s.idx, (size_t)s.N * s.k, s.D, s.blk_hist, s.node_ptr, s.node_list, st);
