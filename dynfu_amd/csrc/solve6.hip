@@ -773,10 +773,9 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
         for (int i = 0; i < 4; ++i) o.v[i] = on && c + 4 * c4 + i < qe ? s.pair_list[c + 4 * c4 + i] : 0xffffffffu;
         return o;
     };
-    v2f own[8];
-    float ownG[2] = {0.f, 0.f};  // slot 0 (every row's own neighbour) and -J^T r, this lane's share
-#pragma unroll
-    for (int e = 0; e < 8; ++e) own[e] = v2f{0.f, 0.f};
+    // slot 0 (every row's own neighbour) and -J^T r: accumulated per pass and added to the wave's LDS partial right after
+    // the pass's slot-0 loop, so that their 18 registers are free while the upper blocks are worked on
+    for (int i = tid; i < 4 * 72; i += 256) (&part0[0][0])[i] = 0.f;
     constexpr int RS4 = 2 + K / 4 + 1, NCH = (S6_RC * RS4 + 255) / 256;  // 16-byte chunks of a record; chunks per thread and pass
     constexpr int EPT = (S6_RC + 255) / 256;
     __shared__ uint32_t sent[2][S6_RC];  // (vertex k + slot) of the rows of this pass / the next one
@@ -854,18 +853,37 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
             if (sra[i >> 1].x == 0.f) reinterpret_cast<float4*>(&sl8[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
         // ---- slot 0: 16 rows per wave and step, the waves interleave
+        {
+            v2f own[8];
+            float ownG[2] = {0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) own[e] = v2f{0.f, 0.f};
 #if !(DFA_S6_ABLATE & 2)
-        for (int rb = 16 * wave; rb < nr; rb += 64) {
+            for (int rb = 16 * wave; rb < nr; rb += 64) {
 #else
-        for (int rb = 16 * wave; rb < 0; rb += 64) {
+            for (int rb = 16 * wave; rb < 0; rb += 64) {
 #endif
-            const int rr = rb + g16;
-            if (rr < nr) {  // (whole quads)
-                const float4 ra = sra[rr];
-                const float2 lh = *reinterpret_cast<const float2*>(&sl8[rr][2 * c4]);
-                add_pair(lh.x, lh.y, ra.z, own);
-                ownG[0] = fmaf(-ra.y, lh.x, ownG[0]), ownG[1] = fmaf(-ra.y, lh.y, ownG[1]);
+                const int rr = rb + g16;
+                if (rr < nr) {  // (whole quads)
+                    const float4 ra = sra[rr];
+                    const float2 lh = *reinterpret_cast<const float2*>(&sl8[rr][2 * c4]);
+                    add_pair(lh.x, lh.y, ra.z, own);
+                    ownG[0] = fmaf(-ra.y, lh.x, ownG[0]), ownG[1] = fmaf(-ra.y, lh.y, ownG[1]);
+                }
             }
+            float v[16];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = own[e].x, v[8 + e] = own[e].y;
+            // quads summed; lane (g, c4) is left with element (row 2 c4 + (g >= 8), column g mod 8) — its own word of part0
+            part0[wave][8 * (2 * c4 + (g16 >> 3)) + (g16 & 7)] += quads_reduce_scatter(v, lane);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                ownG[e] += __shfl_xor(ownG[e], 4, 64);
+                ownG[e] += __shfl_xor(ownG[e], 8, 64);
+                ownG[e] += __shfl_xor(ownG[e], 16, 64);
+                ownG[e] += __shfl_xor(ownG[e], 32, 64);
+            }
+            if (g16 == 0) part0[wave][64 + 2 * c4] += ownG[0], part0[wave][64 + 2 * c4 + 1] += ownG[1];
         }
         // ---- upper slots
 #if !(DFA_S6_ABLATE & 1)
@@ -943,23 +961,7 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
         }
         __syncthreads();
     }
-    // slot 0: quads, then waves (fixed order)
-    {
-        float v[16];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = own[e].x, v[8 + e] = own[e].y;
-        // lane (g, c4) is left with element (row 2 c4 + (g >= 8), column g mod 8)
-        part0[wave][8 * (2 * c4 + (g16 >> 3)) + (g16 & 7)] = quads_reduce_scatter(v, lane);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            ownG[e] += __shfl_xor(ownG[e], 4, 64);
-            ownG[e] += __shfl_xor(ownG[e], 8, 64);
-            ownG[e] += __shfl_xor(ownG[e], 16, 64);
-            ownG[e] += __shfl_xor(ownG[e], 32, 64);
-        }
-        if (g16 == 0) part0[wave][64 + 2 * c4] = ownG[0], part0[wave][64 + 2 * c4 + 1] = ownG[1];
-    }
-    __syncthreads();
+    // slot 0: the waves' partials (fixed order)
     if (tid < 64 && cnt > 0) accS[0][tid] = (part0[0][tid] + part0[1][tid]) + (part0[2][tid] + part0[3][tid]);
     if (tid >= 64 && tid < 72) g8s[tid - 64] = (part0[0][tid] + part0[1][tid]) + (part0[2][tid] + part0[3][tid]);
     // H_ab = M_a S_ab M_b^T, regularisation, output: thread (slot, row) finishes row `row` of the block in `slot` — of slot 0
