@@ -994,6 +994,7 @@ int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
     A(bcnt, D);
     A(bfu, D);
     A(rslot, D * cap);
+    A(utab, D * 64);
     A(eslot, N * k * k);
     A(pair_list, N * k * k);
     A(pair_ptr, D * (cap + 1));

@@ -580,6 +580,42 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
     }
     __syncthreads();
     if (tid <= stored) s.pair_ptr[(size_t)a * (s.cap + 1) + tid] = pstart[tid];
+    // ---- work units of the assembly (first wave): every upper block one unit, then the remaining units one at a time to
+    // the block whose units have the most records each (ties: the lower slot) — a wave-wide arg-max per unit handed out
+    if (tid < 64) {
+        const int q    = fu + tid;  // lane = upper block
+        const int mine = q < stored ? pcnt[q] : 0;
+        const bool has = q < stored;
+        int n          = has ? 1 : 0;
+        const int nupper = stored > fu ? stored - fu : 0;
+        for (int left = 64 - nupper; left > 0 && nupper > 0; --left) {
+            // records per unit, compared as cross products to stay in integers: mine / n > other / m  <=>  mine m > other n
+            // arg-max by a 6-step butterfly over (value, n, lane)
+            int bv = has ? mine : -1, bn = has ? n : 1, bl = tid;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const int ov = __shfl_xor(bv, o, 64), on = __shfl_xor(bn, o, 64), ol = __shfl_xor(bl, o, 64);
+                const long long lhs = (long long)ov * bn, rhs = (long long)bv * on;
+                if (lhs > rhs || (lhs == rhs && ol < bl)) bv = ov, bn = on, bl = ol;
+            }
+            if (bv <= 4 * bn) break;  // no block has more than one group of four records per unit left to share
+            if (tid == bl) ++n;
+        }
+        // exclusive scan of n over the lanes = first unit of every block
+        int incl = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (tid >= o) incl += t;
+        }
+        const int u0 = incl - n;
+        __shared__ uint32_t utab_sh[64];
+        utab_sh[tid] = 255u;
+        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < n; ++i) utab_sh[u0 + i] = (uint32_t)q | ((uint32_t)i << 8) | ((uint32_t)n << 16);
+        __builtin_amdgcn_wave_barrier();
+        s.utab[(size_t)a * 64 + tid] = utab_sh[tid];
+    }
     {   // one pass over the pairs per wave: a chunk's slot bytes are read once and matched against the wave's (at most
         // 12) slots — independent ballots instead of one dependent read-compare-ballot chain per slot and chunk
         const int wave = tid >> 6, lane = tid & 63;
@@ -749,30 +785,21 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
             m[e] = __builtin_elementwise_fma(f, le, m[e]);
         }
     };
-    // ---- upper slots: quad g of round r owns slot fu + 16 r + g; this wave's chunks of 16 records of its list are those at
-    // start + 16 wave + 64 i (lane c4 of the quad holds records 4 c4 .. 4 c4 + 3 of the chunk).  Cursors and moments live
-    // in registers across the passes.
-    constexpr int ROUNDS = (S6_MAXSLOT + 15) / 16;
-    const int nup = cnt > fu ? cnt - fu : 0;
-    v2f mq[ROUNDS][8];
-    int cq[ROUNDS], qend[ROUNDS];
+    // ---- upper blocks: the work unit of this quad (s6_pattern: utab) walks groups of four records of ONE block's pair list,
+    // `phase`, `phase + stride`, ... — lane c4 holds record c4 of a group; the block's 8 x 8 moment (this unit's share of
+    // it) lives in the quad's registers for the whole kernel.  Longer lists have more units: every unit of the workgroup
+    // walks about the same number of records, in every pass (the groups of a unit are spread over the whole list).
+    const int nup        = cnt > fu ? cnt - fu : 0;
+    const uint32_t uinfo = s.utab[(size_t)a * 64 + wave * 16 + g16];
+    const int uq         = (int)(uinfo & 255u);
+    const bool uhas      = uq >= fu && uq < cnt;
+    const int ustep      = 4 * (int)((uinfo >> 16) & 255u);  // records from one of the unit's groups to the next
+    int ucur = 0, uend = 0;                                  // this lane's record of the unit's next group; end of the list
+    if (uhas) ucur = pptr[uq] + 4 * (int)((uinfo >> 8) & 255u) + c4, uend = pptr[uq + 1];
+    v2f mu[8];
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) mq[r][e] = v2f{0.f, 0.f};
-        const int q = fu + 16 * r + g16;
-        cq[r] = 0, qend[r] = 0;
-        if (q < cnt) cq[r] = pptr[q] + 16 * wave, qend[r] = pptr[q + 1];
-    }
-    struct Rec4 {
-        uint32_t v[4];
-    };
-    auto load_chunk = [&](int c, int qe, bool on) __attribute__((always_inline)) {
-        Rec4 o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o.v[i] = on && c + 4 * c4 + i < qe ? s.pair_list[c + 4 * c4 + i] : 0xffffffffu;
-        return o;
-    };
+    for (int e = 0; e < 8; ++e) mu[e] = v2f{0.f, 0.f};
+    auto load_rec = [&](int at) __attribute__((always_inline)) { return uhas && at < uend ? s.pair_list[at] : 0xffffffffu; };
     // slot 0 (every row's own neighbour) and -J^T r: accumulated per pass and added to the wave's LDS partial right after
     // the pass's slot-0 loop, so that their 18 registers are free while the upper blocks are worked on
     for (int i = tid; i < 4 * 72; i += 256) (&part0[0][0])[i] = 0.f;
@@ -829,7 +856,8 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
             }
         }
         // the first chunk of records of this pass flies while the rows settle and slot 0 is worked on
-        const Rec4 first0 = load_chunk(cq[0], qend[0], nup > 0);  // (rounds 1, 2 — rows of more than 16 upper blocks — load theirs when they start)
+        // this lane's records of the unit's next three groups fly while the rows settle and slot 0 is worked on
+        uint32_t rec0 = load_rec(ucur), rec1 = load_rec(ucur + ustep), rec2 = load_rec(ucur + 2 * ustep);
         __syncthreads();
         // per row: (weight, weight x residual, own slot) -> (rho f_own, rho res f_own, rho f_own^2)
         for (int i = tid; i < nr; i += 256) {
@@ -885,19 +913,14 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
             }
             if (g16 == 0) part0[wave][64 + 2 * c4] += ownG[0], part0[wave][64 + 2 * c4 + 1] += ownG[1];
         }
-        // ---- upper slots
+        // ---- upper blocks
 #if !(DFA_S6_ABLATE & 1)
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            if (16 * r >= nup) break;  // (uniform)
-            int c = cq[r];
-            const int qe = qend[r];
-            bool act  = c < qe;
-            Rec4 mine = r == 0 ? first0 : load_chunk(c, qe, c < qe);
+        if (nup > 0) {
             const unsigned rlim = (unsigned)(r0 + nr);
+            bool act = uhas && ucur - c4 < uend;  // (quad-uniform: the group starts inside the list)
             while (__any(act)) {
-                const Rec4 nxt = load_chunk(c + 64, qe, act);
-                // a record is in this pass if its row is staged; records of an earlier pass (a chunk that straddled its end)
+                const uint32_t rec3 = act ? load_rec(ucur + 3 * ustep) : 0xffffffffu;
+                // a record is in this pass if its row is staged; records of an earlier pass (a group that straddled its end)
                 // and of later ones contribute nothing (coefficient 0 on a staged row)
                 auto step = [&](const uint32_t pr) __attribute__((always_inline)) {
                     const unsigned rr = (pr >> 4) - (unsigned)r0;
@@ -905,34 +928,22 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
                     const unsigned ri = in ? rr : 0u, j = in ? (pr & 15u) : 0u;
                     const float2 lh   = *reinterpret_cast<const float2*>(&sl8[ri][2 * c4]);
                     const float cf    = scf[ri][j];
-                    add_pair(lh.x, lh.y, in ? cf : 0.f, mq[r]);
+                    add_pair(lh.x, lh.y, in ? cf : 0.f, mu);
                 };
-                // which lanes hold a record of this pass: four steps (the records of one lane of every quad) are skipped
-                // when no quad of the wave has one there
-                bool any_in = false, fin = true;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    any_in = any_in || (act && (mine.v[i] >> 4) - (unsigned)r0 < (unsigned)nr);
-                    fin    = fin && (mine.v[i] == 0xffffffffu || (mine.v[i] >> 4) < rlim);
-                }
-                const uint64_t bin = __ballot(any_in);
-#define S6_STEPS(T)                                                                                        \
-    if (bin & (0x1111111111111111ull << T)) {                                                              \
-        step((uint32_t)__float_as_int(quad_bcast<T>(__int_as_float((int)mine.v[0]))));                     \
-        step((uint32_t)__float_as_int(quad_bcast<T>(__int_as_float((int)mine.v[1]))));                     \
-        step((uint32_t)__float_as_int(quad_bcast<T>(__int_as_float((int)mine.v[2]))));                     \
-        step((uint32_t)__float_as_int(quad_bcast<T>(__int_as_float((int)mine.v[3]))));                     \
-    }
-                S6_STEPS(0) S6_STEPS(1) S6_STEPS(2) S6_STEPS(3)
-#undef S6_STEPS
-                // the chunk is finished when none of its records belongs to a later pass (records past the end of the list
+                const bool mine_in = act && (rec0 >> 4) - (unsigned)r0 < (unsigned)nr;
+                const uint64_t bin = __ballot(mine_in);  // a step (the records of one lane of every quad) is skipped when no quad has one there
+                if (bin & 0x1111111111111111ull) step((uint32_t)__float_as_int(quad_bcast<0>(__int_as_float((int)rec0))));
+                if (bin & 0x2222222222222222ull) step((uint32_t)__float_as_int(quad_bcast<1>(__int_as_float((int)rec0))));
+                if (bin & 0x4444444444444444ull) step((uint32_t)__float_as_int(quad_bcast<2>(__int_as_float((int)rec0))));
+                if (bin & 0x8888888888888888ull) step((uint32_t)__float_as_int(quad_bcast<3>(__int_as_float((int)rec0))));
+                // the group is finished when none of its records belongs to a later pass (records past the end of the list
                 // read as 0xffffffff: finished)
+                const bool fin      = rec0 == 0xffffffffu || (rec0 >> 4) < rlim;
                 const uint64_t bal  = __ballot(fin);
                 const bool quad_fin = ((bal >> (lane & ~3)) & 0xfull) == 0xfull;
-                if (act && quad_fin) c += 64, mine = nxt;
-                act = act && quad_fin && c < qe;
+                if (act && quad_fin) ucur += ustep, rec0 = rec1, rec1 = rec2, rec2 = rec3;
+                act = act && quad_fin && ucur - c4 < uend;
             }
-            cq[r] = c;
         }
 #endif
 #pragma unroll
@@ -941,26 +952,31 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
             if (r < S6_RC) sent[pass ^ 1][r] = nxt_ent[q];
         }
     }
-    // ---- the four waves' partial moments of the upper slots: added through LDS in wave order
+    // ---- the units' partial moments: to LDS (behind the moments and M, in the rows' area), then every block the sum of its
+    // units' partials in unit order
+    __syncthreads();  // the passes are over: the rows' area is free
+    float* upart = reinterpret_cast<float*>(s6_dyn + sizeof(float) * (64 + 48) * S6_MAXSLOT);  // [64 units][64]
+    __shared__ uint32_t uts[64];
+    if (tid < 64) uts[tid] = s.utab[(size_t)a * 64 + tid];
+    if (nup > 0) {
+        float* d0 = upart + 64 * (wave * 16 + g16) + 8 * (2 * c4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d0[e] = mu[e].x, d0[8 + e] = mu[e].y;
+    }
     __syncthreads();
-#pragma unroll 1
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int r = 0; r < ROUNDS; ++r) {
-                const int q = fu + 16 * r + g16;
-                if (q < cnt) {
-                    float* d0 = &accS[q][8 * (2 * c4)];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        d0[e]     = w == 0 ? mq[r][e].x : d0[e] + mq[r][e].x;
-                        d0[8 + e] = w == 0 ? mq[r][e].y : d0[8 + e] + mq[r][e].y;
-                    }
-                }
+    if (nup > 0) {
+        const int e = tid & 63;
+        for (int u = tid >> 6; u < 64; u += 4) {
+            const uint32_t info = uts[u];
+            const int q = (int)(info & 255u), n = (int)((info >> 16) & 255u);
+            if (q >= fu && q < cnt && ((info >> 8) & 255u) == 0u) {  // the first unit of block q
+                float sum = upart[64 * u + e];
+                for (int i = 1; i < n; ++i) sum += upart[64 * (u + i) + e];
+                accS[q][e] = sum;
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
     // slot 0: the waves' partials (fixed order)
     if (tid < 64 && cnt > 0) accS[0][tid] = (part0[0][tid] + part0[1][tid]) + (part0[2][tid] + part0[3][tid]);
     if (tid >= 64 && tid < 72) g8s[tid - 64] = (part0[0][tid] + part0[1][tid]) + (part0[2][tid] + part0[3][tid]);
@@ -1412,7 +1428,7 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
         const int rc = rc_env ? rc_env : (s.k <= 4 ? 320 : 256);
 #define S6A2(KK, RC)                                                                                              \
     do {                                                                                                          \
-        const size_t sh = std::max((size_t)(RC) * (32 + 4 * (KK) + 16), (size_t)S6_MAXSLOT * (64 + 48) * 4);        \
+        const size_t sh = std::max((size_t)(RC) * (32 + 4 * (KK) + 16), (size_t)S6_MAXSLOT * (64 + 48) * 4 + 64 * 64 * 4); \
         if (sh > 48 * 1024) {                                                                                     \
             const hipError_t ae = allow_dynamic_lds((const void*)s6_assemble2_kernel<KK, RC>, (int)sh);             \
             if (ae != hipSuccess) return ae;                                                                      \

@@ -93,6 +93,10 @@ struct Solve6View {
     int32_t* bcnt;   // D
     int32_t* bfu;    // D  first "upper" slot of the row (column > row; slots 1 .. bfu-1 are mirrored from their columns' rows)
     uint8_t* rslot;  // D x cap  slot of the row's node in the row of each of its columns
+    // The 64 work units (4 waves x 16 quads) of a node's assembly workgroup: unit u walks groups phase, phase + stride, ...
+    // (4 records each) of the pair list of block `slot` — longer lists get more units, so that every unit walks about
+    // the same number of records.  utab[64 a + u] = slot | phase << 8 | stride << 16; slot 255: idle.
+    uint32_t* utab;  // D x 64
     uint8_t* eslot;  // (N k) x k scratch of s6_pattern (nodes whose slot bytes do not fit its LDS buffer)
     // the same relation by slot: for node a and slot q >= 1, pair_list[pair_ptr[a (cap+1) + q] .. pair_ptr[.. q+1]) are
     // the (row of a's list << 4 | neighbour) pairs that land in slot q, ascending (slot 0 = every row's own neighbour)
