@@ -469,7 +469,7 @@ def northstar_rooflines(seq, config, st, tm, fuse_ms):
 
     kk = 4 if k <= 4 else 8
     ents = [
-        entry("s6_assemble2_kernel<%d,%d> (block normal matrix of one Gauss-Newton iteration)" % (kk, 320 if kk == 4 else 256),
+        entry("s6_assemble2_kernel<%d,320> (block normal matrix of one Gauss-Newton iteration)" % kk,
               "s6_assemble", asm_ms, asm_bytes, gn, tm["assemble_ms"],
               note="a quad of lanes per matrix block walks the block's (row, neighbour) list; bound by LDS latency and the "
                    "imbalance between lists, not by HBM (DESIGN.md 4.5)"),

@@ -725,7 +725,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int S6_REGIN = 24;  // arriving regularisation edges staged in LDS (more: read from global memory)
 
 #ifndef DFA_S6_WAVES
-#define DFA_S6_WAVES 3
+#define DFA_S6_WAVES 4  // waves per SIMD the register allocation aims at (<= 128 VGPRs): C2 0.087 -> 0.077 ms, C3 0.340 -> 0.321
 #endif
 template <int K, int S6_RC>
 __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6View s, Solve6State* st, float wreg2, float damping, float tol2) {
@@ -733,9 +733,11 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
     float(*sl8)[8]  = reinterpret_cast<float(*)[8]>(s6_dyn);                                      // l = (lW, lD)
     float(*scf)[K]  = reinterpret_cast<float(*)[K]>(s6_dyn + sizeof(float) * 8 * S6_RC);          // rho f_own f_j
     float4* sra     = reinterpret_cast<float4*>(s6_dyn + sizeof(float) * (8 + K) * S6_RC);       // rho f_own, rho res f_own, rho f_own^2
-    // after the passes the rows' area holds the finished moments (64 floats per slot) and M of the column nodes (48 per slot)
-    float(*accS)[64] = reinterpret_cast<float(*)[64]>(s6_dyn);
-    float* smb       = reinterpret_cast<float*>(s6_dyn + sizeof(float) * 64 * S6_MAXSLOT);
+    // after the passes the dynamic segment holds, in turn: the 64 units' partial moments [0, 16 KiB); the finished moments
+    // (64 floats per slot) behind them; M of the column nodes (48 floats per slot) over the — by then dead — partials
+    float* upart     = reinterpret_cast<float*>(s6_dyn);                                                   // [64 units][64]
+    float(*accS)[64] = reinterpret_cast<float(*)[64]>(s6_dyn + sizeof(float) * 64 * 64);
+    float* smb       = reinterpret_cast<float*>(s6_dyn);
     // (the launcher sizes the dynamic segment for the larger of the two uses)
     __shared__ float part0[4][72];        // slot 0 per wave: 8 x 8 moment + g8
     __shared__ float g8s[8];
@@ -955,7 +957,6 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
     // ---- the units' partial moments: to LDS (behind the moments and M, in the rows' area), then every block the sum of its
     // units' partials in unit order
     __syncthreads();  // the passes are over: the rows' area is free
-    float* upart = reinterpret_cast<float*>(s6_dyn + sizeof(float) * (64 + 48) * S6_MAXSLOT);  // [64 units][64]
     __shared__ uint32_t uts[64];
     if (tid < 64) uts[tid] = s.utab[(size_t)a * 64 + tid];
     if (nup > 0) {
@@ -1422,13 +1423,13 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
     }
     const float tol2 = eta * eta;
     {
-        // rows staged per pass (DFA_S6_RC for A/B).  Third form, C2 (k = 4) / C3 (k = 8): 192 0.101 / 0.386 ms, 256 0.100 /
-        // 0.358, 320 0.096 / 0.384, 448 0.097 / 0.360 — flat: the passes are no longer what costs
+        // rows staged per pass (DFA_S6_RC for A/B).  Work-unit form, C2 (k = 4) / C3 (k = 8): 192 - / 0.354 ms, 256 0.087 /
+        // 0.322, 320 0.078 / 0.315, 448 0.082 / - (up to 358 rows at k = 8 the dynamic segment is set by the closing phase)
         static const int rc_env = getenv("DFA_S6_RC") ? atoi(getenv("DFA_S6_RC")) : 0;
-        const int rc = rc_env ? rc_env : (s.k <= 4 ? 320 : 256);
+        const int rc = rc_env ? rc_env : 320;
 #define S6A2(KK, RC)                                                                                              \
     do {                                                                                                          \
-        const size_t sh = std::max((size_t)(RC) * (32 + 4 * (KK) + 16), (size_t)S6_MAXSLOT * (64 + 48) * 4 + 64 * 64 * 4); \
+        const size_t sh = std::max((size_t)(RC) * (32 + 4 * (KK) + 16), (size_t)(64 * 64 + S6_MAXSLOT * 64) * 4);      \
         if (sh > 48 * 1024) {                                                                                     \
             const hipError_t ae = allow_dynamic_lds((const void*)s6_assemble2_kernel<KK, RC>, (int)sh);             \
             if (ae != hipSuccess) return ae;                                                                      \
@@ -1438,6 +1439,7 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
         if (s.k <= 4) {
             if (rc <= 256) S6A2(4, 256);
             else if (rc <= 320) S6A2(4, 320);
+            else if (rc <= 448) S6A2(4, 448);
             else S6A2(4, 640);
         } else {
             if (rc <= 192) S6A2(8, 192);
