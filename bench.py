@@ -88,6 +88,8 @@ def parse():
                     help="ref: the reference's translation-only energy (energy.t); northstar: 6-DoF DQ-blend / "
                          "projective point-to-plane / ARAP solve (DESIGN.md 4.5) against the live depth map")
     ap.add_argument("--linear-iter", type=int, default=0, help="PCG iteration cap (default: 256 ref, 64 northstar)")
+    ap.add_argument("--forcing", default="adaptive", choices=["adaptive", "geometric"],
+                    help="northstar: PCG tolerance per Gauss-Newton iteration — Eisenstat-Walker (default) or 0.1 x 0.5^i")
     ap.add_argument("--no-adaptive-launch", action="store_true",
                     help="northstar: enqueue the full PCG launch budget of every Gauss-Newton iteration (A/B of "
                          "dfa_solve6_params.adaptive_launch)")
@@ -278,7 +280,8 @@ class Sequence:
         self.plan_free[i] = ev
 
 
-NS_PCG = dict(pcg_tol=1e-3, pcg_tol_first=0.1, pcg_tol_decay=0.5, adaptive_launch=1)  # inexact Newton
+# inexact Newton with the Eisenstat-Walker forcing term (--forcing geometric: 0.1 x 0.5^i instead)
+NS_PCG = dict(pcg_tol=1e-3, pcg_tol_first=0.1, pcg_tol_decay=0.5, pcg_tol_adapt=0.9, adaptive_launch=1)
 
 
 class Sequence6(Sequence):
@@ -489,8 +492,12 @@ def northstar_fields(seq, st):
     return dict(gn_iterations=st["gn_iters"], pcg_iterations=st["pcg_iters"], pcg_iterations_per_gn=st["pcg_it_hist"],
                 pcg_iteration_cap=seq.params.linear_iter,
                 pcg_relative_residual_per_gn=[round(r, 5) for r in st["pcg_rel_hist"]],
-                pcg_tolerance_schedule="max(%g, %g x %g^i) at Gauss-Newton iteration i of an outer iteration" %
-                                       (seq.pcg["pcg_tol"], seq.pcg["pcg_tol_first"], seq.pcg["pcg_tol_decay"]),
+                pcg_tolerance_per_gn=[round(t, 5) for t in st["pcg_tol_hist"]],
+                pcg_tolerance_schedule=("Eisenstat-Walker: %g first, then clamp(%g x (r.z)_0,i / (r.z)_0,i-1, %g, %g)" %
+                                        (seq.pcg["pcg_tol_first"], seq.pcg["pcg_tol_adapt"], seq.pcg["pcg_tol"], seq.pcg["pcg_tol_first"])
+                                        if seq.pcg.get("pcg_tol_adapt", 0) > 0 else
+                                        "max(%g, %g x %g^i) at Gauss-Newton iteration i of an outer iteration" %
+                                        (seq.pcg["pcg_tol"], seq.pcg["pcg_tol_first"], seq.pcg["pcg_tol_decay"])),
                 pcg_launches=st["pcg_launches"], pcgs_cut_short_by_the_launch_budget=st["pcg_short"],
                 valid_rows=st["valid_last"], cost_per_gn=[float("%.5g" % c) for c in st["cost_hist"]])
 
@@ -534,7 +541,12 @@ def main_northstar(args, torch, replicas, rank, world, device):
     last timed frame)."""
     n_gpus = world
     lin = args.linear_iter or 64
-    seq = Sequence6(args.config, device, lin, dict(NS_PCG, adaptive_launch=0) if args.no_adaptive_launch else None)
+    pcg = dict(NS_PCG)
+    if args.no_adaptive_launch:
+        pcg["adaptive_launch"] = 0
+    if args.forcing == "geometric":
+        pcg["pcg_tol_adapt"] = 0.0
+    seq = Sequence6(args.config, device, lin, pcg)
     seq.fuse_first = args.fuse_first
     cfg = seq.cfg
     K, Wm = args.steps, args.warmup

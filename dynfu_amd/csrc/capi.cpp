@@ -1088,10 +1088,12 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
     REQUIRE(prm->num_iter >= 0 && prm->gn_iter >= 0 && prm->linear_iter >= 0, "negative iteration count");
     REQUIRE(prm->tukey_offset > 0.f && prm->psi_data > 0.f && prm->psi_reg > 0.f, "non-positive robust parameter");
     REQUIRE(prm->damping >= 0.f && prm->lambda >= 0.f, "negative damping / lambda");
-    REQUIRE(prm->pcg_tol_first <= 0.f || (prm->pcg_tol_decay > 0.f && prm->pcg_tol_decay <= 1.f), "forcing decay outside (0, 1]");
+    REQUIRE(prm->pcg_tol_first <= 0.f || prm->pcg_tol_adapt > 0.f || (prm->pcg_tol_decay > 0.f && prm->pcg_tol_decay <= 1.f),
+            "forcing decay outside (0, 1]");
+    REQUIRE(prm->pcg_tol_adapt >= 0.f, "negative adaptive forcing factor");
     dfa::Solve6Params p{prm->num_iter, prm->gn_iter, prm->linear_iter, prm->tukey_offset, prm->psi_data, prm->lambda,
                         prm->psi_reg, prm->dist_thresh, prm->cos_thresh, prm->damping, prm->pcg_tol, prm->pcg_tol_first,
-                        prm->pcg_tol_decay};
+                        prm->pcg_tol_decay, prm->pcg_tol_adapt};
     dfa::Solve6Image img{live_vertex_map, live_normal_map, vertex_step, normal_step, cols, rows, fx, fy, cx, cy};
     hipStream_t st = S(stream);
     s->ev_used = 0;
@@ -1217,6 +1219,7 @@ int dfa_solver6_get_stats(dfa_solver6* s, dfa_solve6_stats* out, dfa_stream_t st
         const bool in = i < h.gn_iters;
         out->cost_hist[i] = in ? h.cost_hist[i] : 0.0;
         out->pcg_rel_hist[i] = in ? h.pcg_rel_hist[i] : 0.f;
+        out->pcg_tol_hist[i] = in ? h.pcg_tol_hist[i] : 0.f;
         out->pcg_it_hist[i] = in ? h.pcg_it_hist[i] : 0;
     }
     return h.overflow ? fail(DFA_ERR_CAPACITY, "a block row of the normal matrix exceeded the plan's capacity") : DFA_OK;

@@ -410,13 +410,14 @@ __device__ void inv6(const float* M, float* out) {
 
 // bookkeeping of the linearisation that just finished (one thread of the assembly launch): costs, the slot of this
 // Gauss-Newton iteration in the per-iteration history, the stop test of the PCG that follows
-__device__ __forceinline__ void s6_bookkeeping(Solve6State* st, float tol2) {
+__device__ __forceinline__ void s6_bookkeeping(Solve6State* st, const S6Forcing f) {
     if (!st->have_first) st->initial_cost = st->cost, st->valid_first = st->valid, st->have_first = 1;
     st->final_cost = st->cost, st->valid_last = st->valid;
     const int h = st->gn_iters;
-    if (h < S6_HIST) st->cost_hist[h] = st->cost, st->pcg_it_hist[h] = 0, st->pcg_rel_hist[h] = 1.f;
+    if (h < S6_HIST) st->cost_hist[h] = st->cost, st->pcg_it_hist[h] = 0, st->pcg_rel_hist[h] = 1.f, st->pcg_tol_hist[h] = sqrtf(f.tol2);
     st->gn_iters = h + 1;
-    st->tol2 = tol2, st->pcg_last_it = 0, st->pcg_done = 0;
+    st->tol2 = f.tol2, st->pcg_last_it = 0, st->pcg_done = 0;
+    st->ew_gamma = f.ew_gamma, st->ew_min2 = f.ew_min2, st->ew_max2 = f.ew_max2, st->ew_slot = f.ew_slot;
 }
 
 // column c of the inverse of a symmetric positive definite 6x6 (every caller lane factorises for itself: six lanes invert
@@ -728,7 +729,8 @@ constexpr int S6_REGIN = 24;  // arriving regularisation edges staged in LDS (mo
 #define DFA_S6_WAVES 4  // waves per SIMD the register allocation aims at (<= 128 VGPRs): C2 0.087 -> 0.077 ms, C3 0.340 -> 0.321
 #endif
 template <int K, int S6_RC>
-__global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6View s, Solve6State* st, float wreg2, float damping, float tol2) {
+__global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6View s, Solve6State* st, float wreg2, float damping,
+                                                                         const S6Forcing forcing) {
     extern __shared__ __attribute__((aligned(16))) char s6_dyn[];
     float(*sl8)[8]  = reinterpret_cast<float(*)[8]>(s6_dyn);                                      // l = (lW, lD)
     float(*scf)[K]  = reinterpret_cast<float(*)[K]>(s6_dyn + sizeof(float) * 8 * S6_RC);          // rho f_own f_j
@@ -746,7 +748,7 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
     __shared__ float rout[8][24];         // edges leaving a: neighbour (bits), weight, residual (3), vectors (18)
     __shared__ float rin[S6_REGIN][24];   // edges arriving at a: source node (bits), weight, residual (3), vectors (18)
     const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
-    if (a == 0 && tid == 0) s6_bookkeeping(st, tol2);
+    if (a == 0 && tid == 0) s6_bookkeeping(st, forcing);
     const int cnt = s.bcnt[a], fu = s.bfu[a];
     const int beg = s.node_ptr[a], len = s.node_ptr[a + 1] - beg;
     const int wave = tid >> 6, lane = tid & 63, g16 = lane >> 2, c4 = lane & 3;
@@ -1127,7 +1129,7 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(So
     const int done = st->pcg_done;
     float gp[MAXP], dp[MAXP];
     float gamma_prev = 1.f, alpha_prev = 1.f, rz0 = 0.f;
-    const float tol2 = st->tol2;
+    float tol2 = st->tol2;
     if (it >= 0) {
 #pragma unroll
         for (int q = 0; q < MAXP; ++q) {
@@ -1189,6 +1191,24 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(So
             denom -= beta * gamma / alpha_prev;
         } else {
             rz0 = gamma;
+            // Eisenstat-Walker forcing term (choice 2, alpha = 2): the tolerance of this PCG from the gradients of this and
+            // of the previous linearisation — the same value in every workgroup; one thread records it for the launches
+            // that follow
+            const int slot   = st->ew_slot & 1;
+            const float prev = st->rz0_gn[slot ^ 1];
+            const float eg   = st->ew_gamma;
+            if (eg > 0.f && prev > 0.f) {
+                const float eta = eg * gamma / prev;
+                tol2            = fminf(fmaxf(eta * eta, st->ew_min2), st->ew_max2);
+            }
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                st->rz0_gn[slot] = gamma;
+                if (eg > 0.f && prev > 0.f) {
+                    st->tol2 = tol2;
+                    const int h = st->gn_iters - 1;
+                    if (h >= 0 && h < S6_HIST) st->pcg_tol_hist[h] = sqrtf(tol2);
+                }
+            }
         }
         // converged, or breakdown: the same decision in every workgroup
         if (!(gamma > 0.f) || gamma <= tol2 * rz0 || !(denom > 0.f)) {
@@ -1329,7 +1349,7 @@ __global__ __launch_bounds__(256) void s6_begin_kernel(Solve6View s, Solve6State
         st->cost = 0.0, st->initial_cost = 0.0, st->final_cost = 0.0;
         st->valid = st->valid_first = st->valid_last = 0ull;
         st->have_first = 0, st->gn_iters = 0, st->pcg_iters = 0;  // overflow / max_row_blocks belong to the pattern
-        st->pcg_done = 0, st->rz0 = 0.f, st->pcg_short = 0;
+        st->pcg_done = 0, st->rz0 = 0.f, st->pcg_short = 0, st->rz0_gn[0] = st->rz0_gn[1] = 0.f;
     }
     if (i < 8 * s.D) s.dq[i] = node_dq[i];
     if (i < s.N) s.rho[i] = 0.f;
@@ -1415,13 +1435,19 @@ hipError_t s6_linearise(const Solve6View& s, Solve6State* state, const Solve6Ima
 
 hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Params& p, int gn_in_outer, hipStream_t st) {
     const float wreg2 = p.lambda / ((float)s.D * (float)s.k);
-    float eta = p.pcg_tol;
-    if (p.pcg_tol_first > 0.f) {
+    S6Forcing f{p.pcg_tol * p.pcg_tol, 0.f, 0.f, 0.f, gn_in_outer & 1};
+    if (p.pcg_tol_first > 0.f && p.pcg_tol_adapt > 0.f) {
+        // adaptive: the first iteration of an outer iteration at pcg_tol_first (no previous gradient under these weights),
+        // the others decided on the device; ew_gamma = 0 keeps the tolerance given here
+        const float hi = std::max(p.pcg_tol_first, p.pcg_tol);
+        f.tol2 = hi * hi, f.ew_min2 = p.pcg_tol * p.pcg_tol, f.ew_max2 = hi * hi;
+        f.ew_gamma = gn_in_outer > 0 ? p.pcg_tol_adapt : 0.f;
+    } else if (p.pcg_tol_first > 0.f) {
         float e = p.pcg_tol_first;
         for (int i = 0; i < gn_in_outer; ++i) e *= p.pcg_tol_decay;
-        eta = std::max(eta, e);
+        const float eta = std::max(p.pcg_tol, e);
+        f.tol2 = eta * eta;
     }
-    const float tol2 = eta * eta;
     {
         // rows staged per pass (DFA_S6_RC for A/B).  Work-unit form, C2 (k = 4) / C3 (k = 8): 192 - / 0.354 ms, 256 0.087 /
         // 0.322, 320 0.078 / 0.315, 448 0.082 / - (up to 358 rows at k = 8 the dynamic segment is set by the closing phase)
@@ -1434,7 +1460,7 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
             const hipError_t ae = allow_dynamic_lds((const void*)s6_assemble2_kernel<KK, RC>, (int)sh);             \
             if (ae != hipSuccess) return ae;                                                                      \
         }                                                                                                         \
-        s6_assemble2_kernel<KK, RC><<<s.D, 256, sh, st>>>(s, state, wreg2, p.damping, tol2);                            \
+        s6_assemble2_kernel<KK, RC><<<s.D, 256, sh, st>>>(s, state, wreg2, p.damping, f);                            \
     } while (0)
         if (s.k <= 4) {
             if (rc <= 256) S6A2(4, 256);

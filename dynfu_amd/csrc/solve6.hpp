@@ -12,6 +12,9 @@ struct Solve6Params {
     // inexact-Newton forcing: Gauss-Newton iteration i of an outer iteration stops its PCG at
     // max(pcg_tol, pcg_tol_first * pcg_tol_decay^i); pcg_tol_first <= 0: constant pcg_tol
     float pcg_tol_first, pcg_tol_decay;
+    // pcg_tol_adapt > 0: Eisenstat-Walker forcing (choice 2, alpha = 2) instead of the geometric schedule: iteration i > 0
+    // of an outer iteration stops at clamp(pcg_tol_adapt (r.z)_0,i / (r.z)_0,i-1, pcg_tol, pcg_tol_first)
+    float pcg_tol_adapt;
 };
 
 constexpr int S6_HIST = 32;  // = DFA_SOLVE6_HIST of include/dynfu_amd.h
@@ -29,7 +32,12 @@ struct Solve6State {
     int pcg_done;        // sticky flag of the PCG in flight
     float rz0;           // (r, u) of its first iteration
     float gamma_prev[2], alpha_prev[2];  // scalars of the previous iteration (ping-pong)
-    float tol2;          // stop test of the PCG in flight: (r, u) <= tol2 (r, u)_0   (set by the assembly launch)
+    float tol2;          // stop test of the PCG in flight: (r, u) <= tol2 (r, u)_0   (set by the assembly launch; with the
+                         // adaptive forcing term: by the PCG's first step, from the two gradients)
+    float ew_gamma, ew_min2, ew_max2;  // adaptive forcing of the PCG in flight: factor (0: off), bounds of tol2
+    int ew_slot;         // parity of the Gauss-Newton iteration inside its outer iteration
+    float rz0_gn[2];     // (r, u)_0 of this and of the previous Gauss-Newton iteration (by parity)
+    float pcg_tol_hist[S6_HIST];  // the relative residual every PCG was asked for
     int pcg_last_it;     // iterations the PCG in flight has completed
     int pcg_short;       // PCGs of this solve that used every launch enqueued for them — fewer than linear_iter, by the plan's
                          // prediction — without reaching their tolerance
@@ -124,6 +132,10 @@ hipError_t s6_linearise(const Solve6View& s, Solve6State* state, const Solve6Ima
                         int update_weights, hipStream_t st);
 // gn_in_outer: index of the Gauss-Newton iteration inside its outer iteration (selects the PCG tolerance of the forcing schedule)
 hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Params& p, int gn_in_outer, hipStream_t st);
+struct S6Forcing {  // what the assembly launch leaves in the state block for the PCG that follows
+    float tol2, ew_gamma, ew_min2, ew_max2;
+    int ew_slot;
+};
 hipError_t s6_pcg(const Solve6View& s, Solve6State* state, const Solve6Params& p, hipStream_t st);
 // launched: step launches enqueued for this PCG (<= linear_iter); mirror: pinned host int[S6_HIST] or null — iterations of
 // every PCG of the solve as the device finishes them, negative when the PCG used every launch without converging

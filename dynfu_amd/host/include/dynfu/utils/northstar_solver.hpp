@@ -28,6 +28,8 @@ struct NorthStarParameters {
     float pcgTol      = 1e-3f;
     float pcgTolFirst = 0.1f;
     float pcgTolDecay = 0.5f;
+    // > 0: the Eisenstat-Walker forcing term instead of the geometric schedule (dfa_solve6_params.pcg_tol_adapt)
+    float pcgTolAdapt = 0.9f;
     // enqueue only as many PCG launches per Gauss-Newton iteration as the previous frames needed (+ a quarter): see
     // dfa_solve6_params.adaptive_launch in dynfu_amd.h
     bool adaptiveLaunch = true;

@@ -135,6 +135,7 @@ void NorthStarSolver::solveAll(const kfusion::cuda::Cloud& vmap, const kfusion::
     p.pcg_tol      = m_params.pcgTol;
     p.pcg_tol_first = m_params.pcgTolFirst;
     p.pcg_tol_decay = m_params.pcgTolDecay;
+    p.pcg_tol_adapt = m_params.pcgTolAdapt;
     p.adaptive_launch = m_params.adaptiveLaunch ? 1 : 0;
     dfa::check(dfa_solver6_solve(I.plan, (const float*)vmap.ptr(), (int)vmap.step(), (const float*)nmap.ptr(), (int)nmap.step(),
                                  vmap.cols(), vmap.rows(), intr.fx, intr.fy, intr.cx, intr.cy, &p, nullptr),

@@ -400,6 +400,14 @@ typedef struct dfa_solve6_params {
     /* Inexact-Newton forcing schedule: Gauss-Newton iteration i (from 0, inside its outer iteration) stops its PCG at
      * the relative residual max(pcg_tol, pcg_tol_first * pcg_tol_decay^i).  pcg_tol_first <= 0: constant pcg_tol. */
     float pcg_tol_first, pcg_tol_decay;
+    /* pcg_tol_adapt > 0 (with pcg_tol_first > 0): the Eisenstat-Walker forcing term ("Choosing the forcing terms in an
+     * inexact Newton method", 1996, choice 2 with alpha = 2) instead of the geometric schedule.  The first Gauss-Newton
+     * iteration of an outer iteration stops its PCG at pcg_tol_first; iteration i > 0 at
+     *     clamp(pcg_tol_adapt * (r.z)_0,i / (r.z)_0,i-1, pcg_tol, pcg_tol_first),
+     * (r.z)_0 = g^T M^-1 g of the linearisation: a gradient that is still falling fast is followed by a tight solve, one
+     * that stagnates (the fit has reached the noise of the depth data) by a loose one.  Decided on the device, by the
+     * first step of every PCG; the value used is reported in dfa_solve6_stats.pcg_tol_hist. */
+    float pcg_tol_adapt;
     /* A PCG iteration is one kernel launch, and a launch whose PCG has already converged still costs ~3.5 us of stream
      * time.  adaptive_launch != 0: the plan enqueues, for Gauss-Newton iteration i of the solve, only as many launches as
      * iteration i of its previous solves needed plus a quarter (at least 2 more, at most linear_iter) — read from a
@@ -425,6 +433,7 @@ typedef struct dfa_solve6_stats {
     double cost_hist[DFA_SOLVE6_HIST];
     float pcg_rel_hist[DFA_SOLVE6_HIST];
     int pcg_it_hist[DFA_SOLVE6_HIST];
+    float pcg_tol_hist[DFA_SOLVE6_HIST]; /* the relative residual every PCG was asked for (the forcing term) */
 } dfa_solve6_stats;
 
 int dfa_solver6_create(int max_D, int max_N, int k /* 1..8 */, dfa_solver6** out);

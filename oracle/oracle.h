@@ -204,6 +204,11 @@ typedef struct {
     /* inexact-Newton forcing schedule: Gauss-Newton iteration i (counted from 0 within its outer iteration) stops
      * its PCG at max(pcg_tol, pcg_tol_first * pcg_tol_decay^i); pcg_tol_first <= 0 = constant pcg_tol */
     float pcg_tol_first, pcg_tol_decay;
+    /* pcg_tol_adapt > 0: Eisenstat-Walker forcing (choice 2, alpha = 2) instead of the geometric schedule — the first
+     * iteration of an outer iteration stops at pcg_tol_first, iteration i > 0 at
+     * clamp(pcg_tol_adapt (r.z)_0,i / (r.z)_0,i-1, pcg_tol, pcg_tol_first): tight while the gradient still falls fast,
+     * loose once it stagnates (at the noise floor of the data) */
+    float pcg_tol_adapt;
     int threads;
 } orc6_params;
 
@@ -218,6 +223,7 @@ typedef struct {
      * relative residual sqrt((r.z) / (r.z)_0) its PCG stopped at */
     double cost_hist[ORC6_HIST], pcg_rel_hist[ORC6_HIST];
     int pcg_it_hist[ORC6_HIST];
+    double pcg_tol_hist[ORC6_HIST]; /* the relative residual every PCG was asked for */
 } orc6_stats;
 
 /* kfusion::device::computePointNormals (src/kfusion/cuda/imgproc.cu:187-215): float4 vertex and

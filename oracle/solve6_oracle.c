@@ -389,6 +389,7 @@ void orc6_solve(const float* node_pos, const float* node_dq_in, const float* nod
 
     memset(stats, 0, sizeof(*stats));
     int first = 1;
+    double rz0_prev = 0;
     for (int outer = 0; outer < prm->num_iter; ++outer) {
         for (int gn = 0; gn < prm->gn_iter; ++gn) {
             const int update_w = gn == 0;
@@ -549,11 +550,18 @@ void orc6_solve(const float* node_pos, const float* node_dq_in, const float* nod
             memcpy(pp, z, sizeof(double) * 6 * (size_t)D);
             const double rz0 = rz;
             double tol = prm->pcg_tol;
-            if (prm->pcg_tol_first > 0) {
+            if (prm->pcg_tol_first > 0 && prm->pcg_tol_adapt > 0) { /* Eisenstat-Walker */
+                double eta = prm->pcg_tol_first;
+                if (gn > 0 && rz0_prev > 0) eta = (double)prm->pcg_tol_adapt * rz0 / rz0_prev;
+                if (eta > prm->pcg_tol_first) eta = prm->pcg_tol_first;
+                if (eta > tol) tol = eta;
+            } else if (prm->pcg_tol_first > 0) {
                 double eta = prm->pcg_tol_first;
                 for (int i = 0; i < gn; ++i) eta *= prm->pcg_tol_decay;
                 if (eta > tol) tol = eta;
             }
+            rz0_prev = rz0;
+            if (hist >= 0) stats->pcg_tol_hist[hist] = tol;
             if (hist >= 0 && !(rz0 > 0)) stats->pcg_rel_hist[hist] = 0.0;
             for (int it = 0; it < prm->linear_iter && rz > 0; ++it) {
                 double pq = 0;

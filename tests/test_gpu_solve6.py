@@ -159,6 +159,37 @@ def test_forcing_schedule_matches_the_oracle(A, name, frame):
     assert 1e-6 < st5["pcg_rel_hist"][0] < 1.0
 
 
+@pytest.mark.parametrize("name,frame", [("T1", 6), ("C2", 7)])
+def test_adaptive_forcing_matches_the_oracle(A, name, frame):
+    """dfa_solve6_params.pcg_tol_adapt: the Eisenstat-Walker forcing term.  The tolerance every PCG was asked for comes out
+    of the device's own gradients — it agrees with the fp64 statement's (15 %: a ratio of two inner products of truncated
+    solves), is tight behind a gradient that fell fast and sits at its upper bound once the fit stagnates; iteration counts
+    and energies as in test_forcing_schedule_matches_the_oracle."""
+    cfg, c, intr, depth = _scene(name, frame)
+    kw = dict(num_iter=2, gn_iter=3, linear_iter=64, lambda_=200.0, pcg_tol=1e-3, pcg_tol_first=0.1, pcg_tol_adapt=0.9)
+    s, dq, st, wv, wn_, dq_ref, st_ref = _solve_both(A, cfg, c, intr, depth, c["node_dq"], threads=_threads(), **kw)
+    assert st["gn_iters"] == st_ref["gn_iters"] == 6
+    assert st["pcg_tol_hist"][0] == pytest.approx(0.1) and st["pcg_tol_hist"][3] == pytest.approx(0.1)  # first of an outer iteration
+    assert st["pcg_tol_hist"][1] < 0.03  # the first step took the energy down by orders of magnitude: a tight solve follows
+    for i in range(6):
+        assert 1e-3 <= st["pcg_tol_hist"][i] <= 0.1 * (1 + 1e-6)
+        assert st["pcg_tol_hist"][i] == pytest.approx(st_ref["pcg_tol_hist"][i], rel=0.15)
+        assert st["pcg_it_hist"][i] < 64 and abs(st["pcg_it_hist"][i] - st_ref["pcg_it_hist"][i]) <= 2 + 0.15 * st_ref["pcg_it_hist"][i]
+        assert 0 < st["pcg_rel_hist"][i] <= st["pcg_tol_hist"][i] * (1 + 1e-5)
+    assert st["final_cost"] == pytest.approx(st_ref["final_cost"], rel=0.02)
+    assert st["final_cost"] < 0.05 * st["initial_cost"]
+    # the same energy as the geometric schedule reaches (which is cheaper over 3 iterations per outer iteration and dearer
+    # over 5: it keeps tightening after the fit has reached the noise — bench.py --forcing geometric)
+    s.solve(*A.compute_points_normals(dev(depth), *intr), *intr,
+            A.Solve6Params(**dict(kw, pcg_tol_adapt=0.0, pcg_tol_decay=0.5)))
+    geo = s.stats()
+    assert st["final_cost"] < 1.1 * geo["final_cost"]
+    # same inputs, same bits
+    s.solve(*A.compute_points_normals(dev(depth), *intr), *intr, A.Solve6Params(**kw))
+    assert np.array_equal(host(s.node_dq()), dq)
+    s.close()
+
+
 def test_more_than_8192_nodes_matches_the_oracle(A):
     """9 216 nodes (k = 4, 1 179 648 vertices): the PCG's scalars are sums of one partial per workgroup of 8 nodes, of
     which a lane keeps 16 in registers — beyond 8 192 nodes the rest is summed in a loop (a round-2 build dropped them:
