@@ -17,7 +17,7 @@ SYMBOLS = [
     "dfa_compute_points_normals", "dfa_solver6_create", "dfa_solver6_destroy", "dfa_solver6_set_problem",
     "dfa_solver6_solve", "dfa_solver6_set_node_transforms", "dfa_solver6_node_dq", "dfa_solver6_warp", "dfa_solver6_get_stats",
     "dfa_solver6_enable_timing", "dfa_solver6_get_timing",
-    "dfa_solver_create", "dfa_solver_destroy", "dfa_solver_set_problem", "dfa_solver_solve",
+    "dfa_solver_create", "dfa_solver_destroy", "dfa_solver_set_problem", "dfa_solver_solve", "dfa_solver_set_deterministic", "dfa_solver_matrix_entries", "dfa_solver_matrix_row_lengths", "dfa_solver_gradient",
     "dfa_solver_translations", "dfa_solver_node_dq", "dfa_solver_tukey_weights", "dfa_solver_huber_weights",
     "dfa_solver_data_graph", "dfa_solver_reg_graph", "dfa_solver_get_stats", "dfa_solver_enable_timing",
     "dfa_solver_get_timing", "dfa_solver_warp_to_live", "dfa_solver_set_overlap_callback",
@@ -147,7 +147,9 @@ def load():
     L.dfa_solver_destroy.restype = None
     L.dfa_solver_set_problem.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, i, vp]
     L.dfa_solver_solve.argtypes = [vp, C.POINTER(SolveParams), vp]
-    for n in ("translations", "node_dq", "tukey_weights", "huber_weights", "data_graph", "reg_graph"):
+    L.dfa_solver_set_deterministic.argtypes = [vp, i]
+    for n in ("translations", "node_dq", "tukey_weights", "huber_weights", "data_graph", "reg_graph", "matrix_entries",
+              "matrix_row_lengths", "gradient"):
         fn = getattr(L, "dfa_solver_" + n)
         fn.argtypes = [vp]
         fn.restype = vp
@@ -466,6 +468,10 @@ class Solver:
                                              _dev(canon_normals, f32), _dev(live, f32, "live"),
                                              _dev(live_normals, f32), self.N, _stream()))
 
+    def set_deterministic(self, on=True):
+        """order-stable variant (dfa_solver_set_deterministic); applies from the next set_problem"""
+        _check(load().dfa_solver_set_deterministic(self._h, 1 if on else 0))
+
     def solve(self, params):
         _check(load().dfa_solver_solve(self._h, C.byref(params), _stream()))
         err, self._overlap_error = getattr(self, "_overlap_error", None), None
@@ -487,6 +493,12 @@ class Solver:
             __cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(int(ptr), False), version=2)
 
         return torch.as_tensor(_Holder(), device="cuda").clone()
+
+    def matrix(self):
+        """(entries (256, D, 2) float32 — value, column bits —, row lengths (D,), gradient (D, 3)) of the last iteration"""
+        torch = _torch()
+        return (self._view("matrix_entries", (256, self.D, 2), torch.float32), self._view("matrix_row_lengths", (self.D,), torch.int32),
+                self._view("gradient", (self.D, 3), torch.float32))
 
     def translations(self):
         return self._view("translations", (self.D, 3), _torch().float32)

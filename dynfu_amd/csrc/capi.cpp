@@ -159,6 +159,7 @@ struct dfa_solver {
     size_t ev_used;
     int timed_solves = 0;
     dfa::MbGraphCache mb_graphs;  // HIP graphs of the many-workgroup PCG's launch chunks
+    bool deterministic = false;  // order-stable variant (dfa_solver_set_deterministic), applied by the next set_problem
     bool just_reset = false;  // the unknowns and the state block were zeroed by set_problem and not touched since
     long long* iters_total = nullptr;  // device: PCG iterations of all solves since enable_timing(1)
     dfa_overlap_fn overlap_fn = nullptr;  // called behind the first assembly launch of every solve
@@ -655,6 +656,10 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
     s->ell_cap     = 256;
     s->has_problem = false;
     s->timing      = false;
+    {
+        const char* e    = getenv("DFA_ASSEMBLE_DETERMINISTIC");
+        s->deterministic = e && atoi(e) != 0;
+    }
     s->ev_used     = 0;
     std::memset(&s->v, 0, sizeof(s->v));
     const size_t R = s->max_R, D = (size_t)max_D;
@@ -677,6 +682,7 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
     A(g_base, D * 3);
     A(t_base, D * 3);
     A(pk_perm, D);
+    A(pk_perm2, D);
     A(pk_vals, D * s->ell_cap);
     A(pk_cols, D * s->ell_cap);
     A(mb_x, D);
@@ -741,6 +747,7 @@ int dfa_solver_set_problem(dfa_solver* s, const float* node_pos, const float* no
                     s->max_D, s->max_N);
     dfa::SolveView& v = s->v;
     v.N = N, v.D = D, v.k = s->k, v.Dpad = (D + 3) & ~3, v.ell_cap = s->ell_cap;
+    v.deterministic = s->deterministic ? 1 : 0;
     v.node_pos = node_pos, v.node_dq = node_dq, v.node_w = node_w;
     v.canon = canon_vertices, v.live = live_vertices;
     hipStream_t st = S(stream);
@@ -757,6 +764,12 @@ int dfa_solver_set_problem(dfa_solver* s, const float* node_pos, const float* no
     HIP_TRY(dfa::solve_build_graph(v, s->state, s->ticket, 64, st));
     s->has_problem = true;
     s->just_reset  = true;
+    return DFA_OK;
+}
+
+int dfa_solver_set_deterministic(dfa_solver* s, int on) {
+    REQUIRE(s, "null plan");
+    s->deterministic = on != 0;
     return DFA_OK;
 }
 
@@ -865,6 +878,9 @@ const float* dfa_solver_tukey_weights(const dfa_solver* s) { return s ? s->v.rta
 const float* dfa_solver_huber_weights(const dfa_solver* s) { return s ? s->v.huber : nullptr; }
 const int32_t* dfa_solver_data_graph(const dfa_solver* s) { return s ? s->v.ridx : nullptr; }
 const int32_t* dfa_solver_reg_graph(const dfa_solver* s) { return s ? s->v.reg_idx : nullptr; }
+const float* dfa_solver_matrix_entries(const dfa_solver* s) { return s ? (const float*)s->v.ell : nullptr; }
+const int32_t* dfa_solver_matrix_row_lengths(const dfa_solver* s) { return s ? s->v.ell_cnt : nullptr; }
+const float* dfa_solver_gradient(const dfa_solver* s) { return s ? s->v.g : nullptr; }
 
 int dfa_solver_warp_to_live(dfa_solver* s, const float* normals, float* out_vertices, float* out_normals,
                             dfa_stream_t stream) {

@@ -563,6 +563,171 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
 }
 
 // ------------------------------------------------------------------------------------------
+// Order-stable variant (SolveView::deterministic).  Three things make two runs of the default path differ in the last
+// bits: the transposition fills a node's row list in the order its LDS cursor atomics land, the assembly above adds
+// into LDS with float atomics from four waves and compacts the hash in slot order (which depends on who inserted a key
+// first), and the PCG kernels place rows of equal length by an atomic cursor (which thread owns which row decides the
+// order of the inner products' partial sums).  Here: lists sorted, per-wave private sums added in wave order, rows of
+// the matrix sorted by column, equal-length rows in index order.
+constexpr int DET_SORT_MAX = 4096;
+
+__global__ __launch_bounds__(256) void sort_node_lists_kernel(const int32_t* __restrict__ node_ptr, uint32_t* __restrict__ node_list) {
+    __shared__ uint32_t buf[DET_SORT_MAX];
+    const int a = blockIdx.x, tid = threadIdx.x;
+    const int beg = node_ptr[a], len = node_ptr[a + 1] - beg;
+    if (len < 2 || len > DET_SORT_MAX) return;  // (longer lists keep the order of the transposition)
+    int n2 = 1;
+    while (n2 < len) n2 <<= 1;
+    for (int i = tid; i < n2; i += 256) buf[i] = i < len ? node_list[beg + i] : 0xffffffffu;
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < n2 / 2; i += 256) {
+                const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint32_t x = buf[lo], y = buf[hi];
+                if ((x > y) == up) buf[lo] = y, buf[hi] = x;
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < len; i += 256) node_list[beg + i] = buf[i];
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void assemble_det_kernel(SolveView s, SolveState* __restrict__ st, int save_base) {
+    __shared__ int key[HASH];
+    __shared__ float val[4][HASH];  // a private copy per wave: LDS adds of ONE wave execute in program order
+    __shared__ float gpart[4][3], dpart[4];
+    __shared__ int ovf, nkeys;
+    if (st->done || st->converged) return;
+    const int a    = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < HASH; i += 256) key[i] = -1, val[0][i] = val[1][i] = val[2][i] = val[3][i] = 0.f;
+    if (threadIdx.x == 0) ovf = 0, nkeys = 0;
+    __syncthreads();
+    const int beg = s.node_ptr[a], end = s.node_ptr[a + 1];
+    // pass 1: the set of columns (keys only), the gradient and the diagonal
+    float gx = 0.f, gy = 0.f, gz = 0.f, dsum = 0.f;
+    for (int p = beg + (int)threadIdx.x; p < end; p += 256) {
+        const uint32_t e = s.node_list[p];
+        const size_t r   = e / (uint32_t)s.k;
+        const int slot   = (int)(e - (uint32_t)r * (uint32_t)s.k);
+        int idx[K];
+        float w[K];
+        const float4 et = load_record<K>(s, r, idx, w);
+        float wa = 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) wa = (j == slot) ? w[j] : wa;
+        const float tw = et.w * wa;
+        gx += tw * et.x, gy += tw * et.y, gz += tw * et.z;
+        if (et.w != 0.f) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int b = idx[j];
+                if (b < 0) continue;
+                if (b == a) {
+                    dsum += tw * w[j];
+                    continue;
+                }
+                uint32_t h = ((uint32_t)b * 2654435761u) >> (32 - 9);
+                for (int probes = 0;; ++probes) {
+                    const int cur = atomicCAS(&key[h], -1, b);
+                    if (cur == -1 || cur == b) break;
+                    if (probes >= HASH) {
+                        ovf = 1;
+                        break;
+                    }
+                    h = (h + 1) & HASH_MASK;
+                }
+            }
+        }
+    }
+    dsum = wave_total(dsum), gx = wave_total(gx), gy = wave_total(gy), gz = wave_total(gz);
+    if (lane == 0) dpart[wave] = dsum, gpart[wave][0] = gx, gpart[wave][1] = gy, gpart[wave][2] = gz;
+    __syncthreads();
+    const float dtot = (dpart[0] + dpart[1]) + (dpart[2] + dpart[3]);
+    if (threadIdx.x == 0 && dtot != 0.f) {  // the diagonal is a column like the others (as in assemble_kernel: only if non-zero)
+        uint32_t h = ((uint32_t)a * 2654435761u) >> (32 - 9);
+        for (int probes = 0; probes < HASH; ++probes, h = (h + 1) & HASH_MASK)
+            if (key[h] == -1) {
+                key[h] = a;
+                break;
+            }
+    }
+    __syncthreads();
+    // pass 2: the values, into this wave's copy (the slot of a column: read-only probes now)
+    for (int p = beg + (int)threadIdx.x; p < end; p += 256) {
+        const uint32_t e = s.node_list[p];
+        const size_t r   = e / (uint32_t)s.k;
+        const int slot   = (int)(e - (uint32_t)r * (uint32_t)s.k);
+        int idx[K];
+        float w[K];
+        const float4 et = load_record<K>(s, r, idx, w);
+        if (et.w == 0.f) continue;
+        float wa = 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) wa = (j == slot) ? w[j] : wa;
+        const float tw = et.w * wa;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int b = idx[j];
+            if (b < 0 || b == a) continue;
+            uint32_t h = ((uint32_t)b * 2654435761u) >> (32 - 9);
+            for (int probes = 0; probes <= HASH && key[h] != b; ++probes) h = (h + 1) & HASH_MASK;
+            if (key[h] == b) atomicAdd(&val[wave][h], tw * w[j]);
+        }
+    }
+    __syncthreads();
+    // output: entry of column c at the position of c among the row's columns (ascending)
+    int total = 0;
+    for (int i = threadIdx.x; i < HASH; i += 256) total += key[i] >= 0;
+    total = (int)wave_total((float)total);
+    if (lane == 0) atomicAdd(&nkeys, total);
+    __syncthreads();
+    total = nkeys;
+    bool has_diag = false;
+    for (int i = threadIdx.x; i < HASH; i += 256) {
+        const int kk = key[i];
+        if (kk < 0) continue;
+        int pos = 0;
+        for (int q = 0; q < HASH; ++q) pos += key[q] >= 0 && key[q] < kk;
+        const float vv = kk == a ? dtot : (val[0][i] + val[1][i]) + (val[2][i] + val[3][i]);
+        if (pos < s.ell_cap) s.ell[(size_t)pos * s.D + a] = make_float2(vv, __int_as_float(kk));
+        if (kk == a) s.diag[a] = vv, has_diag = true;
+    }
+    const bool any_diag = __syncthreads_or(has_diag);
+    if (threadIdx.x == 0) {
+        s.ell_cnt[a] = min(total, s.ell_cap);
+        if (!any_diag) s.diag[a] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float gc = (gpart[0][c] + gpart[1][c]) + (gpart[2][c] + gpart[3][c]);
+            s.g[3 * a + c] = gc;
+            if (save_base) s.g_base[3 * a + c] = gc, s.t_base[3 * a + c] = s.t[3 * a + c];
+        }
+        if (total > *(volatile int*)&st->max_row_nnz) atomicMax(&st->max_row_nnz, total);
+        if (total > s.ell_cap || ovf) st->overflow = 1;
+    }
+}
+
+// rows of equal length in index order: `from` holds the permutation as the atomic cursors left it (ranks in [0, D), rows
+// grouped by length, hist[b] = end of bin b), `to` receives the order-stable one.  Called by all NT threads.
+template <int NT, int R>
+__device__ __forceinline__ void stable_equal_runs(const int32_t* from, int32_t* to, const int32_t* cnt_of_row, const int* hist, int D) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int rank = (int)threadIdx.x + NT * i;
+        if (rank >= D) continue;
+        const int row = from[rank];
+        const int bin = 256 - min(cnt_of_row[row], 256);
+        const int beg = bin > 0 ? hist[bin - 1] : 0, end = hist[bin];
+        int before = 0;
+        for (int q = beg; q < end; ++q) before += from[q] < row;
+        to[beg + before] = row;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // block-Jacobi PCG, one persistent workgroup of 1024 threads; thread owns rows tid + 1024*i.
 
 // Workgroup total: DPP wave totals (float) -> one LDS slot per wave -> ONE barrier -> every
@@ -667,8 +832,12 @@ __device__ __forceinline__ void pcg_stream_body(const SolveView& s, SolveState* 
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < RPT; ++h)
-        if (my_cnt[h] >= 0) s.pk_perm[atomicAdd(&hist[256 - my_cnt[h]], 1)] = tid + NT * h;
+        if (my_cnt[h] >= 0) (s.deterministic ? s.pk_perm2 : s.pk_perm)[atomicAdd(&hist[256 - my_cnt[h]], 1)] = tid + NT * h;
     __syncthreads();  // workgroup-scope visibility of pk_perm
+    if (s.deterministic) {  // (hist[b] is now the end of bin b)
+        stable_equal_runs<NT, RPT>(s.pk_perm2, s.pk_perm, s.ell_cnt, hist, D);
+        __syncthreads();
+    }
 
     // ---- my rows = ranks tid + NT*i; repack them rank-major (coalesced from now on)
     int row[RPT], rcnt[RPT], wmax[RPT];
@@ -915,8 +1084,12 @@ __global__ __launch_bounds__(NT) void pcg_paired_kernel(SolveView s, SolveState*
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < R; ++h)
-        if (my_cnt[h] >= 0) perm[atomicAdd(&hist[256 - my_cnt[h]], 1)] = tid + NT * h;
+        if (my_cnt[h] >= 0) (s.deterministic ? perm + s.Dpad : perm)[atomicAdd(&hist[256 - my_cnt[h]], 1)] = tid + NT * h;
     __syncthreads();
+    if (s.deterministic) {  // (the launcher sized the LDS for a second array of row ids; hist[b] is now the end of bin b)
+        stable_equal_runs<NT, R>(perm + s.Dpad, perm, s.ell_cnt, hist, D);
+        __syncthreads();
+    }
 
     // ---- this thread's pairs: pair j = rank j*NT + t (long, "A") and rank D-1-j*NT-t (short, "B")
     int rowA[P], rowB[P], nA[P], nB[P], cntA_[P], cntB_[P];
@@ -1278,6 +1451,7 @@ hipError_t solve_build_graph(const SolveView& s, SolveState* state, unsigned int
     tg_count_kernel<<<TG_BLOCKS, 1024, lds, st>>>(s.ridx, total, D, s.blk_hist);
     tg_colscan_kernel<<<(D + 255) / 256, 256, 0, st>>>(s.blk_hist, D);
     tg_fill_kernel<<<TG_BLOCKS, 1024, lds, st>>>(s.ridx, total, D, s.blk_hist, s.node_ptr, s.node_list);
+    if (s.deterministic) sort_node_lists_kernel<<<D, 256, 0, st>>>(s.node_ptr, s.node_list);
     return hipGetLastError();
 }
 
@@ -1307,7 +1481,8 @@ hipError_t solve_huber(const SolveView& s, float psi_reg, hipStream_t st) {
 }
 
 hipError_t solve_assemble(const SolveView& s, SolveState* state, int save_base, hipStream_t st) {
-    KDISPATCH(assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base));
+    if (s.deterministic) KDISPATCH(assemble_det_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base));
+    else KDISPATCH(assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base));
     return hipGetLastError();
 }
 
@@ -1740,7 +1915,7 @@ static hipError_t launch_paired_pcg(const SolveView& s, SolveState* state, int m
                                     hipStream_t st) {
     hipError_t e = allow_big_lds(pcg_paired_kernel<NT, P, E, NC>);
     if (e != hipSuccess) return e;
-    const size_t sh = sizeof(float4) * (size_t)s.Dpad + 32 * sizeof(float) + sizeof(int) * (260 + (size_t)s.Dpad);
+    const size_t sh = sizeof(float4) * (size_t)s.Dpad + 32 * sizeof(float) + sizeof(int) * (260 + (size_t)s.Dpad * (s.deterministic ? 2 : 1));
     pcg_paired_kernel<NT, P, E, NC><<<NC == 1 ? 3 : 1, NT, sh, st>>>(s, state, max_iter, pcg_tol);
     return hipGetLastError();
 }

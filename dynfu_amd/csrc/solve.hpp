@@ -54,6 +54,10 @@ __device__ __forceinline__ void solve_mark_at_floor(SolveState* st) {
 
 struct SolveView {
     int N, D, k, Dpad, ell_cap;
+    // Order-stable variant of the solve (dfa_solver_set_deterministic / DFA_ASSEMBLE_DETERMINISTIC=1): node lists sorted,
+    // matrix assembled without cross-wave float atomics into rows sorted by column, rows of equal length in index order
+    // in the PCG kernels — the same bits from the same inputs, for ~1.3x the assembly time.
+    int deterministic;
     // problem (borrowed from the caller)
     const float* node_pos;  // D x 3
     const float* node_dq;   // D x 8
@@ -81,6 +85,7 @@ struct SolveView {
     float* t_base;     // D x 3   ... and the t it was taken at (inner iterations: g = g_base - A (t - t_base))
     // workspace of the streaming PCG: rows sorted by length, rank-major repacked matrix
     int32_t* pk_perm;   // D
+    int32_t* pk_perm2;  // D   (deterministic variant: the permutation before its equal-length runs are put in index order)
     float* pk_vals;     // ell_cap x D
     uint16_t* pk_cols;  // ell_cap x D
     // unknown and outputs

@@ -310,6 +310,16 @@ int dfa_solver_set_problem(dfa_solver* s, const float* node_pos, const float* no
  * the stop flag.  Only the first case (<= 2048 nodes and <= 8 Gauss-Newton iterations) is therefore asynchronous and
  * capturable into a caller's HIP graph; in the others the call blocks the calling thread (hipStreamSynchronize on
  * `stream`) between its launches, also between two invocations of the overlap callback. */
+/* Order-stable variant of the reference-parity solve: the same bits from the same inputs ("or
+ * deterministic segmented reduction for bit-stable results").  The default path reduces a node's rows with LDS float
+ * atomics, compacts the matrix rows in hash order and places rows of equal length by an atomic cursor: two runs of the
+ * same frame differ in the last bits (measured: up to 2e-5 m in the translations after 24 x 16 iterations).  With
+ * on != 0 the node lists are sorted, the assembly adds per-wave private sums in a fixed order into rows sorted by column
+ * (two passes over a node's rows: ~1.3x the assembly time), and the PCG kernels keep equal-length rows in index order.
+ * Takes effect at the next dfa_solver_set_problem.  New plans start with the value of the environment variable
+ * DFA_ASSEMBLE_DETERMINISTIC (unset / 0: off). */
+int dfa_solver_set_deterministic(dfa_solver* s, int on);
+
 int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* params, dfa_stream_t stream);
 
 /* Results (device pointers, valid until the next set_problem/solve on this plan):
@@ -323,6 +333,12 @@ const float* dfa_solver_tukey_weights(const dfa_solver* s);
 const float* dfa_solver_huber_weights(const dfa_solver* s);
 const int32_t* dfa_solver_data_graph(const dfa_solver* s); /* N x k */
 const int32_t* dfa_solver_reg_graph(const dfa_solver* s);  /* D x k */
+/* The normal equations of the LAST Gauss-Newton iteration (for inspection and the reproducibility tests): ELL, slot-major
+ * — entry q of row a at [q * D + a] as two floats (value, column as int bits), capacity 256 slots per row; row lengths
+ * (D); right-hand side -J^T r (D x 3). */
+const float* dfa_solver_matrix_entries(const dfa_solver* s);
+const int32_t* dfa_solver_matrix_row_lengths(const dfa_solver* s);
+const float* dfa_solver_gradient(const dfa_solver* s);
 
 /* Copies the statistics of the last solve to host memory; synchronises `stream`. */
 /* Warpfield::warpToLive (warp_field.cpp:150-171) of the plan's canonical vertices with the SOLVED node transforms
