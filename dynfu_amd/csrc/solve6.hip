@@ -996,9 +996,11 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
 #else
     const int nfin = (1 + nup) * 6;
 #endif
-    for (int t0 = 0; t0 < nfin; t0 += 256) {
-        const int t = t0 + tid;
-        if (t < nfin) {
+    float* ttile = reinterpret_cast<float*>(s6_dyn) + S6_MAXSLOT * 48;  // 256 x 6 floats behind M (the partial moments are dead)
+    for (int t0 = 0; t0 < nfin; t0 += 252) {  // 42 whole blocks per round (a block's six rows stay together)
+        const int t   = t0 + tid;
+        const bool on = tid < 252 && t < nfin;
+        if (on) {
             const int sidx = t / 6, my_row = t - 6 * sidx;
             const int slot = sidx == 0 ? 0 : fu + sidx - 1;
             const int col  = s.bcols[(size_t)a * s.cap + slot];
@@ -1068,20 +1070,30 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
 #pragma unroll
                 for (int d = 0; d < 6; ++d) diag[my_row * 6 + d] = accr[d];
             }
-            float* out = s.bvals + ((size_t)a * s.cap + slot) * 36 + 6 * my_row;
+            float2* out = reinterpret_cast<float2*>(s.bvals + ((size_t)a * s.cap + slot) * 36 + 6 * my_row);
+            out[0] = make_float2(accr[0], accr[1]), out[1] = make_float2(accr[2], accr[3]), out[2] = make_float2(accr[4], accr[5]);
+            // the mirror block H_ba = H_ab^T goes out row by row too (24 contiguous bytes per thread, the block's 144 from six
+            // neighbouring lanes): transposed through LDS — written element by element it cost 4 bytes per store into
+            // somebody else's cache lines (PMC: 135 MB written per launch at C3 for a 21 MB matrix)
+            float* tile = ttile + 6 * (t - t0 - my_row) + my_row;  // block of this thread's slot: 36 floats; column my_row of its transpose
 #pragma unroll
-            for (int d = 0; d < 6; ++d) out[d] = accr[d];
-            if (slot != 0) {  // the mirror block H_ba = H_ab^T: column my_row of it
+            for (int d = 0; d < 6; ++d) tile[6 * d] = accr[d];
+        }
+        __syncthreads();
+        if (on) {
+            const int sidx = t / 6, my_row = t - 6 * sidx;
+            const int slot = sidx == 0 ? 0 : fu + sidx - 1;
+            if (slot != 0) {
                 const int rs = s.rslot[(size_t)a * s.cap + slot];
                 if (rs != 255) {
-                    float* out2 = s.bvals + ((size_t)col * s.cap + rs) * 36 + my_row;
-#pragma unroll
-                    for (int d = 0; d < 6; ++d) out2[6 * d] = accr[d];
+                    const float* tr = ttile + 6 * (t - t0 - my_row) + 6 * my_row;  // row my_row of the transposed block
+                    float2* out2    = reinterpret_cast<float2*>(s.bvals + ((size_t)s.bcols[(size_t)a * s.cap + slot] * s.cap + rs) * 36 + 6 * my_row);
+                    out2[0] = make_float2(tr[0], tr[1]), out2[1] = make_float2(tr[2], tr[3]), out2[2] = make_float2(tr[4], tr[5]);
                 }
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
     if (tid < 6) {
         // column tid of M^-1 (= its row tid: symmetric), and with it the start of the PCG for this node:
         // x = 0, r = g, u = M^-1 g, p = s = t = 0
