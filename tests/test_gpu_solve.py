@@ -145,10 +145,10 @@ def test_early_exit_tolerances_reach_same_solution(A):
     assert out[1][1]["pcg_iters"] < 2 * 3 * 256 and out[0][1]["pcg_iters"] < 2 * 3 * 256
 
 
-@pytest.mark.parametrize("name", ["C1", "C3"])
+@pytest.mark.parametrize("name", ["C1", "C3", "C4"])
 def test_large_configs_recover_the_ground_truth_field(A, name):
-    """BASELINE configs C1 (512 nodes, k = 8) and C3 (4096 nodes, k = 8, 524288 vertices): the
-    register-resident (C1) and the streaming (C3) PCG kernels recover the synthetic node
+    """BASELINE configs C1 (512 nodes, k = 8), C3 (4096 nodes, k = 8, 524288 vertices) and C4 (8192 nodes, k = 8,
+    1048576 vertices): the register-resident (C1) and the many-workgroup (C3, C4) PCG kernels recover the synthetic node
     translations; the graph equals the exhaustive-search graph on a sample of the vertices."""
     import torch
     cfg = synth.CONFIGS[name]
