@@ -455,7 +455,9 @@ typedef struct dfa_solve6_stats {
 int dfa_solver6_create(int max_D, int max_N, int k /* 1..8 */, dfa_solver6** out);
 void dfa_solver6_destroy(dfa_solver6* s);
 /* graphs of the frame: k-NN + normalised weights of the canonical vertices, the k nearest other
- * nodes of every node.  All arrays are borrowed until the next set_problem. */
+ * nodes of every node.  The node arrays are borrowed until the next set_problem; the canonical vertices / normals are read
+ * by the work this call enqueues only (the plan keeps its own copy, sorted by nearest node — every output comes back in the
+ * caller's vertex order). */
 int dfa_solver6_set_problem(dfa_solver6* s, const float* node_pos, const float* node_dq, const float* node_w, int D,
                             const float* canon_vertices, const float* canon_normals /* may be NULL */, int N,
                             dfa_stream_t stream);
