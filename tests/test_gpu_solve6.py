@@ -58,7 +58,7 @@ def _solve_both(A, cfg, c, intr, depth, node_dq, threads=8, **kw):
     return s, dq, st, host(wv), host(wn_), dq_ref, st_ref
 
 
-@pytest.mark.parametrize("name,frame,k_override", [("T0", 4, None), ("T1", 6, None), ("T1", 9, 4)])
+@pytest.mark.parametrize("name,frame,k_override", [("T0", 4, None), ("T1", 6, None), ("T1", 9, 4), ("T0", 5, 3), ("T1", 4, 6), ("T0", 2, 1)])
 def test_solve_matches_the_oracle(A, name, frame, k_override):
     cfg, c, intr, depth = _scene(name, frame)
     if k_override:
