@@ -1115,6 +1115,7 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
     s->ev_used = 0;
     HIP_TRY(dfa::s6_begin(s->v, s->state, s->node_dq, st));
     s->last_launches = 0;
+    const bool no_graph = getenv("DFA_S6_NO_GRAPH") != nullptr;  // (A/B; read once per solve)
     for (int outer = 0; outer < p.num_iter; ++outer)
         for (int gn = 0; gn < p.gn_iter; ++gn) {
             auto mark = [&]() {  // 4 events per Gauss-Newton iteration: | linearise | assemble | pcg |
@@ -1147,7 +1148,7 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
             // the PCG launches of one Gauss-Newton iteration are replayed as a HIP graph (one per launch count); if capture
             // is not possible here (it never is on some stream configurations) the launches are issued one by one
             bool replayed = false;
-            if (!s->graph_disabled && !getenv("DFA_S6_NO_GRAPH")) {
+            if (!s->graph_disabled && !no_graph) {
                 if (std::memcmp(&s->pcg_key_view, &s->v, sizeof(s->v)) != 0) {
                     for (auto& g : s->pcg_graphs) (void)hipGraphExecDestroy(g.second);
                     s->pcg_graphs.clear();
