@@ -80,7 +80,7 @@ def parse():
                          "(prints the line of that workload alone)")
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the DynFusion::operator() sequence (the reference's own timed region, C++ adaptor classes)")
-    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded CPU sample")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the bounded CPU sample")
     ap.add_argument("--serial", action="store_true", help="run fuse and solve on one stream (A/B of the overlap)")
     ap.add_argument("--pipeline", action="store_true",
                     help="ref mode: build frame f+1's graphs (k-NN, transposition) on a third stream while frame f is "

@@ -838,7 +838,11 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
                 val[q]      = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < nr) {
                     const uint32_t en = sent[pass][r];
+#if DFA_S6_ABLATE & 8
+                    const size_t v    = (e0 + r) % (size_t)s.N + 0 * en;  // (timing only: contiguous rows instead of the gather)
+#else
                     const size_t v    = k == K ? en / (unsigned)K : en / (unsigned)k;  // (K: a shift)
+#endif
                     if (c < RS4 - 1) val[q] = reinterpret_cast<const float4*>(s.rec + 16 * v)[c];
                     else {
                         const float2 m = *reinterpret_cast<const float2*>(s.rmeta + 2 * v);
