@@ -175,6 +175,32 @@ def test_regulariser_alone_keeps_a_rigid_field_and_smooths_a_rough_one(scene):
     assert st["final_cost"] < 0.05 * st["initial_cost"]
 
 
+def test_forcing_schedules_set_the_tolerance_each_linearisation_stops_at(scene):
+    """Inexact Newton: the geometric schedule is pcg_tol_first * decay^i floored at pcg_tol; the
+    Eisenstat-Walker one starts there and is then gamma * (rz0_i / rz0_(i-1)), clamped to [pcg_tol, pcg_tol_first].  Each PCG
+    stops at the first iterate under its tolerance, and either schedule ends within a few percent of the tight solve."""
+    cfg, c, intr, P, Nm = scene
+    k = cfg["k"]
+    base = dict(num_iter=2, gn_iter=3, linear_iter=400, lambda_=200.0, pcg_tol=1e-4)
+    run = lambda **kw: O.solve6(c["node_pos"], c["node_dq"], c["node_w"], k, c["verts"], c["normals"], P, Nm, intr,
+                                **dict(base, **kw))[1]
+    tight = run()
+    assert np.allclose(tight["pcg_tol_hist"], 1e-4, rtol=1e-6)
+    geo = run(pcg_tol_first=0.1, pcg_tol_decay=0.1)  # the schedule restarts with every re-association (outer iteration)
+    assert np.allclose(geo["pcg_tol_hist"], [0.1, 0.01, 1e-3] * 2, rtol=1e-5)
+    assert np.allclose(run(pcg_tol_first=0.1, pcg_tol_decay=0.1, num_iter=1, gn_iter=6)["pcg_tol_hist"],
+                       [0.1, 0.01, 1e-3, 1e-4, 1e-4, 1e-4], rtol=1e-5)
+    ew = run(pcg_tol_first=0.1, pcg_tol_adapt=0.9)
+    tol = np.array(ew["pcg_tol_hist"])
+    assert tol[0] == pytest.approx(0.1, rel=1e-6) and np.all(tol >= 1e-4 * (1 - 1e-6)) and np.all(tol <= 0.1 * (1 + 1e-6))
+    assert np.any((tol > 1e-4 * 1.01) & (tol < 0.1 * 0.99))  # it follows the residuals: a value strictly inside the clamp
+    for st in (tight, geo, ew):
+        rel, it, t = map(np.array, (st["pcg_rel_hist"], st["pcg_it_hist"], st["pcg_tol_hist"]))
+        assert np.all((rel <= t * (1 + 1e-5)) | (it >= 400))
+    assert geo["pcg_iters"] < tight["pcg_iters"] and ew["pcg_iters"] < tight["pcg_iters"]
+    assert geo["final_cost"] < 1.05 * tight["final_cost"] and ew["final_cost"] < 1.05 * tight["final_cost"]
+
+
 def test_projective_association_oracle_obeys_its_gates():
     """orc_correspond_projective (the gates of find_coresp, proj_icp.cu:72-98) on a hand-made map"""
     fx = fy = 2.0
