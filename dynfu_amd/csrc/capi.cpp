@@ -999,8 +999,7 @@ int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
     A(rnode_list, D * k);
     A(dq, D * 8);
     A(ghat, D * 3);
-    A(rec, N * 16);
-    A(rmeta, N * 2);
+    A(rec, N * (12 + (k <= 4 ? 4 : 8)));
     A(mnode, D * 48);
     A(rho, N);
     A(rres, D * k * 3);
@@ -1010,7 +1009,7 @@ int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
     A(bcnt, D);
     A(bfu, D);
     A(rslot, D * cap);
-    A(utab, D * 64);
+    A(utab, D * 256);
     A(eslot, N * k * k);
     A(pair_list, N * k * k);
     A(pair_ptr, D * (cap + 1));
@@ -1243,3 +1242,15 @@ int dfa_solver6_get_stats(dfa_solver6* s, dfa_solve6_stats* out, dfa_stream_t st
 }
 
 }  // extern "C"
+
+#ifdef DFA_S6_DEBUG  // development builds only: device pointers of the north-star plan (tools/_dbg*.py)
+extern "C" __attribute__((visibility("default"))) int dfa_dev_solver6_ptrs(dfa_solver6* s, void** out) {
+    const dfa::Solve6View& v = s->v;
+    void* p[] = {v.utab, v.pair_ptr, v.pair_list, v.bcnt, v.bfu, (void*)v.node_ptr, (void*)v.node_list, v.bcols, v.bvals, v.g,
+                 (void*)v.idx, v.rec, nullptr, v.mnode, v.rslot};
+    out[18] = v.minv;
+    for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); ++i) out[i] = p[i];
+    out[15] = (void*)(size_t)v.cap, out[16] = (void*)(size_t)v.D, out[17] = (void*)(size_t)v.N;
+    return 0;
+}
+#endif

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void s6_linearise_kernel(Solve6View s, Solve6S
             float f[K];
 #pragma unroll
             for (int j = 0; j < K; ++j) f[j] = j < k ? wn[j] * B.s[j] * im : 0.f;
-            float4* rec = reinterpret_cast<float4*>(s.rec + 16 * (size_t)v);  // one 64-byte line per vertex
+            float4* rec = reinterpret_cast<float4*>(s.rec + (12 + K) * (size_t)v);  // 2 + K / 4 + 1 chunks of 16 bytes per vertex
             rec[0] = make_float4(lW.w, lW.x, lW.y, lW.z), rec[1] = make_float4(lD.w, lD.x, lD.y, lD.z);
 #pragma unroll
             for (int q = 0; q < K / 4; ++q) rec[2 + q] = make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void s6_linearise_kernel(Solve6View s, Solve6S
             nvalid = w_eff > 0.f;
         }
         const float w_out = ok ? w_eff : 0.f;  // (no association: the stale l / f of the record are never used)
-        *reinterpret_cast<float2*>(s.rmeta + 2 * (size_t)v) = make_float2(w_out, w_out * rr);
+        reinterpret_cast<float4*>(s.rec + (12 + K) * (size_t)v)[2 + K / 4] = make_float4(w_out, w_out * rr, 0.f, 0.f);  // the record's last chunk
     }
     block_add_cost(cost, nvalid, st);
 }
@@ -462,6 +462,7 @@ __device__ __forceinline__ void inv6_column(const float* M, float* out, int c, f
 // the diagonal first, then every node that shares a vertex with a or is joined to it by a
 // regularisation edge, ascending.
 constexpr int S6_MAXSLOT_PATTERN = 48;  // = S6_MAXSLOT (declared below), the plan capacity of a block row
+constexpr int S6_UNITS = 256;           // work units of a node's assembly = threads of its workgroup
 
 __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6State* st) {
     __shared__ int keys[S6_HASH];
@@ -537,8 +538,8 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
     // then wave w compacts the lists of slots 1 + w, 5 + w, ... in ascending pair order with ballots: run-to-run identical
     // lists, hence identical sums.
     // The matrix is symmetric, H_ba = H_ab^T: the assembly computes a block once, in the row of the smaller node index, and
-    // writes it to both rows.  Lists are kept for the "upper" slots only (column > a; the columns ascend, so these are
-    // the slots from `fu` on), the others stay empty.
+    // writes it to both rows.  Lists are kept for slot 0 (the row's own neighbour: one record per row) and for the "upper" slots (column > a; the
+    // columns ascend, so these are the slots from `fu` on), the others stay empty.
     __shared__ int pcnt[64], pstart[64];
     __shared__ int fu_sh;
     if (tid < 64) pcnt[tid] = 0;
@@ -569,53 +570,47 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
                 if (lo < stored && cols[lo] == b) sl = lo;
             }
             es[(size_t)r * k + j] = (uint8_t)sl;
-            if (sl >= fu && sl < stored) atomicAdd(&pcnt[sl], 1);
+            if (sl >= fu && sl < stored) atomicAdd(&pcnt[sl], 1);  // (slot 0: one pair per row, counted below)
         }
     }
     __syncthreads();
     if (tid == 0) {
-        int run = pbeg * k;  // the lists of node a live in pair_list[pbeg k, (pbeg + plen) k)
-        for (int q = 1; q < stored; ++q) pstart[q] = run, run += pcnt[q];
+        int run = pbeg * k;  // the lists of node a live in pair_list[pbeg k, (pbeg + plen) k): slot 0 (every row), then the upper slots
+        pcnt[0] = plen;
+        for (int q = 0; q < stored; ++q) pstart[q] = run, run += pcnt[q];
         pstart[stored] = run;
-        pstart[0]      = pbeg * k;
     }
     __syncthreads();
     if (tid <= stored) s.pair_ptr[(size_t)a * (s.cap + 1) + tid] = pstart[tid];
-    // ---- work units of the assembly (first wave): every upper block one unit, then the remaining units one at a time to
-    // the block whose units have the most records each (ties: the lower slot) — a wave-wide arg-max per unit handed out
+    // ---- work units of the assembly: S6_UNITS per node, one per LANE of its workgroup.  A unit walks every n-th record of ONE
+    // block's list (slot 0 — every row — or an upper slot), starting at its `phase`; a block with c of the node's T records
+    // gets 1 + floor((S6_UNITS - blocks) c / T) units, so every unit of the workgroup walks about T / S6_UNITS records and
+    // the units of a block are neighbours (neighbouring lanes read neighbouring rows).
+    __shared__ int ustart[64], ucount[64];
     if (tid < 64) {
-        const int q    = fu + tid;  // lane = upper block
-        const int mine = q < stored ? pcnt[q] : 0;
-        const bool has = q < stored;
-        int n          = has ? 1 : 0;
-        const int nupper = stored > fu ? stored - fu : 0;
-        for (int left = 64 - nupper; left > 0 && nupper > 0; --left) {
-            // records per unit, compared as cross products to stay in integers: mine / n > other / m  <=>  mine m > other n
-            // arg-max by a 6-step butterfly over (value, n, lane)
-            int bv = has ? mine : -1, bn = has ? n : 1, bl = tid;
+        const int q    = tid == 0 ? 0 : fu + tid - 1;  // lane = block: slot 0, then the upper slots
+        const int mine = (tid == 0 || q < stored) ? pcnt[tid == 0 ? 0 : q] : 0;
+        const int nblk2 = __popcll(__ballot(mine > 0));
+        int total = mine;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const int ov = __shfl_xor(bv, o, 64), on = __shfl_xor(bn, o, 64), ol = __shfl_xor(bl, o, 64);
-                const long long lhs = (long long)ov * bn, rhs = (long long)bv * on;
-                if (lhs > rhs || (lhs == rhs && ol < bl)) bv = ov, bn = on, bl = ol;
-            }
-            if (bv <= 4 * bn) break;  // no block has more than one group of four records per unit left to share
-            if (tid == bl) ++n;
-        }
-        // exclusive scan of n over the lanes = first unit of every block
+        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+        const int n = mine > 0 ? 1 + (int)(((long long)(S6_UNITS - nblk2) * mine) / total) : 0;
         int incl = n;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int t = __shfl_up(incl, o, 64);
             if (tid >= o) incl += t;
         }
-        const int u0 = incl - n;
-        __shared__ uint32_t utab_sh[64];
-        utab_sh[tid] = 255u;
-        __builtin_amdgcn_wave_barrier();
-        for (int i = 0; i < n; ++i) utab_sh[u0 + i] = (uint32_t)q | ((uint32_t)i << 8) | ((uint32_t)n << 16);
-        __builtin_amdgcn_wave_barrier();
-        s.utab[(size_t)a * 64 + tid] = utab_sh[tid];
+        ustart[tid] = incl - n, ucount[tid] = n;
+    }
+    __syncthreads();
+    {
+        uint32_t info = 63u;  // idle
+        for (int i = 0; i < 64; ++i) {
+            const int u0 = ustart[i], n = ucount[i];
+            if (tid >= u0 && tid < u0 + n) info = (uint32_t)(i == 0 ? 0 : fu + i - 1) | ((uint32_t)(tid - u0) << 6) | ((uint32_t)n << 16);
+        }
+        s.utab[(size_t)a * S6_UNITS + tid] = info;
     }
     {   // one pass over the pairs per wave: a chunk's slot bytes are read once and matched against the wave's (at most
         // 12) slots — independent ballots instead of one dependent read-compare-ballot chain per slot and chunk
@@ -623,7 +618,7 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
         constexpr int SPW = (S6_MAXSLOT_PATTERN + 3) / 4;
         int out[SPW];
 #pragma unroll
-        for (int i = 0; i < SPW; ++i) out[i] = 1 + wave + 4 * i < stored ? pstart[1 + wave + 4 * i] : 0;
+        for (int i = 0; i < SPW; ++i) out[i] = wave + 4 * i < stored ? pstart[wave + 4 * i] : 0;
         for (int base = 0; base < npairs; base += 64) {
             const int p  = base + lane;
             const int sl = p < npairs ? (int)es[p] : 255;
@@ -631,8 +626,8 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
             const uint32_t packed = ((uint32_t)r << 4) | (uint32_t)(p - r * k);
 #pragma unroll
             for (int i = 0; i < SPW; ++i) {
-                const int q = 1 + wave + 4 * i;
-                if (q < stored && q >= fu) {  // wave-uniform
+                const int q = wave + 4 * i;
+                if (q < stored && (q >= fu || q == 0)) {  // wave-uniform
                     const bool match  = sl == q;
                     const uint64_t mk = __ballot(match);
                     if (match) s.pair_list[out[i] + __popcll(mk & ((1ull << lane) - 1ull))] = packed;
@@ -669,91 +664,105 @@ __global__ __launch_bounds__(256) void s6_rslot_kernel(Solve6View s) {
 // History at 4 k nodes, k = 8 (one Gauss-Newton iteration): one lane per row with LDS atomics 3.7 ms (64-way
 // same-address conflicts); every (slot, c) thread scanning every row 2.2 ms (VALU-bound); per-wave private LDS copies
 // of the moments, rows streamed 1.0 ms, with factored rows 0.81 ms (LDS-bandwidth-bound: 4 KiB read + written per row
-// and wave; the "first form", in the tree until round 3); registers instead of LDS copies 0.65 ms (second form,
-// below); the third form 0.36 ms.
+// and wave; the "first form", in the tree until round 3); registers instead of LDS copies, a wave per slot, 0.65 ms (second
+// form); symmetric blocks, a quad of lanes per work unit 0.315 ms (third form); a LANE per work unit — below.
 constexpr int S6_MAXSLOT = S6_MAXSLOT_PATTERN;  // = plan capacity of a block row
-
-// Second form of the assembly: the moments are accumulated in REGISTERS, slot by slot.
-//
-// The kernel above adds every row into the LDS copies of up to k slots: 4 KiB read + 4 KiB written per row and wave,
-// LDS-bandwidth-bound (0.82 ms per Gauss-Newton iteration at 4 k nodes, k = 8).  Here a wave takes ONE slot at a time and
-// walks the list of the (row, neighbour) pairs that land in it (s6_pattern_kernel, once per frame): 8 pairs per step,
-// lane (g, c) adds rho f_a f_j l_c l[0..7] of pair g to row c of the slot's moment — 8 registers, LDS is only read
-// (broadcasts of the staged rows).  After the list the 8 groups are summed with three shuffles and lanes 0..7 add the
-// moment to the slot's 8 x 8 in LDS.  Slot 0 (every row's own neighbour) is shared by the four waves.
-// Rows are staged S6_RC at a time (f_own and rho f_own precomputed, rows without association zeroed); a node with
-// more rows takes several passes, each slot's cursor continues where the pass before stopped (lists are ascending).
-// value of lane QQ of the caller's quad (DPP quad_perm broadcast: a VALU move, no LDS)
-template <int QQ>
-__device__ __forceinline__ float quad_bcast(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), QQ | (QQ << 2) | (QQ << 4) | (QQ << 6), 0xf, 0xf, true));
-}
-// Sum over the 16 quads of a wave of 16 registers per lane, scattered: lane (quad g, c4) returns the total of v[g]
-// over the lanes with its c4.  Halving exchange: 8 + 4 + 2 + 1 shuffles instead of 16 x 4.
-__device__ __forceinline__ float quads_reduce_scatter(float (&v)[16], int lane) {
-    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
-    float w8[8], w4[4], w2[2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) w8[i] = (b5 ? v[i + 8] : v[i]) + __shfl_xor(b5 ? v[i] : v[i + 8], 32, 64);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w4[i] = (b4 ? w8[i + 4] : w8[i]) + __shfl_xor(b4 ? w8[i] : w8[i + 4], 16, 64);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) w2[i] = (b3 ? w4[i + 2] : w4[i]) + __shfl_xor(b3 ? w4[i] : w4[i + 2], 8, 64);
-    return (b2 ? w2[1] : w2[0]) + __shfl_xor(b2 ? w2[0] : w2[1], 4, 64);
-}
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef DFA_S6_ABLATE
-#define DFA_S6_ABLATE 0  // development builds only (-DDFA_S6_ABLATE=mask): 1 no pair lists, 2 no slot 0, 4 no off-diagonal epilogue
+#define DFA_S6_ABLATE 0  // development builds only (-DDFA_S6_ABLATE=mask): 1 no record walk, 4 no off-diagonal epilogue, 8 contiguous rows
 #endif
 
-// Third form (round 3).  What the second form (a wave walks ONE slot's list, its 16 quads take 16 pairs of it per step
-// and are summed by a 15-shuffle halving exchange per list and pass) spent its time on was not the products but the
-// per-list overhead — ~13 list visits per wave, each with pointer loads, a partly filled last block and the exchange
-// (ablation at C3: pair lists 0.34 of 0.65 ms for 60 FMA-steps' worth of work per wave).  Now:
-//  (1) SYMMETRY: block (a, b) is computed once, by the workgroup of the smaller index, and written to both rows
-//      (H_ba = H_ab^T bit for bit): half the pairs, half the M_a S M_b^T products;
-//  (2) a QUAD PER SLOT: quad g of every wave walks the list of upper slot fu + g (16 lists at a time; the four waves
-//      take interleaved groups of four records of each list), so the 4 lanes of a quad own the slot's 8 x 8 moment (rows
-//      2 c4, 2 c4 + 1: 16 registers) for the whole kernel — no cross-lane reduction at all, the four waves' partial
-//      moments are added through LDS once per node in a fixed order;
-//  (3) two LDS reads per pair instead of five LDS operations per 16: a lane's two l values are neighbours in the staged
-//      row (one 8-byte read), the coefficient rho f_a f_j of every (row, neighbour) is formed once when the rows are
-//      staged, and the quad's lanes hold its next four records (DPP quad broadcast, no cross-lane LDS shuffle);
-//  (4) packed fp32 FMAs (v_pk_fma_f32: both rows of a lane in one instruction);
-//  (5) the regulariser's edges of the node are staged in LDS by the whole workgroup (the six threads of the diagonal
-//      block used to chase them through ~50 dependent global loads), the diagonal block is inverted by six lanes.
+// Fourth form (round 3).  The third form (a quad of lanes owned a unit's 8 x 8 moment, 16 records per wave instruction) was
+// bound by instruction ISSUE, not by memory or LDS: SQ counters at C3 gave 22 k vector instructions per workgroup of which
+// 10 % were the products, the SIMDs' issue slots ~90 % taken, and neither removing exposed load waits nor an XCD-aware
+// node order moved the time (tools/ns_assemble_phases.py).  Per 16 records a wave spent ~30 instructions
+// on decoding the record, the validity selects, the addresses and eight DPP broadcasts, for eight packed FMAs.  Now:
+//  (1) a LANE PER UNIT: every lane walks its own records (s6_pattern: S6_UNITS units per node, every n-th record of one
+//      block's list) and owns that unit's whole moment — decode, addresses and LDS reads serve 64 records per wave
+//      instruction instead of 16, and nothing is exchanged between lanes until the node is finished;
+//  (2) SYMMETRY of the moment itself: S = sum c l l^T has 36 distinct entries, not 64 — 16 packed + 4 scalar FMAs per
+//      record (and 4 packed multiplies for c l);
+//  (3) slot 0 (every row's own neighbour) is a list like the others (its records are (row, own slot), its coefficient the
+//      same rho f_a f_j): no separate loop, no per-pass cross-lane reduction; the gradient's 8 sums ride on its units;
+//  (4) a lane's records come in batches of NG registers, loaded from clamped addresses before the staging barrier;
+//  (5) rows staged by unconditional 16-byte loads from selected addresses (with a branch per kind of chunk the compiler
+//      waited for every load before issuing the next: two loads of different width into one register).
+// Kept from the third form: block (a, b) computed once, by the workgroup of the smaller index, written to both rows
+// (H_ba = H_ab^T bit for bit); the coefficient rho f_a f_j of every (row, neighbour) formed once when the rows are staged;
+// the regulariser's edges of the node staged in LDS; mirror blocks transposed through LDS; the PCG's start in the tail.
 constexpr int S6_REGIN = 24;  // arriving regularisation edges staged in LDS (more: read from global memory)
 
+// position of S[i][j] (= S[j][i]) in a unit's 36 accumulators: even rows i = 2t as pairs (j, j + 1) from j = i — 20
+// numbers; odd rows i = 2t + 1 as pairs from j = i + 1 — 12 numbers; the odd rows' diagonal entries — 4 numbers
+__host__ __device__ constexpr int s6_sym(int i, int j) {
+    if (i > j) { const int t = i; i = j; j = t; }
+    const int t = i >> 1;
+    if ((i & 1) == 0) return 2 * ((t == 0 ? 0 : t == 1 ? 4 : t == 2 ? 7 : 9)) + (j - i);
+    if (j == i) return 32 + t;
+    return 20 + 2 * (t == 0 ? 0 : t == 1 ? 3 : 5) + (j - i - 1);
+}
+
 #ifndef DFA_S6_WAVES
-#define DFA_S6_WAVES 4  // waves per SIMD the register allocation aims at (<= 128 VGPRs): C2 0.087 -> 0.077 ms, C3 0.340 -> 0.321
+#define DFA_S6_WAVES 3  // waves per SIMD the register allocation aims at (three workgroups per CU by LDS: <= 168 VGPRs)
 #endif
-template <int K, int S6_RC>
+#ifdef DFA_S6_TIMING  // development builds only: per-workgroup phase clocks of the assembly (tools/ns_assemble_phases.py)
+__device__ unsigned long long s6_tbuf[16384 * 16];
+#define S6_TICK(var) const unsigned long long var = clock64()
+extern "C" __attribute__((visibility("default"))) int dfa_dev_s6_timing(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(s6_tbuf), sizeof(unsigned long long) * 16 * (size_t)n);
+}
+#else
+#define S6_TICK(var)
+#endif
+#ifdef DFA_S6_DEBUG
+__device__ float s6_dbg[256 * (S6_MAXSLOT * 36 + 8)];
+extern "C" __attribute__((visibility("default"))) int dfa_dev_s6_moments(float* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(s6_dbg), sizeof(float) * 256 * (S6_MAXSLOT * 36 + 8));
+}
+#endif
+#ifdef DFA_S6_DEBUG
+__device__ float s6_dbgm[256 * S6_MAXSLOT * 48];
+extern "C" __attribute__((visibility("default"))) int dfa_dev_s6_m(float* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(s6_dbgm), sizeof(float) * 256 * S6_MAXSLOT * 48);
+}
+#endif
+constexpr size_t s6_assemble_lds(int K, int RC) {  // dynamic segment: the staged rows, later the units' moments + the blocks' sums
+    const size_t rows = (size_t)RC * (32 + 4 * K + 16), closing = (size_t)(S6_UNITS * 36 + S6_MAXSLOT * 36) * 4;
+    return rows > closing ? rows : closing;
+}
+template <int K, int S6_RC, bool KEXACT>  // KEXACT: k == K (the common case: divisions by k are shifts)
 __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6View s, Solve6State* st, float wreg2, float damping,
                                                                          const S6Forcing forcing) {
     extern __shared__ __attribute__((aligned(16))) char s6_dyn[];
-    float(*sl8)[8]  = reinterpret_cast<float(*)[8]>(s6_dyn);                                      // l = (lW, lD)
-    float(*scf)[K]  = reinterpret_cast<float(*)[K]>(s6_dyn + sizeof(float) * 8 * S6_RC);          // rho f_own f_j
-    float4* sra     = reinterpret_cast<float4*>(s6_dyn + sizeof(float) * (8 + K) * S6_RC);       // rho f_own, rho res f_own, rho f_own^2
-    // after the passes the dynamic segment holds, in turn: the 64 units' partial moments [0, 16 KiB); the finished moments
-    // (64 floats per slot) behind them; M of the column nodes (48 floats per slot) over the — by then dead — partials
-    float* upart     = reinterpret_cast<float*>(s6_dyn);                                                   // [64 units][64]
-    float(*accS)[64] = reinterpret_cast<float(*)[64]>(s6_dyn + sizeof(float) * 64 * 64);
+    // a staged row: l = (lW, lD) (32 bytes) | rho f_own f_j, j < K | rho f_own, rho res f_own, rho f_own^2, - : RS bytes, the
+    // order of the 16-byte chunks the row is fetched in (the LDS-DMA writes a wave's 64 chunks to 1 KiB in lane order)
+    constexpr int RS = 32 + 4 * K + 16, CFO = 32, MTO = 32 + 4 * K;
+    // after the passes the dynamic segment holds, in turn: the units' moments [0, 36 KiB); the blocks' sums (36 floats per
+    // slot) behind them; M of the column nodes (48 floats per slot) and the transposition tile over the — by then dead — units
+    float* upart     = reinterpret_cast<float*>(s6_dyn);                                                   // [S6_UNITS][36]
+    float(*accS)[36] = reinterpret_cast<float(*)[36]>(s6_dyn + sizeof(float) * 36 * S6_UNITS);
     float* smb       = reinterpret_cast<float*>(s6_dyn);
-    // (the launcher sizes the dynamic segment for the larger of the two uses)
-    __shared__ float part0[4][72];        // slot 0 per wave: 8 x 8 moment + g8
+    __shared__ float g8w[4][8];           // -J^T r in l coordinates, per wave
     __shared__ float g8s[8];
     __shared__ float diag[36];
     __shared__ float gsh[6];              // -J^T W r of the node
     __shared__ float rout[8][24];         // edges leaving a: neighbour (bits), weight, residual (3), vectors (18)
     __shared__ float rin[S6_REGIN][24];   // edges arriving at a: source node (bits), weight, residual (3), vectors (18)
+    __shared__ uint32_t bfirst[S6_MAXSLOT];  // first unit | units << 16 of every block that has units
     const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
+    S6_TICK(tk0);
+#ifdef DFA_S6_TIMING
+    const unsigned long long wk0 = wall_clock64();
+    unsigned long long tk_stage = 0, tk_prep = 0, tk_up = 0;
+#endif
     if (a == 0 && tid == 0) s6_bookkeeping(st, forcing);
     const int cnt = s.bcnt[a], fu = s.bfu[a];
     const int beg = s.node_ptr[a], len = s.node_ptr[a + 1] - beg;
-    const int wave = tid >> 6, lane = tid & 63, g16 = lane >> 2, c4 = lane & 3;
+    const int wave = tid >> 6, lane = tid & 63;
     const int32_t* pptr = s.pair_ptr + (size_t)a * (s.cap + 1);
     const int rib = s.rnode_ptr[a], nri = s.rnode_ptr[a + 1] - rib;
+    if (tid < S6_MAXSLOT) bfirst[tid] = 0u;
     // ---- the node's regularisation edges (used by the epilogue; loaded first, they fly while the rows are worked on)
     for (int i = tid; i < k * 24; i += 256) {
         const int q = i / 24, f = i - 24 * q, e = a * k + q;
@@ -774,39 +783,35 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
         else if (f < 23) v = s.rvec[18 * (size_t)entry + f - 5];
         rin[q][f] = v;
     }
-    // Lane (g, c4): rows 2 c4 and 2 c4 + 1 of an 8 x 8 outer product.  It reads l[2 c4], l[2 c4 + 1] from LDS (one 8-byte
-    // read) and gets the other six from its quad by DPP.  m[e] = (row 2 c4, row 2 c4 + 1) of column e.
-    auto add_pair = [&](float lo, float hi, float cf, v2f (&m)[8]) __attribute__((always_inline)) {
-        float l[8];
-        l[0] = quad_bcast<0>(lo), l[1] = quad_bcast<0>(hi), l[2] = quad_bcast<1>(lo), l[3] = quad_bcast<1>(hi);
-        l[4] = quad_bcast<2>(lo), l[5] = quad_bcast<2>(hi), l[6] = quad_bcast<3>(lo), l[7] = quad_bcast<3>(hi);
-        v2f f;
-        f.x = cf * lo, f.y = cf * hi;
+    // ---- this lane's work unit (s6_pattern: utab): every un-th record of block uq's list, from its phase on
+    const int nup        = cnt > fu ? cnt - fu : 0;
+    const uint32_t uinfo = s.utab[(size_t)a * S6_UNITS + tid];
+    const int uq         = (int)(uinfo & 63u);
+    const int un         = (int)((uinfo >> 16) & 1023u);
+    const bool uhas      = uq < cnt && (uq == 0 || uq >= fu) && un > 0;
+    const bool uown      = uhas && uq == 0;  // a unit of slot 0: it also sums the gradient
+    int ucur = 0, uend = 0;                  // this lane's next record; end of the list
+    if (uhas) ucur = pptr[uq] + (int)((uinfo >> 6) & 1023u), uend = pptr[uq + 1];
+    v2f me[10], mo[6], G[4];  // even rows of the moment (pairs), odd rows beyond the diagonal (pairs); the gradient
+    float md[4];              // the odd rows' diagonal entries
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            v2f le;
-            le.x = l[e], le.y = l[e];
-            m[e] = __builtin_elementwise_fma(f, le, m[e]);
+    for (int e = 0; e < 10; ++e) me[e] = v2f{0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 6; ++e) mo[e] = v2f{0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) G[e] = v2f{0.f, 0.f}, md[e] = 0.f;
+    // a lane's records are fetched a BATCH of NG at a time into registers that are indexed statically: unconditional loads
+    // from clamped addresses, all in flight together.  The first batch of a pass flies during the staging; a second one in a
+    // pass is rare.  (One record ahead in a rotating register made the compiler wait for the load in the same trip.)
+    constexpr int NG = 8;
+    uint32_t rb[NG];
+    auto load_batch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int at = ucur + g * un;
+            rb[g]        = s.pair_list[uhas && at < uend ? at : 0];
         }
     };
-    // ---- upper blocks: the work unit of this quad (s6_pattern: utab) walks groups of four records of ONE block's pair list,
-    // `phase`, `phase + stride`, ... — lane c4 holds record c4 of a group; the block's 8 x 8 moment (this unit's share of
-    // it) lives in the quad's registers for the whole kernel.  Longer lists have more units: every unit of the workgroup
-    // walks about the same number of records, in every pass (the groups of a unit are spread over the whole list).
-    const int nup        = cnt > fu ? cnt - fu : 0;
-    const uint32_t uinfo = s.utab[(size_t)a * 64 + wave * 16 + g16];
-    const int uq         = (int)(uinfo & 255u);
-    const bool uhas      = uq >= fu && uq < cnt;
-    const int ustep      = 4 * (int)((uinfo >> 16) & 255u);  // records from one of the unit's groups to the next
-    int ucur = 0, uend = 0;                                  // this lane's record of the unit's next group; end of the list
-    if (uhas) ucur = pptr[uq] + 4 * (int)((uinfo >> 8) & 255u) + c4, uend = pptr[uq + 1];
-    v2f mu[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) mu[e] = v2f{0.f, 0.f};
-    auto load_rec = [&](int at) __attribute__((always_inline)) { return uhas && at < uend ? s.pair_list[at] : 0xffffffffu; };
-    // slot 0 (every row's own neighbour) and -J^T r: accumulated per pass and added to the wave's LDS partial right after
-    // the pass's slot-0 loop, so that their 18 registers are free while the upper blocks are worked on
-    for (int i = tid; i < 4 * 72; i += 256) (&part0[0][0])[i] = 0.f;
     constexpr int RS4 = 2 + K / 4 + 1, NCH = (S6_RC * RS4 + 255) / 256;  // 16-byte chunks of a record; chunks per thread and pass
     constexpr int EPT = (S6_RC + 255) / 256;
     __shared__ uint32_t sent[2][S6_RC];  // (vertex k + slot) of the rows of this pass / the next one
@@ -816,8 +821,10 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
         if (r < min(S6_RC, len)) sent[0][r] = s.node_list[beg + r];
     }
     int pass = 0;
+    S6_TICK(tk1);
     for (int r0 = 0; r0 < len; r0 += S6_RC, pass ^= 1) {
         const int nr = min(S6_RC, len - r0);
+        S6_TICK(tp0);
         __syncthreads();  // the pass before is done with the staged rows (and has stored this pass's list entries)
         const size_t e0 = (size_t)(beg + r0);
         // the next pass's list entries: loaded now, parked in LDS at the end of this pass (one register meanwhile)
@@ -827,130 +834,102 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
             const int r = tid + 256 * q;
             nxt_ent[q]  = r0 + S6_RC + r < len ? s.node_list[e0 + S6_RC + r] : 0u;
         }
-        {   // The rows of the pass: one record per vertex (s6_linearise), gathered through the node's row list; RS4 chunks per
-            // row — l (2 x 16 bytes), f (K / 4 x 16 bytes) from the vertex's 64-byte line, (weight, weight x residual) from
-            // the small per-vertex array — one chunk per thread and step, the chunks of a row on neighbouring lanes.  The list entries of this pass were loaded
-            // during the pass before; all of a thread's row loads are issued before the first LDS store.
-            float4 val[NCH];
+        // The rows of the pass: one record per vertex (s6_linearise), gathered through the node's row list; RS4 chunks per row —
+        // l (2 x 16 bytes), f (K / 4 x 16 bytes) from the vertex's 64-byte line, (weight, weight x residual, 0, 0) from the
+        // per-vertex array — one chunk per lane and step, straight into LDS (global_load_lds_dwordx4: no staging registers, no
+        // ds_write pass; rows past the end fetch row 0 again, into rows nobody reads).
+        // (the chunk's row and part are recomputed in every pass: hoisted out of the pass loop, as the compiler would have it,
+        // they are 2 x NCH registers that live — spilled — through the whole kernel.  The list entries are all read before the
+        // first DMA is issued: the compiler orders a ds_read behind an LDS-DMA in flight with s_waitcnt vmcnt(0), one memory
+        // round trip per chunk.)
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+        uint32_t ens[NCH];
 #pragma unroll
-            for (int q = 0; q < NCH; ++q) {
-                const int i = tid + 256 * q, r = i / RS4, c = i - RS4 * r;
-                val[q]      = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r < nr) {
-                    const uint32_t en = sent[pass][r];
+        for (int q = 0; q < NCH; ++q) {
+            const int r = (tl + 256 * q) / RS4;
+            ens[q]      = sent[pass][r < nr ? r : 0];
+        }
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int i = tl + 256 * q, r = i / RS4, c = i - RS4 * r;
 #if DFA_S6_ABLATE & 8
-                    const size_t v    = (e0 + r) % (size_t)s.N + 0 * en;  // (timing only: contiguous rows instead of the gather)
+            const size_t v = (e0 + r) % (size_t)s.N + 0 * ens[q];  // (timing only: contiguous rows instead of the gather)
 #else
-                    const size_t v    = k == K ? en / (unsigned)K : en / (unsigned)k;  // (K: a shift)
+            const size_t v = KEXACT ? ens[q] / (unsigned)K : ens[q] / (unsigned)k;  // (K: a shift)
 #endif
-                    if (c < RS4 - 1) val[q] = reinterpret_cast<const float4*>(s.rec + 16 * v)[c];
-                    else {
-                        const float2 m = *reinterpret_cast<const float2*>(s.rmeta + 2 * v);
-                        val[q]         = make_float4(m.x, m.y, 0.f, 0.f);
-                    }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < NCH; ++q) {
-                const int i = tid + 256 * q, r = i / RS4, c = i - RS4 * r;
-                if (r < nr) {
-                    if (c < 2) reinterpret_cast<float4*>(&sl8[r][0])[c] = val[q];
-                    else if (c < 2 + K / 4) reinterpret_cast<float4*>(&scf[r][0])[c - 2] = val[q];
-                    else {
-                        const uint32_t en = sent[pass][r];
-                        sra[r] = make_float4(val[q].x, val[q].y, __int_as_float((int)(k == K ? en % (unsigned)K : en % (unsigned)k)), 0.f);
-                    }
-                }
-            }
+            const float4* src = reinterpret_cast<const float4*>(s.rec + (12 + K) * v) + c;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(s6_dyn + 16 * (256 * q + 64 * wave)), 16, 0, 0);
         }
-        // the first chunk of records of this pass flies while the rows settle and slot 0 is worked on
-        // this lane's records of the unit's next three groups fly while the rows settle and slot 0 is worked on
-        uint32_t rec0 = load_rec(ucur), rec1 = load_rec(ucur + ustep), rec2 = load_rec(ucur + 2 * ustep);
+        // this lane's next NG records fly while the rows settle
+        load_batch();
         __syncthreads();
-        // per row: (weight, weight x residual, own slot) -> (rho f_own, rho res f_own, rho f_own^2)
+        S6_TICK(tp1);
+        // per row: (weight, weight x residual) -> (rho f_own, rho res f_own, rho f_own^2); f_j -> rho f_own f_j, once per (row,
+        // neighbour).  Rows without association hold stale numbers (0 * NaN is NaN): zero what the products read.
         for (int i = tid; i < nr; i += 256) {
-            const float4 m  = sra[i];
-            const float fo  = scf[i][__float_as_int(m.z)];
-            const float rf  = m.x * fo;
-            sra[i] = m.x != 0.f ? make_float4(rf, m.y * fo, rf * fo, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            char* rp          = s6_dyn + RS * i;
+            const uint32_t en = sent[pass][i];
+            const int oj      = (int)(KEXACT ? en % (unsigned)K : en % (unsigned)k);
+            const float4 m    = *reinterpret_cast<const float4*>(rp + MTO);
+            const float fo    = reinterpret_cast<const float*>(rp + CFO)[oj];
+            const float rf    = m.x * fo;
+            const bool on     = m.x != 0.f;
+            *reinterpret_cast<float4*>(rp + MTO) = on ? make_float4(rf, m.y * fo, rf * fo, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < K / 4; ++c) {
+                float4* p = reinterpret_cast<float4*>(rp + CFO) + c;
+                float4 v  = *p;
+                *p        = on ? make_float4(v.x * rf, v.y * rf, v.z * rf, v.w * rf) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (!on) reinterpret_cast<float4*>(rp)[0] = make_float4(0.f, 0.f, 0.f, 0.f), reinterpret_cast<float4*>(rp)[1] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
-        // f_j -> rho f_own f_j, once per (row, neighbour); rows without association hold stale numbers (0 * NaN is NaN):
-        // zero what the products read
-        for (int i = tid; i < nr * (K / 4); i += 256) {
-            const int r    = i / (K / 4);
-            const float rf = sra[r].x;
-            float4* p      = reinterpret_cast<float4*>(&scf[0][0]) + i;
-            float4 v       = *p;
-            v = rf != 0.f ? make_float4(v.x * rf, v.y * rf, v.z * rf, v.w * rf) : make_float4(0.f, 0.f, 0.f, 0.f);
-            *p = v;
-        }
-        for (int i = tid; i < nr * 2; i += 256)
-            if (sra[i >> 1].x == 0.f) reinterpret_cast<float4*>(&sl8[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        __syncthreads();
-        // ---- slot 0: 16 rows per wave and step, the waves interleave
-        {
-            v2f own[8];
-            float ownG[2] = {0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) own[e] = v2f{0.f, 0.f};
-#if !(DFA_S6_ABLATE & 2)
-            for (int rb = 16 * wave; rb < nr; rb += 64) {
-#else
-            for (int rb = 16 * wave; rb < 0; rb += 64) {
-#endif
-                const int rr = rb + g16;
-                if (rr < nr) {  // (whole quads)
-                    const float4 ra = sra[rr];
-                    const float2 lh = *reinterpret_cast<const float2*>(&sl8[rr][2 * c4]);
-                    add_pair(lh.x, lh.y, ra.z, own);
-                    ownG[0] = fmaf(-ra.y, lh.x, ownG[0]), ownG[1] = fmaf(-ra.y, lh.y, ownG[1]);
-                }
-            }
-            float v[16];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = own[e].x, v[8 + e] = own[e].y;
-            // quads summed; lane (g, c4) is left with element (row 2 c4 + (g >= 8), column g mod 8) — its own word of part0
-            part0[wave][8 * (2 * c4 + (g16 >> 3)) + (g16 & 7)] += quads_reduce_scatter(v, lane);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                ownG[e] += __shfl_xor(ownG[e], 4, 64);
-                ownG[e] += __shfl_xor(ownG[e], 8, 64);
-                ownG[e] += __shfl_xor(ownG[e], 16, 64);
-                ownG[e] += __shfl_xor(ownG[e], 32, 64);
-            }
-            if (g16 == 0) part0[wave][64 + 2 * c4] += ownG[0], part0[wave][64 + 2 * c4 + 1] += ownG[1];
-        }
-        // ---- upper blocks
+        S6_TICK(tp2);
+        // ---- the records of this pass: a lane takes its unit's records while their rows are staged (the lists ascend)
 #if !(DFA_S6_ABLATE & 1)
-        if (nup > 0) {
-            const unsigned rlim = (unsigned)(r0 + nr);
-            bool act = uhas && ucur - c4 < uend;  // (quad-uniform: the group starts inside the list)
+        {
+            bool act       = uhas && ucur < uend;
+            const bool gw  = __any(uown);  // (this wave has units of slot 0)
             while (__any(act)) {
-                const uint32_t rec3 = act ? load_rec(ucur + 3 * ustep) : 0xffffffffu;
-                // a record is in this pass if its row is staged; records of an earlier pass (a group that straddled its end)
-                // and of later ones contribute nothing (coefficient 0 on a staged row)
-                auto step = [&](const uint32_t pr) __attribute__((always_inline)) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (!__any(act)) break;
+                    // (an active lane is at the g-th record of its batch: it advanced in every trip so far)
+                    const uint32_t pr = rb[g];
                     const unsigned rr = (pr >> 4) - (unsigned)r0;
                     const bool in     = act && rr < (unsigned)nr;
                     const unsigned ri = in ? rr : 0u, j = in ? (pr & 15u) : 0u;
-                    const float2 lh   = *reinterpret_cast<const float2*>(&sl8[ri][2 * c4]);
-                    const float cf    = scf[ri][j];
-                    add_pair(lh.x, lh.y, in ? cf : 0.f, mu);
-                };
-                const bool mine_in = act && (rec0 >> 4) - (unsigned)r0 < (unsigned)nr;
-                const uint64_t bin = __ballot(mine_in);  // a step (the records of one lane of every quad) is skipped when no quad has one there
-                if (bin & 0x1111111111111111ull) step((uint32_t)__float_as_int(quad_bcast<0>(__int_as_float((int)rec0))));
-                if (bin & 0x2222222222222222ull) step((uint32_t)__float_as_int(quad_bcast<1>(__int_as_float((int)rec0))));
-                if (bin & 0x4444444444444444ull) step((uint32_t)__float_as_int(quad_bcast<2>(__int_as_float((int)rec0))));
-                if (bin & 0x8888888888888888ull) step((uint32_t)__float_as_int(quad_bcast<3>(__int_as_float((int)rec0))));
-                // the group is finished when none of its records belongs to a later pass (records past the end of the list
-                // read as 0xffffffff: finished)
-                const bool fin      = rec0 == 0xffffffffu || (rec0 >> 4) < rlim;
-                const uint64_t bal  = __ballot(fin);
-                const bool quad_fin = ((bal >> (lane & ~3)) & 0xfull) == 0xfull;
-                if (act && quad_fin) ucur += ustep, rec0 = rec1, rec1 = rec2, rec2 = rec3;
-                act = act && quad_fin && ucur - c4 < uend;
+                    const char* rp  = s6_dyn + RS * ri;
+                    const float4 la = reinterpret_cast<const float4*>(rp)[0], lb = reinterpret_cast<const float4*>(rp)[1];
+                    const float c0  = reinterpret_cast<const float*>(rp + CFO)[j];
+                    const float cf  = in ? c0 : 0.f;
+                    const v2f L[4]  = {v2f{la.x, la.y}, v2f{la.z, la.w}, v2f{lb.x, lb.y}, v2f{lb.z, lb.w}};
+                    const v2f cc    = v2f{cf, cf};
+                    v2f F[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) F[t] = cc * L[t];
+                    constexpr int eo[4] = {0, 4, 7, 9}, oo[4] = {0, 3, 5, 6};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const v2f fe = v2f{F[t].x, F[t].x}, fo = v2f{F[t].y, F[t].y};
+#pragma unroll
+                        for (int q = 0; q < 4 - t; ++q) me[eo[t] + q] = __builtin_elementwise_fma(fe, L[t + q], me[eo[t] + q]);
+                        md[t] = fmaf(F[t].y, L[t].y, md[t]);
+#pragma unroll
+                        for (int q = 0; q < 3 - t; ++q) mo[oo[t] + q] = __builtin_elementwise_fma(fo, L[t + 1 + q], mo[oo[t] + q]);
+                    }
+                    if (gw) {  // -J^T r: the slot-0 units' rows, each once
+                        const float gr = uown && in ? -reinterpret_cast<const float*>(rp + MTO)[1] : 0.f;
+                        const v2f gg   = v2f{gr, gr};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) G[t] = __builtin_elementwise_fma(gg, L[t], G[t]);
+                    }
+                    if (in) ucur += un;
+                    act = in && ucur < uend;
+                }
+                if (__any(act)) load_batch();  // (more than NG records of a unit in one pass)
             }
         }
 #endif
@@ -959,34 +938,58 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
             const int r = tid + 256 * q;
             if (r < S6_RC) sent[pass ^ 1][r] = nxt_ent[q];
         }
+#ifdef DFA_S6_TIMING
+        {
+            S6_TICK(tp4);
+            tk_stage += tp1 - tp0, tk_prep += tp2 - tp1, tk_up += tp4 - tp2;
+        }
+#endif
     }
-    // ---- the units' partial moments: to LDS (behind the moments and M, in the rows' area), then every block the sum of its
-    // units' partials in unit order
-    __syncthreads();  // the passes are over: the rows' area is free
-    __shared__ uint32_t uts[64];
-    if (tid < 64) uts[tid] = s.utab[(size_t)a * 64 + tid];
-    if (nup > 0) {
-        float* d0 = upart + 64 * (wave * 16 + g16) + 8 * (2 * c4);
+    S6_TICK(tk2);
+    // ---- the units' moments: to LDS (in the rows' area), then every block the sum of its units' in unit order
+    __syncthreads();  // the passes are over: the rows' area is free (and bfirst is cleared)
+    if (uhas && ((uinfo >> 6) & 1023u) == 0u) bfirst[uq] = (uint32_t)tid | ((uint32_t)un << 16);
+    {
+        float4* d0 = reinterpret_cast<float4*>(upart + 36 * tid);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) d0[e] = mu[e].x, d0[8 + e] = mu[e].y;
-    }
-    __syncthreads();
-    if (nup > 0) {
-        const int e = tid & 63;
-        for (int u = tid >> 6; u < 64; u += 4) {
-            const uint32_t info = uts[u];
-            const int q = (int)(info & 255u), n = (int)((info >> 16) & 255u);
-            if (q >= fu && q < cnt && ((info >> 8) & 255u) == 0u) {  // the first unit of block q
-                float sum = upart[64 * u + e];
-                for (int i = 1; i < n; ++i) sum += upart[64 * (u + i) + e];
-                accS[q][e] = sum;
-            }
+        for (int e = 0; e < 5; ++e) d0[e] = make_float4(me[2 * e].x, me[2 * e].y, me[2 * e + 1].x, me[2 * e + 1].y);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) d0[5 + e] = make_float4(mo[2 * e].x, mo[2 * e].y, mo[2 * e + 1].x, mo[2 * e + 1].y);
+        d0[8] = make_float4(md[0], md[1], md[2], md[3]);
+        // the gradient: summed over the wave (only the slot-0 units hold anything)
+        float gv[8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) gv[2 * t] = G[t].x, gv[2 * t + 1] = G[t].y;
+        if (__any(uown)) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gv[e] = wave_sum_all(gv[e]);
+        }
+        if (lane < 8) {
+            float x = gv[0];
+#pragma unroll
+            for (int e = 1; e < 8; ++e) x = lane == e ? gv[e] : x;
+            g8w[wave][lane] = x;
         }
     }
     __syncthreads();
-    // slot 0: the waves' partials (fixed order)
-    if (tid < 64 && cnt > 0) accS[0][tid] = (part0[0][tid] + part0[1][tid]) + (part0[2][tid] + part0[3][tid]);
-    if (tid >= 64 && tid < 72) g8s[tid - 64] = (part0[0][tid] + part0[1][tid]) + (part0[2][tid] + part0[3][tid]);
+    for (int i = tid; i < (1 + nup) * 36; i += 256) {
+        const int bi = i / 36, e = i - 36 * bi, slot = bi == 0 ? 0 : fu + bi - 1;
+        const uint32_t bf = bfirst[slot];
+        const int u0 = (int)(bf & 0xffffu), n = (int)(bf >> 16);
+        float sum = 0.f;
+        for (int u = 0; u < n; ++u) sum += upart[36 * (u0 + u) + e];
+        accS[slot][e] = sum;
+    }
+    if (tid < 8) g8s[tid] = (g8w[0][tid] + g8w[1][tid]) + (g8w[2][tid] + g8w[3][tid]);
+    __syncthreads();
+#ifdef DFA_S6_DEBUG
+    if (a >= DFA_S6_DEBUG && a < DFA_S6_DEBUG + 256) {
+        const int da = a - DFA_S6_DEBUG;
+        for (int i = tid; i < S6_MAXSLOT * 36; i += 256) s6_dbg[(size_t)da * (S6_MAXSLOT * 36 + 8) + i] = (&accS[0][0])[i];
+        if (tid < 8) s6_dbg[(size_t)da * (S6_MAXSLOT * 36 + 8) + S6_MAXSLOT * 36 + tid] = g8s[tid];
+    }
+#endif
+    S6_TICK(tk3);
     // H_ab = M_a S_ab M_b^T, regularisation, output: thread (slot, row) finishes row `row` of the block in `slot` — of slot 0
     // and of the upper slots; an upper block also goes, transposed, to the row of its column.
     // M of the row's column nodes: 48 floats per slot, coalesced
@@ -995,6 +998,11 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
         smb[i]         = s.mnode[48 * (size_t)s.bcols[(size_t)a * s.cap + slot] + (i - 48 * slot)];
     }
     __syncthreads();
+#ifdef DFA_S6_DEBUG
+    if (a >= DFA_S6_DEBUG && a < DFA_S6_DEBUG + 256)
+        for (int i = tid; i < cnt * 48; i += 256) s6_dbgm[(size_t)(a - DFA_S6_DEBUG) * S6_MAXSLOT * 48 + i] = smb[i];
+#endif
+    S6_TICK(tk4);
 #if DFA_S6_ABLATE & 4
     const int nfin = 6;
 #else
@@ -1016,7 +1024,7 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
 #pragma unroll
             for (int p = 0; p < 8; ++p)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) vq[q] = fmaf(ma[p], S0[8 * p + q], vq[q]);
+                for (int q = 0; q < 8; ++q) vq[q] = fmaf(ma[p], S0[s6_sym(p, q)], vq[q]);
             float accr[6];
 #pragma unroll
             for (int d = 0; d < 6; ++d) {
@@ -1098,6 +1106,7 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
         }
         __syncthreads();
     }
+    S6_TICK(tk5);
     if (tid < 6) {
         // column tid of M^-1 (= its row tid: symmetric), and with it the start of the PCG for this node:
         // x = 0, r = g, u = M^-1 g, p = s = t = 0
@@ -1110,6 +1119,15 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
         s.x[i] = 0.f, s.r[i] = gsh[tid], s.u[0][i] = u;
         s.p[i] = 0.f, s.s[i] = 0.f, s.t[0][i] = 0.f, s.t[1][i] = 0.f;
     }
+#ifdef DFA_S6_TIMING
+    if (tid == 0 && a < 16384) {
+        unsigned long long* o = s6_tbuf + 16 * (size_t)a;
+        const unsigned long long tk6 = clock64();
+        o[0] = tk0, o[1] = tk1 - tk0, o[2] = tk_stage, o[3] = tk_prep, o[4] = 0, o[5] = tk_up, o[6] = tk3 - tk2, o[7] = tk4 - tk3,
+        o[8] = tk5 - tk4, o[9] = tk6 - tk5, o[10] = tk6 - tk0, o[11] = wall_clock64() - wk0, o[12] = (unsigned long long)len,
+        o[13] = (unsigned long long)cnt, o[14] = wk0, o[15] = 0;
+    }
+#endif
 }
 
 // -------------------------------------------------------------------------------------- PCG
@@ -1465,31 +1483,32 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
         f.tol2 = eta * eta;
     }
     {
-        // rows staged per pass (DFA_S6_RC for A/B).  Work-unit form, C2 (k = 4) / C3 (k = 8): 192 - / 0.354 ms, 256 0.087 /
-        // 0.322, 320 0.078 / 0.315, 448 0.082 / - (up to 358 rows at k = 8 the dynamic segment is set by the closing phase)
+        // rows staged per pass (DFA_S6_RC for A/B): as many as fit beside the closing phase's 43 KiB (three workgroups per CU)
         static const int rc_env = getenv("DFA_S6_RC") ? atoi(getenv("DFA_S6_RC")) : 0;
-        const int rc = rc_env ? rc_env : 320;
+        const int rc = rc_env ? rc_env : (s.k <= 4 ? 640 : 512);
 #define S6A2(KK, RC)                                                                                              \
     do {                                                                                                          \
-        const size_t sh = std::max((size_t)(RC) * (32 + 4 * (KK) + 16), (size_t)(64 * 64 + S6_MAXSLOT * 64) * 4);      \
+        if (s.k == (KK)) S6A2X(KK, RC, true);                                                                     \
+        else S6A2X(KK, RC, false);                                                                                \
+    } while (0)
+#define S6A2X(KK, RC, EX)                                                                                         \
+    do {                                                                                                          \
+        constexpr size_t sh = s6_assemble_lds(KK, RC);                                                            \
         if (sh > 48 * 1024) {                                                                                     \
-            const hipError_t ae = allow_dynamic_lds((const void*)s6_assemble2_kernel<KK, RC>, (int)sh);             \
+            const hipError_t ae = allow_dynamic_lds((const void*)s6_assemble2_kernel<KK, RC, EX>, (int)sh);         \
             if (ae != hipSuccess) return ae;                                                                      \
         }                                                                                                         \
-        s6_assemble2_kernel<KK, RC><<<s.D, 256, sh, st>>>(s, state, wreg2, p.damping, f);                            \
+        s6_assemble2_kernel<KK, RC, EX><<<s.D, 256, sh, st>>>(s, state, wreg2, p.damping, f);                        \
     } while (0)
         if (s.k <= 4) {
-            if (rc <= 256) S6A2(4, 256);
-            else if (rc <= 320) S6A2(4, 320);
-            else if (rc <= 448) S6A2(4, 448);
+            if (rc <= 320) S6A2(4, 320);
             else S6A2(4, 640);
         } else {
-            if (rc <= 192) S6A2(8, 192);
-            else if (rc <= 256) S6A2(8, 256);
-            else if (rc <= 320) S6A2(8, 320);
-            else S6A2(8, 640);
+            if (rc <= 320) S6A2(8, 320);
+            else S6A2(8, 512);
         }
 #undef S6A2
+#undef S6A2X
     }
     return hipGetLastError();
 }

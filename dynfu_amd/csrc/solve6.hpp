@@ -87,10 +87,10 @@ struct Solve6View {
     float* ghat;  // D x 3  current node positions T_i(g_i)
     // linearisation
     // rows of the data term, one record per VERTEX: the row's 6-vector for neighbour j is f_j M_j l with the per-vertex
-    // functional l = (lW, lD).  rec[v] = { l[8], f[8] } (f_j = w~_j s_j / |a|^2): one 64-byte line; rmeta[v] = { robust
-    // weight (0 = no association), weight * residual }
-    float* rec;    // N x 16
-    float* rmeta;  // N x 2
+    // functional l = (lW, lD).  rec[v] = { l[8], f[K] (f_j = w~_j s_j / |a|^2), robust weight (0 = no association),
+    // weight * residual, 0, 0 }, K = 4 or 8 (the kernels' template): 2 + K / 4 + 1 chunks of 16 bytes, the unit the
+    // assembly's LDS-DMA fetches them in
+    float* rec;    // N x (12 + K)
     float* mnode;  // D x 6 x 8  M_n: twist components of node n as (W, Wd) increments
     float* rho;   // N           Tukey weight (frozen between re-weightings)
     float* rres;  // D x k x 3   regularisation residuals
@@ -101,13 +101,13 @@ struct Solve6View {
     int32_t* bcnt;   // D
     int32_t* bfu;    // D  first "upper" slot of the row (column > row; slots 1 .. bfu-1 are mirrored from their columns' rows)
     uint8_t* rslot;  // D x cap  slot of the row's node in the row of each of its columns
-    // The 64 work units (4 waves x 16 quads) of a node's assembly workgroup: unit u walks groups phase, phase + stride, ...
-    // (4 records each) of the pair list of block `slot` — longer lists get more units, so that every unit walks about
-    // the same number of records.  utab[64 a + u] = slot | phase << 8 | stride << 16; slot 255: idle.
-    uint32_t* utab;  // D x 64
+    // The 256 work units of a node's assembly workgroup, one per lane: unit u walks records phase, phase + n, ... of the pair
+    // list of block `slot` (slot 0 or an upper slot) — longer lists get more units, so that every unit walks about the same
+    // number of records.  utab[256 a + u] = slot | phase << 6 | n << 16; slot 63: idle.
+    uint32_t* utab;  // D x 256
     uint8_t* eslot;  // (N k) x k scratch of s6_pattern (nodes whose slot bytes do not fit its LDS buffer)
     // the same relation by slot: for node a and slot q >= 1, pair_list[pair_ptr[a (cap+1) + q] .. pair_ptr[.. q+1]) are
-    // the (row of a's list << 4 | neighbour) pairs that land in slot q, ascending (slot 0 = every row's own neighbour)
+    // the (row of a's list << 4 | neighbour) pairs that land in slot q, ascending; slot 0 = every row with its own neighbour
     uint32_t* pair_list;  // (N k) x k
     int32_t* pair_ptr;    // D x (cap + 1)
     float* bvals;    // D x cap x 36
