@@ -268,6 +268,10 @@ __global__ __launch_bounds__(256) void s6_linearise_kernel(Solve6View s, Solve6S
         }
         float w_eff = 0.f, rr = 0.f;
         bool ok     = false;
+        float h[K], swr = 0.f;
+        float4 l0 = make_float4(0.f, 0.f, 0.f, 0.f), l1 = l0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) h[j] = 0.f;
         Blend<K> B;
         blend<K>(s.dq, idx, wn, k, B);
         const f3 c = mk3(s.canon[3 * (size_t)v], s.canon[3 * (size_t)v + 1], s.canon[3 * (size_t)v + 2]);
@@ -311,18 +315,22 @@ __global__ __launch_bounds__(256) void s6_linearise_kernel(Solve6View s, Solve6S
             // l, the k scalars f, the robust weight — which the assembly gathers through each node's row list (round 2
             // wrote the record once per neighbour, at the row's place in that node's list: k times the bytes, and an
             // index scatter to build per frame)
-            float f[K];
+            // ... with the robust weight folded in: h_j = sqrt(rho) f_j, so that rho f_a f_b = h_a h_b is ONE product in the
+            // assembly, rows without weight vanish by themselves, and -J^T r needs (sqrt(rho) r) h_a
+            const float sw = sqrtf(w_eff);
 #pragma unroll
-            for (int j = 0; j < K; ++j) f[j] = j < k ? wn[j] * B.s[j] * im : 0.f;
-            float4* rec = reinterpret_cast<float4*>(s.rec + (12 + K) * (size_t)v);  // 2 + K / 4 + 1 chunks of 16 bytes per vertex
-            rec[0] = make_float4(lW.w, lW.x, lW.y, lW.z), rec[1] = make_float4(lD.w, lD.x, lD.y, lD.z);
-#pragma unroll
-            for (int q = 0; q < K / 4; ++q) rec[2 + q] = make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
+            for (int j = 0; j < K; ++j) h[j] = j < k ? sw * (wn[j] * B.s[j] * im) : 0.f;
+            l0 = make_float4(lW.w, lW.x, lW.y, lW.z), l1 = make_float4(lD.w, lD.x, lD.y, lD.z);
+            swr    = sw * rr;
             cost   = (double)w_eff * (double)rr * (double)rr;
             nvalid = w_eff > 0.f;
         }
-        const float w_out = ok ? w_eff : 0.f;  // (no association: the stale l / f of the record are never used)
-        reinterpret_cast<float4*>(s.rec + (12 + K) * (size_t)v)[2 + K / 4] = make_float4(w_out, w_out * rr, 0.f, 0.f);  // the record's last chunk
+        // no association: a record of zeros (l too: 0 x a stale NaN would be NaN)
+        float4* rec = reinterpret_cast<float4*>(s.rec + (12 + K) * (size_t)v);  // 2 + K / 4 + 1 chunks of 16 bytes per vertex
+        rec[0] = l0, rec[1] = l1;
+#pragma unroll
+        for (int q = 0; q < K / 4; ++q) rec[2 + q] = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
+        rec[2 + K / 4] = make_float4(swr, 0.f, 0.f, 0.f);
     }
     block_add_cost(cost, nvalid, st);
 }
@@ -463,6 +471,7 @@ __device__ __forceinline__ void inv6_column(const float* M, float* out, int c, f
 // regularisation edge, ascending.
 constexpr int S6_MAXSLOT_PATTERN = 48;  // = S6_MAXSLOT (declared below), the plan capacity of a block row
 constexpr int S6_UNITS = 256;           // work units of a node's assembly = threads of its workgroup
+constexpr int S6_DEAL  = 8;             // a node's sorted rows are dealt out in this many interleaved runs (s6_pattern_kernel)
 
 __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6State* st) {
     __shared__ int keys[S6_HASH];
@@ -481,7 +490,15 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
             for (int i = tid; i < n2; i += 256) sortbuf[i] = i < len ? s.node_list[beg + i] : 0xffffffffu;
             __syncthreads();
             s6_sort_lds(sortbuf, n2, tid);
-            for (int i = tid; i < len; i += 256) s.node_list[beg + i] = sortbuf[i];
+            // ... and deal the sorted rows out in S6_DEAL interleaved runs (rows 0, 8, 16, ..., then 1, 9, ...): the assembly
+            // stages the list a few hundred rows at a time, and a vertex's neighbours come in clusters along the sorted list —
+            // in sorted order one pass held all the records of some blocks and none of others, and the lanes (one block each)
+            // waited for the fullest (records phase at C3: 9.9 -> 6.x us per workgroup).  Now every pass is a uniform sample.
+            const int per = len / S6_DEAL, extra = len - per * S6_DEAL;
+            for (int i = tid; i < len; i += 256) {
+                const int g = i % S6_DEAL, t = i / S6_DEAL;
+                s.node_list[beg + g * per + min(g, extra) + t] = sortbuf[i];
+            }
         }
         if (tid == 0) {  // the few regularisation edges arriving at a: insertion sort
             const int rb = s.rnode_ptr[a], re = s.rnode_ptr[a + 1];
@@ -584,8 +601,9 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
     if (tid <= stored) s.pair_ptr[(size_t)a * (s.cap + 1) + tid] = pstart[tid];
     // ---- work units of the assembly: S6_UNITS per node, one per LANE of its workgroup.  A unit walks every n-th record of ONE
     // block's list (slot 0 — every row — or an upper slot), starting at its `phase`; a block with c of the node's T records
-    // gets 1 + floor((S6_UNITS - blocks) c / T) units, so every unit of the workgroup walks about T / S6_UNITS records and
-    // the units of a block are neighbours (neighbouring lanes read neighbouring rows).
+    // gets 2 (1 + floor((S6_UNITS / 2 - blocks) c / T)) units, so every unit of the workgroup walks about T / S6_UNITS records,
+    // the units of a block are neighbours (neighbouring lanes read neighbouring rows) and lanes 2 i, 2 i + 1 always work
+    // for the same block.
     __shared__ int ustart[64], ucount[64];
     if (tid < 64) {
         const int q    = tid == 0 ? 0 : fu + tid - 1;  // lane = block: slot 0, then the upper slots
@@ -594,7 +612,7 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
         int total = mine;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
-        const int n = mine > 0 ? 1 + (int)(((long long)(S6_UNITS - nblk2) * mine) / total) : 0;
+        const int n = mine > 0 ? 2 * (1 + (int)(((long long)(S6_UNITS / 2 - nblk2) * mine) / total)) : 0;  // (even: see the assembly's closing part)
         int incl = n;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -623,7 +641,8 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
             const int p  = base + lane;
             const int sl = p < npairs ? (int)es[p] : 255;
             const int r  = p / k;
-            const uint32_t packed = ((uint32_t)r << 4) | (uint32_t)(p - r * k);
+            const uint32_t oj     = p < npairs ? s.node_list[pbeg + r] % (unsigned)k : 0u;  // the row's own neighbour slot
+            const uint32_t packed = ((uint32_t)r << 8) | (oj << 4) | (uint32_t)(p - r * k);
 #pragma unroll
             for (int i = 0; i < SPW; ++i) {
                 const int q = wave + 4 * i;
@@ -704,7 +723,7 @@ __host__ __device__ constexpr int s6_sym(int i, int j) {
 }
 
 #ifndef DFA_S6_WAVES
-#define DFA_S6_WAVES 3  // waves per SIMD the register allocation aims at (three workgroups per CU by LDS: <= 168 VGPRs)
+#define DFA_S6_WAVES 4  // waves per SIMD the register allocation aims at (four workgroups per CU by LDS: <= 128 VGPRs, 3-4 spilled)
 #endif
 #ifdef DFA_S6_TIMING  // development builds only: per-workgroup phase clocks of the assembly (tools/ns_assemble_phases.py)
 __device__ unsigned long long s6_tbuf[16384 * 16];
@@ -728,20 +747,22 @@ extern "C" __attribute__((visibility("default"))) int dfa_dev_s6_m(float* out) {
 }
 #endif
 constexpr size_t s6_assemble_lds(int K, int RC) {  // dynamic segment: the staged rows, later the units' moments + the blocks' sums
-    const size_t rows = (size_t)RC * (32 + 4 * K + 16), closing = (size_t)(S6_UNITS * 36 + S6_MAXSLOT * 36) * 4;
+    const size_t rows = (size_t)((RC * (2 + K / 4 + 1) + 255) / 256) * 4096, closing = (size_t)(S6_UNITS / 2 * 36 + S6_MAXSLOT * 36) * 4;
     return rows > closing ? rows : closing;
 }
 template <int K, int S6_RC, bool KEXACT>  // KEXACT: k == K (the common case: divisions by k are shifts)
 __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6View s, Solve6State* st, float wreg2, float damping,
                                                                          const S6Forcing forcing) {
     extern __shared__ __attribute__((aligned(16))) char s6_dyn[];
-    // a staged row: l = (lW, lD) (32 bytes) | rho f_own f_j, j < K | rho f_own, rho res f_own, rho f_own^2, - : RS bytes, the
-    // order of the 16-byte chunks the row is fetched in (the LDS-DMA writes a wave's 64 chunks to 1 KiB in lane order)
+    // a staged row = the vertex's record as s6_linearise wrote it: l = (lW, lD) (32 bytes) | h_j = sqrt(rho) f_j, j < K |
+    // sqrt(rho) r, -, -, - : RS bytes, in the order of the 16-byte chunks the row is fetched in (the LDS-DMA writes a wave's 64
+    // chunks to 1 KiB in lane order).  Nothing is prepared per pass: rho f_a f_j = h_a h_j is formed where it is used.
     constexpr int RS = 32 + 4 * K + 16, CFO = 32, MTO = 32 + 4 * K;
-    // after the passes the dynamic segment holds, in turn: the units' moments [0, 36 KiB); the blocks' sums (36 floats per
-    // slot) behind them; M of the column nodes (48 floats per slot) and the transposition tile over the — by then dead — units
-    float* upart     = reinterpret_cast<float*>(s6_dyn);                                                   // [S6_UNITS][36]
-    float(*accS)[36] = reinterpret_cast<float(*)[36]>(s6_dyn + sizeof(float) * 36 * S6_UNITS);
+    // after the passes the dynamic segment holds, in turn: the moments of half of the units [0, 18 KiB); the blocks' sums (36
+    // floats per slot) behind them; M of the column nodes (48 floats per slot) and the transposition tile over the — by then
+    // dead — units.  (All 256 units at once would be 36 KiB: the fourth workgroup of a CU would not fit.)
+    float* upart     = reinterpret_cast<float*>(s6_dyn);                                                   // [S6_UNITS / 2][36]
+    float(*accS)[36] = reinterpret_cast<float(*)[36]>(s6_dyn + sizeof(float) * 36 * (S6_UNITS / 2));
     float* smb       = reinterpret_cast<float*>(s6_dyn);
     __shared__ float g8w[4][8];           // -J^T r in l coordinates, per wave
     __shared__ float g8s[8];
@@ -763,25 +784,15 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
     const int32_t* pptr = s.pair_ptr + (size_t)a * (s.cap + 1);
     const int rib = s.rnode_ptr[a], nri = s.rnode_ptr[a + 1] - rib;
     if (tid < S6_MAXSLOT) bfirst[tid] = 0u;
-    // ---- the node's regularisation edges (used by the epilogue; loaded first, they fly while the rows are worked on)
-    for (int i = tid; i < k * 24; i += 256) {
-        const int q = i / 24, f = i - 24 * q, e = a * k + q;
-        float v = 0.f;
-        if (f == 0) v = __int_as_float(s.reg_idx[e]);
-        else if (f == 1) v = wreg2 * s.rhub[e];
-        else if (f < 5) v = s.rres[3 * (size_t)e + f - 2];
-        else if (f < 23) v = s.rvec[18 * (size_t)e + f - 5];
-        rout[q][f] = v;
-    }
-    for (int i = tid; i < min(nri, S6_REGIN) * 24; i += 256) {
-        const int q = i / 24, f = i - 24 * q;
-        const unsigned entry = s.rnode_list[rib + q];
-        float v = 0.f;
-        if (f == 0) v = __int_as_float((int)(entry / (unsigned)k));
-        else if (f == 1) v = wreg2 * s.rhub[entry];
-        else if (f < 5) v = s.rres[3 * (size_t)entry + f - 2];
-        else if (f < 23) v = s.rvec[18 * (size_t)entry + f - 5];
-        rin[q][f] = v;
+    // the row's columns and the mirror slots: read by every phase of the closing part (two dependent global loads there)
+    __shared__ int32_t scol[S6_MAXSLOT];
+    __shared__ uint8_t srs[S6_MAXSLOT];
+    __shared__ uint32_t rent[S6_REGIN];  // the arriving edges' (source node k + slot): one round trip less in the closing part
+    if (tid < S6_MAXSLOT) {
+        const bool in = tid < cnt;
+        scol[tid] = in ? s.bcols[(size_t)a * s.cap + tid] : -1, srs[tid] = in ? s.rslot[(size_t)a * s.cap + tid] : (uint8_t)255;
+    } else if (tid >= 64 && tid < 64 + S6_REGIN) {
+        rent[tid - 64] = tid - 64 < nri ? s.rnode_list[rib + tid - 64] : 0u;
     }
     // ---- this lane's work unit (s6_pattern: utab): every un-th record of block uq's list, from its phase on
     const int nup        = cnt > fu ? cnt - fu : 0;
@@ -842,17 +853,17 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
         // they are 2 x NCH registers that live — spilled — through the whole kernel.  The list entries are all read before the
         // first DMA is issued: the compiler orders a ds_read behind an LDS-DMA in flight with s_waitcnt vmcnt(0), one memory
         // round trip per chunk.)
-        int tl = tid;
+        unsigned tl = (unsigned)tid;
         asm volatile("" : "+v"(tl));
         uint32_t ens[NCH];
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
-            const int r = (tl + 256 * q) / RS4;
-            ens[q]      = sent[pass][r < nr ? r : 0];
+            const unsigned r = (tl + 256u * q) / (unsigned)RS4;
+            ens[q]           = sent[pass][min(r, (unsigned)nr - 1u)];
         }
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
-            const int i = tl + 256 * q, r = i / RS4, c = i - RS4 * r;
+            const unsigned i = tl + 256u * q, r = i / (unsigned)RS4, c = i - (unsigned)RS4 * r;
 #if DFA_S6_ABLATE & 8
             const size_t v = (e0 + r) % (size_t)s.N + 0 * ens[q];  // (timing only: contiguous rows instead of the gather)
 #else
@@ -866,26 +877,6 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
         load_batch();
         __syncthreads();
         S6_TICK(tp1);
-        // per row: (weight, weight x residual) -> (rho f_own, rho res f_own, rho f_own^2); f_j -> rho f_own f_j, once per (row,
-        // neighbour).  Rows without association hold stale numbers (0 * NaN is NaN): zero what the products read.
-        for (int i = tid; i < nr; i += 256) {
-            char* rp          = s6_dyn + RS * i;
-            const uint32_t en = sent[pass][i];
-            const int oj      = (int)(KEXACT ? en % (unsigned)K : en % (unsigned)k);
-            const float4 m    = *reinterpret_cast<const float4*>(rp + MTO);
-            const float fo    = reinterpret_cast<const float*>(rp + CFO)[oj];
-            const float rf    = m.x * fo;
-            const bool on     = m.x != 0.f;
-            *reinterpret_cast<float4*>(rp + MTO) = on ? make_float4(rf, m.y * fo, rf * fo, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int c = 0; c < K / 4; ++c) {
-                float4* p = reinterpret_cast<float4*>(rp + CFO) + c;
-                float4 v  = *p;
-                *p        = on ? make_float4(v.x * rf, v.y * rf, v.z * rf, v.w * rf) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            if (!on) reinterpret_cast<float4*>(rp)[0] = make_float4(0.f, 0.f, 0.f, 0.f), reinterpret_cast<float4*>(rp)[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        __syncthreads();
         S6_TICK(tp2);
         // ---- the records of this pass: a lane takes its unit's records while their rows are staged (the lists ascend)
 #if !(DFA_S6_ABLATE & 1)
@@ -897,14 +888,15 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
                 for (int g = 0; g < NG; ++g) {
                     if (!__any(act)) break;
                     // (an active lane is at the g-th record of its batch: it advanced in every trip so far)
-                    const uint32_t pr = rb[g];
-                    const unsigned rr = (pr >> 4) - (unsigned)r0;
+                    const uint32_t pr = rb[g];  // row of the node's list << 8 | the row's own slot << 4 | neighbour slot
+                    const unsigned rr = (pr >> 8) - (unsigned)r0;
                     const bool in     = act && rr < (unsigned)nr;
-                    const unsigned ri = in ? rr : 0u, j = in ? (pr & 15u) : 0u;
+                    const unsigned ri = in ? rr : 0u;
                     const char* rp  = s6_dyn + RS * ri;
                     const float4 la = reinterpret_cast<const float4*>(rp)[0], lb = reinterpret_cast<const float4*>(rp)[1];
-                    const float c0  = reinterpret_cast<const float*>(rp + CFO)[j];
-                    const float cf  = in ? c0 : 0.f;
+                    const float ho  = *reinterpret_cast<const float*>(rp + CFO + ((pr >> 2) & 60u));  // h_a: sqrt(rho) f_a
+                    const float hj  = *reinterpret_cast<const float*>(rp + CFO + ((pr << 2) & 60u));  // h_j
+                    const float cf  = in ? ho * hj : 0.f;                                             // rho f_a f_j
                     const v2f L[4]  = {v2f{la.x, la.y}, v2f{la.z, la.w}, v2f{lb.x, lb.y}, v2f{lb.z, lb.w}};
                     const v2f cc    = v2f{cf, cf};
                     v2f F[4];
@@ -921,7 +913,7 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
                         for (int q = 0; q < 3 - t; ++q) mo[oo[t] + q] = __builtin_elementwise_fma(fo, L[t + 1 + q], mo[oo[t] + q]);
                     }
                     if (gw) {  // -J^T r: the slot-0 units' rows, each once
-                        const float gr = uown && in ? -reinterpret_cast<const float*>(rp + MTO)[1] : 0.f;
+                        const float gr = uown && in ? -*reinterpret_cast<const float*>(rp + MTO) * ho : 0.f;  // -(sqrt(rho) r) h_a
                         const v2f gg   = v2f{gr, gr};
 #pragma unroll
                         for (int t = 0; t < 4; ++t) G[t] = __builtin_elementwise_fma(gg, L[t], G[t]);
@@ -946,17 +938,12 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
 #endif
     }
     S6_TICK(tk2);
-    // ---- the units' moments: to LDS (in the rows' area), then every block the sum of its units' in unit order
-    __syncthreads();  // the passes are over: the rows' area is free (and bfirst is cleared)
-    if (uhas && ((uinfo >> 6) & 1023u) == 0u) bfirst[uq] = (uint32_t)tid | ((uint32_t)un << 16);
-    {
-        float4* d0 = reinterpret_cast<float4*>(upart + 36 * tid);
-#pragma unroll
-        for (int e = 0; e < 5; ++e) d0[e] = make_float4(me[2 * e].x, me[2 * e].y, me[2 * e + 1].x, me[2 * e + 1].y);
-#pragma unroll
-        for (int e = 0; e < 3; ++e) d0[5 + e] = make_float4(mo[2 * e].x, mo[2 * e].y, mo[2 * e + 1].x, mo[2 * e + 1].y);
-        d0[8] = make_float4(md[0], md[1], md[2], md[3]);
-        // the gradient: summed over the wave (only the slot-0 units hold anything)
+    // ---- the units' moments: lanes 2 i and 2 i + 1 (the same block, s6_pattern) are added by DPP, the even lanes park the
+    // pair's moment in LDS (128 x 36 floats, in the rows' area), then every block is the sum of its pairs in unit order
+    __syncthreads();  // the passes are over: the rows' area is free (and bfirst is cleared, scol / rent are written)
+    S6_TICK(tk2a);
+    if (uhas && ((uinfo >> 6) & 1023u) == 0u) bfirst[uq] = (uint32_t)(tid >> 1) | ((uint32_t)(un >> 1) << 16);
+    {   // the gradient: summed over the wave (only the slot-0 units hold anything)
         float gv[8];
 #pragma unroll
         for (int t = 0; t < 4; ++t) gv[2 * t] = G[t].x, gv[2 * t + 1] = G[t].y;
@@ -971,7 +958,53 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
             g8w[wave][lane] = x;
         }
     }
+    {
+        auto pair = [](float x) __attribute__((always_inline)) {  // x + the other lane of the pair's (quad_perm [1, 0, 3, 2])
+            return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true));
+        };
+        float w[36];
+#pragma unroll
+        for (int e = 0; e < 10; ++e) w[2 * e] = pair(me[e].x), w[2 * e + 1] = pair(me[e].y);
+#pragma unroll
+        for (int e = 0; e < 6; ++e) w[20 + 2 * e] = pair(mo[e].x), w[21 + 2 * e] = pair(mo[e].y);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[32 + e] = pair(md[e]);
+        if ((tid & 1) == 0) {
+            float4* d0 = reinterpret_cast<float4*>(upart + 36 * (tid >> 1));
+#pragma unroll
+            for (int e = 0; e < 9; ++e) d0[e] = make_float4(w[4 * e], w[4 * e + 1], w[4 * e + 2], w[4 * e + 3]);
+        }
+    }
+    // ---- what the epilogue needs from global memory is requested now (the moments' registers are free), into registers — the
+    // node's regularisation edges (leaving: 1 value per thread, arriving: up to 3) and M of the row's column nodes (48 floats
+    // per slot) — and parked in LDS once the moments are summed: the round trip passes under the sums and their barriers
+    constexpr int RINQ = (S6_REGIN * 24 + 255) / 256, MQ = (S6_MAXSLOT * 48 + 255) / 256;
+    // (one unconditional 4-byte load from a selected address per value: a branch per field makes them wait for each other)
+    auto edge_field = [&](int f, size_t e) __attribute__((always_inline)) {  // field f of edge e: 0 neighbour, 1 weight, 2-4 residual, 5-22 vectors
+        const float* p = reinterpret_cast<const float*>(s.reg_idx + e);
+        p = f == 1 ? s.rhub + e : p;
+        p = f >= 2 && f < 5 ? s.rres + 3 * e + (f - 2) : p;
+        p = f >= 5 && f < 23 ? s.rvec + 18 * e + (f - 5) : p;
+        return *p;
+    };
+    float rov, riv[RINQ], mreg[MQ];
+    {
+        const int q = tid < k * 24 ? tid / 24 : 0, f = tid - 24 * (tid / 24);
+        rov = edge_field(f, (size_t)(a * k + q));
+    }
+#pragma unroll
+    for (int t = 0; t < RINQ; ++t) {
+        const int i = tid + 256 * t, q = i / 24, f = i - 24 * q;
+        riv[t]      = edge_field(f, (size_t)rent[i < min(nri, S6_REGIN) * 24 ? q : 0]);
+    }
+#pragma unroll
+    for (int t = 0; t < MQ; ++t) {
+        const int i = tid + 256 * t, slot = i / 48;
+        mreg[t]     = i < cnt * 48 ? s.mnode[48 * (size_t)scol[slot] + (i - 48 * slot)] : 0.f;
+    }
+    S6_TICK(tk2b);
     __syncthreads();
+    S6_TICK(tk2c);
     for (int i = tid; i < (1 + nup) * 36; i += 256) {
         const int bi = i / 36, e = i - 36 * bi, slot = bi == 0 ? 0 : fu + bi - 1;
         const uint32_t bf = bfirst[slot];
@@ -992,10 +1025,21 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
     S6_TICK(tk3);
     // H_ab = M_a S_ab M_b^T, regularisation, output: thread (slot, row) finishes row `row` of the block in `slot` — of slot 0
     // and of the upper slots; an upper block also goes, transposed, to the row of its column.
-    // M of the row's column nodes: 48 floats per slot, coalesced
-    for (int i = tid; i < cnt * 48; i += 256) {
-        const int slot = i / 48;
-        smb[i]         = s.mnode[48 * (size_t)s.bcols[(size_t)a * s.cap + slot] + (i - 48 * slot)];
+    // M of the row's column nodes (48 floats per slot) and the edges: from the registers they arrived in
+#pragma unroll
+    for (int t = 0; t < MQ; ++t) {
+        const int i = tid + 256 * t;
+        if (i < cnt * 48) smb[i] = mreg[t];
+    }
+    if (tid < k * 24) {
+        const int f = tid - 24 * (tid / 24);
+        (&rout[0][0])[tid] = f == 1 ? wreg2 * rov : f == 23 ? 0.f : rov;
+    }
+#pragma unroll
+    for (int t = 0; t < RINQ; ++t) {
+        const int i = tid + 256 * t, q = i / 24, f = i - 24 * q;
+        if (i < min(nri, S6_REGIN) * 24)
+            (&rin[0][0])[i] = f == 0 ? __int_as_float((int)(rent[q] / (unsigned)k)) : f == 1 ? wreg2 * riv[t] : f == 23 ? 0.f : riv[t];
     }
     __syncthreads();
 #ifdef DFA_S6_DEBUG
@@ -1015,7 +1059,7 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
         if (on) {
             const int sidx = t / 6, my_row = t - 6 * sidx;
             const int slot = sidx == 0 ? 0 : fu + sidx - 1;
-            const int col  = s.bcols[(size_t)a * s.cap + slot];
+            const int col  = scol[slot];
             float ma[8];
 #pragma unroll
             for (int p = 0; p < 8; ++p) ma[p] = smb[8 * my_row + p];  // slot 0 is node a itself
@@ -1096,10 +1140,10 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
             const int sidx = t / 6, my_row = t - 6 * sidx;
             const int slot = sidx == 0 ? 0 : fu + sidx - 1;
             if (slot != 0) {
-                const int rs = s.rslot[(size_t)a * s.cap + slot];
+                const int rs = srs[slot];
                 if (rs != 255) {
                     const float* tr = ttile + 6 * (t - t0 - my_row) + 6 * my_row;  // row my_row of the transposed block
-                    float2* out2    = reinterpret_cast<float2*>(s.bvals + ((size_t)s.bcols[(size_t)a * s.cap + slot] * s.cap + rs) * 36 + 6 * my_row);
+                    float2* out2    = reinterpret_cast<float2*>(s.bvals + ((size_t)scol[slot] * s.cap + rs) * 36 + 6 * my_row);
                     out2[0] = make_float2(tr[0], tr[1]), out2[1] = make_float2(tr[2], tr[3]), out2[2] = make_float2(tr[4], tr[5]);
                 }
             }
@@ -1123,9 +1167,9 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
     if (tid == 0 && a < 16384) {
         unsigned long long* o = s6_tbuf + 16 * (size_t)a;
         const unsigned long long tk6 = clock64();
-        o[0] = tk0, o[1] = tk1 - tk0, o[2] = tk_stage, o[3] = tk_prep, o[4] = 0, o[5] = tk_up, o[6] = tk3 - tk2, o[7] = tk4 - tk3,
+        o[0] = tk0, o[1] = tk1 - tk0, o[2] = tk_stage, o[3] = tk_prep, o[4] = tk2a - tk2, o[5] = tk_up, o[6] = tk3 - tk2, o[7] = tk4 - tk3,
         o[8] = tk5 - tk4, o[9] = tk6 - tk5, o[10] = tk6 - tk0, o[11] = wall_clock64() - wk0, o[12] = (unsigned long long)len,
-        o[13] = (unsigned long long)cnt, o[14] = wk0, o[15] = 0;
+        o[13] = (unsigned long long)cnt, o[14] = wk0, o[15] = ((tk2b - tk2a) << 32) | (tk2c - tk2b);
     }
 #endif
 }
@@ -1483,9 +1527,9 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
         f.tol2 = eta * eta;
     }
     {
-        // rows staged per pass (DFA_S6_RC for A/B): as many as fit beside the closing phase's 43 KiB (three workgroups per CU)
+        // rows staged per pass (DFA_S6_RC for A/B): what fits in 28 KiB — with the static arrays 36 KiB, four workgroups per CU
         static const int rc_env = getenv("DFA_S6_RC") ? atoi(getenv("DFA_S6_RC")) : 0;
-        const int rc = rc_env ? rc_env : (s.k <= 4 ? 640 : 512);
+        const int rc = rc_env ? rc_env : (s.k <= 4 ? 448 : 352);
 #define S6A2(KK, RC)                                                                                              \
     do {                                                                                                          \
         if (s.k == (KK)) S6A2X(KK, RC, true);                                                                     \
@@ -1502,10 +1546,10 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
     } while (0)
         if (s.k <= 4) {
             if (rc <= 320) S6A2(4, 320);
-            else S6A2(4, 640);
+            else S6A2(4, 448);
         } else {
-            if (rc <= 320) S6A2(8, 320);
-            else S6A2(8, 512);
+            if (rc <= 256) S6A2(8, 256);
+            else S6A2(8, 352);
         }
 #undef S6A2
 #undef S6A2X

@@ -80,7 +80,7 @@ def test_solve_matches_the_oracle(A, name, frame, k_override):
     d = np.linalg.norm(wv - p_ref, axis=1)
     # (k = 1: diagonal blocks with condition numbers of 1e5 in fp32 — the same wider band)
     assert d.mean() < (2e-4 if cfg["k"] == 1 else 5e-5) and d.max() < (2e-3 if cfg["k"] == 1 else 1e-3)
-    assert np.abs(wn_ - n_ref).max() < 2e-3
+    assert np.abs(wn_ - n_ref).max() < (5e-3 if cfg["k"] == 1 else 2e-3)
     # the device warp is the oracle's DQ blend of the device's own transforms
     p_same, _ = O.warp6(dq, idx, wn, c["verts"])
     assert np.abs(wv - p_same).max() < 2e-6

@@ -31,7 +31,7 @@ buf = np.zeros((n, 16), np.uint64)
 L.dfa_dev_s6_timing.argtypes = [C.c_void_p, C.c_int]
 assert L.dfa_dev_s6_timing(buf.ctypes.data, n) == 0
 t = buf.astype(np.float64)
-names = ["prologue", "stage", "prep", "(unused)", "records", "unit sums", "M load", "epilogue", "tail"]
+names = ["prologue", "stage", "(no prep)", "(wait 1)", "records", "unit sums", "M load", "epilogue", "tail"]
 tot, wall = t[:, 10], t[:, 11]
 ratio = np.median(tot / np.maximum(wall, 1))
 print("%s: %d workgroups; clock64 per wall_clock64 tick: %.2f (wall = 100 MHz -> clock64 at %.0f MHz)" % (name, n, ratio, ratio * 100))
@@ -41,9 +41,14 @@ print("workgroup lifetime: mean %.1f us, median %.1f, p95 %.1f, max %.1f" % (us(
 for i, nm in enumerate(names):
     col = t[:, 1 + i]
     print("  %-10s mean %7.2f us  (%4.1f %%)   p95 %7.2f" % (nm, us(col.mean()), 100 * col.sum() / tot.sum(), us(np.percentile(col, 95))))
+sub = buf[:, 15]
+print("  inside unit sums: waves wait for each other %.2f us, pair sums + stores + requests %.2f, second barrier %.2f, sums + barrier %.2f" %
+      (us(t[:, 4].mean()), us((sub >> np.uint64(32)).astype(np.float64).mean()), us((sub & np.uint64(0xffffffff)).astype(np.float64).mean()),
+       us((t[:, 6] - t[:, 4] - (sub >> np.uint64(32)).astype(np.float64) - (sub & np.uint64(0xffffffff)).astype(np.float64)).mean())))
 start = t[:, 14] - t[:, 14].min()
 end = start + wall
 print("launch span (first start -> last end): %.1f us; last start at %.1f us" % (end.max() / 100.0, start.max() / 100.0))
+print("start times [us], deciles:", " ".join("%.1f" % (x / 100.0) for x in np.percentile(start, np.arange(0, 101, 10))))
 # concurrency: how many workgroups are alive at a time
 ev = np.concatenate([np.stack([start, np.ones(n)], 1), np.stack([end, -np.ones(n)], 1)])
 ev = ev[np.argsort(ev[:, 0], kind="stable")]

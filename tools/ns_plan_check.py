@@ -1,7 +1,7 @@
 """dev (GPU; a -DDFA_S6_DEBUG=<first node> build): the north-star plan and assembly against sums made here in fp64.
   1. the pair lists of s6_pattern: slot 0 holds every row with its own neighbour, every upper slot exactly the pairs whose
      neighbour is the slot's column, ascending; the 256 work units of a node tile its lists (every record once);
-  2. the moments S the assembly sums (dumped by the debug build for 256 nodes from <first node>) against sum rho f_a f_j l l^T
+  2. the moments S the assembly sums (dumped by the debug build for 256 nodes from <first node>) against sum h_a h_j l l^T
      over the same records of the vertex records in global memory, and -J^T r in l coordinates;
   3. the blocks it writes against M_a S M_b^T with the M it staged, their mirrors, and M^-1 of the diagonal block.
 usage: DFA_EXTRA_CXXFLAGS=-DDFA_S6_DEBUG=1024 python dynfu_amd/build.py --force; BASE=1024 CFG=C3 FR=7 python tools/ns_plan_check.py
@@ -52,7 +52,7 @@ for a in range(BASE, BASE + DD):
     rows = nlist[beg:beg + ln]
     # slot 0 list
     l0 = plist[pptr[a, 0]:pptr[a, 1]]
-    exp0 = (np.arange(ln, dtype=np.uint32) << 4) | (rows % k)
+    exp0 = (np.arange(ln, dtype=np.uint32) << 8) | ((rows % k) << 4) | (rows % k)
     if len(l0) != ln or not np.array_equal(l0, exp0):
         bad += 1
         if bad < 4: print("node", a, "slot-0 list wrong: len", len(l0), "rows", ln, l0[:6], exp0[:6])
@@ -73,15 +73,16 @@ for a in range(BASE, BASE + DD):
     nb = idx[vv]                      # (ln, k)
     for q in range(fu, cnt):
         rr, jj = np.nonzero(nb == bcols[a, q])
-        exp = (rr.astype(np.uint32) << 4) | jj.astype(np.uint32)
+        exp = (rr.astype(np.uint32) << 8) | ((rows[rr] % k).astype(np.uint32) << 4) | jj.astype(np.uint32)
         got = plist[pptr[a, q]:pptr[a, q + 1]]
         if len(exp) != len(got) or not np.array_equal(exp, got):
             bad += 1
             if bad < 12: print("node", a, "slot", q, "list differs: len", len(got), "expected", len(exp))
 print("bad", bad)
 # ---- moments against a CPU sum
-rec = fetch(out[11], N * 16, torch.float32).reshape(N, 16)
-rmeta = fetch(out[12], N * 4, torch.float32).reshape(N, 4)
+KT = 4 if k <= 4 else 8  # the kernels' template K: a record is l[8], f[KT], (weight, weight x residual, 0, 0)
+rec = fetch(out[11], N * (12 + KT), torch.float32).reshape(N, 12 + KT)
+rmeta = rec[:, 8 + KT:]
 mom = np.zeros(256 * (48 * 36 + 8), np.float32)
 L.dfa_dev_s6_moments.argtypes = [C.c_void_p]
 assert L.dfa_dev_s6_moments(mom.ctypes.data) == 0
@@ -99,13 +100,11 @@ for a in (BASE, BASE + 1, BASE + 17, BASE + 200):
     for q in [0] + list(range(fu, min(cnt, fu + 2))):
         S = np.zeros((8, 8)); g8 = np.zeros(8)
         for pr in plist[pptr[a, q]:pptr[a, q + 1]]:
-            r, j = int(pr) >> 4, int(pr) & 15
+            r, j = int(pr) >> 8, int(pr) & 15
             en = int(rows[r]); v, oj = en // k, en % k
-            rho, wres = rmeta[v, 0], rmeta[v, 1]
-            if rho == 0: continue
-            l = rec[v, :8].astype(np.float64); f = rec[v, 8:8 + k].astype(np.float64)
-            S += rho * f[oj] * f[j] * np.outer(l, l)
-            if q == 0: g8 += -wres * f[oj] * l
+            l = rec[v, :8].astype(np.float64); h = rec[v, 8:8 + k].astype(np.float64)  # h_j = sqrt(rho) f_j
+            S += h[oj] * h[j] * np.outer(l, l)
+            if q == 0: g8 += -float(rmeta[v, 0]) * h[oj] * l                           # rmeta[v, 0] = sqrt(rho) r
         got = np.array([[mom[a - BASE, q * 36 + sym(i, j)] for j in range(8)] for i in range(8)])
         err = np.abs(got - S).max() / max(np.abs(S).max(), 1e-30)
         print("node %d slot %d: |S| %.3e  rel err %.2e" % (a, q, np.abs(S).max(), err), end="")
@@ -144,13 +143,11 @@ for a in range(BASE, BASE + DD):
     rows = nlist[beg:beg + ln]
     for q in [0] + list(range(fu, cnt)):
         prs = plist[pptr[a, q]:pptr[a, q + 1]].astype(np.int64)
-        r, j = prs >> 4, prs & 15
+        r, j = prs >> 8, prs & 15
         en = rows[r].astype(np.int64); v, oj = en // k, en % k
-        rho = rmeta[v, 0].astype(np.float64)
         l = rec[v, :8].astype(np.float64)
         f = rec[v, 8:8 + k].astype(np.float64)
-        cf = np.where(rho != 0, rho * f[np.arange(len(v)), oj] * f[np.arange(len(v)), j], 0.0)
-        l = np.where((rho != 0)[:, None], l, 0.0)
+        cf = f[np.arange(len(v)), oj] * f[np.arange(len(v)), j]
         S = (l * cf[:, None]).T @ l
         got = np.array([[mom[a - BASE, q * 36 + sym(i, jj)] for jj in range(8)] for i in range(8)])
         err = np.abs(got - S).max() / max(np.abs(S).max(), 1e-30)
