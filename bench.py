@@ -448,18 +448,20 @@ def northstar_rooflines(seq, config, st, tm, fuse_ms):
     """roofline entries of the north-star kernels from the hipEvent timings of the last timed frame (dfa_solver6_get_timing:
     events on the solve's stream around every launch group) — the dominant one first.  Algorithmic bytes:
     linearise reads a vertex (canon 12 + normal 12 + k indices and weights 8 k + the live pixel 32 bytes; the k node
-    transforms come from L2) and writes its row once per neighbour, entry-major (l 32 + f 4 k + weights 8 bytes); the
-    assembly reads every row once per node it touches (the same 40 + 4 k bytes + 4 of the row's list entry) and writes the
-    block matrix (36 floats per block, the upper half computed and mirrored); a PCG iteration reads the matrix (36 floats
-    + a column id per block), three gathered 6-vectors per block and ~12 vectors of 6 D floats."""
+    transforms come from L2) and writes ONE record per vertex (l 32 + h 4 K + 16 bytes, K = 4 or 8 the kernels' template);
+    the assembly reads that record once per node it touches (k times: 48 + 4 K bytes + 4 of the row's list entry), a 4-byte
+    pair record per (row, neighbour) of slot 0 and of the upper blocks (1 + (k - 1) / 2 per row), and writes the block matrix
+    (36 floats per block, the upper half computed and mirrored); a PCG iteration reads the matrix (36 floats + a column id
+    per block), three gathered 6-vectors per block and ~12 vectors of 6 D floats."""
     cfg = seq.cfg
     dim, Wd, Hd, k = cfg["dim"], cfg["width"], cfg["height"], seq.k
     V = dim ** 3
     gn, nblk = max(1, tm["gn_iterations"]), tm["matrix_blocks"]
     launches = max(1, st["pcg_launches"])
     fuse_bytes = 4.0 * V + 2.0 * Wd * Hd
-    lin_bytes = seq.N * (24 + 8 * k + 32) + seq.N * k * (40 + 4 * k)
-    asm_bytes = seq.N * k * (44 + 4 * k) + nblk * 36 * 4
+    kk = 4 if k <= 4 else 8
+    lin_bytes = seq.N * (24 + 8 * k + 32) + seq.N * (48 + 4 * kk)
+    asm_bytes = seq.N * k * (52 + 4 * kk) + seq.N * k * (1 + (k - 1) / 2.0) * 4 + nblk * 36 * 4
     pcg_bytes = nblk * (36 * 4 + 4 + 3 * 24) + 12 * 24.0 * seq.D
     asm_ms, lin_ms, pcg_ms = tm["assemble_ms"] / gn, tm["linearise_ms"] / gn, tm["pcg_ms"] / launches
 
@@ -471,12 +473,12 @@ def northstar_rooflines(seq, config, st, tm, fuse_ms):
                     avg_launch_ms=round(ms, 5), launches_per_frame=per_frame, algorithmic_bytes_per_launch=nbytes,
                     ms_per_frame=round(total_ms, 4), **extra)
 
-    kk = 4 if k <= 4 else 8
     ents = [
-        entry("s6_assemble2_kernel<%d,320> (block normal matrix of one Gauss-Newton iteration)" % kk,
+        entry("s6_assemble2_kernel<%d,%d> (block normal matrix of one Gauss-Newton iteration)" % (kk, 448 if kk == 4 else 352),
               "s6_assemble", asm_ms, asm_bytes, gn, tm["assemble_ms"],
-              note="a quad of lanes per matrix block walks the block's (row, neighbour) list; bound by LDS latency and the "
-                   "imbalance between lists, not by HBM (DESIGN.md 4.5)"),
+              note="a lane per work unit walks its share of one block's (row, neighbour) list and owns the 36 distinct entries "
+                   "of its 8 x 8 moment; rows staged by LDS-DMA.  Bound by instruction issue and the per-workgroup chain of "
+                   "barriers and round trips (SQ counters, phase clocks: DESIGN.md 4.5), not by HBM"),
         entry("s6_linearise_kernel<%d> (+ s6_nodes, s6_reg: residuals and row factors of one Gauss-Newton iteration)" % kk,
               "s6_linearise", lin_ms, lin_bytes, gn, tm["linearise_ms"]),
         entry("s6_pcg_step_kernel (one Chronopoulos-Gear PCG iteration per launch)", "s6_pcg_step", pcg_ms, pcg_bytes, launches,

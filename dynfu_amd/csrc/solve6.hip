@@ -771,6 +771,9 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
     __shared__ float rout[8][24];         // edges leaving a: neighbour (bits), weight, residual (3), vectors (18)
     __shared__ float rin[S6_REGIN][24];   // edges arriving at a: source node (bits), weight, residual (3), vectors (18)
     __shared__ uint32_t bfirst[S6_MAXSLOT];  // first unit | units << 16 of every block that has units
+    // (workgroup -> node in launch order.  Consecutive nodes on one XCD — node (b mod 8) D / 8 + b / 8 for workgroup b, so that
+    // a vertex record is fetched into one L2 instead of up to k — measured 0.048 against 0.050 ms at C2 and 0.156 against
+    // 0.150 at C3: not kept.)
     const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
     S6_TICK(tk0);
 #ifdef DFA_S6_TIMING
@@ -784,6 +787,9 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
     const int32_t* pptr = s.pair_ptr + (size_t)a * (s.cap + 1);
     const int rib = s.rnode_ptr[a], nri = s.rnode_ptr[a + 1] - rib;
     if (tid < S6_MAXSLOT) bfirst[tid] = 0u;
+    // positions of the moment's entries the closing part's lane z reads: S[p][2 z + h] at symt[z][2 p + h]
+    __shared__ __attribute__((aligned(16))) int symt[4][16];
+    if (tid >= 128 && tid < 192) symt[(tid - 128) >> 4][tid & 15] = s6_sym((tid & 15) >> 1, 2 * ((tid - 128) >> 4) + (tid & 1));
     // the row's columns and the mirror slots: read by every phase of the closing part (two dependent global loads there)
     __shared__ int32_t scol[S6_MAXSLOT];
     __shared__ uint8_t srs[S6_MAXSLOT];
@@ -1047,44 +1053,54 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
         for (int i = tid; i < cnt * 48; i += 256) s6_dbgm[(size_t)(a - DFA_S6_DEBUG) * S6_MAXSLOT * 48 + i] = smb[i];
 #endif
     S6_TICK(tk4);
+    // A QUAD of lanes per (block, row), ten blocks (240 threads) per round: lane z takes columns 2 z, 2 z + 1 of M_a S and every
+    // fourth regularisation edge, the four partial rows are added by DPP.  (One thread per (block, row) — 102 of the 256 at C3 —
+    // walked 112 FMAs, ~90 LDS reads and both edge loops alone: 7 of the workgroup's 42 us.)
 #if DFA_S6_ABLATE & 4
-    const int nfin = 6;
+    const int nfin = 1;
 #else
-    const int nfin = (1 + nup) * 6;
+    const int nfin = 1 + nup;
 #endif
-    float* ttile = reinterpret_cast<float*>(s6_dyn) + S6_MAXSLOT * 48;  // 256 x 6 floats behind M (the partial moments are dead)
-    for (int t0 = 0; t0 < nfin; t0 += 252) {  // 42 whole blocks per round (a block's six rows stay together)
-        const int t   = t0 + tid;
-        const bool on = tid < 252 && t < nfin;
+    constexpr int BPR = 10;
+    float* ttile = reinterpret_cast<float*>(s6_dyn) + S6_MAXSLOT * 48;  // BPR x 36 floats behind M (the units' moments are dead)
+    auto quad_sum = [](float x) __attribute__((always_inline)) {
+        x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true));  // quad_perm [1, 0, 3, 2]
+        x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true));  // quad_perm [2, 3, 0, 1]
+        return x;
+    };
+    for (int b0 = 0; b0 < nfin; b0 += BPR) {
+        const int quad = tid >> 2, z = tid & 3, lb = quad / 6, my_row = quad - 6 * lb, sidx = b0 + lb;
+        const bool on  = tid < 4 * 6 * BPR && sidx < nfin;
+        const int slot = on ? (sidx == 0 ? 0 : fu + sidx - 1) : 0;
+        const int col  = scol[slot];
+        float accr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gacc = 0.f;
         if (on) {
-            const int sidx = t / 6, my_row = t - 6 * sidx;
-            const int slot = sidx == 0 ? 0 : fu + sidx - 1;
-            const int col  = scol[slot];
-            float ma[8];
+            // columns 2 z, 2 z + 1 of row my_row of M_a S (slot 0 of M is node a itself), then their share of (M_a S) M_b^T
+            const int4* st4 = reinterpret_cast<const int4*>(&symt[z][0]);
+            int sy[16];
 #pragma unroll
-            for (int p = 0; p < 8; ++p) ma[p] = smb[8 * my_row + p];  // slot 0 is node a itself
-            float vq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // row my_row of M_a S
+            for (int e = 0; e < 4; ++e) {
+                const int4 v = st4[e];
+                sy[4 * e] = v.x, sy[4 * e + 1] = v.y, sy[4 * e + 2] = v.z, sy[4 * e + 3] = v.w;
+            }
             const float* S0 = &accS[slot][0];
+            float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-            for (int p = 0; p < 8; ++p)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) vq[q] = fmaf(ma[p], S0[s6_sym(p, q)], vq[q]);
-            float accr[6];
+            for (int p = 0; p < 8; ++p) {
+                const float ma = smb[8 * my_row + p];
+                v0 = fmaf(ma, S0[sy[2 * p]], v0), v1 = fmaf(ma, S0[sy[2 * p + 1]], v1);
+            }
 #pragma unroll
             for (int d = 0; d < 6; ++d) {
-                const float* mb = smb + 48 * slot + 8 * d;
-                float h = 0.f;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) h = fmaf(vq[q], mb[q], h);
-                accr[d] = h;
+                const float2 mb = *reinterpret_cast<const float2*>(smb + 48 * slot + 8 * d + 2 * z);
+                accr[d]         = fmaf(v1, mb.y, v0 * mb.x);
             }
-            float gacc = 0.f;
             if (slot == 0) {
-#pragma unroll
-                for (int p = 0; p < 8; ++p) gacc += ma[p] * g8s[p];
+                const float2 mo2 = *reinterpret_cast<const float2*>(smb + 8 * my_row + 2 * z);
+                gacc             = fmaf(mo2.y, g8s[2 * z + 1], mo2.x * g8s[2 * z]);
             }
             // regularisation edges leaving a (a -> m): rows c of e = T_a g_m - g^_m with vectors (an_c at a, -e_{3+c} at m)
-            for (int q = 0; q < k; ++q) {
+            for (int q = z; q < k; q += 4) {
                 const float* E = rout[q];
                 const int m    = __float_as_int(E[0]);
                 if (m < 0 || (slot != 0 && col != m)) continue;
@@ -1103,7 +1119,7 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
             // regularisation edges arriving at a (n -> a)
             if (my_row >= 3) {
                 const int cc = my_row - 3;
-                for (int e = 0; e < nri; ++e) {
+                for (int e = z; e < nri; e += 4) {
                     const bool staged    = e < S6_REGIN;  // (rarely not: more arriving edges than the staged ones)
                     const float* E       = rin[staged ? e : 0];
                     const unsigned entry = staged ? 0u : s.rnode_list[rib + e];
@@ -1120,6 +1136,11 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
                     }
                 }
             }
+        }
+#pragma unroll
+        for (int d = 0; d < 6; ++d) accr[d] = quad_sum(accr[d]);
+        gacc = quad_sum(gacc);
+        if (on && z == 0) {
             if (slot == 0) {
                 accr[my_row] += damping;
                 s.g[6 * (size_t)a + my_row] = gacc, gsh[my_row] = gacc;
@@ -1129,26 +1150,22 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
             float2* out = reinterpret_cast<float2*>(s.bvals + ((size_t)a * s.cap + slot) * 36 + 6 * my_row);
             out[0] = make_float2(accr[0], accr[1]), out[1] = make_float2(accr[2], accr[3]), out[2] = make_float2(accr[4], accr[5]);
             // the mirror block H_ba = H_ab^T goes out row by row too (24 contiguous bytes per thread, the block's 144 from six
-            // neighbouring lanes): transposed through LDS — written element by element it cost 4 bytes per store into
-            // somebody else's cache lines (PMC: 135 MB written per launch at C3 for a 21 MB matrix)
-            float* tile = ttile + 6 * (t - t0 - my_row) + my_row;  // block of this thread's slot: 36 floats; column my_row of its transpose
+            // threads): transposed through LDS — written element by element it cost 4 bytes per store into somebody else's
+            // cache lines (PMC: 135 MB written per launch at C3 for a 21 MB matrix)
+            float* tile = ttile + 36 * lb + my_row;  // column my_row of the block's transpose
 #pragma unroll
             for (int d = 0; d < 6; ++d) tile[6 * d] = accr[d];
         }
         __syncthreads();
-        if (on) {
-            const int sidx = t / 6, my_row = t - 6 * sidx;
-            const int slot = sidx == 0 ? 0 : fu + sidx - 1;
-            if (slot != 0) {
-                const int rs = srs[slot];
-                if (rs != 255) {
-                    const float* tr = ttile + 6 * (t - t0 - my_row) + 6 * my_row;  // row my_row of the transposed block
-                    float2* out2    = reinterpret_cast<float2*>(s.bvals + ((size_t)scol[slot] * s.cap + rs) * 36 + 6 * my_row);
-                    out2[0] = make_float2(tr[0], tr[1]), out2[1] = make_float2(tr[2], tr[3]), out2[2] = make_float2(tr[4], tr[5]);
-                }
+        if (on && z == 0 && slot != 0) {
+            const int rs = srs[slot];
+            if (rs != 255) {
+                const float* tr = ttile + 36 * lb + 6 * my_row;  // row my_row of the transposed block
+                float2* out2    = reinterpret_cast<float2*>(s.bvals + ((size_t)col * s.cap + rs) * 36 + 6 * my_row);
+                out2[0] = make_float2(tr[0], tr[1]), out2[1] = make_float2(tr[2], tr[3]), out2[2] = make_float2(tr[4], tr[5]);
             }
         }
-        __syncthreads();
+        if (b0 + BPR < nfin) __syncthreads();  // (the tile is reused by the next round)
     }
     S6_TICK(tk5);
     if (tid < 6) {
