@@ -65,6 +65,9 @@ constexpr int S6_SORT_MAX = 4096;
 
 // bitonic sort of n <= S6_SORT_MAX keys in LDS by one 256-thread workgroup (buf holds the next power of two, padded with
 // 0xffffffff)
+// Stages with a stride of at most 64 keep a wave inside its own 128-key blocks (compare-exchange i = tid + 256 m touches the
+// 2-stride-aligned block of key 2 i): the wave's LDS operations are ordered among themselves, no workgroup barrier is needed
+// between such stages — 10 barriers instead of 66 for 2 048 keys.
 __device__ __forceinline__ void s6_sort_lds(uint32_t* buf, int n2, int tid) {
     for (int size = 2; size <= n2; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -74,7 +77,10 @@ __device__ __forceinline__ void s6_sort_lds(uint32_t* buf, int n2, int tid) {
                 const uint32_t x = buf[lo], y = buf[hi];
                 if ((x > y) == up) buf[lo] = y, buf[hi] = x;
             }
-            __syncthreads();
+            // the next stage leaves the wave's blocks (or there is none): everybody waits; else only the compiler does
+            const int next = stride > 1 ? stride >> 1 : size;  // (after stride 1 comes size 2 x size with stride = size)
+            if (stride > 64 || next > 64 || (stride == 1 && size == n2)) __syncthreads();
+            else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"), __builtin_amdgcn_wave_barrier(), __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
 }
 
@@ -369,7 +375,10 @@ constexpr int S6_HASH = 128;
 __device__ __forceinline__ int hash_slot(int* keys, int b) {
     unsigned h = ((unsigned)b * 2654435761u) >> 25;  // 7 bits
     for (int probe = 0; probe < S6_HASH; ++probe) {
-        const int seen = atomicCAS(&keys[h], -1, b);
+        // (a plain read first: thousands of pairs look up a few dozen keys, and an LDS atomic per look-up on a handful of
+        // addresses serialises the wave; an entry, once written, never changes)
+        int seen = __atomic_load_n(&keys[h], __ATOMIC_RELAXED);
+        if (seen == -1) seen = atomicCAS(&keys[h], -1, b);
         if (seen == -1 || seen == b) return (int)h;
         h = (h + 1) & (S6_HASH - 1);
     }
@@ -473,11 +482,21 @@ constexpr int S6_MAXSLOT_PATTERN = 48;  // = S6_MAXSLOT (declared below), the pl
 constexpr int S6_UNITS = 256;           // work units of a node's assembly = threads of its workgroup
 constexpr int S6_DEAL  = 8;             // a node's sorted rows are dealt out in this many interleaved runs (s6_pattern_kernel)
 
+#ifdef DFA_S6_TIMING  // development builds only: per-workgroup phase clocks of the assembly (tools/ns_assemble_phases.py)
+__device__ unsigned long long s6_tbuf[16384 * 16];
+#define S6_TICK(var) const unsigned long long var = clock64()
+extern "C" __attribute__((visibility("default"))) int dfa_dev_s6_timing(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(s6_tbuf), sizeof(unsigned long long) * 16 * (size_t)n);
+}
+#else
+#define S6_TICK(var)
+#endif
 __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6State* st) {
     __shared__ int keys[S6_HASH];
     __shared__ int cnt_sh;
     __shared__ uint32_t sortbuf[S6_SORT_MAX];
     const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
+    S6_TICK(pk0);
     for (int i = tid; i < S6_HASH; i += 256) keys[i] = -1;
     if (tid == 0) cnt_sh = 0;
     // The transposition fills a node's list in whatever order its workgroups' atomics land; sort it so
@@ -493,7 +512,7 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
             // ... and deal the sorted rows out in S6_DEAL interleaved runs (rows 0, 8, 16, ..., then 1, 9, ...): the assembly
             // stages the list a few hundred rows at a time, and a vertex's neighbours come in clusters along the sorted list —
             // in sorted order one pass held all the records of some blocks and none of others, and the lanes (one block each)
-            // waited for the fullest (records phase at C3: 9.9 -> 6.x us per workgroup).  Now every pass is a uniform sample.
+            // waited for the fullest (3.5 us of a workgroup's 42 at C3).  Now every pass is a uniform sample.
             const int per = len / S6_DEAL, extra = len - per * S6_DEAL;
             for (int i = tid; i < len; i += 256) {
                 const int g = i % S6_DEAL, t = i / S6_DEAL;
@@ -511,12 +530,27 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
         }
     }
     __syncthreads();
+    S6_TICK(pk1);
+    // ---- the columns of block row a: every neighbour of every vertex of a's rows (and the regularisation partners) into a
+    // 128-entry LDS hash; the position a pair's neighbour landed at is remembered per pair (a byte: 254 = a itself, 255 =
+    // none), so that the pair's slot is a table look-up once the columns are ranked.  The bytes live in the (now idle) sort
+    // buffer when they fit, else in global scratch.
+    const int pbeg = s.node_ptr[a], plen = s.node_ptr[a + 1] - pbeg, npairs = plen * k;
+    uint8_t* es_lds   = reinterpret_cast<uint8_t*>(sortbuf);
+    const bool in_lds = npairs <= (int)sizeof(sortbuf);
+    uint8_t* es       = in_lds ? es_lds : s.eslot + (size_t)pbeg * k;
     bool lost = false;
-    for (int e = s.node_ptr[a] + tid; e < s.node_ptr[a + 1]; e += 256) {
-        const unsigned v = s.node_list[e] / (unsigned)k;
+    for (int r = tid; r < plen; r += 256) {
+        const unsigned v = s.node_list[pbeg + r] / (unsigned)k;
         for (int j = 0; j < k; ++j) {
             const int b = s.idx[(size_t)v * k + j];
-            if (b >= 0 && b != a && hash_slot(keys, b) < 0) lost = true;
+            int hp      = 255;
+            if (b == a) hp = 254;
+            else if (b >= 0) {
+                hp = hash_slot(keys, b);
+                if (hp < 0) lost = true, hp = 255;
+            }
+            es[(size_t)r * k + j] = (uint8_t)hp;
         }
     }
     if (tid < k) {
@@ -528,11 +562,17 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
         if (n != a && hash_slot(keys, n) < 0) lost = true;
     }
     __syncthreads();
-    if (tid < S6_HASH && keys[tid] >= 0) {
-        int r = 0;
-        for (int h = 0; h < S6_HASH; ++h) r += keys[h] >= 0 && keys[h] < keys[tid];
-        if (r + 1 < s.cap) s.bcols[(size_t)a * s.cap + r + 1] = keys[tid];
-        atomicAdd(&cnt_sh, 1);
+    S6_TICK(pk2);
+    __shared__ uint8_t hrank[S6_HASH];  // hash position -> slot of that column (255: not stored)
+    if (tid < S6_HASH) {
+        int r = 254;
+        if (keys[tid] >= 0) {
+            r = 0;
+            for (int h = 0; h < S6_HASH; ++h) r += keys[h] >= 0 && keys[h] < keys[tid];
+            if (r + 1 < s.cap) s.bcols[(size_t)a * s.cap + r + 1] = keys[tid];
+            atomicAdd(&cnt_sh, 1);
+        }
+        hrank[tid] = (uint8_t)(r + 1 < s.cap ? r + 1 : 255);
     }
     __syncthreads();
     const int nblk = cnt_sh + 1, stored = nblk < s.cap ? nblk : s.cap;
@@ -541,59 +581,67 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
         s.bcols[(size_t)a * s.cap] = a;
         s.bcnt[a] = stored;
         atomicMax(&st->max_row_blocks, nblk);
-        if (nblk > s.cap) st->overflow = 1;
+        if (nblk > s.cap || plen > 60000) st->overflow = 1;  // (16-bit offsets in the split below)
     }
     if (lost) st->overflow = 1;
-    __syncthreads();  // (the column list of this row was written by this workgroup: visible after the barrier)
-    // slot of every neighbour of every row that touches a: the assembly adds a row's k x k products
-    // straight into the right 6x6 blocks
-    __shared__ int cols[64];  // the finished column list of this row (searched 8 times per row of the energy)
-    if (tid < 64) cols[tid] = tid < stored ? s.bcols[(size_t)a * s.cap + tid] : -1;
-    __syncthreads();
-    // ---- the pattern by slot (s6_assemble2_kernel): for every row that touches a and every neighbour of its vertex, the slot
-    // of that neighbour in a's block row; then a stable split of these (row, neighbour) pairs by slot.  Counts by LDS atomics,
-    // then wave w compacts the lists of slots 1 + w, 5 + w, ... in ascending pair order with ballots: run-to-run identical
-    // lists, hence identical sums.
     // The matrix is symmetric, H_ba = H_ab^T: the assembly computes a block once, in the row of the smaller node index, and
-    // writes it to both rows.  Lists are kept for slot 0 (the row's own neighbour: one record per row) and for the "upper" slots (column > a; the
-    // columns ascend, so these are the slots from `fu` on), the others stay empty.
+    // writes it to both rows.  Pair lists are kept for slot 0 (the row's own neighbour: one record per row) and for the "upper"
+    // slots (column > a; the columns ascend, so these are the slots from `fu` on), the others stay empty.
     __shared__ int pcnt[64], pstart[64];
     __shared__ int fu_sh;
-    if (tid < 64) pcnt[tid] = 0;
-    if (tid < 64) {
-        const uint64_t lower = __ballot(tid >= 1 && tid < stored && cols[tid] < a);
-        if (tid == 0) fu_sh = 1 + __popcll(lower), s.bfu[a] = 1 + __popcll(lower);
+    if (tid < S6_HASH / 2) {  // first wave: slots 1 .. fu - 1 are the columns below a = the keys below a
+        const uint64_t l0 = __ballot(keys[tid] >= 0 && keys[tid] < a), l1 = __ballot(keys[tid + 64] >= 0 && keys[tid + 64] < a);
+        if (tid == 0) {
+            const int f = min(1 + __popcll(l0) + __popcll(l1), stored);
+            fu_sh = f, s.bfu[a] = f;
+        }
     }
     __syncthreads();
-    const int fu   = fu_sh;
-    const int pbeg = s.node_ptr[a], plen = s.node_ptr[a + 1] - pbeg, npairs = plen * k;
-    // the node's slot bytes live in the (now idle) sort buffer when they fit, else in global scratch
-    uint8_t* es_lds   = reinterpret_cast<uint8_t*>(sortbuf);
-    const bool in_lds = npairs <= (int)sizeof(sortbuf);
-    uint8_t* es       = in_lds ? es_lds : s.eslot + (size_t)pbeg * k;
-    for (int r = tid; r < plen; r += 256) {
-        const unsigned v = s.node_list[pbeg + r] / (unsigned)k;
-        for (int j = 0; j < k; ++j) {
-            const int b = s.idx[(size_t)v * k + j];
-            int sl      = 255;
-            if (b == a) sl = 0;
-            else if (b >= 0) {  // the columns of slots 1 .. stored - 1 ascend: binary search
-                int lo = 1, hi = stored - 1;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (cols[mid] < b) lo = mid + 1;
-                    else hi = mid;
-                }
-                if (lo < stored && cols[lo] == b) sl = lo;
+    S6_TICK(pk3);
+    const int fu = fu_sh;
+    // ---- the pattern by slot (s6_assemble2_kernel): a STABLE split of the (row, neighbour) pairs by slot, as a counting sort —
+    // thread t takes a contiguous run of pairs, counts its pairs per slot into its own column of hist (16-bit), the columns
+    // are scanned per slot (wave w: slots w, w + 4, ...), then every thread writes its pairs, in order, from its offsets on:
+    // lists in ascending pair order, run-to-run identical, O(pairs) work (ballots per slot and 64 pairs: 83 of the kernel's
+    // 194 us per workgroup at C3).
+    __shared__ uint16_t hist[S6_MAXSLOT_PATTERN][256];
+    for (int i = tid; i < S6_MAXSLOT_PATTERN * 256 / 8; i += 256) reinterpret_cast<uint4*>(&hist[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    const int per_thread = (npairs + 255) / 256, p0 = min(tid * per_thread, npairs), p1 = min(p0 + per_thread, npairs);
+    for (int p = p0; p < p1; ++p) {
+        const int hp = es[p];
+        const int sl = hp == 254 ? 0 : hp == 255 ? 255 : (int)hrank[hp];
+        const bool listed = sl == 0 || (sl >= fu && sl < stored);
+        es[p] = (uint8_t)(listed ? sl : 255);
+        if (listed) hist[sl][tid] += 1;
+    }
+    __syncthreads();
+    S6_TICK(pk4);
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int q = wave; q < stored; q += 4) {
+            if (q != 0 && q < fu) {  // (uniform)
+                if (lane == 0) pcnt[q] = 0;
+                continue;
             }
-            es[(size_t)r * k + j] = (uint8_t)sl;
-            if (sl >= fu && sl < stored) atomicAdd(&pcnt[sl], 1);  // (slot 0: one pair per row, counted below)
+            uint2* hq      = reinterpret_cast<uint2*>(&hist[q][4 * lane]);  // threads 4 lane .. 4 lane + 3
+            const uint2 hv = *hq;
+            const uint32_t c0 = hv.x & 0xffffu, c1 = hv.x >> 16, c2 = hv.y & 0xffffu, c3 = hv.y >> 16;
+            const uint32_t mine = c0 + c1 + c2 + c3;
+            uint32_t incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            const uint32_t e0 = incl - mine, e1 = e0 + c0, e2 = e1 + c1, e3 = e2 + c2;
+            *hq = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
+            if (lane == 63) pcnt[q] = (int)incl;
         }
     }
     __syncthreads();
     if (tid == 0) {
         int run = pbeg * k;  // the lists of node a live in pair_list[pbeg k, (pbeg + plen) k): slot 0 (every row), then the upper slots
-        pcnt[0] = plen;
         for (int q = 0; q < stored; ++q) pstart[q] = run, run += pcnt[q];
         pstart[stored] = run;
     }
@@ -630,31 +678,24 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
         }
         s.utab[(size_t)a * S6_UNITS + tid] = info;
     }
-    {   // one pass over the pairs per wave: a chunk's slot bytes are read once and matched against the wave's (at most
-        // 12) slots — independent ballots instead of one dependent read-compare-ballot chain per slot and chunk
-        const int wave = tid >> 6, lane = tid & 63;
-        constexpr int SPW = (S6_MAXSLOT_PATTERN + 3) / 4;
-        int out[SPW];
-#pragma unroll
-        for (int i = 0; i < SPW; ++i) out[i] = wave + 4 * i < stored ? pstart[wave + 4 * i] : 0;
-        for (int base = 0; base < npairs; base += 64) {
-            const int p  = base + lane;
-            const int sl = p < npairs ? (int)es[p] : 255;
-            const int r  = p / k;
-            const uint32_t oj     = p < npairs ? s.node_list[pbeg + r] % (unsigned)k : 0u;  // the row's own neighbour slot
-            const uint32_t packed = ((uint32_t)r << 8) | (oj << 4) | (uint32_t)(p - r * k);
-#pragma unroll
-            for (int i = 0; i < SPW; ++i) {
-                const int q = wave + 4 * i;
-                if (q < stored && (q >= fu || q == 0)) {  // wave-uniform
-                    const bool match  = sl == q;
-                    const uint64_t mk = __ballot(match);
-                    if (match) s.pair_list[out[i] + __popcll(mk & ((1ull << lane) - 1ull))] = packed;
-                    out[i] += __popcll(mk);
-                }
-            }
-        }
+    S6_TICK(pk5);
+    // the pairs of this thread, in order, each to the next free place of its slot's list
+    for (int p = p0; p < p1; ++p) {
+        const int sl = es[p];
+        if (sl == 255) continue;
+        const int r = p / k;
+        const uint32_t oj   = s.node_list[pbeg + r] % (unsigned)k;  // the row's own neighbour slot
+        const uint32_t off  = hist[sl][tid];
+        hist[sl][tid]       = (uint16_t)(off + 1u);
+        s.pair_list[pstart[sl] + (int)off] = ((uint32_t)r << 8) | (oj << 4) | (uint32_t)(p - r * k);
     }
+#ifdef DFA_S6_TIMING
+    if (tid == 0 && a < 16384) {
+        unsigned long long* o = s6_tbuf + 16 * (size_t)a;
+        const unsigned long long pk6 = clock64();
+        o[0] = pk0, o[1] = pk1 - pk0, o[2] = pk2 - pk1, o[3] = pk3 - pk2, o[4] = pk4 - pk3, o[5] = pk5 - pk4, o[6] = pk6 - pk5, o[10] = pk6 - pk0;
+    }
+#endif
 }
 
 // slot of node a in the block row of each of its columns (the mirror position of block (a, slot)); 255 = not there
@@ -724,15 +765,6 @@ __host__ __device__ constexpr int s6_sym(int i, int j) {
 
 #ifndef DFA_S6_WAVES
 #define DFA_S6_WAVES 4  // waves per SIMD the register allocation aims at (four workgroups per CU by LDS: <= 128 VGPRs, 3-4 spilled)
-#endif
-#ifdef DFA_S6_TIMING  // development builds only: per-workgroup phase clocks of the assembly (tools/ns_assemble_phases.py)
-__device__ unsigned long long s6_tbuf[16384 * 16];
-#define S6_TICK(var) const unsigned long long var = clock64()
-extern "C" __attribute__((visibility("default"))) int dfa_dev_s6_timing(unsigned long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(s6_tbuf), sizeof(unsigned long long) * 16 * (size_t)n);
-}
-#else
-#define S6_TICK(var)
 #endif
 #ifdef DFA_S6_DEBUG
 __device__ float s6_dbg[256 * (S6_MAXSLOT * 36 + 8)];
