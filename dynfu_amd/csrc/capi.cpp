@@ -1000,6 +1000,8 @@ int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
     A(dq, D * 8);
     A(ghat, D * 3);
     A(rec, N * (12 + (k <= 4 ? 4 : 8)));
+    A(cost_part, (N + 255) / 256 + (D * k + 255) / 256 + 1);
+    A(valid_part, (N + 255) / 256 + (D * k + 255) / 256 + 1);
     A(mnode, D * 48);
     A(rho, N);
     A(rres, D * k * 3);

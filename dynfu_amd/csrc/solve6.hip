@@ -173,16 +173,29 @@ __device__ __forceinline__ void blend(const float* __restrict__ dq, const int32_
     B.a = Quat{0.f, 0.f, 0.f, 0.f}, B.b = B.a;
     Quat r0   = Quat{1.f, 0.f, 0.f, 0.f};
     bool have = false;
+    // the node transforms four at a time, by unconditional loads (a neighbour that is not there reads node 0 and is not
+    // used): with the load inside the `if` the k gathers were k dependent round trips to L2
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        B.s[j] = 0.f;
-        if (j >= k || idx[j] < 0 || wn[j] == 0.f) continue;
-        const DQ q = dq_load(dq + 8 * (size_t)idx[j]);
-        if (!have) r0 = q.r, have = true;
-        const float sg = qdot(q.r, r0) < 0.f ? -1.f : 1.f;
-        B.s[j]         = sg;
-        const float w  = wn[j] * sg;
-        B.a = qadd(B.a, qscale(q.r, w)), B.b = qadd(B.b, qscale(q.d, w));
+    for (int h = 0; h < K; h += 4) {
+        DQ q[4];
+        bool on[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = h + jj;
+            on[jj]      = j < k && idx[j] >= 0 && wn[j] != 0.f;
+            q[jj]       = dq_load(dq + 8 * (size_t)(on[jj] ? idx[j] : 0));
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = h + jj;
+            B.s[j]      = 0.f;
+            if (!on[jj]) continue;
+            if (!have) r0 = q[jj].r, have = true;
+            const float sg = qdot(q[jj].r, r0) < 0.f ? -1.f : 1.f;
+            B.s[j]         = sg;
+            const float w  = wn[j] * sg;
+            B.a = qadd(B.a, qscale(q[jj].r, w)), B.b = qadd(B.b, qscale(q[jj].d, w));
+        }
     }
     B.m = qdot(B.a, B.a);
 }
@@ -232,7 +245,11 @@ __device__ __forceinline__ float tukey6(float err, float offset, float c) {  // 
     return 0.f;
 }
 
-__device__ __forceinline__ void block_add_cost(double cost, unsigned int nvalid, Solve6State* st) {
+// The energy of a linearisation: every workgroup leaves ITS sum (and count of valid rows) in cost_part / valid_part, the
+// first workgroup of the assembly that follows adds them up in a fixed order (s6_cost_total).  Two atomicAdds per workgroup
+// on the state block's two words — 4 000 same-address fp64 atomics per launch at C3 — cost 15-25 us of the launch
+// (C2 0.033 -> 0.017 ms, C3 0.061 -> 0.041), and their order decided the last bits of the sum.
+__device__ __forceinline__ void block_add_cost(double cost, unsigned int nvalid, const Solve6View& s) {
     __shared__ double sc[8];
     __shared__ unsigned int sn[8];
     cost   = wave_sum_all(cost);
@@ -244,9 +261,23 @@ __device__ __forceinline__ void block_add_cost(double cost, unsigned int nvalid,
         double c = 0;
         unsigned int n = 0;
         for (int w = 0; w < nw; ++w) c += sc[w], n += sn[w];
-        if (c != 0.0) atomicAdd(&st->cost, c);
-        if (n) atomicAdd(&st->valid, (unsigned long long)n);
+        s.cost_part[blockIdx.x] = c, s.valid_part[blockIdx.x] = n;
     }
+}
+__host__ __device__ inline int s6_linearise_blocks(int N, int D, int k) { return (N + 255) / 256 + (D * k + 255) / 256; }
+// by all 256 threads of one workgroup: the partial sums of the last linearisation, in a fixed order, into the state block
+__device__ __forceinline__ void s6_cost_total(const Solve6View& s, Solve6State* st) {
+    __shared__ double tc[4];
+    __shared__ unsigned long long tn[4];
+    const int n = s6_linearise_blocks(s.N, s.D, s.k), tid = threadIdx.x;
+    double c = 0.0;
+    unsigned long long v = 0ull;
+    for (int i = tid; i < n; i += 256) c += s.cost_part[i], v += s.valid_part[i];
+    c = wave_sum_all(c);
+    v = (unsigned long long)wave_sum_all((double)v);  // (counts below 2^53: exact)
+    if ((tid & 63) == 0) tc[tid >> 6] = c, tn[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) st->cost = (tc[0] + tc[1]) + (tc[2] + tc[3]), st->valid = (tn[0] + tn[1]) + (tn[2] + tn[3]);
 }
 
 __device__ __forceinline__ double s6_reg_edge(const Solve6View& s, int e, float wreg2, float psi_reg, int update_w);
@@ -257,7 +288,7 @@ __global__ __launch_bounds__(256) void s6_linearise_kernel(Solve6View s, Solve6S
                                                            Solve6Params prm, int update_w, int nlin, float wreg2) {
     if ((int)blockIdx.x >= nlin) {  // (uniform)
         const int e = ((int)blockIdx.x - nlin) * 256 + (int)threadIdx.x;
-        block_add_cost(e < s.D * s.k ? s6_reg_edge(s, e, wreg2, prm.psi_reg, update_w) : 0.0, 0u, st);
+        block_add_cost(e < s.D * s.k ? s6_reg_edge(s, e, wreg2, prm.psi_reg, update_w) : 0.0, 0u, s);
         return;
     }
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -338,7 +369,7 @@ __global__ __launch_bounds__(256) void s6_linearise_kernel(Solve6View s, Solve6S
         for (int q = 0; q < K / 4; ++q) rec[2 + q] = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
         rec[2 + K / 4] = make_float4(swr, 0.f, 0.f, 0.f);
     }
-    block_add_cost(cost, nvalid, st);
+    block_add_cost(cost, nvalid, s);
 }
 
 __device__ __forceinline__ double s6_reg_edge(const Solve6View& s, int e, float wreg2, float psi_reg, int update_w) {
@@ -580,7 +611,8 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
     if (tid == 0) {
         s.bcols[(size_t)a * s.cap] = a;
         s.bcnt[a] = stored;
-        atomicMax(&st->max_row_blocks, nblk);
+        // (a running maximum: most workgroups find it already at or above theirs and skip the same-address atomic)
+        if (nblk > __atomic_load_n(&st->max_row_blocks, __ATOMIC_RELAXED)) atomicMax(&st->max_row_blocks, nblk);
         if (nblk > s.cap || plen > 60000) st->overflow = 1;  // (16-bit offsets in the split below)
     }
     if (lost) st->overflow = 1;
@@ -604,47 +636,77 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
     // are scanned per slot (wave w: slots w, w + 4, ...), then every thread writes its pairs, in order, from its offsets on:
     // lists in ascending pair order, run-to-run identical, O(pairs) work (ballots per slot and 64 pairs: 83 of the kernel's
     // 194 us per workgroup at C3).
-    __shared__ uint16_t hist[S6_MAXSLOT_PATTERN][256];
-    for (int i = tid; i < S6_MAXSLOT_PATTERN * 256 / 8; i += 256) reinterpret_cast<uint4*>(&hist[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
+    // (S6_SPLIT listed slots — slot 0 and the upper ones, in slot order — per round: all 48 at once are 24 KiB of counters, which
+    // left room for three workgroups per CU instead of five)
+    constexpr int S6_SPLIT = 24;
+    __shared__ uint16_t hist[S6_SPLIT][256];
+    __shared__ int run_sh;
+    const int nlisted = stored > fu ? 1 + stored - fu : 1;  // listed slot li: slot 0 (li = 0) or slot fu + li - 1
     const int per_thread = (npairs + 255) / 256, p0 = min(tid * per_thread, npairs), p1 = min(p0 + per_thread, npairs);
-    for (int p = p0; p < p1; ++p) {
+    for (int p = p0; p < p1; ++p) {  // hash position -> listed slot index (255: none)
         const int hp = es[p];
         const int sl = hp == 254 ? 0 : hp == 255 ? 255 : (int)hrank[hp];
-        const bool listed = sl == 0 || (sl >= fu && sl < stored);
-        es[p] = (uint8_t)(listed ? sl : 255);
-        if (listed) hist[sl][tid] += 1;
+        es[p] = (uint8_t)(sl == 0 ? 0 : (sl >= fu && sl < stored) ? sl - fu + 1 : 255);
     }
-    __syncthreads();
-    S6_TICK(pk4);
-    {
-        const int wave = tid >> 6, lane = tid & 63;
-        for (int q = wave; q < stored; q += 4) {
-            if (q != 0 && q < fu) {  // (uniform)
-                if (lane == 0) pcnt[q] = 0;
-                continue;
-            }
-            uint2* hq      = reinterpret_cast<uint2*>(&hist[q][4 * lane]);  // threads 4 lane .. 4 lane + 3
-            const uint2 hv = *hq;
-            const uint32_t c0 = hv.x & 0xffffu, c1 = hv.x >> 16, c2 = hv.y & 0xffffu, c3 = hv.y >> 16;
-            const uint32_t mine = c0 + c1 + c2 + c3;
-            uint32_t incl = mine;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t t = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += t;
-            }
-            const uint32_t e0 = incl - mine, e1 = e0 + c0, e2 = e1 + c1, e3 = e2 + c2;
-            *hq = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
-            if (lane == 63) pcnt[q] = (int)incl;
+    if (tid < 64) pcnt[tid] = 0;
+    if (tid == 0) run_sh = pbeg * k;  // the lists of node a live in pair_list[pbeg k, (pbeg + plen) k): slot 0 (every row), then the upper slots
+    for (int l0 = 0; l0 < nlisted; l0 += S6_SPLIT) {
+        const int nl = min(S6_SPLIT, nlisted - l0);
+        for (int i = tid; i < S6_SPLIT * 256 / 8; i += 256) reinterpret_cast<uint4*>(&hist[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        for (int p = p0; p < p1; ++p) {
+            const int li = (int)es[p] - l0;
+            if (li >= 0 && li < nl) hist[li][tid] += 1;
         }
+        __syncthreads();
+        {
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int li = wave; li < nl; li += 4) {
+                uint2* hq      = reinterpret_cast<uint2*>(&hist[li][4 * lane]);  // threads 4 lane .. 4 lane + 3
+                const uint2 hv = *hq;
+                const uint32_t c0 = hv.x & 0xffffu, c1 = hv.x >> 16, c2 = hv.y & 0xffffu, c3 = hv.y >> 16;
+                const uint32_t mine = c0 + c1 + c2 + c3;
+                uint32_t incl = mine;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t t = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += t;
+                }
+                const uint32_t e0 = incl - mine, e1 = e0 + c0, e2 = e1 + c1, e3 = e2 + c2;
+                *hq = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
+                if (lane == 63) pcnt[l0 + li == 0 ? 0 : fu + l0 + li - 1] = (int)incl;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int run = run_sh;
+            for (int li = l0; li < l0 + nl; ++li) {
+                const int q = li == 0 ? 0 : fu + li - 1;
+                if (li == 1)
+                    for (int z = 1; z < fu; ++z) pstart[z] = run;  // (the lower slots: empty lists)
+                pstart[q] = run, run += pcnt[q];
+            }
+            run_sh = run;
+            if (l0 + nl >= nlisted) {
+                if (nlisted == 1)
+                    for (int z = 1; z < stored; ++z) pstart[z] = run;
+                pstart[stored] = run;
+            }
+        }
+        __syncthreads();
+        // the pairs of this thread, in order, each to the next free place of its slot's list
+        for (int p = p0; p < p1; ++p) {
+            const int li = (int)es[p] - l0;
+            if (li < 0 || li >= nl) continue;
+            const int r = p / k, q = l0 + li == 0 ? 0 : fu + l0 + li - 1;
+            const uint32_t oj  = s.node_list[pbeg + r] % (unsigned)k;  // the row's own neighbour slot
+            const uint32_t off = hist[li][tid];
+            hist[li][tid]      = (uint16_t)(off + 1u);
+            s.pair_list[pstart[q] + (int)off] = ((uint32_t)r << 8) | (oj << 4) | (uint32_t)(p - r * k);
+        }
+        if (l0 + S6_SPLIT < nlisted) __syncthreads();  // (the counters are cleared for the next round)
     }
-    __syncthreads();
-    if (tid == 0) {
-        int run = pbeg * k;  // the lists of node a live in pair_list[pbeg k, (pbeg + plen) k): slot 0 (every row), then the upper slots
-        for (int q = 0; q < stored; ++q) pstart[q] = run, run += pcnt[q];
-        pstart[stored] = run;
-    }
+    S6_TICK(pk4);
     __syncthreads();
     if (tid <= stored) s.pair_ptr[(size_t)a * (s.cap + 1) + tid] = pstart[tid];
     // ---- work units of the assembly: S6_UNITS per node, one per LANE of its workgroup.  A unit walks every n-th record of ONE
@@ -679,16 +741,6 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
         s.utab[(size_t)a * S6_UNITS + tid] = info;
     }
     S6_TICK(pk5);
-    // the pairs of this thread, in order, each to the next free place of its slot's list
-    for (int p = p0; p < p1; ++p) {
-        const int sl = es[p];
-        if (sl == 255) continue;
-        const int r = p / k;
-        const uint32_t oj   = s.node_list[pbeg + r] % (unsigned)k;  // the row's own neighbour slot
-        const uint32_t off  = hist[sl][tid];
-        hist[sl][tid]       = (uint16_t)(off + 1u);
-        s.pair_list[pstart[sl] + (int)off] = ((uint32_t)r << 8) | (oj << 4) | (uint32_t)(p - r * k);
-    }
 #ifdef DFA_S6_TIMING
     if (tid == 0 && a < 16384) {
         unsigned long long* o = s6_tbuf + 16 * (size_t)a;
@@ -807,12 +859,17 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
     // a vertex record is fetched into one L2 instead of up to k — measured 0.048 against 0.050 ms at C2 and 0.156 against
     // 0.150 at C3: not kept.)
     const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
+    if (a == s.D) {  // one workgroup more than nodes: the energy of the linearisation this launch follows, the state block's bookkeeping
+        s6_cost_total(s, st);
+        if (tid == 0) s6_bookkeeping(st, forcing);
+        return;
+    }
     S6_TICK(tk0);
 #ifdef DFA_S6_TIMING
     const unsigned long long wk0 = wall_clock64();
     unsigned long long tk_stage = 0, tk_prep = 0, tk_up = 0;
 #endif
-    if (a == 0 && tid == 0) s6_bookkeeping(st, forcing);
+
     const int cnt = s.bcnt[a], fu = s.bfu[a];
     const int beg = s.node_ptr[a], len = s.node_ptr[a + 1] - beg;
     const int wave = tid >> 6, lane = tid & 63;
@@ -1591,7 +1648,7 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
             const hipError_t ae = allow_dynamic_lds((const void*)s6_assemble2_kernel<KK, RC, EX>, (int)sh);         \
             if (ae != hipSuccess) return ae;                                                                      \
         }                                                                                                         \
-        s6_assemble2_kernel<KK, RC, EX><<<s.D, 256, sh, st>>>(s, state, wreg2, p.damping, f);                        \
+        s6_assemble2_kernel<KK, RC, EX><<<s.D + 1, 256, sh, st>>>(s, state, wreg2, p.damping, f);                    \
     } while (0)
         if (s.k <= 4) {
             if (rc <= 320) S6A2(4, 320);

@@ -91,6 +91,8 @@ struct Solve6View {
     // weight * residual, 0, 0 }, K = 4 or 8 (the kernels' template): 2 + K / 4 + 1 chunks of 16 bytes, the unit the
     // assembly's LDS-DMA fetches them in
     float* rec;    // N x (12 + K)
+    double* cost_part;        // per workgroup of s6_linearise: its share of the energy (summed by the assembly's first workgroup)
+    unsigned int* valid_part; // ... and of the valid rows
     float* mnode;  // D x 6 x 8  M_n: twist components of node n as (W, Wd) increments
     float* rho;   // N           Tukey weight (frozen between re-weightings)
     float* rres;  // D x k x 3   regularisation residuals

@@ -26,7 +26,7 @@ buf = np.zeros((n, 16), np.uint64)
 L.dfa_dev_s6_timing.argtypes = [C.c_void_p, C.c_int]
 assert L.dfa_dev_s6_timing(buf.ctypes.data, n) == 0
 t = buf.astype(np.float64)
-names = ["sort + deal", "hash the neighbours", "rank the columns", "slot bytes + counts", "scan, lists' starts, units", "scatter"]
+names = ["sort + deal", "hash the neighbours", "rank the columns", "split by slot", "work units", "(end)"]
 tot = t[:, 10]
 us = lambda x: x / 2250.0
 print("%s: %d workgroups, lifetime mean %.1f us (p95 %.1f)" % (name, n, us(tot.mean()), us(np.percentile(tot, 95))))
