@@ -1292,7 +1292,10 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
 // the same launch: the gather rebuilds it from u_i, m_i, t_{i-1} and the two scalars (18 floats per
 // neighbour block next to the block's own 36).  Same iterates as textbook PCG in exact arithmetic.
 // launch `it` = -1: w_0 = A u_0, m_0, gamma_0, delta_0.   launch it >= 0: iteration `it` as above.
-__global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(Solve6View s, Solve6State* st, int it) {
+#ifndef DFA_S6_PCG_WAVES
+#define DFA_S6_PCG_WAVES 5
+#endif
+__global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK, DFA_S6_PCG_WAVES) void s6_pcg_step_kernel(Solve6View s, Solve6State* st, int it) {
     __shared__ float stage[S6_NODES_PER_BLOCK][3][64];
     __shared__ float gd_sh[S6_NODES_PER_BLOCK][2];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1308,7 +1311,12 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(So
     // products A u, A m, A t are gathered separately and w = A u - alpha (A m + beta A t) is formed at
     // the end, so round (2) does not wait for the scalars either.
     constexpr int MAXIT = 5;  // 10 slots per pass, plan capacity 48
-    constexpr int MAXP  = 16; // partials per lane held in registers: 64 x 16 = 1024 workgroups = 8192 nodes (more: a loop)
+    // The partial inner products of the previous launch (one pair per workgroup) are read ONCE per workgroup — thread t takes
+    // partials t, t + 512, ... —, added over the wave, and the eight waves' sums go through LDS: the same value, in the same
+    // order, in every wave of every workgroup.  (Every wave used to read all of them: 2 x 16 registers per lane, which kept
+    // the kernel at 92 VGPRs — two of these 512-thread workgroups per CU.)
+    constexpr int MAXP  = 4;  // partials per thread held in registers: 512 x 4 = 2048 workgroups = 16 384 nodes (more: a loop)
+    constexpr int NT    = 64 * S6_NODES_PER_BLOCK;
     const int nb   = s6_matvec_blocks(s.D);
     const int done = st->pcg_done;
     float gp[MAXP], dp[MAXP];
@@ -1317,12 +1325,11 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(So
     if (it >= 0) {
 #pragma unroll
         for (int q = 0; q < MAXP; ++q) {
-            const int i = lane + 64 * q;
+            const int i = (int)threadIdx.x + NT * q;
             gp[q] = i < nb ? s.g_part[it & 1][i] : 0.f;
             dp[q] = i < nb ? s.d_part[it & 1][i] : 0.f;
         }
-        // more than 64 MAXP workgroups (8 192 nodes): the rest in a loop, into the last register (same order in every wave)
-        for (int i = lane + 64 * MAXP; i < nb; i += 64) gp[MAXP - 1] += s.g_part[it & 1][i], dp[MAXP - 1] += s.d_part[it & 1][i];
+        for (int i = (int)threadIdx.x + NT * MAXP; i < nb; i += NT) gp[MAXP - 1] += s.g_part[it & 1][i], dp[MAXP - 1] += s.d_part[it & 1][i];
         if (it > 0) gamma_prev = st->gamma_prev[(it + 1) & 1], alpha_prev = st->alpha_prev[(it + 1) & 1], rz0 = st->rz0;
     }
     const int ss = lane / 6, c = lane - 6 * ss;
@@ -1342,6 +1349,15 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(So
         if (it >= 0) own_m = mcur[i], own_t = tprev[i], own_p = s.p[i], own_s = s.s[i], own_w = s.w[i], own_x = s.x[i];
     }
     if (done) return;  // (uniform)
+    // (the partials arrive with the first round of loads, before the columns the gathers need anyway)
+    __shared__ float gd_wave[S6_NODES_PER_BLOCK][2];
+    if (it >= 0) {
+        float gsum = 0.f, dsum = 0.f;
+#pragma unroll
+        for (int q = 0; q < MAXP; ++q) gsum += gp[q], dsum += dp[q];
+        gsum = wave_sum_all(gsum), dsum = wave_sum_all(dsum);
+        if (lane == 0) gd_wave[wave][0] = gsum, gd_wave[wave][1] = dsum;
+    }
     float au = 0.f, am = 0.f, at = 0.f;
 #pragma unroll
     for (int q = 0; q < MAXIT; ++q) {
@@ -1365,10 +1381,10 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK) void s6_pcg_step_kernel(So
     // scalars of this iteration
     float alpha = 0.f, beta = 0.f;
     if (it >= 0) {
-        float g = 0.f, d = 0.f;
+        __syncthreads();  // (uniform: `it` and `done` are the same everywhere)
+        float gamma = 0.f, delta = 0.f;
 #pragma unroll
-        for (int q = 0; q < MAXP; ++q) g += gp[q], d += dp[q];
-        const float gamma = wave_sum_all(g), delta = wave_sum_all(d);  // the same value, the same order, in every wave
+        for (int w = 0; w < S6_NODES_PER_BLOCK; ++w) gamma += gd_wave[w][0], delta += gd_wave[w][1];
         float denom = delta;
         if (it > 0) {
             beta = gamma / gamma_prev;
