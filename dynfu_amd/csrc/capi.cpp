@@ -994,9 +994,9 @@ int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
     A(reg_idx, D * k);
     A(blk_hist, D * (dfa::SOLVE_TG_BLOCKS + 1));
     A(node_ptr, D + 1);
-    A(node_list, N * k);
+    A(node_list, N * k + 1);  // (+ 1: the assembly reads one entry even of an empty list)
     A(rnode_ptr, D + 1);
-    A(rnode_list, D * k);
+    A(rnode_list, D * k + 1);  // (+ 1: the assembly reads one entry even of an empty list)
     A(dq, D * 8);
     A(ghat, D * 3);
     A(rec, N * (12 + (k <= 4 ? 4 : 8)));

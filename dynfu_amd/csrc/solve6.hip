@@ -883,21 +883,30 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
     __shared__ int32_t scol[S6_MAXSLOT];
     __shared__ uint8_t srs[S6_MAXSLOT];
     __shared__ uint32_t rent[S6_REGIN];  // the arriving edges' (source node k + slot): one round trip less in the closing part
-    if (tid < S6_MAXSLOT) {
-        const bool in = tid < cnt;
-        scol[tid] = in ? s.bcols[(size_t)a * s.cap + tid] : -1, srs[tid] = in ? s.rslot[(size_t)a * s.cap + tid] : (uint8_t)255;
-    } else if (tid >= 64 && tid < 64 + S6_REGIN) {
-        rent[tid - 64] = tid - 64 < nri ? s.rnode_list[rib + tid - 64] : 0u;
-    }
+    // (everything the prologue needs from global memory is requested first, by unconditional loads from clamped indices, and
+    // parked afterwards: a load under its own `if` followed by its LDS store made six dependent round trips of it)
+    constexpr int EPT = (S6_RC + 255) / 256;
+    const int col_i       = (int)((size_t)a * s.cap) + min(tid, s.cap - 1);
+    const int32_t scol_v  = s.bcols[col_i];
+    const uint8_t srs_v   = s.rslot[col_i];
+    const uint32_t rent_v = s.rnode_list[rib + min(tid & 63, max(nri, 1) - 1)];  // (an empty list reads its neighbour's first entry: unused)
+    uint32_t ent0[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) ent0[q] = s.node_list[beg + min(tid + 256 * q, max(len, 1) - 1)];
     // ---- this lane's work unit (s6_pattern: utab): every un-th record of block uq's list, from its phase on
     const int nup        = cnt > fu ? cnt - fu : 0;
     const uint32_t uinfo = s.utab[(size_t)a * S6_UNITS + tid];
+    if (tid < S6_MAXSLOT) scol[tid] = tid < cnt ? scol_v : -1, srs[tid] = tid < cnt ? srs_v : (uint8_t)255;
+    else if (tid >= 64 && tid < 64 + S6_REGIN) rent[tid - 64] = tid - 64 < nri ? rent_v : 0u;
     const int uq         = (int)(uinfo & 63u);
     const int un         = (int)((uinfo >> 16) & 1023u);
     const bool uhas      = uq < cnt && (uq == 0 || uq >= fu) && un > 0;
     const bool uown      = uhas && uq == 0;  // a unit of slot 0: it also sums the gradient
     int ucur = 0, uend = 0;                  // this lane's next record; end of the list
-    if (uhas) ucur = pptr[uq] + (int)((uinfo >> 6) & 1023u), uend = pptr[uq + 1];
+    {
+        const int q0 = uhas ? uq : 0, b0 = pptr[q0], b1 = pptr[q0 + 1];
+        if (uhas) ucur = b0 + (int)((uinfo >> 6) & 1023u), uend = b1;
+    }
     v2f me[10], mo[6], G[4];  // even rows of the moment (pairs), odd rows beyond the diagonal (pairs); the gradient
     float md[4];              // the odd rows' diagonal entries
 #pragma unroll
@@ -919,12 +928,11 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
         }
     };
     constexpr int RS4 = 2 + K / 4 + 1, NCH = (S6_RC * RS4 + 255) / 256;  // 16-byte chunks of a record; chunks per thread and pass
-    constexpr int EPT = (S6_RC + 255) / 256;
     __shared__ uint32_t sent[2][S6_RC];  // (vertex k + slot) of the rows of this pass / the next one
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int r = tid + 256 * q;
-        if (r < min(S6_RC, len)) sent[0][r] = s.node_list[beg + r];
+        if (r < min(S6_RC, len)) sent[0][r] = ent0[q];
     }
     int pass = 0;
     S6_TICK(tk1);
