@@ -138,7 +138,10 @@ struct McScratch {
 
 
 // exhaustive scan below this many distance evaluations (grid build = 4 small launches)
-bool want_grid(int D, long n_query) { return D >= 64 && (long)D * n_query >= (1L << 22); }
+// the uniform-grid k-NN (three small launches to build, ~40 us) against the exhaustive scan: worth it for many queries, and for
+// ANY number of queries over a large node set — a dozen new nodes against 8.5 k existing ones is one workgroup scanning them
+// all, 0.86 ms in the adaptor's 512^3 sequence
+bool want_grid(int D, long n_query) { return D >= 64 && ((long)D * n_query >= (1L << 22) || D >= 1024); }
 
 }  // namespace
 
