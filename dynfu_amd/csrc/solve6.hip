@@ -298,10 +298,20 @@ __global__ __launch_bounds__(256) void s6_linearise_kernel(Solve6View s, Solve6S
         const int k = s.k;
         int32_t idx[K];
         float wn[K];
+        if (k == K) {  // (uniform) the vertex's neighbours and weights as 16-byte loads: K / 4 each instead of K dwords
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            idx[j] = j < k ? s.idx[(size_t)v * k + j] : -1;
-            wn[j]  = j < k ? s.wn[(size_t)v * k + j] : 0.f;
+            for (int q = 0; q < K / 4; ++q) {
+                const int4 iv   = reinterpret_cast<const int4*>(s.idx + (size_t)v * K)[q];
+                const float4 wv = reinterpret_cast<const float4*>(s.wn + (size_t)v * K)[q];
+                idx[4 * q] = iv.x, idx[4 * q + 1] = iv.y, idx[4 * q + 2] = iv.z, idx[4 * q + 3] = iv.w;
+                wn[4 * q] = wv.x, wn[4 * q + 1] = wv.y, wn[4 * q + 2] = wv.z, wn[4 * q + 3] = wv.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                idx[j] = j < k ? s.idx[(size_t)v * k + j] : -1;
+                wn[j]  = j < k ? s.wn[(size_t)v * k + j] : 0.f;
+            }
         }
         float w_eff = 0.f, rr = 0.f;
         bool ok     = false;
