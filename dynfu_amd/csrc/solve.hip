@@ -129,19 +129,47 @@ __global__ __launch_bounds__(1024) void tg_fill_kernel(const int32_t* __restrict
 //       release/acquire around a ticket counter) adds the partials in index order (deterministic)
 //       and runs the Gauss-Newton control logic — no separate control launch.
 
+// a row's k node ids and weights: 16-byte loads when k is the template's K (the common case), k dwords else; absent: -1 / 0
+template <int K>
+__device__ __forceinline__ void load_row_graph(const SolveView& s, size_t r, int (&n)[K], float (&w)[K]) {
+    if (s.k == K) {  // (uniform)
+#pragma unroll
+        for (int q = 0; q < K / 4; ++q) {
+            const int4 iv   = reinterpret_cast<const int4*>(s.ridx + r * K)[q];
+            const float4 wv = reinterpret_cast<const float4*>(s.rw + r * K)[q];
+            n[4 * q] = iv.x, n[4 * q + 1] = iv.y, n[4 * q + 2] = iv.z, n[4 * q + 3] = iv.w;
+            w[4 * q] = wv.x, w[4 * q + 1] = wv.y, w[4 * q + 2] = wv.z, w[4 * q + 3] = wv.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) n[j] = j < s.k ? s.ridx[r * s.k + j] : -1, w[j] = j < s.k ? s.rw[r * s.k + j] : 0.f;
+    }
+}
+
 template <int K>
 __device__ __forceinline__ float tukey_weight(const SolveView& s, size_t v, float tukey_offset, float psi_data) {
     const f3 c = mk3(s.canon[3 * v], s.canon[3 * v + 1], s.canon[3 * v + 2]);
     DQ sum     = dq_identity();
+    int n[K];
+    float w[K];
+    load_row_graph<K>(s, v, n, w);
+    // the neighbours' translations and transforms four at a time, by unconditional loads (an absent neighbour reads node 0
+    // and is skipped): loads inside the `if` were k dependent round trips
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        if (j < s.k) {
-            const int n = s.ridx[v * s.k + j];
-            if (n >= 0) {
-                const float w = s.rw[v * s.k + j];
-                const DQ cur  = dq_mul(dq_from_translation(s.t[3 * n], s.t[3 * n + 1], s.t[3 * n + 2]),
-                                       dq_load(s.node_dq + 8 * (size_t)n));
-                sum           = dq_mul(sum, dq_scale(cur, w));
+    for (int h = 0; h < K; h += 4) {
+        float tx[4], ty[4], tz[4];
+        DQ q[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int nn = n[h + jj] >= 0 ? n[h + jj] : 0;
+            tx[jj] = s.t[3 * nn], ty[jj] = s.t[3 * nn + 1], tz[jj] = s.t[3 * nn + 2];
+            q[jj]  = dq_load(s.node_dq + 8 * (size_t)nn);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            if (n[h + jj] >= 0) {
+                const DQ cur = dq_mul(dq_from_translation(tx[jj], ty[jj], tz[jj]), q[jj]);
+                sum          = dq_mul(sum, dq_scale(cur, w[h + jj]));
             }
         }
     }
@@ -227,15 +255,19 @@ __global__ __launch_bounds__(256) void linearise_kernel(SolveView s, SolveState*
             tau = s.rtau[r];
         }
         float sx = 0.f, sy = 0.f, sz = 0.f;
+        {   // (ids and weights by 16-byte loads, then the k translations by unconditional loads — an absent neighbour reads
+            // node 0 and is skipped —: two rounds of loads; with the loads inside `if (n >= 0)` it was k dependent ones)
+            int n[K];
+            float w[K], tx[K], ty[K], tz[K];
+            load_row_graph<K>(s, r, n, w);
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            if (j < s.k) {
-                const int n = s.ridx[r * s.k + j];
-                if (n >= 0) {
-                    const float w = s.rw[r * s.k + j];
-                    sx += w * s.t[3 * n], sy += w * s.t[3 * n + 1], sz += w * s.t[3 * n + 2];
-                }
+            for (int j = 0; j < K; ++j) {
+                const int nn = n[j] >= 0 ? n[j] : 0;
+                tx[j] = s.t[3 * nn], ty[j] = s.t[3 * nn + 1], tz[j] = s.t[3 * nn + 2];
             }
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                if (n[j] >= 0) sx += w[j] * tx[j], sy += w[j] * ty[j], sz += w[j] * tz[j];
         }
         const float ex = s.rb[3 * r] - sx, ey = s.rb[3 * r + 1] - sy, ez = s.rb[3 * r + 2] - sz;
         // tail of the packed row record (head = k ids + k weights, written once per frame)
