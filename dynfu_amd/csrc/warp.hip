@@ -618,14 +618,26 @@ template <int K>
 __device__ __forceinline__ DQ calc_dqb(const KnnList<K>& nb, int k, const float* __restrict__ node_pos,
                                        const float* __restrict__ node_dq, const float* __restrict__ node_w, f3 p) {
     DQ sum = dq_identity();  // :133
+    // the neighbours' positions, radii and transforms four at a time by unconditional loads (an absent neighbour reads node 0
+    // and is skipped): with the loads inside the `if` they were k dependent round trips.  Same products in the same order.
+    constexpr int G = K < 4 ? K : 4;
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        if (j < k && nb.index(j) >= 0) {
-            const int n   = nb.index(j);
-            const float w = transformation_weight(mk3(node_pos[3 * n], node_pos[3 * n + 1], node_pos[3 * n + 2]),
-                                                  node_w[n], p);
-            sum = dq_mul(sum, dq_scale(dq_load(node_dq + 8 * (size_t)n), w));  // :139-141
+    for (int h = 0; h < K; h += G) {
+        f3 g[G];
+        float r[G];
+        DQ q[G];
+        bool on[G];
+#pragma unroll
+        for (int jj = 0; jj < G; ++jj) {
+            const int j = h + jj;
+            on[jj]      = j < k && nb.index(j) >= 0;
+            const int n = on[jj] ? nb.index(j) : 0;
+            g[jj] = mk3(node_pos[3 * n], node_pos[3 * n + 1], node_pos[3 * n + 2]), r[jj] = node_w[n];
+            q[jj] = dq_load(node_dq + 8 * (size_t)n);
         }
+#pragma unroll
+        for (int jj = 0; jj < G; ++jj)
+            if (on[jj]) sum = dq_mul(sum, dq_scale(q[jj], transformation_weight(g[jj], r[jj], p)));  // :139-141
     }
     return dq_normalize(sum);  // :145
 }
