@@ -357,6 +357,33 @@ def test_no_live_data_regulariser_only_and_errors(A):
         small.set_problem(*keep)  # larger than the plan
 
 
+def test_few_nodes_with_very_long_row_lists(A):
+    """12 nodes under 32 768 vertices (k = 4): ~11 000 rows per node — longer than the 4 096 the pattern kernel sorts in LDS
+    (the list stays in the order the transposition left it), 44 000 pairs per node (the slot bytes go through global scratch
+    instead of LDS), ~25 staged passes per workgroup and record batches that are refilled inside a pass.  Energies and
+    iteration counts against the oracle."""
+    cfg, c, intr, depth = _scene("T1", 6)
+    P, Nm = A.compute_points_normals(dev(depth), *intr)
+    D, k = 12, 4
+    sel = np.linspace(0, len(c["node_pos"]) - 1, D).astype(int)
+    nodes, dq, w = c["node_pos"][sel].copy(), c["node_dq"][sel].copy(), np.full(D, 0.6, np.float32)
+    verts, normals = c["verts"].copy(), c["normals"].copy()
+    kw = dict(num_iter=1, gn_iter=2, linear_iter=60, lambda_=100.0, pcg_tol=1e-3)  # (a 72-unknown system: below 1e-3 fp32 stalls)
+    s = A.Solver6(D, len(verts), k)
+    keep = [dev(nodes), dev(dq), dev(w), dev(verts), dev(normals)]
+    s.set_problem(*keep)
+    s.solve(P, Nm, *intr, A.Solve6Params(**kw))
+    st = s.stats()
+    ref, st_ref = O.solve6(nodes, dq, w, k, verts, normals, host(P), host(Nm), intr, threads=_threads(), **kw)
+    assert len(verts) * k // D > 4096 * 2 and st["overflow"] == 0
+    assert st["valid_first"] == st_ref["valid_first"] and st["gn_iters"] == st_ref["gn_iters"] == 2
+    assert st["initial_cost"] == pytest.approx(st_ref["initial_cost"], rel=1e-4)
+    assert st["final_cost"] == pytest.approx(st_ref["final_cost"], rel=2e-3)
+    assert abs(st["pcg_iters"] - st_ref["pcg_iters"]) <= 0.2 * st_ref["pcg_iters"] + 2
+    assert np.abs(host(s.node_dq()) - ref).max() < 2e-3
+    s.close()
+
+
 def test_degenerate_problems(A):
     import torch
     cfg, c, intr, depth = _scene("T0", 2)
