@@ -449,16 +449,23 @@ __device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32
     }
     const int rmax = max(g.dim[0], max(g.dim[1], g.dim[2]));
     int r_first    = 0;
-    if (!TIGHT) {
-        // Shells 0 and 1 together: the 3 x 3 x 3 block around the query's cell is nine x-rows of cells, and the cells of
-        // an x-row are consecutive in the sorted node array — nine contiguous candidate ranges (18 cell_start loads)
-        // instead of 27 cells (54) walked one by one.  Nearly every query ends here: the stop rule below is that of r = 1.
-        // The query is a chain of dependent loads and little else (a wave of 64 queries is resident from launch to end:
-        // 4 waves per SIMD at C2), so the loads are issued for memory-level parallelism: the nine rows' ranges together
-        // (unconditional loads from clamped cells, a row outside the grid is empty), then every row's candidates four at a
-        // time from clamped indices — pushed in the same order as one by one: z, then y, then along the row.
-        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
+    // candidates [beg, end) of the sorted node array, four at a time from clamped indices
+    auto scan_range = [&](int beg, int end) __attribute__((always_inline)) {
         constexpr int KNN_BATCH = 4;  // (8: the same 48 us at C2, 16: 64; one by one: 54)
+        for (int j = beg; j < end; j += KNN_BATCH) {
+            float4 n[KNN_BATCH];
+#pragma unroll
+            for (int t = 0; t < KNN_BATCH; ++t) n[t] = sorted[min(j + t, end - 1)];
+#pragma unroll
+            for (int t = 0; t < KNN_BATCH; ++t)
+                if (j + t < end) best.push(dist2(q, n[t].x, n[t].y, n[t].z), __float_as_int(n[t].w));
+        }
+    };
+    // the 3 x 3 x 3 block around the query's cell as nine x-rows of cells (the cells of an x-row are consecutive in the sorted
+    // node array): the rows' ranges requested together — unconditional loads from clamped cells, a row outside the grid is
+    // empty —, then every row's candidates
+    auto scan_block3 = [&]() __attribute__((always_inline)) {
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
         int rbeg[9], rend[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
@@ -469,17 +476,28 @@ __device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32
             rbeg[i] = in ? b : 0, rend[i] = in ? e : 0;
         }
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int end = rend[i];
-            for (int j = rbeg[i]; j < end; j += KNN_BATCH) {
-                float4 n[KNN_BATCH];
-#pragma unroll
-                for (int t = 0; t < KNN_BATCH; ++t) n[t] = sorted[min(j + t, end - 1)];
-#pragma unroll
-                for (int t = 0; t < KNN_BATCH; ++t)
-                    if (j + t < end) best.push(dist2(q, n[t].x, n[t].y, n[t].z), __float_as_int(n[t].w));
-            }
-        }
+        for (int i = 0; i < 9; ++i) scan_range(rbeg[i], rend[i]);
+    };
+    if (TIGHT) {
+        // shell 0 (the query's own cell) — a 1-NN search on a fine grid usually ends here —, then, if it does not, shells 0
+        // and 1 together as the nine rows (the own cell's candidates a second time: a set, the order and repeats do not
+        // matter), each followed by the stop rule of its shell; further shells in the loop below
+        const int c0 = cx + g.dim[0] * (cy + g.dim[1] * cz);
+        scan_range(cell_start[c0], cell_start[c0 + 1]);
+        const float b0 = fmaxf(margin - 1e-3f, 0.f) * g.cs;
+        if (best.d[K - 1] < b0 * b0 * 0.9999f) return;
+        scan_block3();
+        const float b1 = fmaxf(1.f + margin - 1e-3f, 0.f) * g.cs;
+        if (best.d[K - 1] < b1 * b1 * 0.9999f) return;
+        r_first = 2;
+    }
+    if (!TIGHT) {
+        // Shells 0 and 1 together: the 3 x 3 x 3 block around the query's cell is nine x-rows of cells, and the cells of
+        // an x-row are consecutive in the sorted node array — nine contiguous candidate ranges (18 cell_start loads)
+        // instead of 27 cells (54) walked one by one.  Nearly every query ends here: the stop rule below is that of r = 1.
+        // The query is a chain of dependent loads and little else (a wave of 64 queries is resident from launch to end:
+        // 4 waves per SIMD at C2), so the loads are issued for memory-level parallelism (scan_block3 above).
+        scan_block3();
         if (best.d[K - 1] < g.cs * g.cs * 0.9999f) return;  // (r = 1: every node not visited is at least one cell away)
         r_first = 2;  // (a grid of at most 2 cells per axis has been visited completely: the loop below does not run)
     }
