@@ -37,18 +37,18 @@ TIMING_SAMPLE = 8  # every 8th timed frame carries the hipEvent brackets of the 
 # was read from and the commit that file was measured at: a figure older than the kernel it describes is visible as such.
 PMC_TRAFFIC = {
     # (config, kernel key): (bytes per launch, profile file, commit of the measured tree)
-    ("C2", "fused_integrate"): (0.5417e9, "profiles/r03g_pmc_c2.md", "c5a0932"),   # WRITE 524 288 KiB + 2 x FETCH 2 354 KiB
-    ("C3", "fused_integrate"): (0.5414e9, "profiles/r03g_pmc_ns_c3.md", "c5a0932"),
+    ("C2", "fused_integrate"): (0.5417e9, "profiles/r03h_pmc_c2.md", "858fb26"),   # WRITE 524 288 KiB + 2 x FETCH 2 354 KiB
+    ("C3", "fused_integrate"): (0.5414e9, "profiles/r03h_pmc_ns_c3.md", "858fb26"),
     ("C4", "fused_integrate"): (4.344e9, "profiles/r02_pmc_tsdf.md", "round 2"),   # 4 194 304 + 2 x 23 775 KiB
     ("C2", "pcg"): (616.6 * 1024, "profiles/r02d_pmc_bench_c2.md", "round 2"),      # pcg_paired_kernel<1024,1,32,1>: FETCH 340.7 + WRITE 275.9 KiB
     # north-star kernels: FETCH + WRITE, uncorrected, for the gather-heavy PCG step and the gathering assembly (the x2 of
     # wide read streams does not apply to 16-80-byte gathers); 2 x FETCH + WRITE for the streaming linearisation.
-    ("C2", "s6_assemble"): (61.50e6, "profiles/r03g_pmc_ns_c2.md", "c5a0932"),
-    ("C2", "s6_linearise"): (42.12e6, "profiles/r03g_pmc_ns_c2.md", "c5a0932"),
-    ("C2", "s6_pcg_step"): (1.844e6, "profiles/r03g_pmc_ns_c2.md", "c5a0932"),
-    ("C3", "s6_assemble"): (249.0e6, "profiles/r03g_pmc_ns_c3.md", "c5a0932"),
-    ("C3", "s6_linearise"): (104.4e6, "profiles/r03g_pmc_ns_c3.md", "c5a0932"),
-    ("C3", "s6_pcg_step"): (4.529e6, "profiles/r03g_pmc_ns_c3.md", "c5a0932"),
+    ("C2", "s6_assemble"): (61.49e6, "profiles/r03h_pmc_ns_c2.md", "858fb26"),
+    ("C2", "s6_linearise"): (42.12e6, "profiles/r03h_pmc_ns_c2.md", "858fb26"),
+    ("C2", "s6_pcg_step"): (1.846e6, "profiles/r03h_pmc_ns_c2.md", "858fb26"),
+    ("C3", "s6_assemble"): (249.3e6, "profiles/r03h_pmc_ns_c3.md", "858fb26"),
+    ("C3", "s6_linearise"): (104.4e6, "profiles/r03h_pmc_ns_c3.md", "858fb26"),
+    ("C3", "s6_pcg_step"): (4.655e6, "profiles/r03h_pmc_ns_c3.md", "858fb26"),
 }
 PMC_TRAFFIC_BYTES = {k: v[0] for k, v in PMC_TRAFFIC.items()}
 
