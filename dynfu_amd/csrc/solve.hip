@@ -1703,19 +1703,20 @@ __global__ __launch_bounds__(256) void pcg_mb_step_kernel(SolveView s, SolveStat
     const float4* tprev = s.mb_t[nxt];
     // The launch is a chain of dependent round trips and little else.  The row's length and each lane's FIRST matrix entry
     // depend on nothing but the launch arguments: they are requested here, with the stop flag and the partial inner products,
-    // and the entry's three gathers go out before the scalars are summed — two rounds instead of three (scalars, then
-    // entries, then gathers).  A launch that turns out to have nothing to do has loaded a few values in vain.
+    // and their gathers go out before the scalars are summed — two rounds instead of three (scalars, then entries, then
+    // gathers), also for the second entry of a lane (rows of 17-32 entries: every k = 8 row).  A launch that turns out to have nothing to do has loaded a few values in vain.
     const int lane16  = threadIdx.x & (MB_LPR - 1);
     const int a       = (blockIdx.x * 256 + threadIdx.x) / MB_LPR;
     const bool row_ok = a < s.D;
     const int cnt     = row_ok ? s.ell_cnt[a] : 0;
     const float2 e0   = row_ok ? s.ell[(size_t)lane16 * s.D + a] : make_float2(0.f, 0.f);  // (rows shorter than 16: not used)
+    const float2 e1   = row_ok ? s.ell[(size_t)(lane16 + MB_LPR) * s.D + a] : make_float2(0.f, 0.f);  // (k = 8 rows have ~27 entries)
     if (st->mb_done) return;
-    const bool has0 = lane16 < cnt;
-    const int col0  = has0 ? __float_as_int(e0.y) : 0;
-    const float4 uu0 = ucur[col0];
-    float4 mm0 = make_float4(0.f, 0.f, 0.f, 0.f), tt0 = mm0;
-    if (it >= 0) mm0 = mcur[col0], tt0 = tprev[col0];
+    const bool has0 = lane16 < cnt, has1 = lane16 + MB_LPR < cnt;
+    const int col0  = has0 ? __float_as_int(e0.y) : 0, col1 = has1 ? __float_as_int(e1.y) : 0;
+    const float4 uu0 = ucur[col0], uu1 = ucur[col1];
+    float4 mm0 = make_float4(0.f, 0.f, 0.f, 0.f), tt0 = mm0, mm1 = mm0, tt1 = mm0;
+    if (it >= 0) mm0 = mcur[col0], tt0 = tprev[col0], mm1 = mcur[col1], tt1 = tprev[col1];
     float alpha = 0.f, beta = 0.f;
     if (it >= 0) {
         // the inner products of the launch before: every workgroup adds the partials in the same order
@@ -1755,14 +1756,14 @@ __global__ __launch_bounds__(256) void pcg_mb_step_kernel(SolveView s, SolveStat
     }
     float au[3] = {0.f, 0.f, 0.f}, am[3] = {0.f, 0.f, 0.f}, at[3] = {0.f, 0.f, 0.f};
     for (int q = lane16; q < cnt; q += MB_LPR) {
-        const bool first = q == lane16;
-        const float2 e   = first ? e0 : s.ell[(size_t)q * s.D + a];
+        const bool first = q == lane16, second = q == lane16 + MB_LPR;
+        const float2 e   = first ? e0 : second ? e1 : s.ell[(size_t)q * s.D + a];
         const int col    = __float_as_int(e.y);
         const float val  = e.x;
-        const float4 uu  = first ? uu0 : ucur[col];
+        const float4 uu  = first ? uu0 : second ? uu1 : ucur[col];
         au[0] = fmaf(val, uu.x, au[0]), au[1] = fmaf(val, uu.y, au[1]), au[2] = fmaf(val, uu.z, au[2]);
         if (it >= 0) {
-            const float4 mm = first ? mm0 : mcur[col], tt = first ? tt0 : tprev[col];
+            const float4 mm = first ? mm0 : second ? mm1 : mcur[col], tt = first ? tt0 : second ? tt1 : tprev[col];
             am[0] = fmaf(val, mm.x, am[0]), am[1] = fmaf(val, mm.y, am[1]), am[2] = fmaf(val, mm.z, am[2]);
             at[0] = fmaf(val, tt.x, at[0]), at[1] = fmaf(val, tt.y, at[1]), at[2] = fmaf(val, tt.z, at[2]);
         }
