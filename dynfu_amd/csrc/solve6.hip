@@ -581,17 +581,33 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
     const bool in_lds = npairs <= (int)sizeof(sortbuf);
     uint8_t* es       = in_lds ? es_lds : s.eslot + (size_t)pbeg * k;
     bool lost = false;
-    for (int r = tid; r < plen; r += 256) {
-        const unsigned v = s.node_list[pbeg + r] / (unsigned)k;
-        for (int j = 0; j < k; ++j) {
-            const int b = s.idx[(size_t)v * k + j];
-            int hp      = 255;
-            if (b == a) hp = 254;
-            else if (b >= 0) {
-                hp = hash_slot(keys, b);
-                if (hp < 0) lost = true, hp = 255;
+    // (four rows of a thread at a time: their list entries requested together, then their neighbour ids — row by row the two
+    // dependent loads of every row were a chain of 2 x rows / 256 round trips)
+    for (int r0 = tid; r0 < plen; r0 += 4 * 256) {
+        unsigned v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = s.node_list[pbeg + min(r0 + 256 * i, plen - 1)] / (unsigned)k;
+        int nb[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) nb[i][j] = j < k ? s.idx[(size_t)v[i] * k + j] : -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + 256 * i;
+            if (r >= plen) break;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j >= k) break;
+                const int b = nb[i][j];
+                int hp      = 255;
+                if (b == a) hp = 254;
+                else if (b >= 0) {
+                    hp = hash_slot(keys, b);
+                    if (hp < 0) lost = true, hp = 255;
+                }
+                es[(size_t)r * k + j] = (uint8_t)hp;
             }
-            es[(size_t)r * k + j] = (uint8_t)hp;
         }
     }
     if (tid < k) {
