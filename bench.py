@@ -90,6 +90,13 @@ def parse():
     ap.add_argument("--linear-iter", type=int, default=0, help="PCG iteration cap (default: 256 ref, 64 northstar)")
     ap.add_argument("--forcing", default="adaptive", choices=["adaptive", "geometric"],
                     help="northstar: PCG tolerance per Gauss-Newton iteration — Eisenstat-Walker (default) or 0.1 x 0.5^i")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend of the N > 1 run: nccl (= RCCL, the GPUs) or gloo (with --dry-run: the CPU test of "
+                         "the rank launcher)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / process-group check without a GPU: every rank sleeps instead of running frames, the line "
+                         "carries the same contract fields (tests/test_bench_contract.py)")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--no-adaptive-launch", action="store_true",
                     help="northstar: enqueue the full PCG launch budget of every Gauss-Newton iteration (A/B of "
                          "dfa_solve6_params.adaptive_launch)")
@@ -541,7 +548,7 @@ def northstar_probe(cfg_name, device, steps=30, warmup=8):
 def main_northstar(args, torch, replicas, rank, world, device):
     """bench line of the north-star mode (same contract; per-kernel figures from hipEvent timings of the phases of the
     last timed frame)."""
-    n_gpus = world
+    n_gpus = ranks_seen(device)
     lin = args.linear_iter or 64
     pcg = dict(NS_PCG)
     if args.no_adaptive_launch:
@@ -580,7 +587,7 @@ def main_northstar(args, torch, replicas, rank, world, device):
                                     "point-to-plane / ARAP energy, lambda=200"
                                     % (args.config, dim, Wd, Hd, seq.D, seq.k, seq.N, seq.gn_total, lin,
                                        northstar_fields(seq, st)["pcg_tolerance_schedule"]),
-                           parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus,
+                           parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus, ranks_seen=n_gpus,
                            streams="serial" if args.serial else ("fuse || graph build + solve on two HIP streams" if args.fuse_first else
                                                                  "graph build, then fuse || solve on two HIP streams"),
                            last_frame=northstar_fields(seq, st)),
@@ -672,21 +679,127 @@ def cpu_baseline(cfg_name, frames):
                                                                                 pcg, threads, os.cpu_count() or 1, dt))
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` outside torchrun: start N fresh rank processes of this very script (one per GPU, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run would), wait for all of them, forward
+    rank 0's JSON line and exit non-zero if any rank failed.  This parent never initialises the GPU (no torch import, no
+    HIP call), and no process that has touched the GPU is ever re-executed: the children are new interpreters."""
+    import socket
+    import subprocess
+    n = args.gpus
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DFA_BENCH_LAUNCHED_BY="bench.py")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True))
+    # a rank that dies leaves the others in a barrier: poll, and end the rest as soon as one has failed
+    failed, out0 = None, None
+    pending = set(range(n))
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while pending and failed is None:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+                break
+        time.sleep(0.05)
+    if failed is not None:
+        for r in pending:
+            procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        print("bench.py: rank %d of %d exited with code %d; no line is printed" % (failed[0], n, failed[1]), file=sys.stderr)
+        raise SystemExit(failed[1] if 0 < failed[1] < 256 else 1)
+    reader.join(timeout=30)
+    out0 = buf[0] if buf else ""
+    lines = [l for l in out0.splitlines() if l.startswith("{")]
+    if not lines:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        raise SystemExit(1)
+    print(lines[-1], flush=True)
+
+
+def ranks_seen(device=None):
+    """number of live ranks of the process group, counted by an all-reduce (not read from the environment)"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    t = torch.ones(1, dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.all_reduce(t)
+    return int(t.item())
+
+
+def main_dry_run(args):
+    """The launcher / process-group path with no GPU work: every rank sleeps 20 ms per step inside the same
+    barrier-bracketed timed region and rank 0 prints a line with the contract's fields (tests only)."""
+    from dynfu_amd import replicas
+    rank, local, world = replicas.env_world()
+    replicas.init(backend=args.backend)
+    seen = ranks_seen()
+    if rank == args.dry_run_fail_rank:
+        os._exit(7)
+    K, Wm = args.steps, args.warmup
+    dt_max = replicas.timed_region(lambda: time.sleep(0.02 * K))
+    if rank == 0:
+        print(json.dumps(dict(metric="frames/sec (warp-solve + TSDF fuse), 512^3 vol / 2k nodes / VGA depth",
+                              value=round(seen * K / dt_max, 2), unit="frames/s", n_gpus=seen, steps=K, warmup=Wm,
+                              ms_per_step=round(dt_max / K * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
+                              dtype="f32", data="none (dry run: sleeps)",
+                              config=dict(workload="dry run of the rank launcher (no GPU work)", ranks_seen=seen,
+                                          parallelism="replicas x%d (one sequence per GPU, no collective; %d ranks counted by "
+                                                      "all-reduce, backend %s)" % (seen, seen, args.backend)))), flush=True)
+    replicas.shutdown()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, sys.argv[1:])
+    if args.dry_run:
+        return main_dry_run(args)
     import torch
 
     from dynfu_amd import replicas
     rank, local, world = replicas.env_world()
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (without torchrun, `python bench.py --gpus N` starts the N ranks "
+                         "itself)" % (args.gpus, world))
+    # The DynFusion::operator() sequence runs in a CHILD process with its own HIP context.  It is started here, before this
+    # process has made its first GPU call (torch.cuda.is_available() below is one), and has finished before the timed
+    # region starts: nothing of it overlaps the measurement.
+    e2e = None
+    if world == 1 and args.mode == "ref" and args.live == "targets" and not args.no_end_to_end:
+        if torch.cuda.device_count() < 1:  # does not initialise the GPU
+            raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+        try:
+            e2e = end_to_end(args.config)
+        except Exception as e:  # noqa: BLE001
+            e2e = dict(error="%s: %s" % (type(e).__name__, e))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    replicas.init(backend="nccl", device=device)  # RCCL; only barriers + one MAX all-reduce use it
-    n_gpus = world
-    if args.gpus != world and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run for N > 1" % (args.gpus, world),
-              file=sys.stderr)
+    replicas.init(backend=args.backend, device=device)  # nccl = RCCL; only barriers, one MAX and one SUM all-reduce use it
+    n_gpus = ranks_seen(device)  # counted, not assumed
+    if n_gpus != world:
+        raise SystemExit("bench.py: %d ranks answered the all-reduce, WORLD_SIZE=%d" % (n_gpus, world))
 
     if args.mode == "northstar":
         return main_northstar(args, torch, replicas, rank, world, device)
@@ -697,8 +810,8 @@ def main():
         dt_max = replicas.timed_region(lambda: [seq.frame(args.warmup + f) for f in range(K)], device)
         if rank == 0:
             rec = live_depth_probe(args.config, device, steps=min(K, 30), warmup=0, seq=seq)
-            rec.update(metric="frames/sec (warp-solve + TSDF fuse), 512^3 vol / 2k nodes / VGA depth", value=round(world * K / dt_max, 2),
-                       n_gpus=world, steps=K, warmup=args.warmup, ms_per_step=round(dt_max / K * 1e3, 4), higher_is_better=True,
+            rec.update(metric="frames/sec (warp-solve + TSDF fuse), 512^3 vol / 2k nodes / VGA depth", value=round(n_gpus * K / dt_max, 2),
+                       n_gpus=n_gpus, steps=K, warmup=args.warmup, ms_per_step=round(dt_max / K * 1e3, 4), higher_is_better=True,
                        scaling="weak", vs_baseline=None, dtype="f32", data="synthetic", config=dict(workload=rec.pop("workload")))
             print(json.dumps(rec), flush=True)
         replicas.shutdown()
@@ -816,7 +929,7 @@ def main():
                                     "entry) x PCG<=256 (tol 1e-6 per linearisation, never below 1e-12 of the solve's first gradient), "
                                     "reference-parity energy (energy.t), "
                                     "lambda=200" % (args.config, dim, Wd, Hd, seq.D, seq.k, seq.N, cfg["gn_iters"]),
-                           parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus,
+                           parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus, ranks_seen=n_gpus,
                            streams="serial" if args.serial else ("fuse || graph build of frame f+1 || solve of frame f on three "
                                                                  "HIP streams, two solver plans" if args.pipeline else
                                                                  ("fuse || graph build + solve on two HIP streams" if args.fuse_first
@@ -850,11 +963,8 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:  # noqa: BLE001
                 out["live_depth_mode"] = dict(error="%s: %s" % (type(e).__name__, e))
-        if not args.no_end_to_end:
-            try:
-                out["end_to_end"] = end_to_end(args.config)
-            except Exception as e:  # noqa: BLE001
-                out["end_to_end"] = dict(error="%s: %s" % (type(e).__name__, e))
+        if e2e is not None:
+            out["end_to_end"] = e2e
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_frames)
     print(json.dumps(out), flush=True)

@@ -35,6 +35,55 @@ def test_bench_refuses_to_run_without_a_gpu():
     assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
 
 
+def _bench(*argv, launcher=None, timeout=300):
+    cmd = [sys.executable] + (launcher or []) + [os.path.join(ROOT, "bench.py")] + list(argv)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_gpus_2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` outside torchrun: the launcher starts two rank processes (gloo, no GPU work), the line
+    comes from two LIVE ranks (counted by an all-reduce) — SURVEY 8(e), BASELINE config 5."""
+    r = _bench("--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "5", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # one line, rank 0's
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["steps"] == 5 and d["scaling"] == "weak"
+    # 5 steps of 20 ms on each of two ranks in the time of one: whole-job value = 2 x 5 / max time
+    assert d["value"] == pytest.approx(2 * 5 / (d["ms_per_step"] * 5e-3), rel=1e-3)
+    assert 60.0 < d["value"] < 100.5
+
+
+def test_launcher_fails_when_a_rank_dies():
+    r = _bench("--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "5", "--warmup", "1", "--dry-run-fail-rank", "1")
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]  # no line from a run that lost a rank
+    assert "rank 1 of 2" in r.stderr
+
+
+def test_same_line_under_torchrun():
+    """the driver's N > 1 command: torch.distributed.run starts the ranks, bench.py must not start more"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = _bench("--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "3", "--warmup", "0",
+               launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port)])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_world_size_must_match_gpus():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-run", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
 @pytest.mark.gpu
 def test_bench_line_has_the_contract_fields():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-frames", "1"],
