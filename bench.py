@@ -77,6 +77,7 @@ def parse():
                     help="targets: index-aligned live vertices canon + sum w t* (SURVEY 8d, the headline workload); depth: the "
                          "reference's data flow — noisy depth, marching-cubes live cloud, nearest-vertex correspondence "
                          "(prints the line of that workload alone)")
+    ap.add_argument("--no-raycast", action="store_true", help="skip the raycast figures (SURVEY 8d: reported separately)")
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the DynFusion::operator() sequence (the reference's own timed region, C++ adaptor classes)")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the bounded CPU sample")
@@ -679,6 +680,47 @@ def cpu_baseline(cfg_name, frames):
                                                                                 pcg, threads, os.cpu_count() or 1, dt))
 
 
+def raycast_probe(seq, config, reps=20):
+    """"+ raycast, reported separately".  Both variants of the raycast (src/kfusion/tsdf_volume.cpp:95-129,
+    tsdf_volume.cu:128-386) through the volume the timed frames have just fused, from the integration pose, timed with
+    events on the launch stream; priced the way SURVEY 8(d) says — rays x steps x 4 B + hits x 64 x 4 B + 32 W H out — with
+    the step / hit / distinct-voxel counts of these very rays (dfa_tsdf_raycast_tally)."""
+    import torch
+    A, synth, cfg = seq.A, seq.synth, seq.cfg
+    W, H, dim = cfg["width"], cfg["height"], cfg["dim"]
+    pts = torch.empty((H, W, 4), dtype=torch.float32, device=seq.vol.device)
+    nrm = torch.empty_like(pts)
+    dep = torch.empty((H, W), dtype=torch.uint16, device=seq.vol.device)
+    args = (seq.vol, seq.voxel, seq.trunc, seq.cam2vol, seq.rinv, *seq.intr, synth.RAYCAST_STEP_FACTOR, synth.GRADIENT_DELTA_FACTOR)
+    tally = A.tsdf_raycast_tally(*args, W, H, unique=True)
+    fetch_bytes = 4.0 * (tally["march_fetches"] + tally["trilinear_fetches"])
+    out = dict(work=tally, survey_formula="rays x steps x 4 B + hits x 64 x 4 B + 32 W H out (depth variant: 18 W H out)")
+    for name, fn, tail, out_bytes in (("points", A.tsdf_raycast_points, (pts, nrm), 32.0 * W * H),
+                                      ("depth", A.tsdf_raycast_depth, (dep, nrm), 18.0 * W * H)):
+        for _ in range(3):
+            fn(*args, *tail)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for e0, e1 in ev:
+            e0.record()
+            fn(*args, *tail)
+            e1.record()
+        torch.cuda.synchronize()
+        ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        nbytes = fetch_bytes + out_bytes
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        low = 4.0 * tally["unique_voxels"] + out_bytes
+        key = "raycast_" + name
+        out[name] = dict(kernel="raycast_%s_kernel (a ray per lane, 8 x 8-pixel tile per wave)" % name, bound="hbm",
+                         achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                         traffic=PMC_TRAFFIC_BYTES.get((config, key)), traffic_source=traffic_source(config, key),
+                         avg_launch_ms=round(ms, 4), launches=reps, survey_bytes_per_launch=nbytes,
+                         unique_voxel_bytes_per_launch=low, frac_of_peak_on_unique_bytes=round(low / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         gathers_per_us=round((tally["march_fetches"] + tally["trilinear_fetches"]) / (ms * 1e3), 1),
+                         note="a gather kernel: every fetch is a 4-byte read of its own; what bounds it is the rate of cache-line "
+                              "requests and the dependent chain of march steps, not HBM (DESIGN.md 4.1)")
+    return out
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` outside torchrun: start N fresh rank processes of this very script (one per GPU, RANK /
     LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run would), wait for all of them, forward
@@ -945,6 +987,11 @@ def main():
                solve_kernels_ms_per_frame=dict(pcg=round(pcg_total_ms, 4), assemble=round(tm["assemble_ms"] / frames_timed, 4)))
     if world == 1:
         # secondary figures: a failure in one of them must not cost the line its contract fields
+        if not args.no_raycast:
+            try:
+                out["raycast"] = raycast_probe(seq, args.config)
+            except Exception as e:  # noqa: BLE001
+                out["raycast"] = dict(error="%s: %s" % (type(e).__name__, e))
         if not (args.pipeline or args.serial or args.no_pipelined_probe):
             try:
                 out["pipelined"] = pipelined_probe(seq, Wm + K, device)

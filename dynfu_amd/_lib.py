@@ -9,7 +9,7 @@ _LIB = None
 # every symbol include/dynfu_amd.h declares (tests/test_capi_symbols.py checks the .so exports them)
 SYMBOLS = [
     "dfa_last_error", "dfa_version", "dfa_compute_dists", "dfa_tsdf_clear", "dfa_tsdf_integrate",
-    "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_tsdf_vertex_normals", "dfa_correspond_projective", "dfa_knn", "dfa_warp_to_live",
+    "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_tsdf_raycast_tally", "dfa_tsdf_vertex_normals", "dfa_correspond_projective", "dfa_knn", "dfa_warp_to_live",
     "dfa_calc_dqb", "dfa_unsupported_vertices", "dfa_icp_sums", "dfa_repack_points", "dfa_compact_points", "dfa_transform_points", "dfa_warp_to_live_graph",
     "dfa_correspond", "dfa_marching_cubes", "dfa_mc_default_tables",
     "dfa_depth_bilateral_filter", "dfa_depth_truncate", "dfa_depth_build_pyramid", "dfa_compute_normals_mask_depth",
@@ -82,7 +82,8 @@ class _SolveTiming(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libdynfu_amd.so")
+    # DFA_LIB_PATH: a library built with other compile-time constants (A/B measurements, tools/ab_variant.sh)
+    return os.environ.get("DFA_LIB_PATH") or os.path.join(_HERE, "libdynfu_amd.so")
 
 
 def load():
@@ -109,6 +110,7 @@ def load():
     ray = [vp, i, i, i, vp, f, vp, vp, f, f, f, f, f, f, vp, i, vp, i, i, i, vp]
     L.dfa_tsdf_raycast_points.argtypes = ray
     L.dfa_tsdf_raycast_depth.argtypes = ray
+    L.dfa_tsdf_raycast_tally.argtypes = [vp, i, i, i, vp, f, vp, vp, f, f, f, f, f, f, i, i, vp, vp, vp]
     L.dfa_tsdf_vertex_normals.argtypes = [vp, i, i, i, vp, f, vp, i, vp, vp]
     L.dfa_correspond_projective.argtypes = [vp, vp, i, vp, i, vp, i, i, i, f, f, f, f, f, f, vp, vp, vp, vp]
     L.dfa_knn.argtypes = [vp, vp, i, vp, i, i, vp, vp, vp]
@@ -275,6 +277,34 @@ def tsdf_raycast_depth(vol, voxel_size, trunc, cam2vol, Rinv, fx, fy, cx, cy, st
                                          delta_factor, _dev(depth, torch.uint16, "depth"), depth.stride(0) * 2,
                                          _dev(normals, torch.float32, "normals"), normals.stride(0) * 4, cols, rows,
                                          _stream()))
+
+
+def tsdf_raycast_tally(vol, voxel_size, trunc, cam2vol, Rinv, fx, fy, cx, cy, step_factor, delta_factor, cols, rows,
+                       unique=True):
+    """work of one raycast (measurement): dict(rays_entered, march_fetches, hits, trilinear_fetches, unique_voxels)"""
+    torch = _torch()
+    X, Y, Z = _vol_dims(vol)
+    counts = torch.zeros(4, dtype=torch.int64, device=vol.device)
+    bits = torch.zeros((X * Y * Z + 31) // 32, dtype=torch.int32, device=vol.device) if unique else None
+    _check(load().dfa_tsdf_raycast_tally(_dev(vol), X, Y, Z, _farr(voxel_size, 3), trunc, _aff12(cam2vol),
+                                         _farr(list(map(float, _flat(Rinv))), 9), fx, fy, cx, cy, step_factor, delta_factor,
+                                         cols, rows, counts.data_ptr(), bits.data_ptr() if unique else None, _stream()))
+    c = counts.cpu().tolist()
+    out = dict(rays_entered=c[0], march_fetches=c[1], hits=c[2], trilinear_fetches=c[3], unique_voxels=None)
+    if unique:
+        n, chunk = 0, 1 << 24
+        for o in range(0, bits.numel(), chunk):  # population count in pieces (no 8x blow-up of a 128 MiB bitmap)
+            b = bits[o:o + chunk]
+            b = (b & 0x55555555) + ((b >> 1) & 0x55555555)
+            b = (b & 0x33333333) + ((b >> 2) & 0x33333333)
+            b = (b + (b >> 4)) & 0x0F0F0F0F
+            n += int(((b * 0x01010101) >> 24 & 0xFF).sum())
+        out["unique_voxels"] = n
+        # distinct 64-byte (16 voxels) and 128-byte (32 voxels) lines of the volume those voxels lie in: what a cache that
+        # never fetched a line twice would have to read
+        out["unique_lines_64B"] = int((bits.view(torch.int16) != 0).sum())
+        out["unique_lines_128B"] = int((bits != 0).sum())
+    return out
 
 
 def tsdf_vertex_normals(vol, voxel_size, delta_factor, points):

@@ -333,6 +333,21 @@ int dfa_tsdf_raycast_depth(const uint32_t* volume, int X, int Y, int Z, const fl
     return DFA_OK;
 }
 
+int dfa_tsdf_raycast_tally(const uint32_t* volume, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
+                           const float cam2vol[12], const float Rinv[9], float fx, float fy, float cx, float cy,
+                           float step_factor, float delta_factor, int cols, int rows, uint64_t* counts,
+                           uint32_t* touched_bits, dfa_stream_t stream) {
+    REQUIRE(volume_args_ok(volume, X, Y, Z), "bad volume");
+    REQUIRE(X >= 2 && Y >= 2 && Z >= 2, "volume needs at least 2 voxels per axis");
+    REQUIRE(counts && cols > 0 && rows > 0, "bad counters / image size");
+    REQUIRE(voxel_size && cam2vol && Rinv, "null parameter block");
+    REQUIRE(trunc_dist > 0.f && step_factor > 0.f, "non-positive ray step");
+    HIP_TRY(hipMemsetAsync(counts, 0, 4 * sizeof(uint64_t), S(stream)));
+    HIP_TRY(dfa::launch_raycast_tally(volume, X, Y, Z, voxel_size, trunc_dist, cam2vol, Rinv, fx, fy, cx, cy, step_factor,
+                                      delta_factor, cols, rows, (unsigned long long*)counts, touched_bits, S(stream)));
+    return DFA_OK;
+}
+
 // -------------------------------------------------------------------- depth pre-processing seam
 
 int dfa_depth_bilateral_filter(const uint16_t* src, int src_step, uint16_t* dst, int dst_step, int cols, int rows,

@@ -24,6 +24,10 @@ hipError_t launch_raycast_points(const uint32_t* vol, int X, int Y, int Z, const
                                  float cx, float cy, float step_factor, float delta_factor, float* points,
                                  int points_step, float* normals, int normals_step, int cols, int rows,
                                  hipStream_t s);
+hipError_t launch_raycast_tally(const uint32_t* vol, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
+                                const float cam2vol[12], const float Rinv[9], float fx, float fy, float cx, float cy,
+                                float step_factor, float delta_factor, int cols, int rows, unsigned long long* counts,
+                                uint32_t* touched, hipStream_t s);
 hipError_t launch_raycast_depth(const uint32_t* vol, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
                                 const float cam2vol[12], const float Rinv[9], float fx, float fy, float cx, float cy,
                                 float step_factor, float delta_factor, uint16_t* depth, int depth_step,

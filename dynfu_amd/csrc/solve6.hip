@@ -55,10 +55,16 @@ __device__ __forceinline__ f3 dq_point(DQ q, f3 c) {
 }
 
 // ------------------------------------------------------------------------------------ graphs
-// nearest node of every vertex (the key of the vertex sort)
-__global__ __launch_bounds__(256) void s6_near_kernel(const int32_t* __restrict__ idx_nat, int N, int k, int32_t* __restrict__ near) {
+// nearest node of every vertex (the key of the vertex sort).  A vertex WITHOUT a nearest node (NaN coordinates: the k-NN
+// returns -1 for it) is filed under the last node: the sort is a permutation of ALL N vertices — a key the transposition
+// skipped would leave positions [vptr[D], N) of the solver's arrays unwritten — and such a vertex keeps its row of -1
+// ids and zero weights, i.e. it is passed through unchanged by every kernel, as it was before the sort existed.
+__global__ __launch_bounds__(256) void s6_near_kernel(const int32_t* __restrict__ idx_nat, int N, int k, int D,
+                                                      int32_t* __restrict__ near) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < N) near[v] = idx_nat[(size_t)v * k];
+    if (v >= N) return;
+    const int n = idx_nat[(size_t)v * k];
+    near[v]     = n >= 0 && n < D ? n : D - 1;
 }
 
 constexpr int S6_SORT_MAX = 4096;
@@ -1644,7 +1650,7 @@ hipError_t s6_build_graph(const Solve6View& s, Solve6State* state, const float* 
     hipError_t e = hipSuccess;
     if (s.N > 0) {
         // the solver's vertex order: by nearest node (counting sort), by index inside a node
-        s6_near_kernel<<<(s.N + 255) / 256, 256, 0, st>>>(s.idx_nat, s.N, s.k, s.near);
+        s6_near_kernel<<<(s.N + 255) / 256, 256, 0, st>>>(s.idx_nat, s.N, s.k, s.D, s.near);
         e = solve_transpose_graph(s.near, (size_t)s.N, s.D, s.blk_hist, s.vptr, s.vlist, st);
         if (e != hipSuccess) return e;
         K6DISPATCH(s6_permute_kernel, s.k, <<<s.D, 256, 0, st>>>(s, canon_user, canon_n_user, raw_w));

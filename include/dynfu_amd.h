@@ -101,6 +101,16 @@ int dfa_tsdf_raycast_depth(const uint32_t* volume, int X, int Y, int Z, const fl
                            float step_factor, float delta_factor, uint16_t* depth, int depth_step, float* normals,
                            int normals_step, int cols, int rows, dfa_stream_t stream);
 
+/* Measurement entry point (no reference counterpart): the rays of dfa_tsdf_raycast_points / _depth cast once more with
+ * their WORK counted — the quantities SURVEY 8(d) prices the raycast by.  counts[4] (device, zeroed here): rays that
+ * enter the volume, nearest-voxel fetches of the march (tsdf_volume.cu:187-193 via :222,:230), hits (:246), voxel
+ * fetches of the trilinear samples (:146-171: 8 per sample).  touched_bits: one bit per voxel, X*Y*Z/32 words zeroed by
+ * the caller, set for every voxel any ray reads (its population count is the lower bound "unique voxels"); may be null. */
+int dfa_tsdf_raycast_tally(const uint32_t* volume, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
+                           const float cam2vol[12], const float Rinv[9], float fx, float fy, float cx, float cy,
+                           float step_factor, float delta_factor, int cols, int rows, uint64_t* counts,
+                           uint32_t* touched_bits, dfa_stream_t stream);
+
 /* ===================================================================================== */
 /* Depth pre-processing seam — replaces the image kernels of kfusion::device declared in    */
 /* include/kfusion/internal.hpp:190-204 (src/kfusion/cuda/imgproc.cu), called by            */

@@ -100,6 +100,8 @@ def _declare(L):
     L.orc_tsdf_clear.restype = None
     L.orc_tsdf_integrate.argtypes = [vp, i, i, i, vp, i, i, i, vp, f, i, vp, f, f, f, f, i]
     L.orc_tsdf_integrate.restype = C.c_long
+    L.orc_tsdf_integrate_slab.argtypes = [vp, i, i, i, vp, i, i, i, i, vp, f, i, vp, f, f, f, f, i]
+    L.orc_tsdf_integrate_slab.restype = C.c_long
     L.orc_tsdf_raycast_points.argtypes = [vp, i, i, i, vp, f, vp, vp, f, f, f, f, f, f, vp, i, vp, i, i, i, i]
     L.orc_tsdf_raycast_points.restype = None
     L.orc_tsdf_vertex_normals.argtypes = [vp, i, i, i, vp, f, vp, i, vp]
@@ -167,6 +169,17 @@ def tsdf_integrate(vol, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, c
     vs, a = _f32(voxel_size), _f32(vol2cam).reshape(-1)
     return int(lib().orc_tsdf_integrate(_p(dists), dists.strides[0], cols, rows, _p(vol), X, Y, Z, _p(vs), trunc,
                                         max_weight, _p(a), fx, fy, cx, cy, threads))
+
+
+def tsdf_integrate_slab(slab, z0, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, cx, cy, threads=1):
+    """slab: uint32 (z1 - z0, Y, X) = slices [z0, z1) of a volume, updated in place exactly as the full sweep would."""
+    assert slab.dtype == np.uint32 and slab.flags.c_contiguous
+    n, Y, X = slab.shape
+    dists = np.ascontiguousarray(dists, dtype=np.uint16)
+    rows, cols = dists.shape
+    vs, a = _f32(voxel_size), _f32(vol2cam).reshape(-1)
+    return int(lib().orc_tsdf_integrate_slab(_p(dists), dists.strides[0], cols, rows, _p(slab), X, Y, z0, z0 + n, _p(vs),
+                                             trunc, max_weight, _p(a), fx, fy, cx, cy, threads))
 
 
 def tsdf_raycast_points(vol, voxel_size, trunc, cam2vol, Rinv, fx, fy, cx, cy, step_factor, delta_factor, cols,

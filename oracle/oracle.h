@@ -52,6 +52,9 @@ void orc_compute_dists(const uint16_t* depth, int depth_step, uint16_t* dists, i
 void orc_tsdf_clear(uint32_t* vol, int X, int Y, int Z);
 
 /* tsdf_volume.cu:43-121. Returns number of voxels updated. threads<=1: serial. */
+long orc_tsdf_integrate_slab(const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* slab, int X, int Y, int z0,
+                             int z1, const float voxel_size[3], float trunc_dist, int max_weight,
+                             const float vol2cam[12], float fx, float fy, float cx, float cy, int threads);
 long orc_tsdf_integrate(const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* vol, int X, int Y, int Z,
                         const float voxel_size[3], float trunc_dist, int max_weight, const float vol2cam[12], float fx,
                         float fy, float cx, float cy, int threads);

@@ -132,9 +132,12 @@ void orc_tsdf_clear(uint32_t* vol, int X, int Y, int Z) { memset(vol, 0, (size_t
 /* ----------------------------------------------------------------------------------- */
 /* integrate — tsdf_volume.cu:43-96                                                      */
 
-long orc_tsdf_integrate(const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* vol, int X, int Y, int Z,
-                        const float voxel_size[3], float trunc_dist, int max_weight, const float vol2cam[12], float fx,
-                        float fy, float cx, float cy, int threads) {
+/* Slices [z0, z1) of the sweep over Z slices, `vol` holding THOSE slices only (slice z0 first): every column still
+ * starts at z = 0 and replays its `vc += zstep` additions below z0, so the slab is bit-for-bit the same as the
+ * corresponding part of a full sweep — what makes a 1024^3 volume checkable in slabs of a few seconds each. */
+long orc_tsdf_integrate_slab(const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* vol, int X, int Y, int z0,
+                             int z1, const float voxel_size[3], float trunc_dist, int max_weight,
+                             const float vol2cam[12], float fx, float fy, float cx, float cy, int threads) {
     const float* R        = vol2cam;
     const f3 t            = mk3(vol2cam[9], vol2cam[10], vol2cam[11]);
     const float trunc_inv = 1.f / trunc_dist; /* tsdf_volume.cu:106 */
@@ -157,9 +160,11 @@ long orc_tsdf_integrate(const uint16_t* dists, int dists_step, int cols, int row
                 f3 vx                     = mk3((float)x * voxel_size[0], (float)y * voxel_size[1], 0.f);
                 vcs[(y - yb) * X + x] = add3(mat_mul(R, vx), t);
             }
-        for (int i = 0; i < Z; ++i) {
+        for (int i = 0; i < z0; ++i) /* :64 on the slices below the slab */
+            for (int j = 0; j < (ye - yb) * X; ++j) vcs[j] = add3(vcs[j], zstep);
+        for (int i = z0; i < z1; ++i) {
             for (int y = yb; y < ye; ++y) {
-                uint32_t* vrow = vol + (size_t)X * y + slice * i;
+                uint32_t* vrow = vol + (size_t)X * y + slice * (i - z0);
                 f3* vcrow      = vcs + (size_t)(y - yb) * X;
                 for (int x = 0; x < X; ++x) {
                     const f3 vc = vcrow[x];
@@ -193,6 +198,13 @@ long orc_tsdf_integrate(const uint16_t* dists, int dists_step, int cols, int row
         free(vcs);
     }
     return updated;
+}
+
+long orc_tsdf_integrate(const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* vol, int X, int Y, int Z,
+                        const float voxel_size[3], float trunc_dist, int max_weight, const float vol2cam[12], float fx,
+                        float fy, float cx, float cy, int threads) {
+    return orc_tsdf_integrate_slab(dists, dists_step, cols, rows, vol, X, Y, 0, Z, voxel_size, trunc_dist, max_weight, vol2cam,
+                                   fx, fy, cx, cy, threads);
 }
 
 /* ----------------------------------------------------------------------------------- */

@@ -22,12 +22,4 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-def rot(axis, ang):
-    axis = np.asarray(axis, float)
-    axis /= np.linalg.norm(axis)
-    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
-    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
-
-
-def aff12(R, t):
-    return np.concatenate([np.asarray(R, np.float32).reshape(-1), np.asarray(t, np.float32)]).astype(np.float32)
+from gpu_util_cpu import aff12, rot  # noqa: E402,F401

@@ -414,3 +414,43 @@ def test_degenerate_problems(A):
     s.set_problem(keep[0], keep[1], keep[2], dev(far), keep[4])
     s.solve(P, Nm, *intr, A.Solve6Params(**kw))
     assert s.stats()["valid_first"] == 0 and np.isfinite(host(s.node_dq())).all()
+
+
+@pytest.mark.parametrize("name", ["T0", "T1"])
+def test_vertices_without_a_nearest_node_are_passed_through(A, name):
+    """a canonical vertex with NaN coordinates has no k-NN (ids -1): the vertex sort must still place it (the solver's
+    arrays are a permutation of ALL vertices), the solve ignores it, and the warp hands it back at the caller's own
+    index — with every other vertex exactly where a run without the broken vertices puts it"""
+    import torch
+    cfg, c, intr, depth = _scene(name, 3)
+    P, Nm = A.compute_points_normals(dev(depth), *intr)
+    kw = dict(num_iter=1, gn_iter=2, linear_iter=30, lambda_=200.0)
+    verts, normals = c["verts"].copy(), c["normals"].copy()
+    N = len(verts)
+    bad = np.array([0, 1, 77, N // 2, N - 1])
+    verts[bad] = np.nan
+    s = A.Solver6(cfg["D"], N, cfg["k"])
+    # stale contents of a previous problem in the plan's buffers: a full problem first
+    first = [dev(c["node_pos"]), dev(c["node_dq"]), dev(c["node_w"]), dev(c["verts"]), dev(c["normals"])]
+    s.set_problem(*first)
+    s.solve(P, Nm, *intr, A.Solve6Params(**kw))
+    keep = [first[0], first[1], first[2], dev(verts), dev(normals)]
+    s.set_problem(*keep)
+    s.solve(P, Nm, *intr, A.Solve6Params(**kw))
+    st = s.stats()
+    wv, wn_ = s.warp()
+    torch.cuda.synchronize()
+    wv, wn_ = host(wv), host(wn_)
+    assert st["overflow"] == 0 and np.isfinite(host(s.node_dq())).all()
+    good = np.ones(N, bool)
+    good[bad] = False
+    assert np.isnan(wv[bad]).all() and np.isfinite(wv[good]).all()      # handed back where the caller put them
+    assert np.array_equal(bits(wn_[bad]), bits(normals[bad]))            # their normals untouched
+    # the same problem without the broken vertices: same transforms (the broken rows carry no weight), same warp
+    s2 = A.Solver6(cfg["D"], int(good.sum()), cfg["k"])
+    keep2 = [first[0], first[1], first[2], dev(verts[good]), dev(normals[good])]
+    s2.set_problem(*keep2)
+    s2.solve(P, Nm, *intr, A.Solve6Params(**kw))
+    assert s2.stats()["valid_first"] == st["valid_first"]
+    assert np.abs(host(s2.node_dq()) - host(s.node_dq())).max() < 2e-5
+    assert np.abs(host(s2.warp()[0]) - wv[good]).max() < 2e-5

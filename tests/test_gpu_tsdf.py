@@ -316,6 +316,113 @@ def test_raycast_bit_exact(A, name):
         assert np.array_equal(bits(host(nrm2)), bits(rn2))
 
 
+def _raycast_both_variants_bit_exact(A, v, vol_host, voxel, trunc, c2v, ri, intr, W, H, min_hits):
+    import torch
+    pts = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    nrm = torch.zeros_like(pts)
+    A.tsdf_raycast_points(v, voxel, trunc, c2v, ri, *intr, synth.RAYCAST_STEP_FACTOR, synth.GRADIENT_DELTA_FACTOR, pts, nrm)
+    rp, rn = O.tsdf_raycast_points(vol_host, voxel, trunc, c2v, ri, *intr, synth.RAYCAST_STEP_FACTOR,
+                                   synth.GRADIENT_DELTA_FACTOR, W, H, threads=8)
+    hits = ~np.isnan(rp[..., 0])
+    assert hits.mean() > min_hits, hits.mean()
+    assert np.array_equal(bits(host(pts)), bits(rp))
+    assert np.array_equal(bits(host(nrm)), bits(rn))
+    dep = torch.full((H, W), 7, dtype=torch.uint16, device="cuda")
+    nrm2 = torch.zeros_like(pts)
+    A.tsdf_raycast_depth(v, voxel, trunc, c2v, ri, *intr, synth.RAYCAST_STEP_FACTOR, synth.GRADIENT_DELTA_FACTOR, dep, nrm2)
+    rd, rn2 = O.tsdf_raycast_depth(vol_host, voxel, trunc, c2v, ri, *intr, synth.RAYCAST_STEP_FACTOR,
+                                   synth.GRADIENT_DELTA_FACTOR, W, H, threads=8)
+    assert np.array_equal(host(dep), rd)
+    assert np.array_equal(bits(host(nrm2)), bits(rn2))
+    return int(hits.sum())
+
+
+@pytest.mark.parametrize("name", ["C1", "C2", "C4"])
+def test_raycast_bit_exact_at_baseline_sizes(A, name):
+    """Both raycast variants at the BASELINE configurations' own sizes — 256^3 / VGA, 512^3 / VGA, 1024^3 / 720p (a
+    4 GiB volume: voxel offsets beyond 2^31 bytes, 2-4x the march steps of the small cases, `tmax -= step` and the
+    NaN edges of the trilinear stencil in other places) — against oracle/tsdf_oracle.c, bit for bit, from the
+    integration pose and from a moved, rotated camera.  The volume is the HIP sweep's (two sweeps: weights 2, averaged
+    values), downloaded once; the oracle casts its rays through that very copy."""
+    import torch
+    cfg, intr, voxel, trunc, vol2cam, cam2vol, rinv, depth = _scene(name)
+    dim, W, H = cfg["dim"], cfg["width"], cfg["height"]
+    dists = torch.empty((H, W), dtype=torch.uint16, device="cuda")
+    A.compute_dists(dev(depth), dists, *intr)
+    v = torch.empty((dim, dim, dim), dtype=torch.int32, device="cuda")
+    A.tsdf_clear_integrate(v, dists, voxel, trunc, 64, vol2cam, *intr)
+    depth2 = _scene(name, frame=12)[7]
+    A.compute_dists(dev(depth2), dists, *intr)
+    A.tsdf_integrate(v, dists, voxel, trunc, 64, vol2cam, *intr)
+    vol_host = host(v, np.uint32)
+    R = rot([0.1, 1, 0.05], 0.07)
+    cam2vol_m = aff12(R, cam2vol[9:] + np.array([0.03, -0.02, 0.01], np.float32))
+    rinv_m = np.linalg.inv(R).astype(np.float32).reshape(-1)
+    for c2v, ri in ((cam2vol, rinv), (cam2vol_m, rinv_m)):
+        nhits = _raycast_both_variants_bit_exact(A, v, vol_host, voxel, trunc, c2v, ri, intr, W, H, 0.5)
+        # the work counters of the measurement entry point describe the same rays
+        t = A.tsdf_raycast_tally(v, voxel, trunc, c2v, ri, *intr, synth.RAYCAST_STEP_FACTOR, synth.GRADIENT_DELTA_FACTOR, W, H,
+                                 unique=(name != "C4"))
+        assert t["hits"] == nhits and t["rays_entered"] <= W * H and t["march_fetches"] >= 2 * t["hits"]
+        assert t["trilinear_fetches"] >= 64 * t["hits"] - 8 * 8 * 64  # 8 samples of 8 voxels per hit (edge samples fall out)
+        if t["unique_voxels"] is not None:
+            assert t["hits"] < t["unique_voxels"] <= t["march_fetches"] + t["trilinear_fetches"]
+
+
+def test_raycast_through_a_volume_with_far_side_surfaces(A):
+    """rays that leave a surface again (tsdf - -> +: the reference's early exit, tsdf_volume.cu:234) and rays that graze:
+    a 256^3 volume fused from TWO poses so that back faces exist, cast from a third pose"""
+    import torch
+    cfg, intr, voxel, trunc, vol2cam, cam2vol, rinv, depth = _scene("C1")
+    dim, W, H = cfg["dim"], cfg["width"], cfg["height"]
+    dists = torch.empty((H, W), dtype=torch.uint16, device="cuda")
+    A.compute_dists(dev(depth), dists, *intr)
+    v = torch.empty((dim, dim, dim), dtype=torch.int32, device="cuda")
+    A.tsdf_clear_integrate(v, dists, voxel, trunc, 64, vol2cam, *intr)
+    R2 = rot([0, 1, 0], 0.6)
+    centre = np.array([0.0, 0.0, 1.5])
+    t2 = (centre - R2 @ centre) + (R2 @ np.array(vol2cam[9:], np.float64))
+    A.tsdf_integrate(v, dists, voxel, trunc, 64, aff12(R2, t2), *intr)
+    vol_host = host(v, np.uint32)
+    R3 = rot([0.2, 1, 0], -0.8)
+    cam_pos_vol = np.array([1.5, 1.5, 1.0]) + R3 @ np.array([0.0, 0.0, -1.4])
+    c2v = aff12(R3, cam_pos_vol)
+    ri = np.linalg.inv(R3).astype(np.float32).reshape(-1)
+    _raycast_both_variants_bit_exact(A, v, vol_host, voxel, trunc, c2v, ri, intr, W, H, 0.05)
+
+
+def test_full_size_sweep_256_bit_exact(A):
+    """BASELINE config C1's volume (256^3) against the oracle, whole: two frames fused, bit for bit"""
+    import torch
+    cfg, intr, voxel, trunc, vol2cam, _, _, depth = _scene("C1")
+    dim = cfg["dim"]
+    ref = np.zeros((dim, dim, dim), np.uint32)
+    v = torch.full((dim, dim, dim), -1, dtype=torch.int32, device="cuda")
+    for i, frame in enumerate((0, 9)):
+        d = O.compute_dists(_scene("C1", frame=frame)[7], *intr)
+        (A.tsdf_clear_integrate if i == 0 else A.tsdf_integrate)(v, dev(d), voxel, trunc, 64, vol2cam, *intr)
+        O.tsdf_integrate(ref, d, voxel, trunc, 64, vol2cam, *intr, threads=8)
+    assert np.array_equal(host(v, np.uint32), ref)
+    assert 0.05 < float((ref >> 16 == 2).mean()) < 0.9
+
+
+@pytest.mark.parametrize("size", [(150, 101), (17, 9), (1040, 24)])
+def test_raycast_ragged_image_sizes(A, size):
+    """image sizes that are not multiples of the 16 x 16-pixel workgroup tile nor of the 64-tile round of the XCD-aware
+    tile order (partial tiles at the right / bottom edge, a partial last round, a single row of tiles)"""
+    cfg, intr, voxel, trunc, vol2cam, cam2vol, rinv, depth = _scene("T0")
+    dim = cfg["dim"]
+    vol = np.zeros((dim, dim, dim), np.uint32)
+    O.tsdf_integrate(vol, O.compute_dists(depth, *intr), voxel, trunc, 64, vol2cam, *intr, threads=8)
+    W, H = size
+    f = 0.82 * W
+    intr2 = (f, f * 1.01, W / 2 - 0.5, H / 2 - 0.5)
+    R = rot([0.3, 1, 0], 0.04)
+    c2v = aff12(R, cam2vol[9:] + np.array([0.01, 0.02, -0.01], np.float32))
+    ri = np.linalg.inv(R).astype(np.float32).reshape(-1)
+    _raycast_both_variants_bit_exact(A, dev(vol), vol, voxel, trunc, c2v, ri, intr2, W, H, 0.02)
+
+
 def test_raycast_miss_everywhere_on_empty_volume(A):
     import torch
     cfg, intr, voxel, trunc, _, cam2vol, rinv, _ = _scene("T0")
@@ -395,6 +502,21 @@ def test_full_size_properties_1024(A):
     finally:
         del os.environ["DFA_TSDF_ZCHUNK"]
     assert torch.equal(checksum(c), ca)
+    del c
+    # ---- bit for bit against the oracle, slab by slab (orc_tsdf_integrate_slab replays the z additions below the slab):
+    # the front of the volume, the slices through the sphere's surface, the slices around the background plane and the
+    # last slices — two sweeps each, as `a` has had
+    dists_h = host(dists)
+    vs = float(voxel[2])
+    z_sphere = int(round((1.0 - float(vol2cam[11])) / vs))   # the sphere's front, z = 1.0 m
+    z_plane = int(round((synth.PLANE_Z - float(vol2cam[11])) / vs))
+    for z0 in (0, z_sphere - 16, z_plane - 16, dim - 32):
+        slab = np.zeros((32, dim, dim), np.uint32)
+        for _ in range(2):
+            O.tsdf_integrate_slab(slab, z0, dists_h, voxel, trunc, 64, vol2cam, *intr, threads=8)
+        assert np.array_equal(host(a[z0:z0 + 32], np.uint32), slab), z0
+        if z0 in (z_sphere - 16, z_plane - 16):
+            assert (slab >> 16 == 2).mean() > 0.01  # the slab is not an empty one
 
 
 def test_argument_errors_are_loud(A):
