@@ -40,7 +40,7 @@ PMC_TRAFFIC = {
     ("C2", "fused_integrate"): (0.5417e9, "profiles/r03h_pmc_c2.md", "858fb26"),   # WRITE 524 288 KiB + 2 x FETCH 2 354 KiB
     ("C3", "fused_integrate"): (0.5414e9, "profiles/r03h_pmc_ns_c3.md", "858fb26"),
     ("C4", "fused_integrate"): (4.344e9, "profiles/r02_pmc_tsdf.md", "round 2"),   # 4 194 304 + 2 x 23 775 KiB
-    ("C2", "pcg"): (616.6 * 1024, "profiles/r02d_pmc_bench_c2.md", "round 2"),      # pcg_paired_kernel<1024,1,32,1>: FETCH 340.7 + WRITE 275.9 KiB
+    ("C2", "pcg"): (0.632e6, "profiles/r03h_pmc_c2.md", "858fb26"),                 # pcg_paired_kernel<1024,1,32,1>: FETCH + WRITE
     # north-star kernels: FETCH + WRITE, uncorrected, for the gather-heavy PCG step and the gathering assembly (the x2 of
     # wide read streams does not apply to 16-80-byte gathers); 2 x FETCH + WRITE for the streaming linearisation.
     ("C2", "s6_assemble"): (61.49e6, "profiles/r03h_pmc_ns_c2.md", "858fb26"),
@@ -77,6 +77,8 @@ def parse():
                     help="targets: index-aligned live vertices canon + sum w t* (SURVEY 8d, the headline workload); depth: the "
                          "reference's data flow — noisy depth, marching-cubes live cloud, nearest-vertex correspondence "
                          "(prints the line of that workload alone)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short C3 / C4 measurements (both modes) of the default run")
     ap.add_argument("--no-raycast", action="store_true", help="skip the raycast figures (SURVEY 8d: reported separately)")
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the DynFusion::operator() sequence (the reference's own timed region, C++ adaptor classes)")
@@ -107,7 +109,7 @@ def parse():
 class Sequence:
     """Device-resident inputs + plan of one synthetic sequence."""
 
-    def __init__(self, cfg_name, device):
+    def __init__(self, cfg_name, device, n_frames=None):
         import torch
 
         import dynfu_amd as A
@@ -117,7 +119,7 @@ class Sequence:
         self.intr = synth.intrinsics(cfg)
         self.voxel, self.trunc, self.vol2cam, self.cam2vol, self.rinv = synth.volume_params(cfg)
         dim, W, H = cfg["dim"], cfg["width"], cfg["height"]
-        self.n_frames = synth.N_FRAMES
+        self.n_frames = n_frames or synth.N_FRAMES  # the sequence repeats after this many frames
         self.depth_np = [synth.depth_frame(cfg, f) for f in range(self.n_frames)]
         self.depth = torch.from_numpy(np.stack(self.depth_np)).to(device)
         self.dists = torch.empty((H, W), dtype=torch.uint16, device=device)
@@ -296,8 +298,8 @@ class Sequence6(Sequence):
     """North-star mode: the live input of the solve is the depth frame itself (vertex / normal maps by
     computePointNormals), the unknowns are 6-DoF node twists (dfa_solver6)."""
 
-    def __init__(self, cfg_name, device, linear_iter, pcg=None):
-        super().__init__(cfg_name, device)
+    def __init__(self, cfg_name, device, linear_iter, pcg=None, n_frames=None):
+        super().__init__(cfg_name, device, n_frames)
         A, cfg = self.A, self.cfg
         del self.solver, self.live
         self.solver = A.Solver6(self.D, self.N, self.k)
@@ -472,28 +474,51 @@ def northstar_rooflines(seq, config, st, tm, fuse_ms):
     pcg_bytes = nblk * (36 * 4 + 4 + 3 * 24) + 12 * 24.0 * seq.D
     asm_ms, lin_ms, pcg_ms = tm["assemble_ms"] / gn, tm["linearise_ms"] / gn, tm["pcg_ms"] / launches
 
-    def entry(kernel, key, ms, nbytes, per_frame, total_ms, **extra):
-        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else float("nan")
+    # SURVEY 8(d)'s own prices (what the PROBLEM needs, independent of this implementation's data flow): per Gauss-Newton
+    # iteration N x (12 canonV + 12 normal + 12 liveV + 4 tau + 4 k idx) + D x 28 in — charged to the linearisation, which
+    # reads the inputs — and nnz_blocks x 36 x 4 out — charged to the assembly, which writes the matrix; per PCG iteration
+    # nnz_blocks x b^2 x 4 + 6 n x 4 with b = 6, n = 6 D.  `frac` is computed from THESE; the bytes this design chose to
+    # move (records re-read once per neighbour through the transposed lists, pair records) stay beside them as
+    # implementation_bytes_per_launch, and traffic_over_survey = counter traffic / survey bytes.
+    sv_lin = seq.N * (12 + 12 + 12 + 4 + 4.0 * k) + 28.0 * seq.D
+    sv_asm = nblk * 36 * 4.0
+    sv_pcg = nblk * 36 * 4.0 + 6 * 6 * seq.D * 4.0
+
+    def entry(kernel, key, ms, survey, impl, per_frame, total_ms, **extra):
+        gbs = survey / (ms * 1e-3) / 1e9 if ms > 0 else float("nan")
         src = PMC_TRAFFIC_BYTES.get((config, key))
         return dict(kernel=kernel, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(gbs / HBM_PEAK_GBS, 4), traffic=src, traffic_source=traffic_source(config, key),
-                    avg_launch_ms=round(ms, 5), launches_per_frame=per_frame, algorithmic_bytes_per_launch=nbytes,
+                    avg_launch_ms=round(ms, 5), launches_per_frame=per_frame, survey_bytes_per_launch=survey,
+                    implementation_bytes_per_launch=impl,
+                    implementation_frac=round(impl / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None,
+                    traffic_over_survey=round(src / survey, 2) if src else None,
                     ms_per_frame=round(total_ms, 4), **extra)
 
+    pair_ms = asm_ms + lin_ms
     ents = [
         entry("s6_assemble2_kernel<%d,%d> (block normal matrix of one Gauss-Newton iteration)" % (kk, 448 if kk == 4 else 352),
-              "s6_assemble", asm_ms, asm_bytes, gn, tm["assemble_ms"],
+              "s6_assemble", asm_ms, sv_asm, asm_bytes, gn, tm["assemble_ms"],
               note="a lane per work unit walks its share of one block's (row, neighbour) list and owns the 36 distinct entries "
                    "of its 8 x 8 moment; rows staged by LDS-DMA.  Bound by instruction issue and the per-workgroup chain of "
                    "barriers and round trips (SQ counters, phase clocks: DESIGN.md 4.5), not by HBM"),
         entry("s6_linearise_kernel<%d> (+ s6_nodes, s6_reg: residuals and row factors of one Gauss-Newton iteration)" % kk,
-              "s6_linearise", lin_ms, lin_bytes, gn, tm["linearise_ms"]),
-        entry("s6_pcg_step_kernel (one Chronopoulos-Gear PCG iteration per launch)", "s6_pcg_step", pcg_ms, pcg_bytes, launches,
-              tm["pcg_ms"], matrix_blocks=nblk,
+              "s6_linearise", lin_ms, sv_lin, lin_bytes, gn, tm["linearise_ms"]),
+        entry("s6_pcg_step_kernel (one Chronopoulos-Gear PCG iteration per launch)", "s6_pcg_step", pcg_ms, sv_pcg, pcg_bytes, launches,
+              tm["pcg_ms"], matrix_blocks=nblk, launches_without_an_iteration=max(0, st["pcg_launches"] - st["pcg_iters"]),
               note="launch/latency-bound below ~2k nodes (two dependent memory round trips + the inter-kernel gap); a launch "
                    "whose PCG has converged costs ~3.5 us, which is why the launch count follows the iteration count"),
-        entry("integrate_runs_kernel<FUSED_CLEAR,32,8> (clear+integrate %d^3)" % dim, "fused_integrate", fuse_ms, fuse_bytes, 1, fuse_ms),
+        entry("integrate_runs_kernel<FUSED_CLEAR,32,8> (clear+integrate %d^3)" % dim, "fused_integrate", fuse_ms, fuse_bytes, fuse_bytes, 1, fuse_ms),
     ]
+    pair_traffic = (PMC_TRAFFIC_BYTES.get((config, "s6_assemble")) or 0) + (PMC_TRAFFIC_BYTES.get((config, "s6_linearise")) or 0)
+    ents.append(dict(kernel="residual / Jacobian assembly of one Gauss-Newton iteration = s6_linearise + s6_assemble2 (SURVEY 8d prices "
+                            "the pair as one piece)", bound="hbm",
+                     achieved=round((sv_lin + sv_asm) / (pair_ms * 1e-3) / 1e9, 1) if pair_ms > 0 else None, peak=HBM_PEAK_GBS,
+                     unit="GB/s", frac=round((sv_lin + sv_asm) / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pair_ms > 0 else None,
+                     traffic=pair_traffic or None, avg_launch_ms=round(pair_ms, 5), launches_per_frame=gn,
+                     survey_bytes_per_launch=sv_lin + sv_asm, implementation_bytes_per_launch=lin_bytes + asm_bytes,
+                     traffic_over_survey=round(pair_traffic / (sv_lin + sv_asm), 2) if pair_traffic else None,
+                     ms_per_frame=0.0))  # (ms_per_frame 0: a derived entry, sorted last)
     ents.sort(key=lambda e: -e["ms_per_frame"])
     return ents
 
@@ -512,7 +537,27 @@ def northstar_fields(seq, st):
                 valid_rows=st["valid_last"], cost_per_gn=[float("%.5g" % c) for c in st["cost_hist"]])
 
 
-def northstar_probe(cfg_name, device, steps=30, warmup=8):
+def northstar_timed_frames(seq, f0, device, frames=5):
+    """`frames` more frames with hipEvent brackets on the solve's stream around every launch group (outside any timed
+    region); per-kernel times are the MEDIAN over those frames (one frame alone moves by 2x with where the concurrent
+    volume sweep happens to land)."""
+    import torch
+    fuse_events, tms = [], []
+    seq.solver.enable_timing(True)
+    for i in range(frames):
+        seq.frame(f0 + i, False, fuse_events)
+        torch.cuda.synchronize(device)
+        tms.append(seq.solver.timing())
+    st = seq.solver.stats()
+    seq.solver.enable_timing(False)
+    tm = dict(tms[-1])
+    for key in ("linearise_ms", "assemble_ms", "pcg_ms"):
+        tm[key] = float(np.median([t[key] for t in tms]))
+    fuse_ms = float(np.median([a.elapsed_time(b) for a, b in fuse_events]))
+    return st, tm, fuse_ms
+
+
+def northstar_probe(cfg_name, device, steps=30, warmup=8, cpu_frames=0):
     """The same frame in north-star mode (6-DoF DQ-blend / projective point-to-plane / ARAP solve), timed
     on this GPU after the main measurement: a secondary figure of the default bench line, with its own rooflines."""
     import torch
@@ -526,14 +571,7 @@ def northstar_probe(cfg_name, device, steps=30, warmup=8):
         seq.frame(warmup + f)
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
-    # one more frame with hipEvent brackets on the solve's stream (outside the timed region) for the per-kernel figures
-    fuse_events = []
-    seq.solver.enable_timing(True)
-    seq.frame(warmup + steps, False, fuse_events)
-    torch.cuda.synchronize(device)
-    st, tm = seq.solver.stats(), seq.solver.timing()
-    seq.solver.enable_timing(False)
-    fuse_ms = float(np.mean([a.elapsed_time(b) for a, b in fuse_events]))
+    st, tm, fuse_ms = northstar_timed_frames(seq, warmup + steps, device)
     rl = northstar_rooflines(seq, cfg_name, st, tm, fuse_ms)
     out = dict(value=round(steps / dt, 2), unit="frames/s", steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 4),
                workload="%s north-star mode: %d GN iterations x block-Jacobi PCG (inexact Newton), 6-DoF twists per node, DQ blend, "
@@ -541,8 +579,11 @@ def northstar_probe(cfg_name, device, steps=30, warmup=8):
                         % (cfg_name, seq.gn_total),
                solve=northstar_fields(seq, st), roofline=rl[0], roofline_other=rl[1:],
                note="parity unpinned (the reference has no such solve): checked against the fp64 statement oracle/solve6_oracle.c")
+    params = seq.params
     del seq
     torch.cuda.empty_cache()
+    if cpu_frames > 0:
+        out["cpu_baseline"] = cpu_baseline6(cfg_name, cpu_frames, params)
     return out
 
 
@@ -718,6 +759,63 @@ def raycast_probe(seq, config, reps=20):
                          gathers_per_us=round((tally["march_fetches"] + tally["trilinear_fetches"]) / (ms * 1e3), 1),
                          note="a gather kernel: every fetch is a 4-byte read of its own; what bounds it is the rate of cache-line "
                               "requests and the dependent chain of march steps, not HBM (DESIGN.md 4.1)")
+    return out
+
+
+def config_probe(cfg_name, mode, device, steps=10, warmup=3, n_frames=6):
+    """One of the OTHER BASELINE configurations (C3: 512^3 / 4 k nodes / k = 8 / 10 GN, "+ ARAP" = north-star mode; C4:
+    1024^3 / 8 k nodes / 720p) under the same clock as the headline: `steps` self-contained frames after `warmup`,
+    device synchronised on both sides; reference-parity energy (`ref`) or the 6-DoF solve (`northstar`).  Short on
+    purpose (the default run must finish in minutes): treat single-digit-percent differences as noise."""
+    import torch
+    t_build = time.perf_counter()
+    if mode == "northstar":
+        seq = Sequence6(cfg_name, device, 64, n_frames=n_frames)
+        seq.fuse_first = False
+    else:
+        seq = Sequence(cfg_name, device, n_frames=n_frames)
+        seq.fuse_first = False
+        if seq.D <= 2048:
+            seq.enable_pcg_shadow()
+    t_build = time.perf_counter() - t_build
+    for f in range(warmup):
+        seq.frame(f)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for f in range(steps):
+        seq.frame(warmup + f)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    cfg = seq.cfg
+    out = dict(value=round(steps / dt, 2), unit="frames/s", steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 4),
+               workload="%s %s: %d^3 TSDF, %dx%d depth, %d nodes, k=%d, %d vertices, %d GN iterations"
+                        % (cfg_name, "north-star mode (6-DoF / projective point-to-plane / ARAP)" if mode == "northstar" else
+                           "reference-parity energy (energy.t)", cfg["dim"], cfg["width"], cfg["height"], seq.D, seq.k, seq.N,
+                           cfg["gn_iters"]), setup_s=round(t_build, 1))
+    if mode == "northstar":
+        st, tm, fuse_ms = northstar_timed_frames(seq, warmup + steps, device, frames=3)
+        rl = northstar_rooflines(seq, cfg_name, st, tm, fuse_ms)
+        f = northstar_fields(seq, st)
+        out.update(solve={k: f[k] for k in ("gn_iterations", "pcg_iterations", "pcg_launches", "pcgs_cut_short_by_the_launch_budget",
+                                            "valid_rows", "cost_per_gn")}, roofline=rl[0], roofline_other=rl[1:])
+    else:
+        st = seq.solver.stats()
+        t_err = float((seq.solver.translations() - seq.t_true[(warmup + steps - 1) % seq.n_frames]).abs().max())
+        out.update(pcg_iterations_last_frame=st["pcg_iters"], gn_iterations_last_frame=st["gn_iters"],
+                   gn_iterations_noop_last_frame=st["gn_noop"], max_abs_translation_error_vs_ground_truth_m=round(t_err, 6))
+    del seq
+    torch.cuda.empty_cache()
+    return out
+
+
+def other_configs(device):
+    out = {}
+    for name in ("C3", "C4"):
+        for mode in ("ref", "northstar"):
+            try:
+                out["%s_%s" % (name, mode)] = config_probe(name, mode, device)
+            except Exception as e:  # noqa: BLE001
+                out["%s_%s" % (name, mode)] = dict(error="%s: %s" % (type(e).__name__, e))
     return out
 
 
@@ -940,7 +1038,11 @@ def main():
                       algorithmic_bytes_per_launch=round(pcg_bytes / max(1e-9, launches_pf), 1),
                       avg_launch_ms=round(pcg_total_ms / max(1e-9, launches_pf), 4),
                       launches_per_frame=round(launches_pf, 2), pcg_iterations_per_frame=round(its, 1), matrix_nnz=nnz,
-                      algorithmic_bytes_per_frame=round(pcg_bytes, 1), frames_measured=frames_timed)
+                      algorithmic_bytes_per_frame=round(pcg_bytes, 1), frames_measured=frames_timed,
+                      # SURVEY 8(d) read literally prices a 3 x 3 block per non-zero (nnz_blocks x 9 x 4 + 6 n x 4, n = 3 D); the
+                      # matrix of the translation-only energy is A (x) I_3, so one scalar per block is stored and the smaller
+                      # figure above is the one `achieved` uses
+                      survey_8d_literal_bytes_per_frame=round(its * (36.0 * nnz + 72.0 * seq.D), 1))
     if split:
         # What bounds it is the gather of p from LDS — 4 B per non-zero and coordinate, on the three CUs the three
         # workgroups occupy — not HBM: the matrix is read once per launch and stays in registers (traffic above: 1/16 of
@@ -1001,7 +1103,8 @@ def main():
         torch.cuda.empty_cache()
         if not args.no_northstar:
             try:
-                out["northstar_mode"] = northstar_probe(args.config, device)
+                out["northstar_mode"] = northstar_probe(args.config, device,
+                                                        cpu_frames=0 if args.no_cpu_baseline else max(1, args.cpu_frames // 8))
             except Exception as e:  # noqa: BLE001
                 out["northstar_mode"] = dict(error="%s: %s" % (type(e).__name__, e))
         if not args.no_live_depth:
@@ -1012,6 +1115,8 @@ def main():
                 out["live_depth_mode"] = dict(error="%s: %s" % (type(e).__name__, e))
         if e2e is not None:
             out["end_to_end"] = e2e
+        if not args.no_other_configs and args.config == "C2":
+            out["other_configs"] = other_configs(device)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_frames)
     print(json.dumps(out), flush=True)

@@ -87,7 +87,7 @@ def test_world_size_must_match_gpus():
 @pytest.mark.gpu
 def test_bench_line_has_the_contract_fields():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-frames", "1"],
-                       capture_output=True, text=True, timeout=900)
+                       capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -107,5 +107,23 @@ def test_bench_line_has_the_contract_fields():
     for e in [ns["roofline"]] + ns["roofline_other"]:
         for key in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms"):
             assert key in e, key
+        # SURVEY 8(d)'s bytes are what `frac` is computed from; the design's own data flow is kept beside them
+        assert e["survey_bytes_per_launch"] > 0 and e["implementation_bytes_per_launch"] >= e["survey_bytes_per_launch"] * 0.99
+        assert abs(e["frac"] - e["survey_bytes_per_launch"] / (e["avg_launch_ms"] * 1e-3) / 1e9 / e["peak"]) < 2e-3
+    cb6 = ns["cpu_baseline"]  # the CPU statement of the north-star frame beside the north-star figure
+    assert cb6["kind"] == "port" and cb6["cores"] >= 1 and cb6["value"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    # the raycast, reported separately, priced by the work of its own rays
+    rc = d["raycast"]
+    assert rc["work"]["hits"] > 0.5 * 640 * 480 and rc["work"]["march_fetches"] > 10 * rc["work"]["hits"]
+    for variant in ("points", "depth"):
+        e = rc[variant]
+        assert 0 < e["avg_launch_ms"] < 1.0 and abs(e["frac"] - e["achieved"] / e["peak"]) < 1e-3
+        assert e["unique_voxel_bytes_per_launch"] < e["survey_bytes_per_launch"]
+    # the other BASELINE configurations under the same clock, both modes
+    oc = d["other_configs"]
+    for key in ("C3_ref", "C3_northstar", "C4_ref", "C4_northstar"):
+        assert "error" not in oc[key], oc[key]
+        assert oc[key]["value"] > 30.0 and oc[key]["unit"] == "frames/s"
+    assert oc["C3_northstar"]["solve"]["pcgs_cut_short_by_the_launch_budget"] == 0
