@@ -8,7 +8,7 @@ _LIB = None
 
 # every symbol include/dynfu_amd.h declares (tests/test_capi_symbols.py checks the .so exports them)
 SYMBOLS = [
-    "dfa_last_error", "dfa_version", "dfa_compute_dists", "dfa_tsdf_clear", "dfa_tsdf_integrate",
+    "dfa_last_error", "dfa_version", "dfa_abi_version", "dfa_abi_struct_size", "dfa_compute_dists", "dfa_tsdf_clear", "dfa_tsdf_integrate",
     "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_tsdf_raycast_tally", "dfa_tsdf_vertex_normals", "dfa_correspond_projective", "dfa_knn", "dfa_warp_to_live",
     "dfa_calc_dqb", "dfa_unsupported_vertices", "dfa_icp_sums", "dfa_repack_points", "dfa_compact_points", "dfa_transform_points", "dfa_warp_to_live_graph",
     "dfa_correspond", "dfa_marching_cubes", "dfa_mc_default_tables",
@@ -45,6 +45,7 @@ class Solve6Params(C.Structure):
 
 
 SOLVE6_HIST = 32  # DFA_SOLVE6_HIST
+ABI_VERSION = 4   # DFA_ABI_VERSION
 
 
 class _Solve6Stats(C.Structure):
@@ -102,6 +103,15 @@ def load():
     vp, i, f = C.c_void_p, C.c_int, C.c_float
     L.dfa_last_error.restype = C.c_char_p
     L.dfa_version.restype = C.c_char_p
+    # ABI guard: the ctypes mirrors above are kept in step with include/dynfu_amd.h by hand
+    L.dfa_abi_struct_size.restype = C.c_size_t
+    L.dfa_abi_struct_size.argtypes = [i]
+    if L.dfa_abi_version() != ABI_VERSION:
+        raise DynfuAmdError("%s implements ABI version %d, this binding expects %d" % (p, L.dfa_abi_version(), ABI_VERSION))
+    for sid, mirror in enumerate((SolveParams, _SolveStats, _SolveTiming, Solve6Params, _Solve6Stats, _Solve6Timing)):
+        if L.dfa_abi_struct_size(sid) != C.sizeof(mirror):
+            raise DynfuAmdError("struct %d: the library assumes %d bytes, the ctypes mirror %s has %d"
+                                % (sid, L.dfa_abi_struct_size(sid), mirror.__name__, C.sizeof(mirror)))
     L.dfa_compute_dists.argtypes = [vp, i, vp, i, i, i, f, f, f, f, vp]
     L.dfa_tsdf_clear.argtypes = [vp, i, i, i, vp]
     integ = [vp, i, i, i, vp, i, i, i, vp, f, i, vp, f, f, f, f, vp]

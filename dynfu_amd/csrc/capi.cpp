@@ -185,14 +185,23 @@ struct dfa_solver6 {
     // re-captured when the problem size or the iteration parameters change
     std::map<int, hipGraphExec_t> pcg_graphs;  // by the number of step launches
     int last_launches = 0;  // step launches enqueued by the last solve
-    int pred[dfa::S6_HIST] = {};  // adaptive launch budget: iterations each Gauss-Newton iteration needed lately
-    int* mirror = nullptr;  // pinned int[S6_HIST]: PCG iterations of the Gauss-Newton iterations of the solves, kept by the device
+    // Adaptive launch budget (dfa_solve6_params.adaptive_launch).  The device writes the PCG iterations of every
+    // Gauss-Newton iteration of solve n into slot n % S6_RING of a pinned mirror; the budget of solve n is a function of
+    // the solves up to n - 2 ONLY, folded into the history in order behind their completion events — never of how far
+    // the device happens to have got: the same sequence of solves gets the same budgets in every run.
+    static constexpr int S6_RING = 4;
+    int* mirror = nullptr;                        // pinned int[S6_RING][S6_HIST]
+    hipEvent_t done_ev[S6_RING] = {};             // end of solve n, n % S6_RING
+    int slot_gn[S6_RING] = {};                    // Gauss-Newton iterations solve n enqueued
+    unsigned long long solve_seq = 0, folded = 0;  // solves started; solves whose counts are in the history
+    int pred[dfa::S6_HIST] = {};                  // iterations per Gauss-Newton iteration: raised at once, lowered by one per solve
+    struct BudgetKey { int D, N, num_iter, gn_iter, linear_iter; float tol, tol_first, tol_decay, tol_adapt; } budget_key = {};
     bool graph_disabled = false;
     hipStream_t capture_stream = nullptr;  // capture is not allowed on the legacy default stream
     bool timing = false;  // hipEvent brackets around linearise / assemble / PCG of every Gauss-Newton iteration
     std::vector<hipEvent_t> events;
     size_t ev_used = 0;
-    dfa::Solve6View pcg_key_view;
+    int pcg_key_D = -1;  // node count the captured PCG graphs were recorded for
 };
 
 namespace {
@@ -242,6 +251,20 @@ extern "C" {
 const char* dfa_last_error(void) { return g_err; }
 
 const char* dfa_version(void) { return "dynfu_amd 0.1 (gfx950, HIP)"; }
+
+int dfa_abi_version(void) { return DFA_ABI_VERSION; }
+
+size_t dfa_abi_struct_size(int id) {
+    switch (id) {
+        case DFA_STRUCT_SOLVE_PARAMS: return sizeof(dfa_solve_params);
+        case DFA_STRUCT_SOLVE_STATS: return sizeof(dfa_solve_stats);
+        case DFA_STRUCT_SOLVE_TIMING: return sizeof(dfa_solve_timing);
+        case DFA_STRUCT_SOLVE6_PARAMS: return sizeof(dfa_solve6_params);
+        case DFA_STRUCT_SOLVE6_STATS: return sizeof(dfa_solve6_stats);
+        case DFA_STRUCT_SOLVE6_TIMING: return sizeof(dfa_solve6_timing);
+        default: return 0;
+    }
+}
 
 // ---------------------------------------------------------------------------------- TSDF seam
 
@@ -1055,10 +1078,18 @@ int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
     if (rc == DFA_OK) rc = plan6_alloc(s, &s->raw_w, N * k);
     if (rc == DFA_OK) rc = plan6_alloc(s, &s->raw_reg, D * (k + 1));
     if (rc == DFA_OK) rc = plan6_alloc(s, &s->state, 1);
-    if (rc == DFA_OK && hipHostMalloc((void**)&s->mirror, dfa::S6_HIST * sizeof(int), hipHostMallocDefault) == hipSuccess)
-        std::memset(s->mirror, 0, dfa::S6_HIST * sizeof(int));
-    else
-        s->mirror = nullptr, (void)hipGetLastError();
+    if (rc == DFA_OK) {
+        bool ok = hipHostMalloc((void**)&s->mirror, dfa_solver6::S6_RING * dfa::S6_HIST * sizeof(int), hipHostMallocDefault) == hipSuccess;
+        for (int i = 0; ok && i < dfa_solver6::S6_RING; ++i)
+            ok = hipEventCreateWithFlags(&s->done_ev[i], hipEventDisableTiming) == hipSuccess;
+        if (ok) {
+            std::memset(s->mirror, 0, dfa_solver6::S6_RING * dfa::S6_HIST * sizeof(int));
+        } else {  // no mirror: every PCG gets its full budget
+            (void)hipGetLastError();
+            if (s->mirror) (void)hipHostFree(s->mirror);
+            s->mirror = nullptr;
+        }
+    }
     if (rc == DFA_OK) {
         hipError_t e = s->grid.reserve(max_D);
         if (e != hipSuccess) rc = hip_fail(e, "hipMalloc (node grid)");
@@ -1075,6 +1106,8 @@ void dfa_solver6_destroy(dfa_solver6* s) {
     if (!s) return;
     for (auto& g : s->pcg_graphs) (void)hipGraphExecDestroy(g.second);
     if (s->mirror) (void)hipHostFree(s->mirror);
+    for (hipEvent_t e : s->done_ev)
+        if (e) (void)hipEventDestroy(e);
     if (s->capture_stream) (void)hipStreamDestroy(s->capture_stream);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     for (void* p : s->blocks) (void)hipFree(p);
@@ -1135,6 +1168,51 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
     HIP_TRY(dfa::s6_begin(s->v, s->state, s->node_dq, st));
     s->last_launches = 0;
     const bool no_graph = getenv("DFA_S6_NO_GRAPH") != nullptr;  // (A/B; read once per solve)
+    // ---- launch budget: fold the solves up to n - 2 into the history (in order, each behind its completion event)
+    const bool adaptive = prm->adaptive_launch && s->mirror;
+    const unsigned long long n = s->solve_seq++;
+    const int slot         = (int)(n % dfa_solver6::S6_RING);
+    if (adaptive) {
+        const dfa_solver6::BudgetKey key{s->v.D, s->v.N, p.num_iter, p.gn_iter, p.linear_iter, p.pcg_tol, p.pcg_tol_first,
+                                         p.pcg_tol_decay, p.pcg_tol_adapt};
+        const dfa_solver6::BudgetKey& old = s->budget_key;
+        auto far = [](int a, int b) { return std::abs(a - b) * 8 > std::max(a, b); };  // changed by more than an eighth
+        const bool reset = far(key.D, old.D) || far(key.N, old.N) || key.num_iter != old.num_iter || key.gn_iter != old.gn_iter ||
+                           key.linear_iter != old.linear_iter || key.tol != old.tol || key.tol_first != old.tol_first ||
+                           key.tol_decay != old.tol_decay || key.tol_adapt != old.tol_adapt;
+        s->budget_key = key;
+        for (; s->folded + 2 <= n; ++s->folded) {
+            const int fs = (int)(s->folded % dfa_solver6::S6_RING);
+            HIP_TRY(hipEventSynchronize(s->done_ev[fs]));  // two solves back: complete long ago unless the caller is far ahead
+            for (int gi = 0; gi < std::min(s->slot_gn[fs], dfa::S6_HIST); ++gi) {
+                const int seen = s->mirror[fs * dfa::S6_HIST + gi];
+                int& pred      = s->pred[gi];
+                if (seen > 0) pred = std::max(seen, pred - 1);
+                else if (seen < 0) pred = std::max(pred, -2 * seen);  // cut short: twice as many
+            }
+        }
+        if (reset) {  // another problem (or other stopping rules): what the previous one needed says nothing
+            std::memset(s->pred, 0, sizeof(s->pred));
+            s->folded = n;  // (solves n - 2, n - 1 of the old problem are never folded)
+        }
+    } else {
+        s->folded = n + 1 >= 2 ? n - 1 : 0;  // nothing to fold later from solves without a budget
+        std::memset(s->pred, 0, sizeof(s->pred));
+    }
+    int* mirror_slot = s->mirror ? s->mirror + slot * dfa::S6_HIST : nullptr;
+    if (mirror_slot) {
+        // the slot's previous owner, solve n - S6_RING, must have finished writing it (it has, unless the caller runs more
+        // than S6_RING - 1 solves ahead of the device)
+        if (n >= (unsigned long long)dfa_solver6::S6_RING) HIP_TRY(hipEventSynchronize(s->done_ev[slot]));
+        std::memset(mirror_slot, 0, dfa::S6_HIST * sizeof(int));
+        s->slot_gn[slot] = p.num_iter * p.gn_iter;
+    }
+    // the graphs replay launches over the plan's own buffers: only the node count is part of what they captured
+    if (s->pcg_key_D != s->v.D) {
+        for (auto& g : s->pcg_graphs) (void)hipGraphExecDestroy(g.second);
+        s->pcg_graphs.clear();
+        s->pcg_key_D = s->v.D;
+    }
     for (int outer = 0; outer < p.num_iter; ++outer)
         for (int gn = 0; gn < p.gn_iter; ++gn) {
             auto mark = [&]() {  // 4 events per Gauss-Newton iteration: | linearise | assemble | pcg |
@@ -1152,27 +1230,17 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
             HIP_TRY(dfa::s6_assemble(s->v, s->state, p, gn, st));
             mark();
             // Launches of this PCG: the caller's cap, or (adaptive_launch) what this Gauss-Newton iteration needed in the
-            // plan's previous solves plus a quarter — the mirror is pinned memory the device writes as it goes; it is read
-            // here without synchronising, so it may be one or two solves old
+            // plan's earlier solves (a maximum that decays by one per solve) plus a quarter, at least two.  (Measured at C2 /
+            // C3 over 30-frame sequences: consecutive frames move a count by up to 2 where it is small and by up to a
+            // quarter where it is 30-40; one launch of slack instead of two cut 1-2 PCGs short in a fifth of the frames.)
             const int gi = outer * p.gn_iter + gn;
             int launches = p.linear_iter;
-            if (prm->adaptive_launch && s->mirror && gi < dfa::S6_HIST) {
-                // pred: what this iteration needed lately — follows an increase at once, forgets it by one launch per solve
-                const int seen = ((volatile int*)s->mirror)[gi];
-                int& pred      = s->pred[gi];
-                if (seen > 0) pred = std::max(seen, pred - 1);
-                else if (seen < 0) pred = std::max(pred, -2 * seen);  // cut short last time: twice as many
-                if (pred > 0) launches = std::min(p.linear_iter, pred + std::max(2, pred / 4));
-            }
+            if (adaptive && gi < dfa::S6_HIST && s->pred[gi] > 0)
+                launches = std::min(p.linear_iter, s->pred[gi] + std::max(2, s->pred[gi] / 4));
             // the PCG launches of one Gauss-Newton iteration are replayed as a HIP graph (one per launch count); if capture
             // is not possible here (it never is on some stream configurations) the launches are issued one by one
             bool replayed = false;
             if (!s->graph_disabled && !no_graph) {
-                if (std::memcmp(&s->pcg_key_view, &s->v, sizeof(s->v)) != 0) {
-                    for (auto& g : s->pcg_graphs) (void)hipGraphExecDestroy(g.second);
-                    s->pcg_graphs.clear();
-                    s->pcg_key_view = s->v;
-                }
                 auto it = s->pcg_graphs.find(launches);
                 if (it == s->pcg_graphs.end()) {
                     hipGraph_t g = nullptr;
@@ -1200,8 +1268,9 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
             if (!replayed) HIP_TRY(dfa::s6_pcg_n(s->v, s->state, launches, st));
             s->last_launches += launches + 1;
             mark();
-            HIP_TRY(dfa::s6_update(s->v, s->state, launches, p.linear_iter, gi < dfa::S6_HIST ? s->mirror : nullptr, st));
+            HIP_TRY(dfa::s6_update(s->v, s->state, launches, p.linear_iter, gi < dfa::S6_HIST ? mirror_slot : nullptr, st));
         }
+    if (mirror_slot) HIP_TRY(hipEventRecord(s->done_ev[slot], st));
     return DFA_OK;
 }
 

@@ -55,6 +55,8 @@ public:
     double finalCost() const { return final_cost_; }
     long long validRows() const { return valid_rows_; }  // data rows with an association at the last linearisation
     int pcgIterations() const { return pcg_iters_; }
+    /* PCGs of the last solveAll that stopped at the end of their adaptive launch budget instead of at their tolerance */
+    int pcgsCutShort() const { return pcg_short_; }
 
 private:
     Warpfield m_warpfield;  // copied by value, Nodes shared (as CombinedSolver, opt_solver.cpp:5)
@@ -65,4 +67,5 @@ private:
     double initial_cost_ = 0.0, final_cost_ = 0.0;
     long long valid_rows_ = 0;
     int pcg_iters_        = 0;
+    int pcg_short_        = 0;
 };

@@ -3,6 +3,7 @@
 
 #include <map>
 #include <mutex>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -13,7 +14,25 @@
 
 namespace dfa {
 
+// The adaptors pass dfa_solve_params / dfa_solve6_params / ..._stats by pointer: a libdynfu_amd.so built from another
+// header would read or write past them.  Checked once, on the first checked call.
+static void require_matching_abi() {
+    static const bool ok = [] {
+        if (dfa_abi_version() != DFA_ABI_VERSION)
+            throw Error(DFA_ERR_INVALID, "libdynfu_amd.so implements ABI version " + std::to_string(dfa_abi_version()) +
+                                             ", the host adaptors were built against " + std::to_string(DFA_ABI_VERSION));
+        const size_t mine[] = {sizeof(dfa_solve_params), sizeof(dfa_solve_stats), sizeof(dfa_solve_timing),
+                               sizeof(dfa_solve6_params), sizeof(dfa_solve6_stats), sizeof(dfa_solve6_timing)};
+        for (int id = 0; id < 6; ++id)
+            if (dfa_abi_struct_size(id) != mine[id])
+                throw Error(DFA_ERR_INVALID, "libdynfu_amd.so and the host adaptors disagree on the size of struct " + std::to_string(id));
+        return true;
+    }();
+    (void)ok;
+}
+
 void check(int rc, const char* where) {
+    require_matching_abi();
     if (rc != DFA_OK) throw Error(rc, std::string(where) + ": " + dfa_last_error());
 }
 

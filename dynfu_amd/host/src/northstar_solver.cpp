@@ -1,4 +1,5 @@
 // northstar_solver.cpp — NorthStarSolver on the dfa_solver6 plan (see dynfu/utils/northstar_solver.hpp).
+#include <cstdio>
 #include <dynfu/utils/northstar_solver.hpp>
 
 #include <algorithm>
@@ -143,6 +144,15 @@ void NorthStarSolver::solveAll(const kfusion::cuda::Cloud& vmap, const kfusion::
     dfa_solve6_stats st;
     dfa::check(dfa_solver6_get_stats(I.plan, &st, nullptr), "NorthStarSolver::solveAll (stats)");  // synchronises
     initial_cost_ = st.initial_cost, final_cost_ = st.final_cost, valid_rows_ = st.valid_last, pcg_iters_ = st.pcg_iters;
+    pcg_short_ = st.pcg_short;
+    if (st.pcg_short > 0) {  // a PCG stopped where its launch budget ended (still a descent step); the plan doubles that budget
+        static bool told = false;
+        if (!told)
+            std::fprintf(stderr, "NorthStarSolver: %d PCG(s) of this solve were cut short by the adaptive launch budget "
+                                 "(pcgsCutShort(); NorthStarParameters::adaptiveLaunch = false enqueues the full budget)\n",
+                         st.pcg_short);
+        told = true;
+    }
     // the solved transforms replace dg_se3 of the shared Nodes (the reference's solver composes a translation onto it,
     // opt_solver.cpp:270-285; here the unknown IS the transform)
     std::vector<float> dq(8 * (size_t)I.D);

@@ -52,6 +52,22 @@ const char* dfa_last_error(void);
 /* library / device identification: "dynfu_amd <ver> gfx950 ..." ; static storage */
 const char* dfa_version(void);
 
+/* ABI guard.  The parameter / statistics structs below are passed by pointer and carry no size field of their own:
+ * DFA_ABI_VERSION changes whenever the layout of one of them does.  dfa_abi_version() is the value the LIBRARY was built
+ * with, dfa_abi_struct_size(id) the sizeof it assumes (0 for an unknown id) — a caller built against another header, or a
+ * binding that mirrors the structs by hand (dynfu_amd/_lib.py), compares both with its own before the first call. */
+#define DFA_ABI_VERSION 4
+enum {
+    DFA_STRUCT_SOLVE_PARAMS  = 0, /* dfa_solve_params  */
+    DFA_STRUCT_SOLVE_STATS   = 1, /* dfa_solve_stats   */
+    DFA_STRUCT_SOLVE_TIMING  = 2, /* dfa_solve_timing  */
+    DFA_STRUCT_SOLVE6_PARAMS = 3, /* dfa_solve6_params */
+    DFA_STRUCT_SOLVE6_STATS  = 4, /* dfa_solve6_stats  */
+    DFA_STRUCT_SOLVE6_TIMING = 5  /* dfa_solve6_timing */
+};
+int dfa_abi_version(void);
+size_t dfa_abi_struct_size(int struct_id);
+
 /* ===================================================================================== */
 /* TSDF seam — replaces the free functions of namespace kfusion::device                  */
 /* (include/kfusion/internal.hpp:158-166,204)                                            */
@@ -435,12 +451,16 @@ typedef struct dfa_solve6_params {
      * first step of every PCG; the value used is reported in dfa_solve6_stats.pcg_tol_hist. */
     float pcg_tol_adapt;
     /* A PCG iteration is one kernel launch, and a launch whose PCG has already converged still costs ~3.5 us of stream
-     * time.  adaptive_launch != 0: the plan enqueues, for Gauss-Newton iteration i of the solve, only as many launches as
-     * iteration i of its previous solves needed plus a quarter (at least 2 more, at most linear_iter) — read from a
-     * pinned-memory mirror the device keeps, without synchronising.  Results do not change while the prediction holds
-     * (the extra launches of the full budget are no-ops); a PCG that would have needed more is stopped where its launches
-     * end (a truncated PCG: still a descent step), counted in dfa_solve6_stats.pcg_short, and the next solve's budget
-     * for that iteration doubles.  0: always linear_iter launches. */
+     * time.  adaptive_launch != 0: the plan enqueues, for Gauss-Newton iteration i of solve n, only as many launches as
+     * iteration i needed in the plan's solves up to n - 2 — a running maximum, raised at once and lowered by one per
+     * solve — plus a quarter (at least 2 more), never more than linear_iter.  The counts come from a pinned-memory ring the device writes; solve n folds solves <= n - 2 into
+     * its history, in order, each behind its completion event — the budgets are a function of the sequence of solves,
+     * NOT of how far the device has got, so a sequence gives the same results in every run whether or not the caller
+     * waits between solves.  The first two solves of a plan, and the first two after the stopping rules (iteration
+     * counts, tolerances, forcing) change or the problem's node / vertex count moves by more than an eighth, enqueue the
+     * full budget.  Results are those of the full budget while the prediction holds (the launches left out are no-ops); a
+     * PCG that would have needed more is stopped where its launches end (a truncated PCG: still a descent step), counted
+     * in dfa_solve6_stats.pcg_short, and its budget doubles.  0: always linear_iter launches. */
     int adaptive_launch;
 } dfa_solve6_params;
 

@@ -218,35 +218,79 @@ def test_more_than_8192_nodes_matches_the_oracle(A):
 
 
 def test_adaptive_launch_budget(A):
-    """dfa_solve6_params.adaptive_launch: the first solve of a plan enqueues the full budget, later ones what the
-    previous solve needed plus a quarter — same bits while the prediction holds; a prediction that falls short (here: the
-    plan last saw an easy problem) cuts the PCG, says so, and the budget recovers on the next solve."""
-    cfg, c, intr, depth = _scene("T1", 6)
-    P, Nm = A.compute_points_normals(dev(depth), *intr)
-    s = A.Solver6(cfg["D"], len(c["verts"]), cfg["k"])
+    """dfa_solve6_params.adaptive_launch: the budget of solve n is a function of the plan's solves up to n - 2 only (folded
+    in order behind their completion events), so (a) the first two solves enqueue the full budget, (b) later ones what the
+    Gauss-Newton iteration needed before (a running maximum + a quarter, at least two) — with the same bits as the full budget while the prediction holds, (c) the budgets, and with
+    them the results, do not depend on whether the host waits for the device between solves, (d) other stopping rules or
+    another problem size start from the full budget again, (e) a PCG that needs more than its budget is cut, says so, and
+    the budget recovers."""
+    cfg, c, intr, _ = _scene("T1", 6)
+    frames = [6, 6, 6, 6, 6, 7, 7, 7]
+    maps = {f: A.compute_points_normals(dev(synth.depth_frame(cfg, f)), *intr) for f in set(frames)}
     keep = [dev(c["node_pos"]), dev(c["node_dq"]), dev(c["node_w"]), dev(c["verts"]), dev(c["normals"])]
-    s.set_problem(*keep)
     kw = dict(num_iter=2, gn_iter=3, linear_iter=64, lambda_=200.0, pcg_tol=1e-3, pcg_tol_first=0.1, pcg_tol_decay=0.5)
-    s.solve(P, Nm, *intr, A.Solve6Params(**kw))
-    ref, st_ref = host(s.node_dq()), s.stats()
-    assert st_ref["pcg_launches"] == 6 * 65 and st_ref["pcg_short"] == 0
-    s.solve(P, Nm, *intr, A.Solve6Params(adaptive_launch=1, **kw))
-    st1 = s.stats()  # (the plan had no history before its first adaptive solve saw the mirror of the solve above)
-    s.solve(P, Nm, *intr, A.Solve6Params(adaptive_launch=1, **kw))
-    st2 = s.stats()
-    assert np.array_equal(host(s.node_dq()), ref) and st2["pcg_short"] == 0
-    assert st2["pcg_it_hist"] == st_ref["pcg_it_hist"] and st2["pcg_rel_hist"] == st_ref["pcg_rel_hist"]
-    want = sum(min(64, n + max(2, n // 4)) + 1 for n in st_ref["pcg_it_hist"])
-    assert st1["pcg_launches"] == st2["pcg_launches"] == want < 6 * 65
-    # a much harder solve on the same plan (tight tolerance): the stale prediction cuts its PCGs short, visibly
+
+    def run(adaptive, wait):
+        s = A.Solver6(cfg["D"], len(c["verts"]), cfg["k"])
+        s.set_problem(*keep)
+        out = []
+        for f in frames:
+            s.solve(*maps[f], *intr, A.Solve6Params(adaptive_launch=adaptive, **kw))
+            if wait:
+                st = s.stats()  # synchronises
+                out.append((host(s.node_dq()).copy(), st))
+        st = s.stats()
+        dq = host(s.node_dq()).copy()
+        s.close()
+        return out, dq, st
+
+    full, dq_full, _ = run(0, True)
+    assert all(st["pcg_launches"] == 6 * 65 and st["pcg_short"] == 0 for _, st in full)
+    seq, dq_seq, st_seq = run(1, True)
+    assert seq[0][1]["pcg_launches"] == seq[1][1]["pcg_launches"] == 6 * 65          # (a)
+    assert all(st["pcg_launches"] < 6 * 65 for _, st in seq[2:])                    # (b)
+    for i in range(2, len(frames)):
+        # the budget of solve i from the counts of solves 0 .. i - 2
+        want = 0
+        for gi in range(6):
+            pred = 0
+            for j in range(0, i - 1):
+                pred = max(full[j][1]["pcg_it_hist"][gi], pred - 1)
+            want += min(64, pred + max(2, pred // 4)) + 1
+        if all(st["pcg_short"] == 0 for _, st in seq[:i]):
+            assert seq[i][1]["pcg_launches"] == want, (i, seq[i][1]["pcg_launches"], want)
+    for (dq_a, st_a), (dq_f, st_f) in zip(seq, full):
+        if st_a["pcg_short"] == 0:  # the prediction held: the launches left out were no-ops
+            assert np.array_equal(dq_a, dq_f) and st_a["pcg_it_hist"] == st_f["pcg_it_hist"]
+    assert sum(st["pcg_short"] for _, st in seq) <= 2  # consecutive frames: counts move by one or two
+    _, dq_async, st_async = run(1, False)                                            # (c)
+    assert np.array_equal(dq_async, dq_seq) and st_async["pcg_launches"] == st_seq["pcg_launches"]
+
+    # (d) other stopping rules on the same plan: no stale prediction, the full budget again
+    s = A.Solver6(cfg["D"], len(c["verts"]), cfg["k"])
+    s.set_problem(*keep)
+    for _ in range(4):
+        s.solve(*maps[6], *intr, A.Solve6Params(adaptive_launch=1, **kw))
+    assert s.stats()["pcg_launches"] < 6 * 65
     hard = dict(kw, pcg_tol=1e-5, pcg_tol_first=0.0)
-    s.solve(P, Nm, *intr, A.Solve6Params(adaptive_launch=1, **hard))
-    st3 = s.stats()
-    assert st3["pcg_short"] > 0 and st3["pcg_launches"] == want
-    assert all(r > 1e-5 for r in st3["pcg_rel_hist"])
-    s.solve(P, Nm, *intr, A.Solve6Params(adaptive_launch=1, **hard))
-    st4 = s.stats()
-    assert st4["pcg_launches"] > st3["pcg_launches"] and st4["pcg_short"] <= st3["pcg_short"]
+    s.solve(*maps[6], *intr, A.Solve6Params(adaptive_launch=1, **hard))
+    st = s.stats()
+    assert st["pcg_launches"] == 6 * 65 and st["pcg_short"] == 0
+    # (e) the same stopping rules on live data that needs more iterations than the plan has seen: transforms far from the
+    # solution.  Cut PCGs are counted; once the plan has seen them (two solves later) the budget covers them
+    for _ in range(4):
+        s.solve(*maps[6], *intr, A.Solve6Params(adaptive_launch=1, **kw))
+    easy = s.stats()
+    rng = np.random.default_rng(5)
+    far = c["node_dq"].copy()
+    far[:, 5:8] += rng.normal(0, 0.004, (len(far), 3)).astype(np.float32)
+    far_dev = dev(far)  # borrowed by the plan: keep it alive
+    s.set_node_transforms(far_dev)
+    shorts = []
+    for _ in range(5):
+        s.solve(*maps[7], *intr, A.Solve6Params(adaptive_launch=1, **kw))
+        shorts.append(s.stats()["pcg_short"])
+    assert easy["pcg_short"] == 0 and shorts[-1] == 0 and shorts[0] >= shorts[-1]
     s.close()
 
 
