@@ -87,15 +87,45 @@ def lib_path():
     return os.environ.get("DFA_LIB_PATH") or os.path.join(_HERE, "libdynfu_amd.so")
 
 
-def load():
+def dev_lib_path():
+    """the development flavour (-DDFA_DEV_AB: environment A/B switches and the non-default kernel variants)"""
+    return os.path.join(_HERE, "libdynfu_amd_dev.so")
+
+
+class use_library:
+    """`with use_library(dev_lib_path()):` — every call of this module goes to another build of the library inside the
+    block (tests that compare kernel variants, A/B scripts); the product library is what everything else uses."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __enter__(self):
+        global _LIB
+        self.saved = _LIB
+        if self.path not in _LOADED:
+            _LIB = None
+            load(self.path)
+        _LIB = _LOADED[self.path]
+        return _LIB
+
+    def __exit__(self, *exc):
+        global _LIB
+        _LIB = self.saved
+        return False
+
+
+_LOADED = {}
+
+
+def load(path=None):
     """Loads libdynfu_amd.so; raises (never falls back) when it has not been built."""
     global _LIB
-    if _LIB is not None:
+    if _LIB is not None and path is None:
         return _LIB
     # torch first: its bundled libamdhip64 (SONAME libamdhip64.so.7) must be the HIP runtime this
     # library binds to, so that torch's streams and device pointers are valid inside it
     import torch  # noqa: F401
-    p = lib_path()
+    p = path or lib_path()
     if not os.path.exists(p):
         raise DynfuAmdError("%s not found: build it with `python dynfu_amd/build.py` "
                             "(__graft_entry__.build()). There is no CPU fallback." % p)
@@ -178,6 +208,7 @@ def load():
     if len(runtimes) > 1:
         raise DynfuAmdError("two HIP runtimes are mapped in this process: %s" % sorted(runtimes))
     _LIB = L
+    _LOADED[p] = L
     return L
 
 

@@ -37,8 +37,17 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    os.makedirs(OBJ, exist_ok=True)
+DEV_LIB = os.path.join(HERE, "libdynfu_amd_dev.so")
+
+
+def build(force=False, verbose=False, dev=False):
+    """dev=False: the product library (no A/B switch, no non-default kernel variant in it).  dev=True: the same sources
+    with -DDFA_DEV_AB -> dynfu_amd/libdynfu_amd_dev.so (csrc/dev_switch.hpp): what the tests that compare kernel variants
+    and the A/B scripts under tools/ load (dynfu_amd._lib.use_library)."""
+    obj_dir = os.path.join(OBJ, "dev") if dev else OBJ
+    lib = DEV_LIB if dev else LIB
+    flags = FLAGS + (["-DDFA_DEV_AB"] if dev else [])
+    os.makedirs(obj_dir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers.append(os.path.join(HERE, "..", "include", "dynfu_amd.h"))
     headers.append(os.path.abspath(__file__))
@@ -47,10 +56,10 @@ def build(force=False, verbose=False):
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
+        o = os.path.join(obj_dir, src.rsplit(".", 1)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [cc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
+            cmd = [cc] + flags + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
             jobs.append(cmd)
 
     def run(cmd):
@@ -64,9 +73,9 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", LIB])
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", lib])
+    return lib
 
 
 HOST = os.path.join(HERE, "host")
@@ -155,6 +164,8 @@ def build_cpp_tests(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--dev" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, dev=True))
     if "--host" in sys.argv:
         print(build_host(force="--force" in sys.argv, verbose=True))
         print(build_cpp_tests(force="--force" in sys.argv, verbose=True))

@@ -15,6 +15,7 @@
 
 #include "../../include/dynfu_amd.h"
 #include "kernels.hpp"
+#include "dev_switch.hpp"
 #include "solve.hpp"
 #include "solve6.hpp"
 
@@ -698,6 +699,8 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
     s->has_problem = false;
     s->timing      = false;
     {
+        // (the one environment variable of the product library, read once per plan: the order-stable assembly for a caller
+        // that cannot reach dfa_solver_set_deterministic — include/dynfu_amd.h)
         const char* e    = getenv("DFA_ASSEMBLE_DETERMINISTIC");
         s->deterministic = e && atoi(e) != 0;
     }
@@ -835,7 +838,7 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
     int gn_launched = 0;  // Gauss-Newton iterations whose assembly has been enqueued
     bool huber_done = false;
     const bool big_budget = (long)p->num_iter * p->nonlinear_iter > 8;
-    const bool no_regradient = getenv("DFA_NO_REGRADIENT") != nullptr;  // (A/B; read per solve: the tests switch it)
+    const bool no_regradient = dfa::dev_env("DFA_NO_REGRADIENT") != nullptr;  // (development builds: the tests compare both ways)
     for (int outer = 0; outer < p->num_iter; ++outer) {
         // preNonlinearSolve (opt_solver.cpp:135-140): the Huber weights are only observable after
         // the solve, so they are evaluated for the last outer iteration alone
@@ -943,10 +946,10 @@ int dfa_solver_get_stats(dfa_solver* s, dfa_solve_stats* host_out, dfa_stream_t 
     host_out->pcg_iters    = h.pcg_iters;
     host_out->max_row_nnz  = h.max_row_nnz;
     host_out->gn_noop      = h.gn_noop;
-    if (getenv("DFA_PCG_PROFILE_PRINT"))
+    if (dfa::dev_env("DFA_PCG_PROFILE_PRINT"))
         fprintf(stderr, "pcg phase cycles: spmv %lld  red_pAp %lld  update %lld  red_rz %lld  p_update+barrier %lld  loop %lld  (iters %d)\n",
                 h.prof[0], h.prof[1], h.prof[2], h.prof[3], h.prof[4], h.prof[5], h.pcg_iters);
-    if (getenv("DFA_PCG_PROFILE_PRINT"))
+    if (dfa::dev_env("DFA_PCG_PROFILE_PRINT"))
         fprintf(stderr, "assemble block 7 cycles: init %lld  list+hash %lld  reduce+barrier %lld  compact %lld\n",
                 h.prof[6] / 1000000, h.prof[6] % 1000000, h.prof[7] / 1000000, h.prof[7] % 1000000);
     if (h.overflow)
@@ -1167,7 +1170,7 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
     s->ev_used = 0;
     HIP_TRY(dfa::s6_begin(s->v, s->state, s->node_dq, st));
     s->last_launches = 0;
-    const bool no_graph = getenv("DFA_S6_NO_GRAPH") != nullptr;  // (A/B; read once per solve)
+    const bool no_graph = dfa::dev_env("DFA_S6_NO_GRAPH") != nullptr;  // (development builds: launches issued one by one)
     // ---- launch budget: fold the solves up to n - 2 into the history (in order, each behind its completion event)
     const bool adaptive = prm->adaptive_launch && s->mirror;
     const unsigned long long n = s->solve_seq++;

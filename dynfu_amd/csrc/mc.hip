@@ -27,6 +27,7 @@
 #include <cstring>
 
 #include "device_math.hpp"
+#include "dev_switch.hpp"
 #include "kernels.hpp"
 
 namespace dfa {
@@ -398,7 +399,7 @@ hipError_t launch_marching_cubes(const uint32_t* vol, int X, int Y, int Z, const
     scan_apply_kernel<<<chunks, 256, 0, s>>>(seg_off, nsegs, seg_off, chunk_sums, total_vertices);
     if (out_points && max_vertices > 0) {
         long want = 8192;
-        if (const char* e = getenv("DFA_MC_EMIT_BLOCKS")) want = std::max(1L, atol(e));
+        if (const char* e = dev_env("DFA_MC_EMIT_BLOCKS")) want = std::max(1L, atol(e));  // (development builds)
         const unsigned eblocks = (unsigned)std::min<long>((nsegs + 3) / 4, want);
         if (vec4) mc_emit_kernel<4><<<eblocks, block, 0, s>>>(a, seg_off, (float4*)out_points, max_vertices, nsegs);
         else mc_emit_kernel<1><<<eblocks, block, 0, s>>>(a, seg_off, (float4*)out_points, max_vertices, nsegs);

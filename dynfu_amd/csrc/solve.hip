@@ -35,6 +35,7 @@
 #include <float.h>
 
 #include "dq_device.hpp"
+#include "dev_switch.hpp"
 #include "kernels.hpp"
 #include "solve.hpp"
 
@@ -1000,6 +1001,7 @@ __device__ __forceinline__ void pcg_stream_body(const SolveView& s, SolveState* 
     }
 }
 
+#ifdef DFA_DEV_AB  // the streaming kernel as a launch of its own (DFA_PCG_VARIANT=0 / 4): development builds only
 template <int NT, int RPT>
 __global__ __launch_bounds__(NT) void pcg_kernel(SolveView s, SolveState* __restrict__ st, int max_iter,
                                                    float pcg_tol) {
@@ -1011,6 +1013,7 @@ __global__ __launch_bounds__(NT) void pcg_kernel(SolveView s, SolveState* __rest
     }
     pcg_stream_body<NT, RPT>(s, st, max_iter, pcg_tol, smem);
 }
+#endif  // DFA_DEV_AB
 
 // ------------------------------------------------------------------------------------------
 // PCG with the WHOLE matrix in registers (D <= 2 * NT rows).
@@ -1591,6 +1594,7 @@ __device__ __forceinline__ float group16_sum(float v) {
     return v;
 }
 
+#ifdef DFA_DEV_AB  // the textbook form (two launches per iteration, DFA_MB_FORM=2): development builds only
 __global__ __launch_bounds__(256) void pcg_mb_matvec_kernel(SolveView s, SolveState* __restrict__ st, int it, float pcg_tol) {
     __shared__ float sh[4];
     if (st->mb_done) return;
@@ -1684,6 +1688,7 @@ __global__ __launch_bounds__(256) void pcg_mb_update_kernel(SolveView s, SolveSt
         if (blockIdx.x == 0) st->mb_iters += 1;
     }
 }
+#endif  // DFA_DEV_AB
 
 // ---- Chronopoulos-Gear form: ONE launch per iteration (the two inner products are taken together after the matrix
 // product, so an iteration needs one grid-wide synchronisation; the textbook form above needs two).  As in
@@ -1831,11 +1836,8 @@ void MbGraphCache::release() {
     if (capture) (void)hipStreamDestroy(capture), capture = nullptr;
 }
 
-// DFA_MB_FORM=2 (A/B): the textbook form, two launches per iteration
-static bool mb_one_launch() {
-    static const bool two = getenv("DFA_MB_FORM") && atoi(getenv("DFA_MB_FORM")) == 2;
-    return !two;
-}
+// development builds: DFA_MB_FORM=2 is the textbook form, two launches per iteration
+static bool mb_one_launch() { return dev_env_int("DFA_MB_FORM", 1) != 2; }
 
 // iterations [it0, it1): from the cache's graph of that range when there is (or can be) one, else launch by launch
 static hipError_t launch_mb_range(const SolveView& s, SolveState* state, int it0, int it1, float pcg_tol,
@@ -1843,16 +1845,18 @@ static hipError_t launch_mb_range(const SolveView& s, SolveState* state, int it0
     const int nb = solve_mb_blocks(s.D), nbu = (s.D + 255) / 256;
     auto direct = [&](hipStream_t q) {
         for (int it = it0; it < it1; ++it) {
-            if (mb_one_launch()) {
-                pcg_mb_step_kernel<<<nb, 256, 0, q>>>(s, state, it, pcg_tol);
-            } else {
+#ifdef DFA_DEV_AB
+            if (!mb_one_launch()) {
                 pcg_mb_matvec_kernel<<<nb, 256, 0, q>>>(s, state, it, pcg_tol);
                 pcg_mb_update_kernel<<<nbu, 256, 0, q>>>(s, state, it);
+                continue;
             }
+#endif
+            pcg_mb_step_kernel<<<nb, 256, 0, q>>>(s, state, it, pcg_tol);
         }
         return hipGetLastError();
     };
-    static const bool no_graph = getenv("DFA_MB_NO_GRAPH") != nullptr;  // A/B
+    const bool no_graph = dev_env("DFA_MB_NO_GRAPH") != nullptr;  // A/B (development builds)
     if (!gc || gc->disabled || no_graph || it1 - it0 < 4) return direct(st);
     MbGraphCache::Entry* hit = nullptr;
     for (int i = 0; i < gc->used && !hit; ++i) {
@@ -1917,6 +1921,7 @@ static hipError_t launch_mb_pcg(const SolveView& s, SolveState* state, int max_i
             chunk = 16;  // the prediction fell short: go on in small chunks
             continue;
         }
+#ifdef DFA_DEV_AB
         if (host_flag && it < max_iter) {
             // one more matvec launch evaluates the stopping rule on the last update's residual
             pcg_mb_matvec_kernel<<<nb, 256, 0, st>>>(s, state, it, pcg_tol);
@@ -1929,6 +1934,7 @@ static hipError_t launch_mb_pcg(const SolveView& s, SolveState* state, int max_i
             ++it;
             chunk *= 2;
         }
+#endif
     }
     pcg_mb_finish_kernel<<<nbu, 256, 0, st>>>(s, state);
     return hipGetLastError();
@@ -1941,6 +1947,7 @@ static hipError_t allow_big_lds(Kernel* k) {
     return allow_dynamic_lds((const void*)k, 160 * 1024 - 1024);  // once per (device, kernel)
 }
 
+#ifdef DFA_DEV_AB
 // streaming kernel (matrix re-read from L2 every iteration): 1024 threads, RPT rows per thread
 template <int RPT>
 static hipError_t launch_streaming_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol,
@@ -1951,6 +1958,7 @@ static hipError_t launch_streaming_pcg(const SolveView& s, SolveState* state, in
     pcg_kernel<1024, RPT><<<1, 1024, shmem, st>>>(s, state, max_iter, pcg_tol);
     return hipGetLastError();
 }
+#endif  // DFA_DEV_AB
 
 // register-resident kernel: NT threads own 2*P*NT rows, P pairs of E matrix slots per thread
 // (NC = 3: one workgroup for the joint system; NC = 1: three workgroups, one coordinate each)
@@ -1964,49 +1972,50 @@ static hipError_t launch_paired_pcg(const SolveView& s, SolveState* state, int m
     return hipGetLastError();
 }
 
+#ifdef DFA_DEV_AB
 static void sync_floor_switch() {
     static int done = -1;
-    const int want = getenv("DFA_PCG_NO_SOLVE_FLOOR") ? 1 : 0;
+    const int want = dev_env("DFA_PCG_NO_SOLVE_FLOOR") ? 1 : 0;
     if (done != want) {
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_floor_off), &want, sizeof(int));
         done = want;
     }
 }
+#endif
 
+// The PCG of one linearisation.  Up to 2 048 nodes: the register-resident kernel, one workgroup per coordinate (a system
+// that does not fit the registers is streamed inside the same launch); above: the many-workgroup PCG, which reads the
+// assembled ELL directly (the single-workgroup streaming kernel spends ~1 ms per launch sorting and repacking the matrix
+// by itself at 8 k nodes).
+// Development builds (-DDFA_DEV_AB) also hold the kernels this routing was measured against, selected by
+// DFA_PCG_VARIANT (read at every call: the tests switch it): 0 streaming, 1 register-resident with the three coordinates
+// in ONE workgroup (shared CG scalars, as the oracle), 2 / 5 its 512-thread flavours, 3 many-workgroup at any size,
+// 4 streaming up to 8 192 nodes.
 static hipError_t route_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag, MbGraphCache* gc,
                             hipEvent_t& main_done, hipStream_t st) {
-    // DFA_PCG_VARIANT (read at every call: the tests switch it) selects a kernel for A/B runs:
-    // 0 streaming, 1 register-resident with the three coordinates in one workgroup, 2 its 512-thread flavour,
-    // 3 many-workgroup, 4 streaming up to 8192 nodes; unset = the default routing below.
-    sync_floor_switch();
-    const char* env  = getenv("DFA_PCG_VARIANT");
-    const int v2     = env ? atoi(env) : -1;
-    const bool force_streaming = v2 == 0;
     const int D = s.D;
-    hipError_t e;
+#ifdef DFA_DEV_AB
+    sync_floor_switch();
+    const int v2 = dev_env_int("DFA_PCG_VARIANT", -1);
     if (v2 == 3) return launch_mb_pcg(s, state, max_iter, pcg_tol, host_flag, gc, st);
-    if (D <= 2048 && !force_streaming) {
-        // Register-resident matrix.  512 threads leave 256 VGPRs per lane (64 slots per row pair: k = 8
-        // rows fit), 1024 threads 128 VGPRs (32 slots: k = 4).  A pair that does not fit sends the launch down the
-        // streaming path (pcg_stream_body) instead.
-        // The three coordinates are solved by three workgroups (see the kernel); DFA_PCG_VARIANT=1 keeps them in one
-        // workgroup with shared CG scalars (A/B and the comparison point of the tests).
-        if (D <= 1024 && v2 == 1) e = launch_paired_pcg<512, 1, 64, 3>(s, state, max_iter, pcg_tol, st);
-        else if (D <= 1024) e = launch_paired_pcg<512, 1, 64, 1>(s, state, max_iter, pcg_tol, st);
-        else if (v2 == 2) e = launch_paired_pcg<512, 2, 32, 3>(s, state, max_iter, pcg_tol, st);
-        else if (v2 == 1) e = launch_paired_pcg<1024, 1, 32, 3>(s, state, max_iter, pcg_tol, st);
-        else if (v2 == 5) e = launch_paired_pcg<512, 2, 32, 1>(s, state, max_iter, pcg_tol, st);
-        else e = launch_paired_pcg<1024, 1, 32, 1>(s, state, max_iter, pcg_tol, st);
-        return e;  // (a system that does not fit the registers is streamed inside the same launch)
+    if (D <= 2048 && v2 != 0) {
+        // 512 threads leave 256 VGPRs per lane (64 slots per row pair: k = 8 rows fit), 1024 threads 128 VGPRs (32 slots: k = 4)
+        if (D <= 1024 && v2 == 1) return launch_paired_pcg<512, 1, 64, 3>(s, state, max_iter, pcg_tol, st);
+        if (D <= 1024) return launch_paired_pcg<512, 1, 64, 1>(s, state, max_iter, pcg_tol, st);
+        if (v2 == 2) return launch_paired_pcg<512, 2, 32, 3>(s, state, max_iter, pcg_tol, st);
+        if (v2 == 1) return launch_paired_pcg<1024, 1, 32, 3>(s, state, max_iter, pcg_tol, st);
+        if (v2 == 5) return launch_paired_pcg<512, 2, 32, 1>(s, state, max_iter, pcg_tol, st);
+        return launch_paired_pcg<1024, 1, 32, 1>(s, state, max_iter, pcg_tol, st);
     }
     if (D <= 1024) return launch_streaming_pcg<1>(s, state, max_iter, pcg_tol, st);
     if (D <= 2048) return launch_streaming_pcg<2>(s, state, max_iter, pcg_tol, st);
-    // Above 2048 nodes the single-workgroup streaming kernel spends ~1 ms per launch sorting and repacking the matrix
-    // by itself (measured: 1.2 ms per launch at 8 k nodes for ~12 iterations); the many-workgroup PCG reads the
-    // assembled ELL directly.  DFA_PCG_VARIANT=4 keeps the streaming kernel (A/B), possible up to 8192 nodes.
-    const bool keep_streaming = v2 == 4;
-    if (keep_streaming && D <= 4096) return launch_streaming_pcg<4>(s, state, max_iter, pcg_tol, st);
-    if (keep_streaming && D <= 8192) return launch_streaming_pcg<8>(s, state, max_iter, pcg_tol, st);
+    if (v2 == 4 && D <= 4096) return launch_streaming_pcg<4>(s, state, max_iter, pcg_tol, st);
+    if (v2 == 4 && D <= 8192) return launch_streaming_pcg<8>(s, state, max_iter, pcg_tol, st);
+#else
+    // 512 threads leave 256 VGPRs per lane (64 slots per row pair: k = 8 rows fit), 1024 threads 128 VGPRs (32 slots: k = 4)
+    if (D <= 1024) return launch_paired_pcg<512, 1, 64, 1>(s, state, max_iter, pcg_tol, st);
+    if (D <= 2048) return launch_paired_pcg<1024, 1, 32, 1>(s, state, max_iter, pcg_tol, st);
+#endif
     return launch_mb_pcg(s, state, max_iter, pcg_tol, host_flag, gc, st);
 }
 

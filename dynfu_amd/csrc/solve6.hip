@@ -30,6 +30,7 @@
 #include <cstdlib>
 
 #include "dq_device.hpp"
+#include "dev_switch.hpp"
 #include "kernels.hpp"
 #include "solve.hpp"
 #include "solve6.hpp"
@@ -1697,8 +1698,9 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
         f.tol2 = eta * eta;
     }
     {
-        // rows staged per pass (DFA_S6_RC for A/B): what fits in 28 KiB — with the static arrays 36 KiB, four workgroups per CU
-        static const int rc_env = getenv("DFA_S6_RC") ? atoi(getenv("DFA_S6_RC")) : 0;
+        // rows staged per pass (development builds: DFA_S6_RC for A/B): what fits in 28 KiB — with the static arrays 36 KiB,
+        // four workgroups per CU
+        static const int rc_env = dev_env_int("DFA_S6_RC", 0);
         const int rc = rc_env ? rc_env : (s.k <= 4 ? 448 : 352);
 #define S6A2(KK, RC)                                                                                              \
     do {                                                                                                          \

@@ -20,6 +20,7 @@
 #include <map>
 
 #include "device_math.hpp"
+#include "dev_switch.hpp"
 #include "kernels.hpp"
 #include "tsdf_classify.hpp"
 
@@ -678,7 +679,7 @@ static int pick_zchunk(int X, int Y, int Z, int vx, bool fused_clear);
 
 hipError_t launch_tsdf_clear(uint32_t* vol, int X, int Y, int Z, hipStream_t s) {
     const size_t n = (size_t)X * Y * Z;
-    static const bool linear = getenv("DFA_TSDF_CLEAR_LINEAR") != nullptr;  // A/B: the grid-stride 16-byte stores
+    const bool linear = dev_env("DFA_TSDF_CLEAR_LINEAR") != nullptr;  // A/B (development builds): the grid-stride 16-byte stores
     if (!linear && X % 64 == 0 && Z >= 32 && (((uintptr_t)vol & 255) == 0)) {
         const int zchunk = pick_zchunk(X, Y, Z, 1, true);
         dim3 block(64, 4), grid(X / 64, (Y + 3) / 4, (Z + zchunk - 1) / zchunk);
@@ -743,7 +744,7 @@ static int pick_zchunk(int X, int Y, int Z, int vx, bool fused_clear) {
     const long want = fused_clear ? 1024 : 4096;
     while (columns_wg * ((Z + zchunk - 1) / zchunk) < want && zchunk > 32) zchunk /= 2;
     zchunk = (zchunk + 3) & ~3;
-    if (const char* e = getenv("DFA_TSDF_ZCHUNK")) {
+    if (const char* e = dev_env("DFA_TSDF_ZCHUNK")) {  // (development builds: the tests of the z-chunk independence)
         int v = atoi(e);
         if (v > 0) zchunk = v;
     }
@@ -765,14 +766,14 @@ hipError_t launch_tsdf_integrate(bool fused_clear, const uint16_t* dists, int di
     for (int i = 0; i < 3; ++i) a.vol2cam.t[i] = vol2cam[9 + i];
     a.fx = fx, a.fy = fy, a.cx = cx, a.cy = cy;
 #ifdef DFA_DEV_ABLATE  // development builds only (-DDFA_DEV_ABLATE): values 1 / 2 write WRONG volumes by design
-    a.ablate = getenv("DFA_TSDF_ABLATE") ? atoi(getenv("DFA_TSDF_ABLATE")) : 0;
+    a.ablate = dev_env_int("DFA_TSDF_ABLATE", 0);
 #else
     a.ablate = 0;
 #endif
-    a.nt     = getenv("DFA_TSDF_NT") ? atoi(getenv("DFA_TSDF_NT")) : 0;
-    // Default: the run-classified sweep.  DFA_TSDF_LEGACY=1 runs the per-voxel sweep (every voxel through the
-    // projection; the round-1 kernel) for A/B timings; DFA_TSDF_WAVE=16 gives a wave a 16 x 4 patch of columns.
-    const bool legacy = getenv("DFA_TSDF_LEGACY") != nullptr;
+    a.nt     = dev_env_int("DFA_TSDF_NT", 0);
+    // The run-classified sweep.  Development builds (-DDFA_DEV_AB): DFA_TSDF_LEGACY=1 runs the per-voxel sweep (every voxel
+    // through the projection; the round-1 kernel) for A/B timings, DFA_TSDF_WAVE=16 gives a wave a 16 x 4 patch of columns.
+    const bool legacy = dev_env("DFA_TSDF_LEGACY") != nullptr;
     if (!legacy) {
         const int tcols = (cols + 7) >> TSDF_TILE_SHIFT, trows = (rows + 7) >> TSDF_TILE_SHIFT;
         uint32_t* tiles = nullptr;
@@ -788,24 +789,30 @@ hipError_t launch_tsdf_integrate(bool fused_clear, const uint16_t* dists, int di
         }
         const float zstep[3] = {vol2cam[2] * a.vsz, vol2cam[5] * a.vsz, vol2cam[8] * a.vsz};
         if (extent == extent && extent < 1e30f) {  // finite poses only; anything else takes the per-voxel sweep
-            const int run_u = getenv("DFA_TSDF_RUN") ? atoi(getenv("DFA_TSDF_RUN")) : RUN_U;
+            const int run_u = dev_env_int("DFA_TSDF_RUN", RUN_U);
             const RunConsts rc = make_run_consts(tiles, cols, rows, fx, fy, cx, cy, trunc_dist, zstep, run_u == 8 ? 8 : 4, extent);
             const uint32_t front_const = 0x3c00u | ((uint32_t)(max_weight < 1 ? max_weight : 1) << 16);  // (1.0h, min(1, max_weight))
             // >= 4 096 workgroups for either sweep: the tile look-ups of a run are dependent loads that only occupancy
             // hides (512^3 fused: 0.147 ms unsplit = 1 024 workgroups, 0.117 ms with z-chunks of 128 slices)
             a.zchunk = pick_zchunk(X, Y, Z, 1, false);
-            const int wave_x = getenv("DFA_TSDF_WAVE") ? atoi(getenv("DFA_TSDF_WAVE")) : 32;
             dim3 block(64, 4), grid((X + 63) / 64, (Y + 3) / 4, (Z + a.zchunk - 1) / a.zchunk);
 #define DFA_RUNS(F, W, UU) integrate_runs_kernel<F, W, UU><<<grid, block, 0, s>>>(a, rc, front_const)
+#ifdef DFA_DEV_AB
+            const int wave_x = dev_env_int("DFA_TSDF_WAVE", 32);
 #define DFA_RUNS_W(F, UU) (wave_x == 16 ? DFA_RUNS(F, 16, UU) : wave_x == 32 ? DFA_RUNS(F, 32, UU) : DFA_RUNS(F, 64, UU))
-            if (run_u == 8) {
-                if (fused_clear) DFA_RUNS_W(true, 8);
-                else DFA_RUNS_W(false, 8);
+            if (run_u != RUN_U) {
+                if (fused_clear) DFA_RUNS_W(true, RUN_U == 8 ? 4 : 8);
+                else DFA_RUNS_W(false, RUN_U == 8 ? 4 : 8);
             } else {
-                if (fused_clear) DFA_RUNS_W(true, 4);
-                else DFA_RUNS_W(false, 4);
+                if (fused_clear) DFA_RUNS_W(true, RUN_U);
+                else DFA_RUNS_W(false, RUN_U);
             }
 #undef DFA_RUNS_W
+#else
+            static_assert(RUN_U == 8 || RUN_U == 4, "run length of the classified sweep");
+            if (fused_clear) DFA_RUNS(true, 32, RUN_U);  // a wave = 32 x 2 voxel columns, runs of RUN_U voxels
+            else DFA_RUNS(false, 32, RUN_U);
+#endif
 #undef DFA_RUNS
             return launch_status();
         }
@@ -814,17 +821,23 @@ hipError_t launch_tsdf_integrate(bool fused_clear, const uint16_t* dists, int di
     // everywhere: a lane then walks its four voxels one after the other, each with its own early exits, and a wave
     // waits for its slowest lane four times per slice (fused sweep 0.289 -> 0.229 ms at 512^3, 1.49 -> 1.38 ms at
     // 1024^3, 0.061 -> 0.044 ms at 256^3); a wave's 256-byte stores are wide enough for HBM.
-    const bool vec4 = getenv("DFA_TSDF_VX4") && (X % 4 == 0) && (((uintptr_t)vol & 15) == 0);
+#ifdef DFA_DEV_AB
+    const bool vec4 = dev_env("DFA_TSDF_VX4") && (X % 4 == 0) && (((uintptr_t)vol & 15) == 0);
+#else
+    constexpr bool vec4 = false;
+#endif
     const int vx    = vec4 ? 4 : 1;
     a.zchunk        = pick_zchunk(X, Y, Z, vx, fused_clear);
     dim3 block(64, 4), grid((X + 64 * vx - 1) / (64 * vx), (Y + 3) / 4, (Z + a.zchunk - 1) / a.zchunk);
+#ifdef DFA_DEV_AB
     if (vec4) {
         if (fused_clear) integrate_kernel<true, 4><<<grid, block, 0, s>>>(a);
         else integrate_kernel<false, 4><<<grid, block, 0, s>>>(a);
-    } else {
-        if (fused_clear) integrate_kernel<true, 1><<<grid, block, 0, s>>>(a);
-        else integrate_kernel<false, 1><<<grid, block, 0, s>>>(a);
+        return launch_status();
     }
+#endif
+    if (fused_clear) integrate_kernel<true, 1><<<grid, block, 0, s>>>(a);
+    else integrate_kernel<false, 1><<<grid, block, 0, s>>>(a);
     return launch_status();
 }
 

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dq_device.hpp"
+#include "dev_switch.hpp"
 #include "kernels.hpp"
 
 namespace dfa {
@@ -831,7 +832,7 @@ hipError_t point_grid_build(const PointGridView& pg, const float* pts, int n, hi
 }
 
 hipError_t knn_grid_build(const KnnGridView& g, const float* node_pos, int D, hipStream_t s) {
-    static const bool four = getenv("DFA_GRID_FOUR_KERNELS") != nullptr;  // A/B: the four-kernel build
+    const bool four = dev_env("DFA_GRID_FOUR_KERNELS") != nullptr;  // A/B (development builds): the four-kernel build below 2 048 nodes
     if (D <= GRID_ONE_MAX && !four) {
         constexpr size_t lds = sizeof(int32_t) * KNN_GRID_MAX_CELLS;
         // 128 KiB of dynamic LDS needs the opt-in, once per device

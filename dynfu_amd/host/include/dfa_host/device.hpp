@@ -116,4 +116,7 @@ void DeviceArray2D<T>::download(T* host, size_t host_step) const {
 
 void device_synchronize();  // kfusion::cuda::waitAllDefaultStream
 
+// A/B switches of the host adaptors (DFA_HOST_*): read ONCE per process, never on a frame's call path.
+bool host_switch(const char* name);
+
 }  // namespace dfa

@@ -1,6 +1,7 @@
 // device.cpp — hipMalloc-backed containers and error translation of the host adaptors.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -29,6 +30,15 @@ static void require_matching_abi() {
         return true;
     }();
     (void)ok;
+}
+
+bool host_switch(const char* name) {
+    static std::mutex mu;
+    static std::map<std::string, bool> seen;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = seen.find(name);
+    if (it == seen.end()) it = seen.emplace(name, std::getenv(name) != nullptr).first;
+    return it->second;
 }
 
 void check(int rc, const char* where) {

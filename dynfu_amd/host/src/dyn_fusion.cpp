@@ -101,7 +101,7 @@ void DynFusion::addLiveFrame(int frameID, dfa::PointCloud<dfa::PointXYZ>& vertic
 namespace {
 // DFA_HOST_PROFILE=1: wall time of the stages of a frame (device synchronised at every mark) on stderr
 struct StageClock {
-    bool on = std::getenv("DFA_HOST_PROFILE") != nullptr;
+    bool on = dfa::host_switch("DFA_HOST_PROFILE");
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
     void mark(const char* what) {
         if (!on) return;

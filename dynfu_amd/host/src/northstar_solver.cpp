@@ -90,7 +90,7 @@ void NorthStarSolver::initializeProblemInstance(const std::shared_ptr<dynfu::Fra
     {
         std::lock_guard<std::mutex> lock(g_built_mu);
         auto it = g_built.find(I.plan);
-        if (it != g_built.end() && !std::getenv("DFA_HOST_NO_GRAPH_REUSE")) {
+        if (it != g_built.end() && !dfa::host_switch("DFA_HOST_NO_GRAPH_REUSE")) {
             const Built& b = it->second;
             if (b.D == D && b.N == N && b.k == k && b.nodes_hash == nodes_hash && b.canon.ptr() == I.canon.ptr() &&
                 b.canon_n.ptr() == I.canon_n.ptr()) {

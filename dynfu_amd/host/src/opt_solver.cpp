@@ -76,7 +76,7 @@ void CombinedSolver::solveAll() {
     // outer loop after the first pass when earlyOut is set — as DynFusion and every OptTest set it
     // (dyn_fusion.cpp:189, opt_optimisation_test.cpp:43): one robust re-weighting, then <= nonLinearIter Gauss-Newton
     // steps.  DFA_HOST_ALL_OUTER=1 runs all numIter passes (the behaviour of round 1) for comparison.
-    const bool one_pass = m_params.earlyOut && !std::getenv("DFA_HOST_ALL_OUTER");
+    const bool one_pass = m_params.earlyOut && !dfa::host_switch("DFA_HOST_ALL_OUTER");
     p.num_iter       = one_pass ? std::min(1, m_params.numIter) : m_params.numIter;
     p.nonlinear_iter = m_params.nonLinearIter;
     p.linear_iter    = m_params.linearIter;

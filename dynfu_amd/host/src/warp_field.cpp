@@ -126,7 +126,7 @@ std::shared_ptr<dynfu::Frame> Warpfield::warpToLive(std::shared_ptr<dynfu::Frame
         return std::make_shared<dynfu::Frame>(0, dfa::PointCloud<dfa::PointXYZ>(), dfa::PointCloud<dfa::Normal>());
     syncTransforms();
     dfa::DeviceArray<float> ov(3 * N), on(3 * N);
-    if (canonicalFrame->deviceResident() && !std::getenv("DFA_HOST_NO_GRAPH_REUSE")) {
+    if (canonicalFrame->deviceResident() && !dfa::host_switch("DFA_HOST_NO_GRAPH_REUSE")) {
         // a device-resident frame never changes its arrays: their address names the cloud
         dfa::DeviceArray<float> v3, n3;
         canonicalFrame->deviceArrays(v3, n3);

@@ -15,3 +15,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture
+def devlib():
+    """the development flavour of the library (-DDFA_DEV_AB, dynfu_amd/libdynfu_amd_dev.so): the DFA_* environment A/B
+    switches and the non-default kernel variants exist there only — tests that compare variants run inside it"""
+    from dynfu_amd import _lib
+    with _lib.use_library(_lib.dev_lib_path()):
+        yield

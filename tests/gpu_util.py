@@ -6,6 +6,8 @@ import torch
 def dev(a):
     """numpy -> CUDA tensor (uint32 volumes travel as int32, same bits)"""
     a = np.ascontiguousarray(a)
+    if not a.flags.writeable:  # (memoised synthetic frames are read-only; torch wants to own writable memory)
+        a = a.copy()
     if a.dtype == np.uint32:
         return torch.from_numpy(a.view(np.int32)).cuda()
     return torch.from_numpy(a).cuda()

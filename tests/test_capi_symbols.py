@@ -60,3 +60,33 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", text, re.M), f
                 assert "liboracle" not in text and "orc_" not in text, f
+
+
+def test_product_library_has_no_ab_switches():
+    """A/B scaffolding is not product: every DFA_* environment switch goes through dev_env() (csrc/dev_switch.hpp), which is
+    getenv only under -DDFA_DEV_AB (libdynfu_amd_dev.so); the product library reads ONE variable, once per plan."""
+    csrc = os.path.join(ROOT, "dynfu_amd", "csrc")
+    sites = []
+    for f in sorted(os.listdir(csrc)):
+        if f == "dev_switch.hpp":
+            continue
+        for n, line in enumerate(open(os.path.join(csrc, f)), 1):
+            code = line.split("//")[0]
+            if re.search(r"(?<![_a-z])getenv\s*\(", code):
+                sites.append((f, n, code.strip()))
+    assert [s[2] for s in sites] == ['const char* e    = getenv("DFA_ASSEMBLE_DETERMINISTIC");'], sites
+    # the product binary does not contain the names of the development switches
+    blob = open(os.path.join(ROOT, "dynfu_amd", "libdynfu_amd.so"), "rb").read()
+    for name in (b"DFA_PCG_VARIANT", b"DFA_TSDF_LEGACY", b"DFA_TSDF_ZCHUNK", b"DFA_MB_FORM", b"DFA_GRID_FOUR_KERNELS",
+                 b"DFA_TSDF_VX4", b"DFA_NO_REGRADIENT", b"DFA_S6_NO_GRAPH"):
+        assert name not in blob, name
+
+
+def test_development_flavour_exports_the_same_abi():
+    import torch  # noqa: F401
+    from dynfu_amd import build as B
+    dev = ctypes.CDLL(B.build(dev=True))
+    for n in _declared_symbols():
+        assert hasattr(dev, n), "libdynfu_amd_dev.so does not export %s" % n
+    blob = open(B.DEV_LIB, "rb").read()
+    assert b"DFA_PCG_VARIANT" in blob and b"DFA_TSDF_ZCHUNK" in blob

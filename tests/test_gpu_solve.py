@@ -244,7 +244,7 @@ def test_config_c2_full_size_properties(A):
     s.close()
 
 
-def test_multi_workgroup_pcg_matches_the_oracle_and_the_single_workgroup_kernels(A, monkeypatch):
+def test_multi_workgroup_pcg_matches_the_oracle_and_the_single_workgroup_kernels(A, devlib, monkeypatch):
     """DFA_PCG_VARIANT=3 forces the many-workgroup PCG (the path of plans above 2048 nodes) on a small problem, =1 the
     register-resident kernel with the three coordinates in ONE workgroup (shared CG scalars, as the oracle);
     the default solves the coordinates in three workgroups."""
@@ -311,7 +311,7 @@ def test_more_than_8192_nodes(A):
 
 
 @pytest.mark.parametrize("variant", [None, "1", "3"])
-def test_iterations_behind_a_converged_one_are_no_ops(A, monkeypatch, variant):
+def test_iterations_behind_a_converged_one_are_no_ops(A, devlib, monkeypatch, variant):
     """Once a linearisation's gradient is at the round-off floor the unknown can no longer change: the remaining
     Gauss-Newton iterations return at entry (gn_noop) — same iteration count, same translations and cost as a solve
     that stops right there.  All three PCG paths (per-coordinate, joint, many-workgroup with its host-side
@@ -339,7 +339,7 @@ def test_iterations_behind_a_converged_one_are_no_ops(A, monkeypatch, variant):
 
 
 @pytest.mark.parametrize("variant", [None, "3"])
-def test_inner_iterations_behind_a_gradient_at_the_floor_are_no_ops(A, monkeypatch, variant):
+def test_inner_iterations_behind_a_gradient_at_the_floor_are_no_ops(A, devlib, monkeypatch, variant):
     """Budgets shaped like the reference's (dyn_fusion.cpp:183-189: outer x 16 inner iterations): while the robust weights
     are frozen the energy is linear least squares, so once an inner iteration finds its gradient at the round-off floor
     the rest of that outer iteration returns at entry; the next outer iteration re-weights and runs again.  Same
@@ -371,7 +371,7 @@ def test_inner_iterations_behind_a_gradient_at_the_floor_are_no_ops(A, monkeypat
 
 
 @pytest.mark.parametrize("name,variant", [("T1", None), ("T1", "3"), ("C1", None)])
-def test_inner_iterations_restart_on_the_true_residual_of_the_same_matrix(A, monkeypatch, name, variant):
+def test_inner_iterations_restart_on_the_true_residual_of_the_same_matrix(A, devlib, monkeypatch, name, variant):
     """While the robust weights are frozen the matrix of an outer iteration's first linearisation holds for its inner
     iterations, whose right-hand side is g_base - A (t - t_base): same translations and final cost as re-linearising and
     re-assembling every inner iteration (DFA_NO_REGRADIENT=1), and as the oracle, which does exactly that."""

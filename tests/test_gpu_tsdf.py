@@ -268,7 +268,7 @@ def test_integrate_random_small_configurations(A, seed):
 
 
 @pytest.mark.parametrize("zchunk", ["4", "7", "20", "1000"])
-def test_integrate_independent_of_z_chunking(A, zchunk, monkeypatch):
+def test_integrate_independent_of_z_chunking(A, devlib, zchunk, monkeypatch):
     # the kernel replays the running `vc += zstep` additions for chunks that start at z0 > 0
     cfg, intr, voxel, trunc, vol2cam, _, _, depth = _scene("T0")
     dim = cfg["dim"]
@@ -460,10 +460,12 @@ def test_full_size_properties_512(A):
         # averaging identical samples: (F*W + F)/(W+1) stays within one half ulp step of F
         diff = ((b & 0xFFFF) - (a & 0xFFFF)).abs()
         assert int(diff.max()) <= 1
-    os.environ["DFA_TSDF_ZCHUNK"] = "48"
+    os.environ["DFA_TSDF_ZCHUNK"] = "48"  # (a switch of the development flavour: the product picks its chunks itself)
     try:
-        c = torch.empty_like(a)
-        A.tsdf_clear_integrate(c, dists, voxel, trunc, 3, vol2cam, *intr)
+        from dynfu_amd import _lib
+        with _lib.use_library(_lib.dev_lib_path()):
+            c = torch.empty_like(a)
+            A.tsdf_clear_integrate(c, dists, voxel, trunc, 3, vol2cam, *intr)
     finally:
         del os.environ["DFA_TSDF_ZCHUNK"]
     assert torch.equal(a, c)
@@ -497,8 +499,10 @@ def test_full_size_properties_1024(A):
     assert int(((a >> 16) == 2).sum()) == touched and int(((a >> 16) == 1).sum()) == 0
     os.environ["DFA_TSDF_ZCHUNK"] = "200"
     try:
-        c = torch.empty_like(a)
-        A.tsdf_clear_integrate(c, dists, voxel, trunc, 64, vol2cam, *intr)
+        from dynfu_amd import _lib
+        with _lib.use_library(_lib.dev_lib_path()):
+            c = torch.empty_like(a)
+            A.tsdf_clear_integrate(c, dists, voxel, trunc, 64, vol2cam, *intr)
     finally:
         del os.environ["DFA_TSDF_ZCHUNK"]
     assert torch.equal(checksum(c), ca)

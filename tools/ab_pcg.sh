@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of the PCG kernels on the bench configurations: tools/ab_pcg.sh "C1 C2" "default 1"
+export DFA_LIB_PATH=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}/dynfu_amd/libdynfu_amd_dev.so  # the switches below exist in the development flavour only
 for cfg in $1; do for v in $2; do
   if [ $v = default ]; then unset DFA_PCG_VARIANT; else export DFA_PCG_VARIANT=$v; fi
   timeout 300 python bench.py --config $cfg --steps ${3:-100} --warmup 10 2>/dev/null | python -c "

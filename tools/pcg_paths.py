@@ -1,5 +1,7 @@
 """compare the PCG paths (default routing vs DFA_PCG_VARIANT) on a synthetic config: iterations and costs per number
 of outer iterations.  usage: DFA_PCG_VARIANT=4 python tools/pcg_paths.py C3"""
+import os as _os
+_os.environ.setdefault("DFA_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "dynfu_amd", "libdynfu_amd_dev.so"))  # the DFA_* switches exist in the development flavour only
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,4 +1,6 @@
 """stats of one solve under every PCG path: python tools/pcg_variants.py T1 3 2   (config, num_iter, nonlinear_iter)"""
+import os as _os
+_os.environ.setdefault("DFA_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "dynfu_amd", "libdynfu_amd_dev.so"))  # the DFA_* switches exist in the development flavour only
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

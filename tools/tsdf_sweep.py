@@ -1,5 +1,7 @@
 """dev tool: times the fused and the read+write TSDF sweep over the A/B switches of tsdf.hip in ONE process
 (DFA_TSDF_RUN / DFA_TSDF_WAVE / DFA_TSDF_ZCHUNK / DFA_TSDF_LEGACY / DFA_TSDF_ABLATE are read per call)."""
+import os as _os
+_os.environ.setdefault("DFA_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "dynfu_amd", "libdynfu_amd_dev.so"))  # the DFA_* switches exist in the development flavour only
 import itertools, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
