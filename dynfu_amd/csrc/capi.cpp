@@ -887,7 +887,7 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
                                          p->gn_tol, p->tukey_offset, p->psi_data, w_reg_sq, with_huber ? p->psi_reg : 0.f, nullptr, st));
             huber_done |= with_huber;
             int ev = s->timing ? timing_begin(s, st) : -1;
-            HIP_TRY(dfa::solve_assemble(v, s->state, gn == 0 && p->nonlinear_iter > 1, st));
+            HIP_TRY(dfa::solve_assemble(v, s->state, gn == 0 && p->nonlinear_iter > 1, w_reg_sq, st));
             timing_end(s, ev, st);
             if (ev >= 0) s->ev_asm.push_back(ev);
             // this iteration's PCG starts here: the caller's chip-wide work may run in its shadow

@@ -398,6 +398,29 @@ __global__ __launch_bounds__(256) void prepare_rows_kernel(SolveView s, SolveSta
 constexpr int HASH      = 512;
 constexpr int HASH_MASK = HASH - 1;
 
+// The hash's sums are 64-bit FIXED-POINT integers, not floats.  On gfx950 an LDS float add (ds_add_f32) executes one lane
+// after the other whatever the addresses — 192 cycles per wave instruction against 8 for ds_add_u64 without conflicts
+// (tools/microbench_lds_atomic.hip) — and 7 of them per row were 56 % of this kernel's time (C4: 345 -> 152 us with the adds
+// taken out).  An addend tau w_a w_b is a float of magnitude <= max(1, w_reg^2) (RBF weights <= 1, Tukey weights <= 1,
+// regularisation rows +-1 x w_reg^2); scaled by 2^40 / (that bound rounded up to a power of two) it is an exact integer
+// unless it is below 2^-17 of the bound (then it is cut to that grid: 2^-41 of the bound per addend).  The sum of up to
+// 2^22 rows fits 63 bits, is EXACT otherwise, and does not depend on the order of the adds.
+struct FixedScale {
+    float up;     // float -> fixed: a power of two
+    double down;  // fixed -> float
+};
+__host__ __device__ inline FixedScale solve_fixed_scale(float w_reg_sq) {
+    int e = 0;
+    while (e < 60 && (float)(1ull << e) < w_reg_sq) ++e;  // bound 2^e >= max(1, w_reg^2)
+    FixedScale f;
+    f.up   = (float)(1ull << (40 - (e < 40 ? e : 40)));
+    f.down = 1.0 / (double)f.up;
+    return f;
+}
+__device__ __forceinline__ void fixed_add(long long* cell, float v, float up) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(cell), (unsigned long long)(long long)(v * up));  // (two's complement)
+}
+
 // one row record = solve_rec_words(k) consecutive words (head: prepare_rows_kernel, tail: linearise_kernel)
 template <int K>
 __device__ __forceinline__ float4 load_record(const SolveView& s, size_t r, int (&idx)[K], float (&w)[K]) {
@@ -451,20 +474,36 @@ __device__ __forceinline__ float4 load_record(const SolveView& s, size_t r, int 
     return make_float4(rec[2 * s.k], rec[2 * s.k + 1], rec[2 * s.k + 2], rec[2 * s.k + 3]);
 }
 
+#ifdef DFA_PCG_PROFILE  // development builds: a workgroup's life in the assembly (tools/ref_assemble_phases.py)
+__device__ unsigned long long asm_tbuf[32768 * 8];
+extern "C" __attribute__((visibility("default"))) int dfa_dev_asm_timing(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(asm_tbuf), sizeof(unsigned long long) * 8 * (size_t)n);
+}
+#endif
+
 template <int K>
-__global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* __restrict__ st, int save_base) {
+__global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* __restrict__ st, int save_base, FixedScale fx) {
     __shared__ int key[HASH];
-    __shared__ float val[HASH];
+    __shared__ long long val[HASH];
     __shared__ float gpart[4][3];
     __shared__ int wave_cnt[4];
     __shared__ int ovf;
     if (st->done || st->converged) return;
+#ifdef DFA_ASM_XCD
+    // workgroups are dealt round-robin to the 8 XCDs: XCD x takes the contiguous node range [x ceil(D / 8), ...) — the rows
+    // of a node are read again by the workgroups of its neighbours, which then find them in the same L2
+    const int per_xcd = (s.D + 7) >> 3;
+    const int a       = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+#else
     const int a    = blockIdx.x;
+#endif
+    if (a >= s.D) return;  // (the grid is a multiple of 8 workgroups)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #ifdef DFA_PCG_PROFILE
     long long t0_ = clock64(), t1_, t2_, t3_, t4_;
+    const unsigned long long w0_ = wall_clock64();
 #endif
-    for (int i = threadIdx.x; i < HASH; i += 256) key[i] = -1, val[i] = 0.f;
+    for (int i = threadIdx.x; i < HASH; i += 256) key[i] = -1, val[i] = 0ll;
     if (threadIdx.x == 0) ovf = 0;
     __syncthreads();
 #ifdef DFA_PCG_PROFILE
@@ -489,28 +528,44 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
             // first probe of all k columns read together (keys never change once set): the common
             // case "column already present" costs one LDS read + one fire-and-forget ds_add instead
             // of a returning CAS per column
+            // Lane l takes its row's columns in the order (l + t) mod K: the rows of neighbouring lanes have nearly the same
+            // neighbours in nearly the same order, and with every lane at ITS j-th column a wave's 64 LDS adds of one step
+            // went to one or two addresses (same-address atomics are executed one after the other: the adds, not the loads,
+            // were the kernel's time — without them a workgroup lived 28 us instead of 61 at 8 192 nodes).  Rotated, a step's
+            // adds spread over the row's K columns.
             uint32_t h0[K];
-            int k0[K];
+            int k0[K], bb[K];
+            float vv[K];
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-                h0[j] = ((uint32_t)idx[j] * 2654435761u) >> (32 - 9);
-                k0[j] = key[h0[j]];
+            for (int t = 0; t < K; ++t) {
+                const int jj = (t + lane) & (K - 1);
+                int b        = idx[0];
+                float wj     = w[0];
+#pragma unroll
+                for (int q = 1; q < K; ++q) b = jj == q ? idx[q] : b, wj = jj == q ? w[q] : wj;
+                bb[t] = b, vv[t] = tw * wj;
+                h0[t] = ((uint32_t)b * 2654435761u) >> (32 - 9);
+                k0[t] = key[h0[t]];
             }
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                const int b = idx[j];
+                const int b = bb[j];
                 if (b < 0) continue;
-                const float v = tw * w[j];
+                const float v = vv[j];
                 if (b == a) {  // the diagonal is hit by every row: kept in a register
                     dsum += v;
                     continue;
                 }
+#if defined(DFA_ASM_ABLATE) && (DFA_ASM_ABLATE & 1)  // (timing only: no LDS atomics)
+                dsum += v * (float)(k0[j] & 1);
+                continue;
+#endif
                 uint32_t h = h0[j];
                 int cur    = k0[j];
                 for (int probes = 0;; ++probes) {
                     if (cur == -1) cur = atomicCAS(&key[h], -1, b), cur = cur == -1 ? b : cur;
                     if (cur == b) {
-                        atomicAdd(&val[h], v);
+                        fixed_add(&val[h], v, fx.up);
                         break;
                     }
                     if (probes >= HASH) {
@@ -530,7 +585,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
         for (int probes = 0; probes < HASH; ++probes, h = (h + 1) & HASH_MASK) {
             const int cur = atomicCAS(&key[h], -1, a);
             if (cur == -1 || cur == a) {
-                atomicAdd(&val[h], dsum);
+                fixed_add(&val[h], dsum, fx.up);
                 break;
             }
         }
@@ -562,7 +617,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
     float diag = 0.f;
     for (int base = 0; base < PER_WAVE; base += 64) {
         const int kk     = key[wave * PER_WAVE + base + lane];
-        const float vv   = val[wave * PER_WAVE + base + lane];
+        const float vv   = (float)((double)val[wave * PER_WAVE + base + lane] * fx.down);
         const bool valid = kk >= 0;
         const uint64_t m = __ballot(valid);
         const int pos    = pos0 + __popcll(m & ((1ull << lane) - 1ull));
@@ -591,6 +646,11 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
 #ifdef DFA_PCG_PROFILE
         t4_ = clock64();
         if (a == 7) st->prof[6] = (t1_ - t0_) * 1000000 + (t2_ - t1_), st->prof[7] = (t3_ - t2_) * 1000000 + (t4_ - t3_);
+        if (a < 32768) {
+            unsigned long long* o = asm_tbuf + 8 * (size_t)a;
+            o[0] = w0_, o[1] = wall_clock64() - w0_, o[2] = (unsigned long long)(end - beg), o[3] = (unsigned long long)total;
+            o[4] = t1_ - t0_, o[5] = t2_ - t1_, o[6] = t3_ - t2_, o[7] = t4_ - t3_;
+        }
 #endif
     }
 }
@@ -627,15 +687,15 @@ __global__ __launch_bounds__(256) void sort_node_lists_kernel(const int32_t* __r
 }
 
 template <int K>
-__global__ __launch_bounds__(256) void assemble_det_kernel(SolveView s, SolveState* __restrict__ st, int save_base) {
+__global__ __launch_bounds__(256) void assemble_det_kernel(SolveView s, SolveState* __restrict__ st, int save_base, FixedScale fx) {
     __shared__ int key[HASH];
-    __shared__ float val[4][HASH];  // a private copy per wave: LDS adds of ONE wave execute in program order
+    __shared__ long long val[HASH];  // fixed-point sums (see FixedScale): integer adds commute, any order gives the same bits
     __shared__ float gpart[4][3], dpart[4];
     __shared__ int ovf, nkeys;
     if (st->done || st->converged) return;
     const int a    = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < HASH; i += 256) key[i] = -1, val[0][i] = val[1][i] = val[2][i] = val[3][i] = 0.f;
+    for (int i = threadIdx.x; i < HASH; i += 256) key[i] = -1, val[i] = 0ll;
     if (threadIdx.x == 0) ovf = 0, nkeys = 0;
     __syncthreads();
     const int beg = s.node_ptr[a], end = s.node_ptr[a + 1];
@@ -707,7 +767,7 @@ __global__ __launch_bounds__(256) void assemble_det_kernel(SolveView s, SolveSta
             if (b < 0 || b == a) continue;
             uint32_t h = ((uint32_t)b * 2654435761u) >> (32 - 9);
             for (int probes = 0; probes <= HASH && key[h] != b; ++probes) h = (h + 1) & HASH_MASK;
-            if (key[h] == b) atomicAdd(&val[wave][h], tw * w[j]);
+            if (key[h] == b) fixed_add(&val[h], tw * w[j], fx.up);
         }
     }
     __syncthreads();
@@ -724,7 +784,7 @@ __global__ __launch_bounds__(256) void assemble_det_kernel(SolveView s, SolveSta
         if (kk < 0) continue;
         int pos = 0;
         for (int q = 0; q < HASH; ++q) pos += key[q] >= 0 && key[q] < kk;
-        const float vv = kk == a ? dtot : (val[0][i] + val[1][i]) + (val[2][i] + val[3][i]);
+        const float vv = kk == a ? dtot : (float)((double)val[i] * fx.down);
         if (pos < s.ell_cap) s.ell[(size_t)pos * s.D + a] = make_float2(vv, __int_as_float(kk));
         if (kk == a) s.diag[a] = vv, has_diag = true;
     }
@@ -1515,9 +1575,10 @@ hipError_t solve_huber(const SolveView& s, float psi_reg, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t solve_assemble(const SolveView& s, SolveState* state, int save_base, hipStream_t st) {
-    if (s.deterministic) KDISPATCH(assemble_det_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base));
-    else KDISPATCH(assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base));
+hipError_t solve_assemble(const SolveView& s, SolveState* state, int save_base, float w_reg_sq, hipStream_t st) {
+    const FixedScale fx = solve_fixed_scale(w_reg_sq);
+    if (s.deterministic) KDISPATCH(assemble_det_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base, fx));
+    else KDISPATCH(assemble_kernel, s.k, <<<((s.D + 7) >> 3) << 3, 256, 0, st>>>(s, state, save_base, fx));
     return hipGetLastError();
 }
 

@@ -113,7 +113,10 @@ hipError_t solve_linearise(const SolveView& s, SolveState* state, double* cost_p
                            long long* iters_total /* mode 2: += the solve's PCG iterations (optional, device) */, hipStream_t st);
 hipError_t solve_huber(const SolveView& s, float psi_reg, hipStream_t st);
 hipError_t solve_reset(const SolveView& s, SolveState* state, unsigned int* ticket, int nticket, hipStream_t st);
-hipError_t solve_assemble(const SolveView& s, SolveState* state, int save_base /* g, t -> g_base, t_base */, hipStream_t st);
+// w_reg_sq: the weight of the regularisation rows — with 1 (the data rows) the bound of an addend's magnitude, which sets the
+// scale of the assembly's fixed-point sums
+hipError_t solve_assemble(const SolveView& s, SolveState* state, int save_base /* g, t -> g_base, t_base */, float w_reg_sq,
+                          hipStream_t st);
 // inner Gauss-Newton iteration of an outer iteration whose robust weights are frozen: the energy is linear least squares,
 // so the matrix of the outer iteration's first linearisation still holds and the new right-hand side is
 // g = g_base - A (t - t_base) — one sparse matrix-vector product instead of a linearisation and an assembly

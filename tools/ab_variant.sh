@@ -1,15 +1,22 @@
 #!/bin/bash
-# Builds dynfu_amd/build/libdynfu_amd_<tag>.so with one source recompiled under extra flags (compile-time A/B):
+# Builds dynfu_amd/build/libdynfu_amd_<tag>.so with one source (or `all`) recompiled under extra flags (compile-time A/B):
 #   bash tools/ab_variant.sh rb8 tsdf.hip -DDFA_RAY_BATCH=8      then      DFA_LIB_PATH=dynfu_amd/build/libdynfu_amd_rb8.so python ...
+#   bash tools/ab_variant.sh prof all -DDFA_PCG_PROFILE -DDFA_DEV_AB
 set -e
 tag=$1; src=$2; shift 2
 R=$(cd $(dirname $0)/.. && pwd)
 B=$R/dynfu_amd/build
-x=""; case $src in *.cpp) x="-x hip";; esac
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function -fno-gpu-rdc "$@" $x -c $R/dynfu_amd/csrc/$src -o $B/${src%.*}_$tag.o
+CC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function -fno-gpu-rdc"
 objs=""
 for o in tsdf warp solve solve6 mc img icp points capi; do
-  if [ "$o" == "${src%.*}" ]; then objs="$objs $B/${o}_$tag.o"; else objs="$objs $B/$o.o"; fi
+  f=$o.hip; x=""; if [ $o == capi ]; then f=capi.cpp; x="-x hip"; fi
+  if [ "$src" == all ] || [ "$f" == "$src" ]; then
+    $CC "$@" $x -c $R/dynfu_amd/csrc/$f -o $B/${o}_$tag.o &
+    objs="$objs $B/${o}_$tag.o"
+  else
+    objs="$objs $B/$o.o"
+  fi
 done
+wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $B/libdynfu_amd_$tag.so
 echo $B/libdynfu_amd_$tag.so
