@@ -489,15 +489,10 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
     __shared__ int wave_cnt[4];
     __shared__ int ovf;
     if (st->done || st->converged) return;
-#ifdef DFA_ASM_XCD
-    // workgroups are dealt round-robin to the 8 XCDs: XCD x takes the contiguous node range [x ceil(D / 8), ...) — the rows
-    // of a node are read again by the workgroups of its neighbours, which then find them in the same L2
-    const int per_xcd = (s.D + 7) >> 3;
-    const int a       = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-#else
+    // (workgroup -> node in launch order.  A contiguous node range per XCD — so that the rows a node shares with its
+    // neighbours are fetched into one L2 instead of up to eight — left the launch at 345 us at C4: it was never bound by
+    // the fetches.)
     const int a    = blockIdx.x;
-#endif
-    if (a >= s.D) return;  // (the grid is a multiple of 8 workgroups)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #ifdef DFA_PCG_PROFILE
     long long t0_ = clock64(), t1_, t2_, t3_, t4_;
@@ -528,38 +523,26 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
             // first probe of all k columns read together (keys never change once set): the common
             // case "column already present" costs one LDS read + one fire-and-forget ds_add instead
             // of a returning CAS per column
-            // Lane l takes its row's columns in the order (l + t) mod K: the rows of neighbouring lanes have nearly the same
-            // neighbours in nearly the same order, and with every lane at ITS j-th column a wave's 64 LDS adds of one step
-            // went to one or two addresses (same-address atomics are executed one after the other: the adds, not the loads,
-            // were the kernel's time — without them a workgroup lived 28 us instead of 61 at 8 192 nodes).  Rotated, a step's
-            // adds spread over the row's K columns.
+            // (measured and not kept, tools/ref_assemble_phases.py at C4 / C3: every lane taking its columns in the order
+            // (lane + t) mod K, so that a step's adds spread over K addresses — 149 / 86 us against 141 / 81, the selects cost
+            // more than the conflicts; a thread's rows 2 or 4 at a time with their loads in flight together — a workgroup
+            // lives 18 us instead of 23 but fewer are resident: 140-163 / 81-91 us)
             uint32_t h0[K];
-            int k0[K], bb[K];
-            float vv[K];
+            int k0[K];
 #pragma unroll
-            for (int t = 0; t < K; ++t) {
-                const int jj = (t + lane) & (K - 1);
-                int b        = idx[0];
-                float wj     = w[0];
-#pragma unroll
-                for (int q = 1; q < K; ++q) b = jj == q ? idx[q] : b, wj = jj == q ? w[q] : wj;
-                bb[t] = b, vv[t] = tw * wj;
-                h0[t] = ((uint32_t)b * 2654435761u) >> (32 - 9);
-                k0[t] = key[h0[t]];
+            for (int j = 0; j < K; ++j) {
+                h0[j] = ((uint32_t)idx[j] * 2654435761u) >> (32 - 9);
+                k0[j] = key[h0[j]];
             }
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                const int b = bb[j];
+                const int b = idx[j];
                 if (b < 0) continue;
-                const float v = vv[j];
+                const float v = tw * w[j];
                 if (b == a) {  // the diagonal is hit by every row: kept in a register
                     dsum += v;
                     continue;
                 }
-#if defined(DFA_ASM_ABLATE) && (DFA_ASM_ABLATE & 1)  // (timing only: no LDS atomics)
-                dsum += v * (float)(k0[j] & 1);
-                continue;
-#endif
                 uint32_t h = h0[j];
                 int cur    = k0[j];
                 for (int probes = 0;; ++probes) {
@@ -1578,7 +1561,7 @@ hipError_t solve_huber(const SolveView& s, float psi_reg, hipStream_t st) {
 hipError_t solve_assemble(const SolveView& s, SolveState* state, int save_base, float w_reg_sq, hipStream_t st) {
     const FixedScale fx = solve_fixed_scale(w_reg_sq);
     if (s.deterministic) KDISPATCH(assemble_det_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base, fx));
-    else KDISPATCH(assemble_kernel, s.k, <<<((s.D + 7) >> 3) << 3, 256, 0, st>>>(s, state, save_base, fx));
+    else KDISPATCH(assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base, fx));
     return hipGetLastError();
 }
 
