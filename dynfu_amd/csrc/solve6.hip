@@ -671,6 +671,11 @@ __global__ __launch_bounds__(256) void s6_pattern_kernel(Solve6View s, Solve6Sta
     // 194 us per workgroup at C3).
     // (S6_SPLIT listed slots — slot 0 and the upper ones, in slot order — per round: all 48 at once are 24 KiB of counters, which
     // left room for three workgroups per CU instead of five)
+    // (Round 4, tools/ns_pattern_phases.py with finer marks at C3: of the split's 29 us a thread spends 6 translating its bytes,
+    // 4 clearing + counting, 3 in the scan and 16 WRITING — 8 300 four-byte stores per workgroup, each lane of a wave to
+    // another list: the store transactions, not LDS, are what it waits for.  Giving every thread whole rows with its bytes in
+    // a run padded to an odd number of words — no bank shared by the lanes of a pass, where 32-40-byte runs share four —
+    // changed nothing: 29.0 us either way.)
     constexpr int S6_SPLIT = 24;
     __shared__ uint16_t hist[S6_SPLIT][256];
     __shared__ int run_sh;
