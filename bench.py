@@ -37,18 +37,24 @@ TIMING_SAMPLE = 8  # every 8th timed frame carries the hipEvent brackets of the 
 # was read from and the commit that file was measured at: a figure older than the kernel it describes is visible as such.
 PMC_TRAFFIC = {
     # (config, kernel key): (bytes per launch, profile file, commit of the measured tree)
-    ("C2", "fused_integrate"): (0.5417e9, "profiles/r03h_pmc_c2.md", "858fb26"),   # WRITE 524 288 KiB + 2 x FETCH 2 354 KiB
-    ("C3", "fused_integrate"): (0.5414e9, "profiles/r03h_pmc_ns_c3.md", "858fb26"),
+    ("C2", "fused_integrate"): (0.5417e9, "profiles/r04_pmc_c2.md", "e45c70c"),   # WRITE 524 288 KiB + 2 x FETCH 2 367 KiB
+    ("C3", "fused_integrate"): (0.5414e9, "profiles/r04_pmc_ns_c3.md", "e45c70c"),
     ("C4", "fused_integrate"): (4.344e9, "profiles/r02_pmc_tsdf.md", "round 2"),   # 4 194 304 + 2 x 23 775 KiB
-    ("C2", "pcg"): (0.632e6, "profiles/r03h_pmc_c2.md", "858fb26"),                 # pcg_paired_kernel<1024,1,32,1>: FETCH + WRITE
+    ("C2", "pcg"): (0.635e6, "profiles/r04_pmc_c2.md", "e45c70c"),                 # pcg_paired_kernel<1024,1,32,1>: FETCH 344.6 + WRITE 275.7 KiB
+    ("C3", "pcg"): (1.796e6, "profiles/r04_pmc_ref_c3.md", "e45c70c"),             # pcg_mb_step_kernel: FETCH 1 339 + WRITE 415 KiB per launch
     # north-star kernels: FETCH + WRITE, uncorrected, for the gather-heavy PCG step and the gathering assembly (the x2 of
     # wide read streams does not apply to 16-80-byte gathers); 2 x FETCH + WRITE for the streaming linearisation.
-    ("C2", "s6_assemble"): (61.49e6, "profiles/r03h_pmc_ns_c2.md", "858fb26"),
-    ("C2", "s6_linearise"): (42.12e6, "profiles/r03h_pmc_ns_c2.md", "858fb26"),
-    ("C2", "s6_pcg_step"): (1.846e6, "profiles/r03h_pmc_ns_c2.md", "858fb26"),
-    ("C3", "s6_assemble"): (249.3e6, "profiles/r03h_pmc_ns_c3.md", "858fb26"),
-    ("C3", "s6_linearise"): (104.4e6, "profiles/r03h_pmc_ns_c3.md", "858fb26"),
-    ("C3", "s6_pcg_step"): (4.655e6, "profiles/r03h_pmc_ns_c3.md", "858fb26"),
+    ("C2", "s6_assemble"): (61.44e6, "profiles/r04_pmc_ns_c2.md", "e45c70c"),
+    ("C2", "s6_linearise"): (42.13e6, "profiles/r04_pmc_ns_c2.md", "e45c70c"),
+    ("C2", "s6_pcg_step"): (1.728e6, "profiles/r04_pmc_ns_c2.md", "e45c70c"),
+    ("C3", "s6_assemble"): (249.1e6, "profiles/r04_pmc_ns_c3.md", "e45c70c"),
+    ("C3", "s6_linearise"): (104.4e6, "profiles/r04_pmc_ns_c3.md", "e45c70c"),
+    ("C3", "s6_pcg_step"): (4.058e6, "profiles/r04_pmc_ns_c3.md", "e45c70c"),
+    # raycast: FETCH + WRITE (4-byte gathers: uncorrected)
+    ("C2", "raycast_points"): ((61764 + 9600) * 1024.0, "profiles/r04_raycast.md", "e45c70c"),
+    ("C2", "raycast_depth"): ((61736 + 5458) * 1024.0, "profiles/r04_raycast.md", "e45c70c"),
+    ("C4", "raycast_points"): ((227663 + 28800) * 1024.0, "profiles/r04_raycast.md", "e45c70c"),
+    ("C4", "raycast_depth"): ((227504 + 16748) * 1024.0, "profiles/r04_raycast.md", "e45c70c"),
 }
 PMC_TRAFFIC_BYTES = {k: v[0] for k, v in PMC_TRAFFIC.items()}
 
