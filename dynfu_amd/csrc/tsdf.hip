@@ -890,7 +890,8 @@ hipError_t launch_raycast_points(const uint32_t* vol, int X, int Y, int Z, const
     RaycastArgs a = make_raycast_args(vol, X, Y, Z, voxel_size, trunc_dist, cam2vol, Rinv, fx, fy, cx, cy,
                                       step_factor, delta_factor, cols, rows);
     dim3 block(256), grid((cols + 15) / 16, (rows + 15) / 16);
-    if ((uint64_t)X * Y * Z <= (1ull << 32)) raycast_points_kernel<true><<<grid, block, 0, s>>>(a, points, points_step, normals, normals_step);
+    // (development builds: DFA_RAY_IDX64=1 runs the 64-bit voxel index of volumes beyond 2^32 voxels on any volume — the tests)
+    if ((uint64_t)X * Y * Z <= (1ull << 32) && !dev_env("DFA_RAY_IDX64")) raycast_points_kernel<true><<<grid, block, 0, s>>>(a, points, points_step, normals, normals_step);
     else raycast_points_kernel<false><<<grid, block, 0, s>>>(a, points, points_step, normals, normals_step);
     return launch_status();
 }
@@ -913,7 +914,7 @@ hipError_t launch_raycast_depth(const uint32_t* vol, int X, int Y, int Z, const 
     RaycastArgs a = make_raycast_args(vol, X, Y, Z, voxel_size, trunc_dist, cam2vol, Rinv, fx, fy, cx, cy,
                                       step_factor, delta_factor, cols, rows);
     dim3 block(256), grid((cols + 15) / 16, (rows + 15) / 16);
-    if ((uint64_t)X * Y * Z <= (1ull << 32)) raycast_depth_kernel<true><<<grid, block, 0, s>>>(a, depth, depth_step, normals, normals_step);
+    if ((uint64_t)X * Y * Z <= (1ull << 32) && !dev_env("DFA_RAY_IDX64")) raycast_depth_kernel<true><<<grid, block, 0, s>>>(a, depth, depth_step, normals, normals_step);
     else raycast_depth_kernel<false><<<grid, block, 0, s>>>(a, depth, depth_step, normals, normals_step);
     return launch_status();
 }

@@ -423,6 +423,40 @@ def test_raycast_ragged_image_sizes(A, size):
     _raycast_both_variants_bit_exact(A, dev(vol), vol, voxel, trunc, c2v, ri, intr2, W, H, 0.02)
 
 
+def test_raycast_with_64_bit_voxel_indices(A, devlib, monkeypatch):
+    """volumes beyond 2^32 voxels (16 GiB) take the kernels' 64-bit voxel index; the development flavour runs that
+    instantiation on a small volume (DFA_RAY_IDX64=1): same bits as the oracle"""
+    monkeypatch.setenv("DFA_RAY_IDX64", "1")
+    cfg, intr, voxel, trunc, vol2cam, cam2vol, rinv, depth = _scene("T1")
+    dim, W, H = cfg["dim"], cfg["width"], cfg["height"]
+    vol = np.zeros((dim, dim, dim), np.uint32)
+    O.tsdf_integrate(vol, O.compute_dists(depth, *intr), voxel, trunc, 64, vol2cam, *intr, threads=8)
+    R = rot([0, 1, 0.1], 0.05)
+    c2v = aff12(R, cam2vol[9:] + np.array([0.02, -0.01, 0.0], np.float32))
+    ri = np.linalg.inv(R).astype(np.float32).reshape(-1)
+    _raycast_both_variants_bit_exact(A, dev(vol), vol, voxel, trunc, c2v, ri, intr, W, H, 0.5)
+
+
+@pytest.mark.parametrize("dims,vox", [((50, 38, 44), (0.05, 0.06, 0.055)), ((96, 20, 33), (0.03, 0.12, 0.08))])
+def test_raycast_non_cubic_volume_and_anisotropic_voxels(A, dims, vox):
+    """the raycaster's per-axis voxel sizes, volume extents (`box_max = size - voxel` per axis) and gradient deltas on a
+    volume that is neither cubic nor isotropic, camera off-axis"""
+    X, Y, Z = dims
+    voxel = np.array(vox, np.float32)
+    trunc = float(max(0.04, 2.1 * voxel.max()))
+    W, H = 160, 120
+    intr = (131.25, 131.25, W / 2 - 0.5, H / 2 - 0.5)
+    size = voxel * np.array(dims, np.float32)
+    vol2cam = aff12(np.eye(3), np.array([-size[0] / 2, -size[1] / 2, 0.6], np.float32))
+    depth = synth.depth_frame(synth.CONFIGS["T0"], 3)
+    vol = np.zeros((Z, Y, X), np.uint32)
+    O.tsdf_integrate(vol, O.compute_dists(depth, *intr), voxel, trunc, 64, vol2cam, *intr, threads=8)
+    R = rot([0.2, 1, 0.1], 0.09)
+    c2v = aff12(R, -vol2cam[9:] + np.array([0.04, -0.03, 0.02], np.float32))
+    ri = np.linalg.inv(R).astype(np.float32).reshape(-1)
+    _raycast_both_variants_bit_exact(A, dev(vol), vol, voxel, trunc, c2v, ri, intr, W, H, 0.05)
+
+
 def test_raycast_miss_everywhere_on_empty_volume(A):
     import torch
     cfg, intr, voxel, trunc, _, cam2vol, rinv, _ = _scene("T0")

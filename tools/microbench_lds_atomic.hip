@@ -36,6 +36,11 @@ __global__ __launch_bounds__(NT) void k(int naddr, float* __restrict__ out, long
             else if (MODE == 4) ((volatile float*)mem)[o] = v;
             else if (MODE == 5) { float x = ((volatile float*)mem)[o]; ((volatile float*)mem)[o] = x + v; }
             else if (MODE == 6) acc += __int_as_float(atomicCAS((int*)mem + o, -1, lane));
+            else if (MODE == 7) acc += (float)((volatile uint8_t*)mem)[o * 4 + (lane & 3)];                       // ds_read_u8
+            else if (MODE == 8) ((volatile uint8_t*)mem)[o * 4 + (lane & 3)] = (uint8_t)lane;                      // ds_write_b8
+            else if (MODE == 9) { volatile uint16_t* h = (volatile uint16_t*)mem + 2 * o + (lane & 1); *h = (uint16_t)(*h + 1); }  // 16-bit read-modify-write
+            else if (MODE == 10) acc += ((volatile float*)mem)[o];                                                 // ds_read_b32
+            else if (MODE == 11) { float4 x; asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(x) : "v"((o & 127u) * 16u)); acc += x.x + x.w; }          // ds_read_b128
         }
     }
     __syncthreads();
@@ -49,12 +54,13 @@ int main() {
     long long* cyc;
     hipMalloc(&out, sizeof(float) * NT * 256);
     hipMalloc(&cyc, sizeof(long long) * 256);
-    const char* names[] = {"ds_add_f32", "ds_add_u32", "ds_add_u64", "ds_add_rtn_f32", "ds_write_b32", "read+add+write", "ds_cmpst_rtn_b32"};
+    const char* names[] = {"ds_add_f32", "ds_add_u32", "ds_add_u64", "ds_add_rtn_f32", "ds_write_b32", "read+add+write", "ds_cmpst_rtn_b32",
+                           "ds_read_u8", "ds_write_b8", "u16 read+add+write", "ds_read_b32", "ds_read_b128"};
     const int naddrs[] = {64, 32, 16, 8, 4, 2, 1};
     printf("cycles per wave instruction (4 waves of one workgroup per CU issuing back to back; 256 workgroups)\n%-18s", "addresses/instr:");
     for (int n : naddrs) printf("%8d", n);
     printf("\n");
-    for (int mode = 0; mode < 7; ++mode) {
+    for (int mode = 0; mode < 12; ++mode) {
         printf("%-18s", names[mode]);
         for (int n : naddrs) {
             auto launch = [&](int m) {
@@ -65,7 +71,12 @@ int main() {
                     case 3: k<3><<<256, NT>>>(n, out, cyc); break;
                     case 4: k<4><<<256, NT>>>(n, out, cyc); break;
                     case 5: k<5><<<256, NT>>>(n, out, cyc); break;
-                    default: k<6><<<256, NT>>>(n, out, cyc); break;
+                    case 6: k<6><<<256, NT>>>(n, out, cyc); break;
+                    case 7: k<7><<<256, NT>>>(n, out, cyc); break;
+                    case 8: k<8><<<256, NT>>>(n, out, cyc); break;
+                    case 9: k<9><<<256, NT>>>(n, out, cyc); break;
+                    case 10: k<10><<<256, NT>>>(n, out, cyc); break;
+                    default: k<11><<<256, NT>>>(n, out, cyc); break;
                 }
             };
             launch(mode);
