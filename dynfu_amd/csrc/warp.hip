@@ -438,6 +438,9 @@ __global__ __launch_bounds__(256) void pgrid_scan_kernel(const KnnGridDesc* __re
 template <int K, bool TIGHT = false>
 __device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32_t* __restrict__ cell_start,
                                                const float4* __restrict__ sorted, f3 q, KnnList<K>& best) {
+    // TIGHT scans the query's own cell twice (alone, then inside the 3 x 3 x 3 block): harmless for K = 1, where a repeated
+    // candidate cannot displace anything, but a K > 1 list would hold the same node twice
+    static_assert(!TIGHT || K == 1, "the tight stop bound re-scans the own cell: 1-NN only");
     best.init();
     int cx, cy, cz;
     cell_of(g, q, cx, cy, cz);
