@@ -417,6 +417,13 @@ __host__ __device__ inline FixedScale solve_fixed_scale(float w_reg_sq) {
     f.down = 1.0 / (double)f.up;
     return f;
 }
+// a node with more than 2^22 rows (a plan of millions of vertices on a handful of nodes) gives up one bit of the grid per
+// doubling of its list instead of overflowing
+__device__ __forceinline__ FixedScale fixed_scale_for_rows(FixedScale f, int rows) {
+    const int extra = 32 - __clz((unsigned)max(rows, 1) >> 22);  // 0 up to 2^22 - 1 rows
+    if (extra > 0) f.up = ldexpf(f.up, -extra), f.down = ldexp(f.down, extra);
+    return f;
+}
 __device__ __forceinline__ void fixed_add(long long* cell, float v, float up) {
     atomicAdd(reinterpret_cast<unsigned long long*>(cell), (unsigned long long)(long long)(v * up));  // (two's complement)
 }
@@ -506,6 +513,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
 #endif
 
     const int beg = s.node_ptr[a], end = s.node_ptr[a + 1];
+    fx = fixed_scale_for_rows(fx, end - beg);
     float gx = 0.f, gy = 0.f, gz = 0.f, dsum = 0.f;
     for (int p = beg + (int)threadIdx.x; p < end; p += 256) {
         const uint32_t e = s.node_list[p];
@@ -682,6 +690,7 @@ __global__ __launch_bounds__(256) void assemble_det_kernel(SolveView s, SolveSta
     if (threadIdx.x == 0) ovf = 0, nkeys = 0;
     __syncthreads();
     const int beg = s.node_ptr[a], end = s.node_ptr[a + 1];
+    fx = fixed_scale_for_rows(fx, end - beg);
     // pass 1: the set of columns (keys only), the gradient and the diagonal
     float gx = 0.f, gy = 0.f, gz = 0.f, dsum = 0.f;
     for (int p = beg + (int)threadIdx.x; p < end; p += 256) {

@@ -579,3 +579,32 @@ def test_deterministic_variant_is_bit_reproducible(A, name):
     ref = run(False)
     assert np.abs(ref[0][0] - t0).max() < 5e-5  # the same solution up to the default path's own scatter
     assert np.abs(t0 - t_true).max() < 2e-3
+
+
+def test_a_node_with_more_than_four_million_rows(A):
+    """the assembly's fixed-point sums (64-bit, 2^40 per unit of the addends' bound) hold up to 2^22 rows per node at full
+    resolution; a longer list gives up a bit of the grid per doubling instead of overflowing: 3 nodes, 4.6 M vertices
+    (1.5 M or more rows each, one of them > 2^22 with k = 3), translations against the float64 oracle"""
+    rng = np.random.default_rng(11)
+    D, k, N = 3, 3, 4_600_000
+    node_pos = np.array([[0.0, 0.0, 1.5], [0.06, 0.0, 1.5], [0.0, 0.07, 1.52]], np.float32)
+    node_w = np.full(D, 0.2, np.float32)
+    node_dq = np.zeros((D, 8), np.float32)
+    node_dq[:, 0] = 1.0
+    verts = (node_pos[rng.integers(0, D, N)] + rng.normal(0, 0.03, (N, 3))).astype(np.float32)
+    idx = O.knn(node_pos, verts, k, threads=8)
+    d2 = ((verts[:, None, :].astype(np.float64) - node_pos[idx].astype(np.float64)) ** 2).sum(-1)
+    w = np.exp(-d2 / (2 * 0.2 ** 2)).astype(np.float32)
+    t_true = np.array([[0.004, -0.002, 0.001], [-0.003, 0.002, 0.002], [0.001, 0.003, -0.002]], np.float32)
+    live = synth.live_vertices(verts, idx, w, t_true)
+    s = A.Solver(D, N, k)
+    keep = [dev(node_pos), dev(node_dq), dev(node_w), dev(verts), dev(live)]
+    s.set_problem(*keep)
+    s.solve(_params(A, num_iter=2, nonlinear_iter=1, linear_iter=60, lambda_=200.0, pcg_tol=1e-6))
+    t, st = host(s.translations()), s.stats()
+    t_ref, _, st_ref = O.solve_ref(node_pos, node_dq, node_w, k, verts, live, num_iter=2, nonlinear_iter=1, linear_iter=60,
+                                   lambda_=200.0, pcg_tol=1e-6, use_double=True, threads=8, tukey_offset=synth.SOLVER["tukey_offset"],
+                                   psi_data=synth.SOLVER["psi_data"], psi_reg=synth.SOLVER["psi_reg"])
+    assert np.isfinite(t).all() and np.abs(t - t_ref).max() <= 2e-5
+    np.testing.assert_allclose(st["final_cost"], st_ref["final_cost"], rtol=2e-3, atol=1e-9)
+    s.close()
