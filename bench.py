@@ -825,6 +825,14 @@ def other_configs(device):
     return out
 
 
+def under_profiler():
+    """rocprofv3 preloads a library that initialises the GPU before this program's first line runs: starting another
+    program from here would then be an exec from a process that has touched the GPU — what this pool forbids.  The children
+    of this script (the rank launcher, the DynFusion::operator() sequence) are skipped / refused under it."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    return "rocprof" in pre or any(k.startswith(("ROCPROFILER_", "ROCPROF_")) for k in os.environ)
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` outside torchrun: start N fresh rank processes of this very script (one per GPU, RANK /
     LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run would), wait for all of them, forward
@@ -917,6 +925,8 @@ def main_dry_run(args):
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if under_profiler():
+            raise SystemExit("bench.py --gpus N starts rank processes: not under rocprofv3 (profile one rank: --gpus 1)")
         return launch_ranks(args, sys.argv[1:])
     if args.dry_run:
         return main_dry_run(args)
@@ -931,7 +941,9 @@ def main():
     # process has made its first GPU call (torch.cuda.is_available() below is one), and has finished before the timed
     # region starts: nothing of it overlaps the measurement.
     e2e = None
-    if world == 1 and args.mode == "ref" and args.live == "targets" and not args.no_end_to_end:
+    if world == 1 and args.mode == "ref" and args.live == "targets" and not args.no_end_to_end and under_profiler():
+        e2e = dict(skipped="running under rocprofv3: no child process is started from a profiled process")
+    elif world == 1 and args.mode == "ref" and args.live == "targets" and not args.no_end_to_end:
         if torch.cuda.device_count() < 1:  # does not initialise the GPU
             raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
         try:
