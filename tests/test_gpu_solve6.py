@@ -498,3 +498,31 @@ def test_vertices_without_a_nearest_node_are_passed_through(A, name):
     assert s2.stats()["valid_first"] == st["valid_first"]
     assert np.abs(host(s2.node_dq()) - host(s.node_dq())).max() < 2e-5
     assert np.abs(host(s2.warp()[0]) - wv[good]).max() < 2e-5
+
+
+def test_one_plan_across_problems_of_different_size(A):
+    """the plan's captured PCG graphs are keyed by what they captured (the node count): a plan that alternates between
+    problems of different node / vertex counts — the adaptor's plan after a node insertion — gives, for each, exactly what a
+    fresh plan gives"""
+    cfg, c, intr, depth = _scene("T1", 5)
+    P, Nm = A.compute_points_normals(dev(depth), *intr)
+    kw = dict(num_iter=1, gn_iter=3, linear_iter=40, lambda_=200.0, pcg_tol=1e-3, pcg_tol_first=0.1, pcg_tol_decay=0.5)
+    problems = []
+    for D, step in ((cfg["D"], 1), (cfg["D"] - 37, 2), (cfg["D"], 1), (cfg["D"] // 2, 3)):
+        problems.append([dev(c["node_pos"][:D]), dev(c["node_dq"][:D]), dev(c["node_w"][:D]), dev(c["verts"][::step]),
+                         dev(c["normals"][::step])])
+    shared = A.Solver6(cfg["D"], len(c["verts"]), cfg["k"])
+    for prob in problems:
+        for adaptive in (0, 1):
+            shared.set_problem(*prob)
+            shared.solve(P, Nm, *intr, A.Solve6Params(adaptive_launch=adaptive, **kw))
+            got, st = host(shared.node_dq()).copy(), shared.stats()
+            fresh = A.Solver6(int(prob[0].shape[0]), int(prob[3].shape[0]), cfg["k"])
+            fresh.set_problem(*prob)
+            fresh.solve(P, Nm, *intr, A.Solve6Params(adaptive_launch=0, **kw))
+            want, st_f = host(fresh.node_dq()).copy(), fresh.stats()
+            fresh.close()
+            assert st["overflow"] == 0 and st["pcg_it_hist"] == st_f["pcg_it_hist"]
+            if st["pcg_short"] == 0:
+                assert np.array_equal(got, want)
+    shared.close()
