@@ -30,8 +30,8 @@ __device__ __forceinline__ bool spin_until(unsigned* p, unsigned want_ne_or_eq, 
     }
 }
 
-template <bool ONE_XCD>
-__global__ __launch_bounds__(256) void k(Ctl* c, int n, float* data, float* out, long long* cyc) {
+template <bool ONE_XCD, bool FLAGS = false>
+__global__ __launch_bounds__(256) void k(Ctl* c, int n, float* data, float* out, long long* cyc, unsigned* flags) {
     __shared__ unsigned me_sh, nmem_sh, ok_sh;
     const bool member = !ONE_XCD || xcc_id() == 0;
     if (threadIdx.x == 0) {
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k(Ctl* c, int n, float* data, float* out,
     float v = 0.f;
     const long long t0 = clock64();
     for (int i = 0; i < n; ++i) {
-        float* mine = data + (size_t)me * 256 + threadIdx.x;
+        float* mine = data + (size_t)(i & 1) * 256 * 256 + (size_t)me * 256 + threadIdx.x;
         if (ONE_XCD) {
             __hip_atomic_store(mine, v + 1.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the stores have left this CU (write-through L1)
@@ -56,6 +56,23 @@ __global__ __launch_bounds__(256) void k(Ctl* c, int n, float* data, float* out,
             *mine = v + 1.f;
         }
         __syncthreads();
+        if (FLAGS) {
+            // barrier without read-modify-writes: every member publishes its round in a word of its own; the first wave polls
+            // all of them with one load per lane (members <= 64)
+            if (threadIdx.x == 0) __hip_atomic_store(&flags[me * 16], (unsigned)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x < 64) {
+                long spins = 0;
+                for (;;) {
+                    const unsigned f = threadIdx.x < nmem ? __hip_atomic_load(&flags[threadIdx.x * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                    if (__all((int)(f >= (unsigned)(i + 1)))) break;
+                    if (++spins > (1L << 21)) {
+                        ok_sh = 0;
+                        __hip_atomic_store(&c->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+        } else
         if (threadIdx.x == 0) {
             if (!ONE_XCD) __atomic_thread_fence(__ATOMIC_RELEASE);  // agent scope: L2 write-back
             const unsigned gen = __hip_atomic_load(&c->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -69,7 +86,7 @@ __global__ __launch_bounds__(256) void k(Ctl* c, int n, float* data, float* out,
         }
         __syncthreads();
         if (!ok_sh) return;
-        const float* theirs = data + (size_t)((me + 1) % nmem) * 256 + threadIdx.x;
+        const float* theirs = data + (size_t)(i & 1) * 256 * 256 + (size_t)((me + 1) % nmem) * 256 + threadIdx.x;
         v += ONE_XCD ? __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *theirs;
         __syncthreads();  // (the next iteration overwrites `mine`: everybody must have read... the barrier of the next round orders it)
     }
@@ -84,19 +101,23 @@ int main(int argc, char** argv) {
     float *data, *out;
     long long* cyc;
     hipMalloc(&c, sizeof(Ctl));
-    hipMalloc(&data, sizeof(float) * 256 * blocks);
+    hipMalloc(&data, sizeof(float) * 2 * 256 * blocks);
+    unsigned* flags;
+    hipMalloc(&flags, sizeof(unsigned) * 16 * blocks);
     hipMalloc(&out, sizeof(float) * 256 * blocks);
     hipMalloc(&cyc, sizeof(long long) * blocks);
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
-    for (int one = 1; one >= 0; --one)
+    for (int one = 2; one >= 0; --one)
         for (int rep = 0; rep < 2; ++rep) {
             hipMemset(c, 0, sizeof(Ctl));
-            hipMemset(data, 0, sizeof(float) * 256 * blocks);
+            hipMemset(data, 0, sizeof(float) * 2 * 256 * blocks);
+            hipMemset(flags, 0, sizeof(unsigned) * 16 * blocks);
             hipMemset(out, 0, sizeof(float) * 256 * blocks);
             hipEventRecord(e0);
-            if (one) k<true><<<blocks, 256>>>(c, n, data, out, cyc);
-            else k<false><<<blocks, 256>>>(c, n, data, out, cyc);
+            if (one == 2) k<true, true><<<blocks, 256>>>(c, n, data, out, cyc, flags);
+            else if (one) k<true><<<blocks, 256>>>(c, n, data, out, cyc, flags);
+            else k<false><<<blocks, 256>>>(c, n, data, out, cyc, flags);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms;
@@ -110,7 +131,7 @@ int main(int argc, char** argv) {
             for (int i = 0; i < n && i < 30; ++i) expect += expect + 1;  // (doubles every round: only small n is checked exactly)
             if (rep)
                 printf("%s: members %u of %u workgroups, abort %u, %.3f us per iteration (kernel %.3f ms / %d)%s\n",
-                       one ? "one XCD, sc1 exchange, no L2 write-back / invalidate" : "all XCDs, agent-scope release / acquire",
+                       one == 2 ? "one XCD, flag barrier (no read-modify-write), sc1 exchange" : one ? "one XCD, atomic-counter barrier, sc1 exchange" : "all XCDs, agent-scope release / acquire",
                        h.members, h.seen, h.abort_flag, ms * 1e3 / n, ms, n, n <= 30 ? (o[0] == (float)expect ? "  values OK" : "  VALUES WRONG") : "");
         }
     return 0;
