@@ -424,8 +424,16 @@ __device__ __forceinline__ FixedScale fixed_scale_for_rows(FixedScale f, int row
     if (extra > 0) f.up = ldexpf(f.up, -extra), f.down = ldexp(f.down, extra);
     return f;
 }
+// The magnitude |v| up goes to `cell` (v >= 0: every data row) or to the cell HASH entries further on (v < 0: the
+// off-diagonal entries of regularisation rows); the sum is their difference.  Converting a NON-NEGATIVE integer-valued
+// float x to 64 bits takes 7 instructions — hi = floor(x / 2^32) and lo = x - hi 2^32 in [0, 2^32) are exact (a power-of-two
+// scaling; x with its high bits removed has no more significant bits than x), and the integer is the register pair
+// {lo, hi} — where the compiler's signed conversion takes 13 (absolute value, two floors, a sign fix-up with carries).
 __device__ __forceinline__ void fixed_add(long long* cell, float v, float up) {
-    atomicAdd(reinterpret_cast<unsigned long long*>(cell), (unsigned long long)(long long)(v * up));  // (two's complement)
+    const float x  = truncf(fabsf(v) * up);
+    const float hf = floorf(x * 2.3283064365386963e-10f);  // 2^-32
+    const uint32_t hi = (uint32_t)hf, lo = (uint32_t)fmaf(hf, -4294967296.f, x);
+    atomicAdd(reinterpret_cast<unsigned long long*>(v < 0.f ? cell + HASH : cell), ((unsigned long long)hi << 32) | lo);
 }
 
 // one row record = solve_rec_words(k) consecutive words (head: prepare_rows_kernel, tail: linearise_kernel)
@@ -491,7 +499,7 @@ extern "C" __attribute__((visibility("default"))) int dfa_dev_asm_timing(unsigne
 template <int K>
 __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* __restrict__ st, int save_base, FixedScale fx) {
     __shared__ int key[HASH];
-    __shared__ long long val[HASH];
+    __shared__ long long val[2 * HASH];  // [0, HASH): sums of the non-negative addends, [HASH, 2 HASH): of the negative ones' magnitudes
     __shared__ float gpart[4][3];
     __shared__ int wave_cnt[4];
     __shared__ int ovf;
@@ -505,7 +513,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
     long long t0_ = clock64(), t1_, t2_, t3_, t4_;
     const unsigned long long w0_ = wall_clock64();
 #endif
-    for (int i = threadIdx.x; i < HASH; i += 256) key[i] = -1, val[i] = 0ll;
+    for (int i = threadIdx.x; i < HASH; i += 256) key[i] = -1, val[i] = val[i + HASH] = 0ll;
     if (threadIdx.x == 0) ovf = 0;
     __syncthreads();
 #ifdef DFA_PCG_PROFILE
@@ -551,8 +559,13 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
                     dsum += v;
                     continue;
                 }
+                if (k0[j] == b) {  // the column is in the table where its first probe looks: nearly every pair after the first rows
+                    fixed_add(&val[h0[j]], v, fx.up);
+                    continue;
+                }
                 uint32_t h = h0[j];
                 int cur    = k0[j];
+#pragma unroll 1
                 for (int probes = 0;; ++probes) {
                     if (cur == -1) cur = atomicCAS(&key[h], -1, b), cur = cur == -1 ? b : cur;
                     if (cur == b) {
@@ -608,7 +621,8 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
     float diag = 0.f;
     for (int base = 0; base < PER_WAVE; base += 64) {
         const int kk     = key[wave * PER_WAVE + base + lane];
-        const float vv   = (float)((double)val[wave * PER_WAVE + base + lane] * fx.down);
+        const int hq     = wave * PER_WAVE + base + lane;
+        const float vv   = (float)((double)(val[hq] - val[hq + HASH]) * fx.down);
         const bool valid = kk >= 0;
         const uint64_t m = __ballot(valid);
         const int pos    = pos0 + __popcll(m & ((1ull << lane) - 1ull));
@@ -680,13 +694,13 @@ __global__ __launch_bounds__(256) void sort_node_lists_kernel(const int32_t* __r
 template <int K>
 __global__ __launch_bounds__(256) void assemble_det_kernel(SolveView s, SolveState* __restrict__ st, int save_base, FixedScale fx) {
     __shared__ int key[HASH];
-    __shared__ long long val[HASH];  // fixed-point sums (see FixedScale): integer adds commute, any order gives the same bits
+    __shared__ long long val[2 * HASH];  // fixed-point sums (see FixedScale, fixed_add): integer adds commute, any order gives the same bits
     __shared__ float gpart[4][3], dpart[4];
     __shared__ int ovf, nkeys;
     if (st->done || st->converged) return;
     const int a    = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < HASH; i += 256) key[i] = -1, val[i] = 0ll;
+    for (int i = threadIdx.x; i < HASH; i += 256) key[i] = -1, val[i] = val[i + HASH] = 0ll;
     if (threadIdx.x == 0) ovf = 0, nkeys = 0;
     __syncthreads();
     const int beg = s.node_ptr[a], end = s.node_ptr[a + 1];
@@ -776,7 +790,7 @@ __global__ __launch_bounds__(256) void assemble_det_kernel(SolveView s, SolveSta
         if (kk < 0) continue;
         int pos = 0;
         for (int q = 0; q < HASH; ++q) pos += key[q] >= 0 && key[q] < kk;
-        const float vv = kk == a ? dtot : (float)((double)val[i] * fx.down);
+        const float vv = kk == a ? dtot : (float)((double)(val[i] - val[i + HASH]) * fx.down);
         if (pos < s.ell_cap) s.ell[(size_t)pos * s.D + a] = make_float2(vv, __int_as_float(kk));
         if (kk == a) s.diag[a] = vv, has_diag = true;
     }
