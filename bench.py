@@ -106,6 +106,9 @@ def parse():
                     help="launcher / process-group check without a GPU: every rank sleeps instead of running frames, the line "
                          "carries the same contract fields (tests/test_bench_contract.py)")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--gn-tol", type=float, default=None,
+                    help="northstar: dfa_solve6_params.gn_tol (default 1e-3: stopping rule + step acceptance; 0: every "
+                         "Gauss-Newton iteration runs)")
     ap.add_argument("--no-adaptive-launch", action="store_true",
                     help="northstar: enqueue the full PCG launch budget of every Gauss-Newton iteration (A/B of "
                          "dfa_solve6_params.adaptive_launch)")
@@ -297,7 +300,10 @@ class Sequence:
 
 
 # inexact Newton with the Eisenstat-Walker forcing term (--forcing geometric: 0.1 x 0.5^i instead)
-NS_PCG = dict(pcg_tol=1e-3, pcg_tol_first=0.1, pcg_tol_decay=0.5, pcg_tol_adapt=0.9, adaptive_launch=1)
+# gn_tol: the Gauss-Newton stopping rule + step acceptance (dfa_solve6_params.gn_tol; the reference runs Opt with earlyOut =
+# true and nonLinearIter as a cap, src/dynfu/dyn_fusion.cpp:183-189) — `fixed_iterations` beside every north-star figure is
+# the same frame with gn_tol = 0 (every iteration runs, as rounds 1-4 measured it)
+NS_PCG = dict(pcg_tol=1e-3, pcg_tol_first=0.1, pcg_tol_decay=0.5, pcg_tol_adapt=0.9, adaptive_launch=1, gn_tol=1e-3)
 
 
 class Sequence6(Sequence):
@@ -471,14 +477,19 @@ def northstar_rooflines(seq, config, st, tm, fuse_ms):
     cfg = seq.cfg
     dim, Wd, Hd, k = cfg["dim"], cfg["width"], cfg["height"], seq.k
     V = dim ** 3
-    gn, nblk = max(1, tm["gn_iterations"]), tm["matrix_blocks"]
+    # (the event brackets cover every Gauss-Newton slot the host enqueued; the slots behind the end of an outer iteration are
+    # launches that return at entry: the averages are over the linearisations evaluated / the normal equations solved)
+    nblk = tm["matrix_blocks"]
+    stop = st["stop_hist"][:seq.gn_total]
+    gn_lin = max(1, sum(1 for c in stop if c != 3))
+    gn = max(1, sum(1 for c in stop if c == 0))
     launches = max(1, st["pcg_launches"])
     fuse_bytes = 4.0 * V + 2.0 * Wd * Hd
     kk = 4 if k <= 4 else 8
     lin_bytes = seq.N * (24 + 8 * k + 32) + seq.N * (48 + 4 * kk)
     asm_bytes = seq.N * k * (52 + 4 * kk) + seq.N * k * (1 + (k - 1) / 2.0) * 4 + nblk * 36 * 4
     pcg_bytes = nblk * (36 * 4 + 4 + 3 * 24) + 12 * 24.0 * seq.D
-    asm_ms, lin_ms, pcg_ms = tm["assemble_ms"] / gn, tm["linearise_ms"] / gn, tm["pcg_ms"] / launches
+    asm_ms, lin_ms, pcg_ms = tm["assemble_ms"] / gn, tm["linearise_ms"] / gn_lin, tm["pcg_ms"] / launches
 
     # SURVEY 8(d)'s own prices (what the PROBLEM needs, independent of this implementation's data flow): per Gauss-Newton
     # iteration N x (12 canonV + 12 normal + 12 liveV + 4 tau + 4 k idx) + D x 28 in — charged to the linearisation, which
@@ -509,7 +520,7 @@ def northstar_rooflines(seq, config, st, tm, fuse_ms):
                    "of its 8 x 8 moment; rows staged by LDS-DMA.  Bound by instruction issue and the per-workgroup chain of "
                    "barriers and round trips (SQ counters, phase clocks: DESIGN.md 4.5), not by HBM"),
         entry("s6_linearise_kernel<%d> (+ s6_nodes, s6_reg: residuals and row factors of one Gauss-Newton iteration)" % kk,
-              "s6_linearise", lin_ms, sv_lin, lin_bytes, gn, tm["linearise_ms"]),
+              "s6_linearise", lin_ms, sv_lin, lin_bytes, gn_lin, tm["linearise_ms"]),
         entry("s6_pcg_step_kernel (one Chronopoulos-Gear PCG iteration per launch)", "s6_pcg_step", pcg_ms, sv_pcg, pcg_bytes, launches,
               tm["pcg_ms"], matrix_blocks=nblk, launches_without_an_iteration=max(0, st["pcg_launches"] - st["pcg_iters"]),
               note="launch/latency-bound below ~2k nodes (two dependent memory round trips + the inter-kernel gap); a launch "
@@ -530,17 +541,58 @@ def northstar_rooflines(seq, config, st, tm, fuse_ms):
 
 
 def northstar_fields(seq, st):
-    return dict(gn_iterations=st["gn_iters"], pcg_iterations=st["pcg_iters"], pcg_iterations_per_gn=st["pcg_it_hist"],
+    # history slots: outer x gn_iter + gn (+ the closing check).  stop_hist 0: linearised and solved; 1: converged there; 2: the
+    # step before it was rejected there; 3: skipped.  cost_per_gn lists the ACCEPTED linearisations (0, 1) in order.
+    stop = st["stop_hist"]
+    solved = [i for i, c in enumerate(stop) if c == 0]
+    accepted = [i for i, c in enumerate(stop) if c in (0, 1)]
+    return dict(gn_iterations=st["gn_iters"], gn_solves=st["gn_solves"], gn_steps_rejected=st["gn_rejected"],
+                gn_outer_iterations_converged=st["gn_converged"], gn_tol=round(float(seq.params.gn_tol), 6),
+                gn_slots="".join("sCRx"[c] for c in stop) + "  (s solved, C converged, R step rejected and undone, x skipped; "
+                         "%d outer x %d%s)" % (seq.params.num_iter, seq.params.gn_iter, " + closing check" if seq.params.gn_tol > 0 else ""),
+                pcg_iterations=st["pcg_iters"], pcg_iterations_per_gn=[st["pcg_it_hist"][i] for i in solved],
                 pcg_iteration_cap=seq.params.linear_iter,
-                pcg_relative_residual_per_gn=[round(r, 5) for r in st["pcg_rel_hist"]],
-                pcg_tolerance_per_gn=[round(t, 5) for t in st["pcg_tol_hist"]],
+                pcg_relative_residual_per_gn=[round(st["pcg_rel_hist"][i], 5) for i in solved],
+                pcg_tolerance_per_gn=[round(st["pcg_tol_hist"][i], 5) for i in solved],
                 pcg_tolerance_schedule=("Eisenstat-Walker: %g first, then clamp(%g x (r.z)_0,i / (r.z)_0,i-1, %g, %g)" %
                                         (seq.pcg["pcg_tol_first"], seq.pcg["pcg_tol_adapt"], seq.pcg["pcg_tol"], seq.pcg["pcg_tol_first"])
                                         if seq.pcg.get("pcg_tol_adapt", 0) > 0 else
                                         "max(%g, %g x %g^i) at Gauss-Newton iteration i of an outer iteration" %
                                         (seq.pcg["pcg_tol"], seq.pcg["pcg_tol_first"], seq.pcg["pcg_tol_decay"])),
                 pcg_launches=st["pcg_launches"], pcgs_cut_short_by_the_launch_budget=st["pcg_short"],
-                valid_rows=st["valid_last"], cost_per_gn=[float("%.5g" % c) for c in st["cost_hist"]])
+                valid_rows=st["valid_last"], final_cost=float("%.5g" % st["final_cost"]),
+                cost_per_gn=[float("%.5g" % st["cost_hist"][i]) for i in accepted],
+                cost_of_rejected_steps=[float("%.5g" % st["cost_hist"][i]) for i, c in enumerate(stop) if c == 2],
+                cost_per_gn_by_outer_iteration=[[float("%.5g" % st["cost_hist"][i]) for i in accepted
+                                                 if i // seq.params.gn_iter == o and i < seq.gn_total]
+                                                for o in range(seq.params.num_iter)],
+                valid_rows_per_gn=[st["valid_hist"][i] for i in accepted],
+                cost_per_valid_row_per_gn=[float("%.4g" % (st["cost_hist"][i] / max(1, st["valid_hist"][i]))) for i in accepted])
+
+
+def northstar_fixed_iterations(seq, f0, device, steps, warmup=3):
+    """the same sequence with gn_tol = 0 — every Gauss-Newton iteration runs, what rounds 1-4 measured — beside the default
+    (stopping rule on).  The plan's launch budget restarts by itself when the stopping rule changes."""
+    import torch
+    A = seq.A
+    keep = seq.params
+    kw = {n: getattr(keep, n) for n, _ in keep._fields_}
+    kw["gn_tol"] = 0.0
+    seq.params = A.Solve6Params(**kw)
+    for f in range(warmup):
+        seq.frame(f0 + f)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for f in range(steps):
+        seq.frame(f0 + warmup + f)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    st = seq.solver.stats()
+    f = northstar_fields(seq, st)
+    seq.params = keep
+    return dict(value=round(steps / dt, 2), unit="frames/s", steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 4),
+                **{k: f[k] for k in ("gn_solves", "pcg_iterations", "pcg_launches", "final_cost", "cost_per_gn", "valid_rows_per_gn",
+                                     "cost_per_valid_row_per_gn")})
 
 
 def northstar_timed_frames(seq, f0, device, frames=5):
@@ -579,11 +631,12 @@ def northstar_probe(cfg_name, device, steps=30, warmup=8, cpu_frames=0):
     dt = time.perf_counter() - t0
     st, tm, fuse_ms = northstar_timed_frames(seq, warmup + steps, device)
     rl = northstar_rooflines(seq, cfg_name, st, tm, fuse_ms)
+    fixed = northstar_fixed_iterations(seq, warmup + steps + 5, device, max(5, steps // 2))
     out = dict(value=round(steps / dt, 2), unit="frames/s", steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 4),
-               workload="%s north-star mode: %d GN iterations x block-Jacobi PCG (inexact Newton), 6-DoF twists per node, DQ blend, "
-                        "projective point-to-plane data term against the live depth map, ARAP regulariser; same fuse"
-                        % (cfg_name, seq.gn_total),
-               solve=northstar_fields(seq, st), roofline=rl[0], roofline_other=rl[1:],
+               workload="%s north-star mode: at most %d GN iterations (stopping rule gn_tol = %g) x block-Jacobi PCG (inexact Newton), "
+                        "6-DoF twists per node, DQ blend, projective point-to-plane data term against the live depth map, ARAP "
+                        "regulariser; same fuse" % (cfg_name, seq.gn_total, seq.params.gn_tol),
+               solve=northstar_fields(seq, st), fixed_iterations=fixed, roofline=rl[0], roofline_other=rl[1:],
                note="parity unpinned (the reference has no such solve): checked against the fp64 statement oracle/solve6_oracle.c")
     params = seq.params
     del seq
@@ -603,6 +656,8 @@ def main_northstar(args, torch, replicas, rank, world, device):
         pcg["adaptive_launch"] = 0
     if args.forcing == "geometric":
         pcg["pcg_tol_adapt"] = 0.0
+    if args.gn_tol is not None:
+        pcg["gn_tol"] = args.gn_tol
     seq = Sequence6(args.config, device, lin, pcg)
     seq.fuse_first = args.fuse_first
     cfg = seq.cfg
@@ -630,10 +685,10 @@ def main_northstar(args, torch, replicas, rank, world, device):
                value=round(n_gpus * K / dt_max, 2), unit="frames/s", n_gpus=n_gpus, steps=K, warmup=Wm,
                ms_per_step=round(dt_max / K * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="f32", data="synthetic",
-               config=dict(workload="%s north-star mode: %d^3 TSDF, %dx%d depth, %d nodes, k=%d, %d vertices, %d GN "
-                                    "iterations x block-Jacobi PCG<=%d (inexact Newton: %s), 6-DoF DQ-blend / projective "
+               config=dict(workload="%s north-star mode: %d^3 TSDF, %dx%d depth, %d nodes, k=%d, %d vertices, at most %d GN "
+                                    "iterations (gn_tol = %g) x block-Jacobi PCG<=%d (inexact Newton: %s), 6-DoF DQ-blend / projective "
                                     "point-to-plane / ARAP energy, lambda=200"
-                                    % (args.config, dim, Wd, Hd, seq.D, seq.k, seq.N, seq.gn_total, lin,
+                                    % (args.config, dim, Wd, Hd, seq.D, seq.k, seq.N, seq.gn_total, seq.params.gn_tol, lin,
                                        northstar_fields(seq, st)["pcg_tolerance_schedule"]),
                            parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus, ranks_seen=n_gpus,
                            streams="serial" if args.serial else ("fuse || graph build + solve on two HIP streams" if args.fuse_first else
@@ -802,8 +857,12 @@ def config_probe(cfg_name, mode, device, steps=10, warmup=3, n_frames=6):
         st, tm, fuse_ms = northstar_timed_frames(seq, warmup + steps, device, frames=3)
         rl = northstar_rooflines(seq, cfg_name, st, tm, fuse_ms)
         f = northstar_fields(seq, st)
-        out.update(solve={k: f[k] for k in ("gn_iterations", "pcg_iterations", "pcg_launches", "pcgs_cut_short_by_the_launch_budget",
-                                            "valid_rows", "cost_per_gn")}, roofline=rl[0], roofline_other=rl[1:])
+        out.update(solve={k: f[k] for k in ("gn_iterations", "gn_solves", "gn_steps_rejected", "gn_outer_iterations_converged", "gn_tol",
+                                            "gn_slots", "pcg_iterations", "pcg_launches", "pcgs_cut_short_by_the_launch_budget",
+                                            "valid_rows", "final_cost", "cost_per_gn", "cost_of_rejected_steps", "valid_rows_per_gn",
+                                            "cost_per_valid_row_per_gn")},
+                   early_out=dict(value=out["value"], ms_per_step=out["ms_per_step"]),
+                   fixed_10=northstar_fixed_iterations(seq, warmup + steps + 3, device, steps), roofline=rl[0], roofline_other=rl[1:])
     else:
         st = seq.solver.stats()
         t_err = float((seq.solver.translations() - seq.t_true[(warmup + steps - 1) % seq.n_frames]).abs().max())

@@ -32,11 +32,11 @@ class Solve6Params(C.Structure):
     _fields_ = [("num_iter", C.c_int), ("gn_iter", C.c_int), ("linear_iter", C.c_int), ("tukey_offset", C.c_float),
                 ("psi_data", C.c_float), ("lambda_", C.c_float), ("psi_reg", C.c_float), ("dist_thresh", C.c_float),
                 ("cos_thresh", C.c_float), ("damping", C.c_float), ("pcg_tol", C.c_float), ("pcg_tol_first", C.c_float),
-                ("pcg_tol_decay", C.c_float), ("pcg_tol_adapt", C.c_float), ("adaptive_launch", C.c_int)]
+                ("pcg_tol_decay", C.c_float), ("pcg_tol_adapt", C.c_float), ("adaptive_launch", C.c_int), ("gn_tol", C.c_float)]
 
     DEFAULTS = dict(num_iter=2, gn_iter=3, linear_iter=100, tukey_offset=4.652, psi_data=0.01, lambda_=200.0,
                     psi_reg=1e-4, dist_thresh=0.1, cos_thresh=0.5, damping=1e-4, pcg_tol=1e-6, pcg_tol_first=0.0,
-                    pcg_tol_decay=1.0, pcg_tol_adapt=0.0, adaptive_launch=0)
+                    pcg_tol_decay=1.0, pcg_tol_adapt=0.0, adaptive_launch=0, gn_tol=0.0)
 
     def __init__(self, **kw):
         d = dict(self.DEFAULTS)
@@ -45,14 +45,16 @@ class Solve6Params(C.Structure):
 
 
 SOLVE6_HIST = 32  # DFA_SOLVE6_HIST
-ABI_VERSION = 4   # DFA_ABI_VERSION
+ABI_VERSION = 5   # DFA_ABI_VERSION
 
 
 class _Solve6Stats(C.Structure):
     _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("gn_iters", C.c_int), ("pcg_iters", C.c_int),
+                ("gn_solves", C.c_int), ("gn_rejected", C.c_int), ("gn_converged", C.c_int), ("hist_n", C.c_int),
                 ("valid_first", C.c_longlong), ("valid_last", C.c_longlong), ("max_row_blocks", C.c_int),
                 ("overflow", C.c_int), ("pcg_short", C.c_int), ("pcg_launches", C.c_int), ("cost_hist", C.c_double * SOLVE6_HIST), ("pcg_rel_hist", C.c_float * SOLVE6_HIST),
-                ("pcg_it_hist", C.c_int * SOLVE6_HIST), ("pcg_tol_hist", C.c_float * SOLVE6_HIST)]
+                ("pcg_it_hist", C.c_int * SOLVE6_HIST), ("pcg_tol_hist", C.c_float * SOLVE6_HIST),
+                ("valid_hist", C.c_longlong * SOLVE6_HIST), ("stop_hist", C.c_int * SOLVE6_HIST)]
 
 
 class _Solve6Timing(C.Structure):
@@ -709,8 +711,8 @@ class Solver6:
         st = _Solve6Stats()
         _check(load().dfa_solver6_get_stats(self._h, C.byref(st), _stream()))
         d = {n: getattr(st, n) for n, _ in _Solve6Stats._fields_}
-        n = min(st.gn_iters, SOLVE6_HIST)
-        for name in ("cost_hist", "pcg_rel_hist", "pcg_it_hist", "pcg_tol_hist"):
+        n = st.hist_n  # slots of the Gauss-Newton loop (gn_tol > 0: + the closing check), skipped ones included
+        for name in ("cost_hist", "pcg_rel_hist", "pcg_it_hist", "pcg_tol_hist", "valid_hist", "stop_hist"):
             d[name] = list(d[name])[:n]
         return d
 

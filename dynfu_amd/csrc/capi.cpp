@@ -196,7 +196,7 @@ struct dfa_solver6 {
     int slot_gn[S6_RING] = {};                    // Gauss-Newton iterations solve n enqueued
     unsigned long long solve_seq = 0, folded = 0;  // solves started; solves whose counts are in the history
     int pred[dfa::S6_HIST] = {};                  // iterations per Gauss-Newton iteration: raised at once, lowered by one per solve
-    struct BudgetKey { int D, N, num_iter, gn_iter, linear_iter; float tol, tol_first, tol_decay, tol_adapt; } budget_key = {};
+    struct BudgetKey { int D, N, num_iter, gn_iter, linear_iter; float tol, tol_first, tol_decay, tol_adapt, gn_tol; } budget_key = {};
     bool graph_disabled = false;
     hipStream_t capture_stream = nullptr;  // capture is not allowed on the legacy default stream
     bool timing = false;  // hipEvent brackets around linearise / assemble / PCG of every Gauss-Newton iteration
@@ -1042,6 +1042,7 @@ int dfa_solver6_create(int max_D, int max_N, int k, dfa_solver6** out) {
     A(rnode_ptr, D + 1);
     A(rnode_list, D * k + 1);  // (+ 1: the assembly reads one entry even of an empty list)
     A(dq, D * 8);
+    A(dq_prev, D * 8);
     A(ghat, D * 3);
     A(rec, N * (12 + (k <= 4 ? 4 : 8)));
     A(cost_part, (N + 255) / 256 + (D * k + 255) / 256 + 1);
@@ -1162,9 +1163,11 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
     REQUIRE(prm->pcg_tol_first <= 0.f || prm->pcg_tol_adapt > 0.f || (prm->pcg_tol_decay > 0.f && prm->pcg_tol_decay <= 1.f),
             "forcing decay outside (0, 1]");
     REQUIRE(prm->pcg_tol_adapt >= 0.f, "negative adaptive forcing factor");
+    REQUIRE(prm->gn_tol >= 0.f && prm->gn_tol < 1.f, "gn_tol outside [0, 1)");
     dfa::Solve6Params p{prm->num_iter, prm->gn_iter, prm->linear_iter, prm->tukey_offset, prm->psi_data, prm->lambda,
                         prm->psi_reg, prm->dist_thresh, prm->cos_thresh, prm->damping, prm->pcg_tol, prm->pcg_tol_first,
-                        prm->pcg_tol_decay, prm->pcg_tol_adapt};
+                        prm->pcg_tol_decay, prm->pcg_tol_adapt, prm->gn_tol};
+    const bool early = p.gn_tol > 0.f;
     dfa::Solve6Image img{live_vertex_map, live_normal_map, vertex_step, normal_step, cols, rows, fx, fy, cx, cy};
     hipStream_t st = S(stream);
     s->ev_used = 0;
@@ -1177,12 +1180,12 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
     const int slot         = (int)(n % dfa_solver6::S6_RING);
     if (adaptive) {
         const dfa_solver6::BudgetKey key{s->v.D, s->v.N, p.num_iter, p.gn_iter, p.linear_iter, p.pcg_tol, p.pcg_tol_first,
-                                         p.pcg_tol_decay, p.pcg_tol_adapt};
+                                         p.pcg_tol_decay, p.pcg_tol_adapt, p.gn_tol};
         const dfa_solver6::BudgetKey& old = s->budget_key;
         auto far = [](int a, int b) { return std::abs(a - b) * 8 > std::max(a, b); };  // changed by more than an eighth
         const bool reset = far(key.D, old.D) || far(key.N, old.N) || key.num_iter != old.num_iter || key.gn_iter != old.gn_iter ||
                            key.linear_iter != old.linear_iter || key.tol != old.tol || key.tol_first != old.tol_first ||
-                           key.tol_decay != old.tol_decay || key.tol_adapt != old.tol_adapt;
+                           key.tol_decay != old.tol_decay || key.tol_adapt != old.tol_adapt || key.gn_tol != old.gn_tol;
         s->budget_key = key;
         for (; s->folded + 2 <= n; ++s->folded) {
             const int fs = (int)(s->folded % dfa_solver6::S6_RING);
@@ -1190,7 +1193,10 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
             for (int gi = 0; gi < std::min(s->slot_gn[fs], dfa::S6_HIST); ++gi) {
                 const int seen = s->mirror[fs * dfa::S6_HIST + gi];
                 int& pred      = s->pred[gi];
-                if (seen > 0) pred = std::max(seen, pred - 1);
+                // (an iteration behind the end of its outer iteration ran no PCG: its budget decays like one that needed
+                // little — the launches enqueued for it are no-ops every time it is skipped again — but stays known)
+                if (seen == dfa::S6_MIRROR_SKIPPED) pred = pred > 1 ? pred - 1 : 1;  // (never back to 0 = unknown = the full cap)
+                else if (seen > 0) pred = std::max(seen, pred - 1);
                 else if (seen < 0) pred = std::max(pred, -2 * seen);  // cut short: twice as many
             }
         }
@@ -1227,8 +1233,12 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
                 }
                 (void)hipEventRecord(s->events[s->ev_used++], st);
             };
+            const int gi = outer * p.gn_iter + gn;
             mark();
             HIP_TRY(dfa::s6_linearise(s->v, s->state, img, p, gn == 0, st));
+            // gn_tol > 0: the stopping rule, decided on the device — launches behind the end of an outer iteration return
+            // at entry (nothing comes back to the host: the launches of the whole solve are enqueued regardless)
+            if (early) HIP_TRY(dfa::s6_decide(s->v, s->state, p, gi, gn, 0, st));
             mark();
             HIP_TRY(dfa::s6_assemble(s->v, s->state, p, gn, st));
             mark();
@@ -1236,7 +1246,6 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
             // plan's earlier solves (a maximum that decays by one per solve) plus a quarter, at least two.  (Measured at C2 /
             // C3 over 30-frame sequences: consecutive frames move a count by up to 2 where it is small and by up to a
             // quarter where it is 30-40; one launch of slack instead of two cut 1-2 PCGs short in a fifth of the frames.)
-            const int gi = outer * p.gn_iter + gn;
             int launches = p.linear_iter;
             if (adaptive && gi < dfa::S6_HIST && s->pred[gi] > 0)
                 launches = std::min(p.linear_iter, s->pred[gi] + std::max(2, s->pred[gi] / 4));
@@ -1271,8 +1280,15 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
             if (!replayed) HIP_TRY(dfa::s6_pcg_n(s->v, s->state, launches, st));
             s->last_launches += launches + 1;
             mark();
-            HIP_TRY(dfa::s6_update(s->v, s->state, launches, p.linear_iter, gi < dfa::S6_HIST ? mirror_slot : nullptr, st));
+            HIP_TRY(dfa::s6_update(s->v, s->state, launches, p.linear_iter, gi < dfa::S6_HIST ? mirror_slot : nullptr, gi, 1, st));
         }
+    if (early && p.num_iter * p.gn_iter > 0) {
+        // the last step of the solve, if its outer iteration ran to the cap: one closing linearisation decides whether it stays
+        const int gi = p.num_iter * p.gn_iter;
+        HIP_TRY(dfa::s6_linearise(s->v, s->state, img, p, 0, st));
+        HIP_TRY(dfa::s6_decide(s->v, s->state, p, gi, p.gn_iter, 1, st));
+        HIP_TRY(dfa::s6_update(s->v, s->state, 0, p.linear_iter, nullptr, gi, 0, st));
+    }
     if (mirror_slot) HIP_TRY(hipEventRecord(s->done_ev[slot], st));
     return DFA_OK;
 }
@@ -1319,12 +1335,15 @@ int dfa_solver6_get_stats(dfa_solver6* s, dfa_solve6_stats* out, dfa_stream_t st
     HIP_TRY(hipStreamSynchronize(S(stream)));
     out->initial_cost = h.initial_cost, out->final_cost = h.final_cost;
     out->gn_iters = h.gn_iters, out->pcg_iters = h.pcg_iters;
+    out->gn_solves = h.gn_solves, out->gn_rejected = h.gn_rejected, out->gn_converged = h.gn_converged, out->hist_n = h.hist_n;
     out->valid_first = (long long)h.valid_first, out->valid_last = (long long)h.valid_last;
     out->max_row_blocks = h.max_row_blocks, out->overflow = h.overflow;
     out->pcg_short = h.pcg_short, out->pcg_launches = s->last_launches;
     static_assert(DFA_SOLVE6_HIST == dfa::S6_HIST, "history length of the C ABI and of the state block");
     for (int i = 0; i < DFA_SOLVE6_HIST; ++i) {
-        const bool in = i < h.gn_iters;
+        const bool in = i < h.hist_n;
+        out->valid_hist[i] = in ? (long long)h.valid_hist[i] : 0ll;
+        out->stop_hist[i] = in ? h.stop_hist[i] : 0;
         out->cost_hist[i] = in ? h.cost_hist[i] : 0.0;
         out->pcg_rel_hist[i] = in ? h.pcg_rel_hist[i] : 0.f;
         out->pcg_tol_hist[i] = in ? h.pcg_tol_hist[i] : 0.f;

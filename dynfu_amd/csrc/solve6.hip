@@ -292,7 +292,8 @@ __device__ __forceinline__ double s6_reg_edge(const Solve6View& s, int e, float 
 // blocks [0, nlin): the data term, a lane per vertex; blocks from nlin on: the regulariser, a lane per edge
 template <int K>
 __global__ __launch_bounds__(256) void s6_linearise_kernel(Solve6View s, Solve6State* st, Solve6Image img,
-                                                           Solve6Params prm, int update_w, int nlin, float wreg2) {
+                                                           Solve6Params prm, int update_w, int nlin, float wreg2, int gate) {
+    if (gate && st->gn_stop) return;  // (uniform) the outer iteration has ended (s6_decide): nothing to linearise
     if ((int)blockIdx.x >= nlin) {  // (uniform)
         const int e = ((int)blockIdx.x - nlin) * 256 + (int)threadIdx.x;
         block_add_cost(e < s.D * s.k ? s6_reg_edge(s, e, wreg2, prm.psi_reg, update_w) : 0.0, 0u, s);
@@ -479,9 +480,59 @@ __device__ __forceinline__ void s6_bookkeeping(Solve6State* st, const S6Forcing 
     if (!st->have_first) st->initial_cost = st->cost, st->valid_first = st->valid, st->have_first = 1;
     st->final_cost = st->cost, st->valid_last = st->valid;
     const int h = st->gn_iters;
-    if (h < S6_HIST) st->cost_hist[h] = st->cost, st->pcg_it_hist[h] = 0, st->pcg_rel_hist[h] = 1.f, st->pcg_tol_hist[h] = sqrtf(f.tol2);
-    st->gn_iters = h + 1;
+    if (h < S6_HIST) {
+        st->cost_hist[h] = st->cost, st->pcg_it_hist[h] = 0, st->pcg_rel_hist[h] = 1.f, st->pcg_tol_hist[h] = sqrtf(f.tol2);
+        st->valid_hist[h] = (unsigned int)st->valid, st->stop_hist[h] = 0, st->hist_n = h + 1;
+    }
+    st->gn_iters = h + 1, st->gn_solves = h + 1, st->cur = h;
     st->tol2 = f.tol2, st->pcg_last_it = 0, st->pcg_done = 0;
+    st->ew_gamma = f.ew_gamma, st->ew_min2 = f.ew_min2, st->ew_max2 = f.ew_max2, st->ew_slot = f.ew_slot;
+}
+
+// gn_tol > 0: the launch between the linearisation and the assembly (one workgroup).  Energy of the linearisation, the
+// Gauss-Newton stopping rule (oracle/oracle.h: orc6_params.gn_tol states it; the reference runs Opt with earlyOut = true
+// and nonLinearIter as a cap, src/dynfu/dyn_fusion.cpp:183-189), the bookkeeping s6_bookkeeping does otherwise.  Decided
+// HERE and not by the assembly's extra workgroup because the assembly's other workgroups must already know: a launch
+// behind an ended outer iteration returns at entry.
+__global__ __launch_bounds__(256) void s6_decide_kernel(Solve6View s, Solve6State* st, const S6Forcing f, int gi, int gn,
+                                                        int closing, float gn_tol) {
+    const int tid = threadIdx.x;
+    const bool in = gi < S6_HIST;
+    if (gn > 0 && st->gn_stop) {  // (uniform) the outer iteration has ended
+        if (tid == 0) {
+            if (!closing && in) {
+                st->cost_hist[gi] = 0.0, st->valid_hist[gi] = 0u, st->pcg_it_hist[gi] = 0, st->pcg_rel_hist[gi] = 0.f;
+                st->pcg_tol_hist[gi] = 0.f, st->stop_hist[gi] = 3, st->hist_n = gi + 1;
+            }
+            st->cur = gi, st->pcg_done = 1, st->pcg_last_it = 0;
+        }
+        return;
+    }
+    s6_cost_total(s, st);  // (a barrier inside: every thread has read gn_stop before thread 0 writes it below)
+    if (tid != 0) return;
+    const double cost = st->cost;
+    const unsigned long long valid = st->valid;
+    if (!st->have_first) st->initial_cost = cost, st->valid_first = valid, st->have_first = 1;
+    int stop = 0;
+    if (gn > 0) {
+        const double ref = st->cost_ref;
+        if (cost > (1.0 + (double)gn_tol) * ref) stop = 2;                            // the step raised the energy: undone
+        else if (closing || ref - cost <= (double)gn_tol * ref) stop = 1;             // converged: kept, no further step
+    }
+    if (stop == 2) {
+        st->final_cost = st->cost_ref, st->valid_last = st->valid_ref, st->gn_rejected += 1;
+    } else {
+        st->final_cost = cost, st->valid_last = valid;
+        if (stop == 1) st->gn_converged += closing ? 0 : 1;
+        else st->cost_ref = cost, st->valid_ref = valid, st->gn_solves += 1;
+    }
+    if (in) {
+        st->cost_hist[gi] = cost, st->valid_hist[gi] = (unsigned int)valid, st->pcg_it_hist[gi] = 0;
+        st->pcg_rel_hist[gi] = stop ? 0.f : 1.f, st->pcg_tol_hist[gi] = stop ? 0.f : sqrtf(f.tol2), st->stop_hist[gi] = stop;
+        st->hist_n = gi + 1;
+    }
+    st->gn_iters += 1, st->cur = gi, st->gn_stop = stop;
+    st->tol2 = f.tol2, st->pcg_last_it = 0, st->pcg_done = stop != 0;
     st->ew_gamma = f.ew_gamma, st->ew_min2 = f.ew_min2, st->ew_max2 = f.ew_max2, st->ew_slot = f.ew_slot;
 }
 
@@ -898,10 +949,12 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
     // 0.150 at C3: not kept.)
     const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
     if (a == s.D) {  // one workgroup more than nodes: the energy of the linearisation this launch follows, the state block's bookkeeping
+        if (forcing.decided) return;  // (s6_decide has done both)
         s6_cost_total(s, st);
         if (tid == 0) s6_bookkeeping(st, forcing);
         return;
     }
+    if (forcing.decided && st->gn_stop) return;  // (uniform) the outer iteration has ended: no normal equations
     S6_TICK(tk0);
 #ifdef DFA_S6_TIMING
     const unsigned long long wk0 = wall_clock64();
@@ -1459,7 +1512,7 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK, DFA_S6_PCG_WAVES) void s6_
                 st->rz0_gn[slot] = gamma;
                 if (eg > 0.f && prev > 0.f) {
                     st->tol2 = tol2;
-                    const int h = st->gn_iters - 1;
+                    const int h = st->cur;
                     if (h >= 0 && h < S6_HIST) st->pcg_tol_hist[h] = sqrtf(tol2);
                 }
             }
@@ -1468,7 +1521,7 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK, DFA_S6_PCG_WAVES) void s6_
         if (!(gamma > 0.f) || gamma <= tol2 * rz0 || !(denom > 0.f)) {
             if (blockIdx.x == 0 && threadIdx.x == 0) {
                 st->pcg_done = 1;
-                const int h = st->gn_iters - 1;
+                const int h = st->cur;
                 if (h >= 0 && h < S6_HIST) st->pcg_rel_hist[h] = gamma > 0.f && rz0 > 0.f ? sqrtf(gamma / rz0) : 0.f;
             }
             return;
@@ -1479,7 +1532,7 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK, DFA_S6_PCG_WAVES) void s6_
             if (it == 0) st->rz0 = gamma;
             st->pcg_iters += 1;
             st->pcg_last_it = it + 1;
-            const int h = st->gn_iters - 1;
+            const int h = st->cur;
             if (h >= 0 && h < S6_HIST) st->pcg_it_hist[h] = it + 1;
         }
     }
@@ -1531,11 +1584,14 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK, DFA_S6_PCG_WAVES) void s6_
 
 // ------------------------------------------------------------------------------------ update
 __global__ __launch_bounds__(256) void s6_update_kernel(Solve6View s, Solve6State* st, int launched, int linear_iter,
-                                                        int* __restrict__ mirror) {
+                                                        int* __restrict__ mirror, int h, int apply) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
+    // Gauss-Newton control (written by s6_decide, by no thread of this launch): 0 = apply the step; 1 = the outer iteration
+    // has ended, nothing moves; 2 = ended by a rejected step: the transforms before that step come back (every update
+    // launch until the next outer iteration does this again: the same values)
+    const int stop = st->gn_stop;
+    if (blockIdx.x == 0 && threadIdx.x < 64 && apply) {
         // a PCG that used every launch it was given: its last (r, u) is still in the per-workgroup partials of the last launch
-        const int h    = st->gn_iters - 1;
         const bool ran = !st->pcg_done && launched > 0 && st->pcg_last_it == launched;  // (uniform)
         bool reached   = !ran;
         if (ran) {
@@ -1551,12 +1607,21 @@ __global__ __launch_bounds__(256) void s6_update_kernel(Solve6View s, Solve6Stat
             st->cost = 0.0, st->valid = 0ull;  // accumulators of the next linearisation
             const bool cut = !reached && launched < linear_iter;  // stopped by the plan's prediction, not by the caller's cap
             if (cut) st->pcg_short += 1;
-            if (mirror && h >= 0 && h < S6_HIST) mirror[h] = cut ? -st->pcg_last_it : st->pcg_last_it;
+            // (an iteration without a PCG — the outer iteration had ended — tells the launch budget so: S6_MIRROR_SKIPPED)
+            if (mirror && h >= 0 && h < S6_HIST) mirror[h] = stop ? S6_MIRROR_SKIPPED : cut ? -st->pcg_last_it : st->pcg_last_it;
         }
     }
     if (n >= s.D) return;
+    if (stop == 2) {
+        const DQ q = dq_load(s.dq_prev + 8 * (size_t)n);
+        dq_store(s.dq + 8 * (size_t)n, q);
+        s6_node_now(s, n, q);
+        return;
+    }
+    if (stop || !apply) return;
     const float* tw = s.x + 6 * (size_t)n;
     const DQ q      = dq_load(s.dq + 8 * (size_t)n);
+    dq_store(s.dq_prev + 8 * (size_t)n, q);
     const f3 gh     = mk3(s.ghat[3 * n], s.ghat[3 * n + 1], s.ghat[3 * n + 2]);
     const float th  = sqrtf(tw[0] * tw[0] + tw[1] * tw[1] + tw[2] * tw[2]);
     const float sc  = th > 1e-6f ? sinf(0.5f * th) / th : 0.5f;
@@ -1604,8 +1669,10 @@ __global__ __launch_bounds__(256) void s6_begin_kernel(Solve6View s, Solve6State
         st->valid = st->valid_first = st->valid_last = 0ull;
         st->have_first = 0, st->gn_iters = 0, st->pcg_iters = 0;  // overflow / max_row_blocks belong to the pattern
         st->pcg_done = 0, st->rz0 = 0.f, st->pcg_short = 0, st->rz0_gn[0] = st->rz0_gn[1] = 0.f;
+        st->cur = 0, st->hist_n = 0, st->gn_stop = 0, st->gn_solves = 0, st->gn_rejected = 0, st->gn_converged = 0;
+        st->cost_ref = 0.0, st->valid_ref = 0ull;
     }
-    if (i < 8 * s.D) s.dq[i] = node_dq[i];
+    if (i < 8 * s.D) s.dq[i] = node_dq[i], s.dq_prev[i] = node_dq[i];
     if (i < s.N) s.rho[i] = 0.f;
     if (i < s.D * s.k) s.rhub[i] = 1.f;
     if (i < s.D) s6_node_now(s, i, dq_load(node_dq + 8 * (size_t)i));
@@ -1683,13 +1750,14 @@ hipError_t s6_linearise(const Solve6View& s, Solve6State* state, const Solve6Ima
     // s6_begin / s6_update)
     const float wreg2 = p.lambda / ((float)s.D * (float)s.k);
     const int nlin = (s.N + 255) / 256, nreg = (s.D * s.k + 255) / 256;
-    K6DISPATCH(s6_linearise_kernel, s.k, <<<nlin + nreg, 256, 0, st>>>(s, state, img, p, update_weights, nlin, wreg2));
+    // gn_tol > 0: a linearisation that does not open an outer iteration is skipped once that iteration has ended
+    const int gate = p.gn_tol > 0.f && !update_weights;
+    K6DISPATCH(s6_linearise_kernel, s.k, <<<nlin + nreg, 256, 0, st>>>(s, state, img, p, update_weights, nlin, wreg2, gate));
     return hipGetLastError();
 }
 
-hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Params& p, int gn_in_outer, hipStream_t st) {
-    const float wreg2 = p.lambda / ((float)s.D * (float)s.k);
-    S6Forcing f{p.pcg_tol * p.pcg_tol, 0.f, 0.f, 0.f, gn_in_outer & 1};
+S6Forcing s6_forcing(const Solve6Params& p, int gn_in_outer) {
+    S6Forcing f{p.pcg_tol * p.pcg_tol, 0.f, 0.f, 0.f, gn_in_outer & 1, p.gn_tol > 0.f ? 1 : 0};
     if (p.pcg_tol_first > 0.f && p.pcg_tol_adapt > 0.f) {
         // adaptive: the first iteration of an outer iteration at pcg_tol_first (no previous gradient under these weights),
         // the others decided on the device; ew_gamma = 0 keeps the tolerance given here
@@ -1702,6 +1770,18 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
         const float eta = std::max(p.pcg_tol, e);
         f.tol2 = eta * eta;
     }
+    return f;
+}
+
+hipError_t s6_decide(const Solve6View& s, Solve6State* state, const Solve6Params& p, int gi, int gn_in_outer, int closing,
+                     hipStream_t st) {
+    s6_decide_kernel<<<1, 256, 0, st>>>(s, state, s6_forcing(p, gn_in_outer), gi, gn_in_outer, closing, p.gn_tol);
+    return hipGetLastError();
+}
+
+hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Params& p, int gn_in_outer, hipStream_t st) {
+    const float wreg2 = p.lambda / ((float)s.D * (float)s.k);
+    const S6Forcing f = s6_forcing(p, gn_in_outer);
     {
         // rows staged per pass (development builds: DFA_S6_RC for A/B): what fits in 28 KiB — with the static arrays 36 KiB,
         // four workgroups per CU
@@ -1748,8 +1828,9 @@ hipError_t s6_pcg_n(const Solve6View& s, Solve6State* state, int launches, hipSt
     return s6_pcg(s, state, p, st);
 }
 
-hipError_t s6_update(const Solve6View& s, Solve6State* state, int launched, int linear_iter, int* mirror, hipStream_t st) {
-    s6_update_kernel<<<(s.D + 255) / 256, 256, 0, st>>>(s, state, launched, linear_iter, mirror);
+hipError_t s6_update(const Solve6View& s, Solve6State* state, int launched, int linear_iter, int* mirror, int gi, int apply,
+                     hipStream_t st) {
+    s6_update_kernel<<<(s.D + 255) / 256, 256, 0, st>>>(s, state, launched, linear_iter, mirror, gi, apply);
     return hipGetLastError();
 }
 

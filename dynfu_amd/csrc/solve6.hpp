@@ -15,9 +15,13 @@ struct Solve6Params {
     // pcg_tol_adapt > 0: Eisenstat-Walker forcing (choice 2, alpha = 2) instead of the geometric schedule: iteration i > 0
     // of an outer iteration stops at clamp(pcg_tol_adapt (r.z)_0,i / (r.z)_0,i-1, pcg_tol, pcg_tol_first)
     float pcg_tol_adapt;
+    // > 0: Gauss-Newton stopping rule + step acceptance (include/dynfu_amd.h: dfa_solve6_params.gn_tol), decided on the
+    // device by s6_decide; <= 0: every iteration runs (the launches are those of the rounds before the rule existed)
+    float gn_tol;
 };
 
 constexpr int S6_HIST = 32;  // = DFA_SOLVE6_HIST of include/dynfu_amd.h
+constexpr int S6_MIRROR_SKIPPED = -(1 << 30);  // launch-budget mirror: the Gauss-Newton iteration ran no PCG (its outer iteration had ended)
 
 // Device-resident scalars of one solve
 struct Solve6State {
@@ -46,6 +50,16 @@ struct Solve6State {
     double cost_hist[S6_HIST];
     float pcg_rel_hist[S6_HIST];
     int pcg_it_hist[S6_HIST];
+    // ---- Gauss-Newton control (gn_tol > 0; all zero / unused otherwise)
+    int cur;             // history slot of the Gauss-Newton iteration in flight (gn_tol <= 0: gn_iters - 1)
+    int hist_n;          // history slots written
+    int gn_stop;         // 0: the outer iteration is running; 1: it has ended (converged); 2: it has ended by a rejected step —
+                         // every s6_update until the next outer iteration puts the transforms before that step back
+    int gn_solves, gn_rejected, gn_converged;
+    double cost_ref;     // energy at the last accepted linearisation of the outer iteration
+    unsigned long long valid_ref;
+    unsigned int valid_hist[S6_HIST];
+    int stop_hist[S6_HIST];  // 0 solved, 1 converged here, 2 rejected here, 3 skipped
 };
 
 struct Solve6Image {  // live vertex / normal maps (borrowed): float4 pixels, NaN where undefined
@@ -84,6 +98,7 @@ struct Solve6View {
     uint32_t* rnode_list;  // (node * k + slot) of the regularisation edges ARRIVING at a node
     // state of the iteration
     float* dq;    // D x 8  current node transforms
+    float* dq_prev;  // D x 8  the transforms before the last step (what a rejected step is undone with)
     float* ghat;  // D x 3  current node positions T_i(g_i)
     // linearisation
     // rows of the data term, one record per VERTEX: the row's 6-vector for neighbour j is f_j M_j l with the per-vertex
@@ -134,14 +149,22 @@ hipError_t s6_linearise(const Solve6View& s, Solve6State* state, const Solve6Ima
                         int update_weights, hipStream_t st);
 // gn_in_outer: index of the Gauss-Newton iteration inside its outer iteration (selects the PCG tolerance of the forcing schedule)
 hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Params& p, int gn_in_outer, hipStream_t st);
-struct S6Forcing {  // what the assembly launch leaves in the state block for the PCG that follows
+struct S6Forcing {  // what the assembly launch (gn_tol > 0: s6_decide) leaves in the state block for the PCG that follows
     float tol2, ew_gamma, ew_min2, ew_max2;
     int ew_slot;
+    int decided;  // s6_decide has done the bookkeeping of this linearisation: the assembly launch only assembles
 };
+S6Forcing s6_forcing(const Solve6Params& p, int gn_in_outer);
+// gn_tol > 0, between s6_linearise and s6_assemble: sums the energy, applies the stopping rule (gn_in_outer > 0; `closing`:
+// the check of the solve's last step — no iteration follows), does the state block's bookkeeping for history slot gi
+hipError_t s6_decide(const Solve6View& s, Solve6State* state, const Solve6Params& p, int gi, int gn_in_outer, int closing,
+                     hipStream_t st);
 hipError_t s6_pcg(const Solve6View& s, Solve6State* state, const Solve6Params& p, hipStream_t st);
 // launched: step launches enqueued for this PCG (<= linear_iter); mirror: pinned host int[S6_HIST] or null — iterations of
 // every PCG of the solve as the device finishes them, negative when the PCG used every launch without converging
-hipError_t s6_update(const Solve6View& s, Solve6State* state, int launched, int linear_iter, int* mirror, hipStream_t st);
+// gi: history slot (the mirror's too); apply = 0: the closing check's launch — a rejected step is undone, nothing is applied
+hipError_t s6_update(const Solve6View& s, Solve6State* state, int launched, int linear_iter, int* mirror, int gi, int apply,
+                     hipStream_t st);
 hipError_t s6_pcg_n(const Solve6View& s, Solve6State* state, int launches, hipStream_t st);
 hipError_t s6_warp(const Solve6View& s, const float* dq, float* out_v, float* out_n, hipStream_t st);
 hipError_t launch_points_normals(const uint16_t* depth, int depth_step, int cols, int rows, float fx, float fy, float cx,

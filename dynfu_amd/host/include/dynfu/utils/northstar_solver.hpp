@@ -33,6 +33,9 @@ struct NorthStarParameters {
     // enqueue only as many PCG launches per Gauss-Newton iteration as the previous frames needed (+ a quarter): see
     // dfa_solve6_params.adaptive_launch in dynfu_amd.h
     bool adaptiveLaunch = true;
+    // Gauss-Newton stopping rule + step acceptance (dfa_solve6_params.gn_tol): gnIter is a cap, as nonLinearIter is for the
+    // reference, which runs Opt with earlyOut = true (src/dynfu/dyn_fusion.cpp:183-189).  0: every iteration runs.
+    float gnTol = 1e-3f;
 };
 
 class NorthStarSolver {
@@ -57,6 +60,9 @@ public:
     int pcgIterations() const { return pcg_iters_; }
     /* PCGs of the last solveAll that stopped at the end of their adaptive launch budget instead of at their tolerance */
     int pcgsCutShort() const { return pcg_short_; }
+    /* normal equations solved / steps undone by the acceptance test in the last solveAll (gnTol > 0) */
+    int gnSolves() const { return gn_solves_; }
+    int gnRejected() const { return gn_rejected_; }
 
 private:
     Warpfield m_warpfield;  // copied by value, Nodes shared (as CombinedSolver, opt_solver.cpp:5)
@@ -68,4 +74,5 @@ private:
     long long valid_rows_ = 0;
     int pcg_iters_        = 0;
     int pcg_short_        = 0;
+    int gn_solves_ = 0, gn_rejected_ = 0;
 };

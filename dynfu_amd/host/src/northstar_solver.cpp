@@ -138,13 +138,14 @@ void NorthStarSolver::solveAll(const kfusion::cuda::Cloud& vmap, const kfusion::
     p.pcg_tol_decay = m_params.pcgTolDecay;
     p.pcg_tol_adapt = m_params.pcgTolAdapt;
     p.adaptive_launch = m_params.adaptiveLaunch ? 1 : 0;
+    p.gn_tol          = m_params.gnTol;
     dfa::check(dfa_solver6_solve(I.plan, (const float*)vmap.ptr(), (int)vmap.step(), (const float*)nmap.ptr(), (int)nmap.step(),
                                  vmap.cols(), vmap.rows(), intr.fx, intr.fy, intr.cx, intr.cy, &p, nullptr),
                "NorthStarSolver::solveAll");
     dfa_solve6_stats st;
     dfa::check(dfa_solver6_get_stats(I.plan, &st, nullptr), "NorthStarSolver::solveAll (stats)");  // synchronises
     initial_cost_ = st.initial_cost, final_cost_ = st.final_cost, valid_rows_ = st.valid_last, pcg_iters_ = st.pcg_iters;
-    pcg_short_ = st.pcg_short;
+    pcg_short_ = st.pcg_short, gn_solves_ = st.gn_solves, gn_rejected_ = st.gn_rejected;
     if (st.pcg_short > 0) {  // a PCG stopped where its launch budget ended (still a descent step); the plan doubles that budget
         static bool told = false;
         if (!told)

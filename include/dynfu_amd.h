@@ -56,7 +56,7 @@ const char* dfa_version(void);
  * DFA_ABI_VERSION changes whenever the layout of one of them does.  dfa_abi_version() is the value the LIBRARY was built
  * with, dfa_abi_struct_size(id) the sizeof it assumes (0 for an unknown id) — a caller built against another header, or a
  * binding that mirrors the structs by hand (dynfu_amd/_lib.py), compares both with its own before the first call. */
-#define DFA_ABI_VERSION 4
+#define DFA_ABI_VERSION 5
 enum {
     DFA_STRUCT_SOLVE_PARAMS  = 0, /* dfa_solve_params  */
     DFA_STRUCT_SOLVE_STATS   = 1, /* dfa_solve_stats   */
@@ -462,13 +462,28 @@ typedef struct dfa_solve6_params {
      * PCG that would have needed more is stopped where its launches end (a truncated PCG: still a descent step), counted
      * in dfa_solve6_stats.pcg_short, and its budget doubles.  0: always linear_iter launches. */
     int adaptive_launch;
+    /* Gauss-Newton stopping rule and step acceptance.  The reference runs Opt with earlyOut = true and nonLinearIter as a
+     * cap (src/dynfu/dyn_fusion.cpp:183-189, test/opt_optimisation_test.cpp:43); dfa_solve_params.gn_tol is the same switch
+     * of the reference-parity solve.  0: every outer iteration runs its gn_iter iterations.  > 0 (relative, below 1): with
+     * E_ref the energy at the last accepted linearisation of the outer iteration (weights frozen) and E the energy
+     * re-linearised after a step,
+     *     E > (1 + gn_tol) E_ref        the step is REJECTED: the transforms before it come back, the outer iteration ends;
+     *     E_ref - E <= gn_tol E_ref     CONVERGED: the step stays, the outer iteration ends without another solve;
+     *     otherwise                     E_ref = E and the iteration goes on;
+     * the last step of the solve, if its outer iteration ran to the cap, is checked by one closing linearisation (first
+     * test only).  Decided on the device (one small launch per linearisation); every launch of the solve is enqueued
+     * regardless and the ones behind the end of an outer iteration return at entry, so nothing waits for the host.
+     * What happened is reported per iteration in dfa_solve6_stats.stop_hist. */
+    float gn_tol;
 } dfa_solve6_params;
 
 #define DFA_SOLVE6_HIST 32
 
 typedef struct dfa_solve6_stats {
-    double initial_cost, final_cost; /* energy at the first / last linearisation */
-    int gn_iters, pcg_iters;
+    double initial_cost, final_cost; /* energy at the first / last (gn_tol > 0: last ACCEPTED) linearisation */
+    int gn_iters, pcg_iters;         /* linearisations evaluated; PCG iterations */
+    int gn_solves, gn_rejected, gn_converged; /* normal equations solved; steps undone; outer iterations ended by convergence */
+    int hist_n;                      /* slots of the histories below that are in use */
     long long valid_first, valid_last; /* data rows with a valid association and non-zero weight */
     int max_row_blocks, overflow;
     int pcg_short;    /* PCGs of this solve cut short by the adaptive launch budget (see dfa_solve6_params.adaptive_launch) */
@@ -480,6 +495,12 @@ typedef struct dfa_solve6_stats {
     float pcg_rel_hist[DFA_SOLVE6_HIST];
     int pcg_it_hist[DFA_SOLVE6_HIST];
     float pcg_tol_hist[DFA_SOLVE6_HIST]; /* the relative residual every PCG was asked for (the forcing term) */
+    /* slot = outer * gn_iter + gn (with gn_tol > 0, slot num_iter * gn_iter is the closing check).  valid_hist: data rows
+     * with an association and non-zero weight at that linearisation — cost_hist / valid_hist tells a fit that drifts from
+     * one that gains rows.  stop_hist: 0 linearised and solved; 1 converged here; 2 the step before it was rejected here
+     * (cost_hist holds the rejected energy); 3 skipped, the outer iteration had ended. */
+    long long valid_hist[DFA_SOLVE6_HIST];
+    int stop_hist[DFA_SOLVE6_HIST];
 } dfa_solve6_stats;
 
 int dfa_solver6_create(int max_D, int max_N, int k /* 1..8 */, dfa_solver6** out);

@@ -406,7 +406,8 @@ class Solve6Params(C.Structure):
     _fields_ = [("num_iter", C.c_int), ("gn_iter", C.c_int), ("linear_iter", C.c_int), ("tukey_offset", C.c_float),
                 ("psi_data", C.c_float), ("lambda_", C.c_float), ("psi_reg", C.c_float), ("dist_thresh", C.c_float),
                 ("cos_thresh", C.c_float), ("damping", C.c_float), ("pcg_tol", C.c_float), ("pcg_tol_first", C.c_float),
-                ("pcg_tol_decay", C.c_float), ("pcg_tol_adapt", C.c_float), ("threads", C.c_int)]
+                ("pcg_tol_decay", C.c_float), ("pcg_tol_adapt", C.c_float), ("threads", C.c_int), ("gn_tol", C.c_float),
+                ("reuse_matrix", C.c_int)]
 
 
 ORC6_HIST = 32
@@ -415,12 +416,14 @@ ORC6_HIST = 32
 class Solve6Stats(C.Structure):
     _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("gn_iters", C.c_int), ("pcg_iters", C.c_int),
                 ("valid_first", C.c_long), ("valid_last", C.c_long), ("cost_hist", C.c_double * ORC6_HIST),
-                ("pcg_rel_hist", C.c_double * ORC6_HIST), ("pcg_it_hist", C.c_int * ORC6_HIST), ("pcg_tol_hist", C.c_double * ORC6_HIST)]
+                ("pcg_rel_hist", C.c_double * ORC6_HIST), ("pcg_it_hist", C.c_int * ORC6_HIST), ("pcg_tol_hist", C.c_double * ORC6_HIST),
+                ("valid_hist", C.c_long * ORC6_HIST), ("stop_hist", C.c_int * ORC6_HIST), ("gn_solves", C.c_int),
+                ("gn_rejected", C.c_int), ("gn_converged", C.c_int), ("hist_n", C.c_int)]
 
 
 SOLVE6_DEFAULTS = dict(num_iter=2, gn_iter=3, linear_iter=100, tukey_offset=4.652, psi_data=0.01, lambda_=200.0,
                        psi_reg=1e-4, dist_thresh=0.1, cos_thresh=0.5, damping=1e-4, pcg_tol=1e-6, pcg_tol_first=0.0,
-                       pcg_tol_decay=1.0, pcg_tol_adapt=0.0, threads=1)
+                       pcg_tol_decay=1.0, pcg_tol_adapt=0.0, threads=1, gn_tol=0.0, reuse_matrix=0)
 
 
 def solve6_params(**kw):
@@ -514,8 +517,8 @@ def solve6(node_pos, node_dq, node_w, k, canon, canon_n, vmap, nmap, intr, **par
     st = Solve6Stats()
     lib6().orc6_solve(*args, _p(out), C.byref(st))
     d = {n: getattr(st, n) for n, _ in Solve6Stats._fields_}
-    n = min(st.gn_iters, ORC6_HIST)
-    for name in ("cost_hist", "pcg_rel_hist", "pcg_it_hist", "pcg_tol_hist"):
+    n = st.hist_n  # slots of the Gauss-Newton loop (gn_tol > 0: + the closing check), skipped ones included
+    for name in ("cost_hist", "pcg_rel_hist", "pcg_it_hist", "pcg_tol_hist", "valid_hist", "stop_hist"):
         d[name] = list(d[name])[:n]
     return out, d
 

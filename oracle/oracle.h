@@ -213,13 +213,27 @@ typedef struct {
      * loose once it stagnates (at the noise floor of the data) */
     float pcg_tol_adapt;
     int threads;
+    /* Gauss-Newton stopping rule and step acceptance (the reference runs Opt with earlyOut = true and nonLinearIter as a
+     * cap: src/dynfu/dyn_fusion.cpp:183-189, test/opt_optimisation_test.cpp:43).  gn_tol <= 0: every outer iteration runs
+     * its gn_iter iterations.  gn_tol > 0: with E_ref the energy at the last accepted linearisation of the outer iteration
+     * (weights frozen) and E the energy re-linearised after a step,
+     *     E > (1 + gn_tol) E_ref         the step is REJECTED: the transforms before it are restored, the outer iteration ends
+     *     E_ref - E <= gn_tol E_ref      CONVERGED: the step is kept, the outer iteration ends (no normal equations)
+     *     otherwise                      E_ref = E, the iteration goes on
+     * and the last step of the solve, if its outer iteration ran to the cap, is checked by one closing linearisation
+     * (rejected or kept by the first test). */
+    float gn_tol;
+    /* != 0: Gauss-Newton iterations >= 1 of an outer iteration keep the normal matrix and the preconditioner of
+     * iteration 0 and re-linearise residuals and gradient only (the pattern of the reference-parity solve's inner
+     * iterations: dynfu_amd/csrc/solve.hip regradient) */
+    int reuse_matrix;
 } orc6_params;
 
 #define ORC6_HIST 32
 
 typedef struct {
     double initial_cost; /* energy at the first linearisation                      */
-    double final_cost;   /* energy at the last linearisation                       */
+    double final_cost;   /* energy at the last (gn_tol > 0: last accepted) linearisation */
     int gn_iters, pcg_iters;
     long valid_first, valid_last; /* data rows with a valid association and non-zero weight */
     /* per Gauss-Newton iteration (the first ORC6_HIST): energy at its linearisation, PCG iterations it ran, and the
@@ -227,6 +241,12 @@ typedef struct {
     double cost_hist[ORC6_HIST], pcg_rel_hist[ORC6_HIST];
     int pcg_it_hist[ORC6_HIST];
     double pcg_tol_hist[ORC6_HIST]; /* the relative residual every PCG was asked for */
+    /* With gn_tol > 0 the histories are indexed by outer * gn_iter + gn (slot num_iter * gn_iter: the closing check);
+     * stop_hist: 0 linearised and solved, 1 converged here, 2 rejected here (cost_hist holds the rejected energy), 3 skipped
+     * (the outer iteration had ended).  gn_iters counts the linearisations evaluated, gn_solves the normal equations solved. */
+    long valid_hist[ORC6_HIST];
+    int stop_hist[ORC6_HIST];
+    int gn_solves, gn_rejected, gn_converged, hist_n;
 } orc6_stats;
 
 /* kfusion::device::computePointNormals (src/kfusion/cuda/imgproc.cu:187-215): float4 vertex and

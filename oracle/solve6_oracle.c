@@ -390,8 +390,26 @@ void orc6_solve(const float* node_pos, const float* node_dq_in, const float* nod
     memset(stats, 0, sizeof(*stats));
     int first = 1;
     double rz0_prev = 0;
-    for (int outer = 0; outer < prm->num_iter; ++outer) {
-        for (int gn = 0; gn < prm->gn_iter; ++gn) {
+    /* Gauss-Newton control (oracle.h: gn_tol): E_ref / the transforms before the last step / whether the outer iteration
+     * has ended.  Slot `total` of the loop is the closing check of the last step (gn_tol > 0 only). */
+    const int early = prm->gn_tol > 0, total = prm->num_iter * prm->gn_iter;
+    int stopped = 0;
+    double cost_ref = 0;
+    long valid_ref  = 0;
+    float* dq_prev  = (float*)malloc(sizeof(float) * 8 * (size_t)D);
+    memcpy(dq_prev, dq, sizeof(float) * 8 * (size_t)D);
+    {
+        for (int gi = 0; gi < total + early; ++gi) {
+            const int closing = gi == total;
+            const int gn      = closing ? prm->gn_iter : gi % prm->gn_iter; /* (closing: behaves as an iteration > 0) */
+            const int hist    = gi < ORC6_HIST ? gi : -1;
+            if (gn == 0) stopped = 0;
+            if (closing && (stopped || total == 0)) break;
+            if (hist >= 0) stats->hist_n = hist + 1;
+            if (stopped) {
+                if (hist >= 0) stats->stop_hist[hist] = 3;
+                continue;
+            }
             const int update_w = gn == 0;
             /* ---- linearise: data rows */
             double cost = 0;
@@ -468,16 +486,36 @@ void orc6_solve(const float* node_pos, const float* node_dq_in, const float* nod
             }
             cost += rcost;
             if (first) stats->initial_cost = cost, stats->valid_first = nvalid, first = 0;
-            stats->valid_last = nvalid;
-            const int hist = stats->gn_iters < ORC6_HIST ? stats->gn_iters : -1;
-            if (hist >= 0) stats->cost_hist[hist] = cost, stats->pcg_it_hist[hist] = 0, stats->pcg_rel_hist[hist] = 1.0;
+            if (hist >= 0)
+                stats->cost_hist[hist] = cost, stats->valid_hist[hist] = nvalid, stats->pcg_it_hist[hist] = 0,
+                stats->pcg_rel_hist[hist] = 1.0;
+            ++stats->gn_iters;
+            if (early && gn > 0) {
+                if (cost > (1.0 + (double)prm->gn_tol) * cost_ref) { /* the step raised the energy: undo it */
+                    memcpy(dq, dq_prev, sizeof(float) * 8 * (size_t)D);
+                    stopped = 1, ++stats->gn_rejected;
+                    if (hist >= 0) stats->stop_hist[hist] = 2;
+                    stats->final_cost = cost_ref, stats->valid_last = valid_ref;
+                    continue;
+                }
+                if (closing || cost_ref - cost <= (double)prm->gn_tol * cost_ref) { /* converged (closing: the step is kept) */
+                    stopped = 1, stats->gn_converged += !closing;
+                    if (hist >= 0) stats->stop_hist[hist] = 1;
+                    stats->final_cost = cost, stats->valid_last = nvalid;
+                    continue;
+                }
+            }
+            cost_ref = cost, valid_ref = nvalid;
+            stats->final_cost = cost, stats->valid_last = nvalid; /* energy at the last accepted linearisation */
+            ++stats->gn_solves;
+            const int build_H = !(prm->reuse_matrix && gn > 0); /* reuse_matrix: H, M^-1 of iteration 0 stay */
 
             /* (no PCG iterations asked for — orc6_cost: the energy is all that is wanted — no normal equations either) */
             if (prm->linear_iter <= 0) memset(x, 0, sizeof(double) * 6 * (size_t)D);
             else {
             /* ---- assemble H, g */
             for (int n = 0; n < D; ++n) {
-                memset(H[n].blk, 0, sizeof(double) * 36 * (size_t)H[n].ncol);
+                if (build_H) memset(H[n].blk, 0, sizeof(double) * 36 * (size_t)H[n].ncol);
                 memset(g + 6 * (size_t)n, 0, sizeof(double) * 6);
             }
             for (int v = 0; v < N; ++v) {
@@ -487,7 +525,7 @@ void orc6_solve(const float* node_pos, const float* node_dq_in, const float* nod
                     const int a = idx[(size_t)v * k + s];
                     if (a < 0 || wn[(size_t)v * k + s] == 0.f) continue;
                     for (int c = 0; c < 6; ++c) g[6 * (size_t)a + c] -= rho[v] * av[s * 6 + c] * res[v];
-                    for (int j = 0; j < k; ++j) {
+                    for (int j = 0; j < k && build_H; ++j) {
                         const int b = idx[(size_t)v * k + j];
                         if (b < 0 || wn[(size_t)v * k + j] == 0.f) continue;
                         double* blk = H[a].blk + 36 * (size_t)brow_find(&H[a], b, 0);
@@ -511,20 +549,21 @@ void orc6_solve(const float* node_pos, const float* node_dq_in, const float* nod
                         const double* an = vec + c * 6; /* node n's 6-vector of row c; node m's is -e_{3+c} */
                         for (int q = 0; q < 6; ++q) {
                             g[6 * (size_t)n + q] -= wt * an[q] * e[c];
+                            if (!build_H) continue;
                             for (int q2 = 0; q2 < 6; ++q2) Hnn[6 * q + q2] += wt * an[q] * an[q2];
                             Hnm[6 * q + 3 + c] -= wt * an[q];
                             Hmn[6 * (3 + c) + q] -= wt * an[q];
                         }
                         g[6 * (size_t)m + 3 + c] += wt * e[c];
-                        Hmm[6 * (3 + c) + 3 + c] += wt;
+                        if (build_H) Hmm[6 * (3 + c) + 3 + c] += wt;
                     }
                 }
-            for (int n = 0; n < D; ++n) {
+            for (int n = 0; n < D && build_H; ++n) {
                 double* Hd = H[n].blk + 36 * (size_t)brow_find(&H[n], n, 0);
                 for (int c = 0; c < 6; ++c) Hd[7 * c] += prm->damping;
             }
 
-            if (s_dump.gn == stats->gn_iters && s_dump.row_ptr) {
+            if (s_dump.gn == gi && s_dump.row_ptr) {
                 long nb = 0;
                 for (int n = 0; n < D; ++n) {
                     s_dump.row_ptr[n] = (int)nb;
@@ -597,15 +636,15 @@ void orc6_solve(const float* node_pos, const float* node_dq_in, const float* nod
             }
             }
             /* ---- update */
+            memcpy(dq_prev, dq, sizeof(float) * 8 * (size_t)D);
             for (int n = 0; n < D; ++n) {
                 float o[8];
                 orc6_apply_twist(node_pos + 3 * n, dq + 8 * (size_t)n, x + 6 * (size_t)n, o);
                 memcpy(dq + 8 * (size_t)n, o, sizeof(o));
             }
-            ++stats->gn_iters;
-            stats->final_cost = cost; /* cost at the last linearisation (before the last update) */
         }
     }
+    free(dq_prev);
     memcpy(node_dq_out, dq, sizeof(float) * 8 * (size_t)D);
     for (int n = 0; n < D; ++n) free(H[n].col), free(H[n].blk);
     free(H), free(g), free(x), free(r), free(z), free(pp), free(qq);

@@ -104,6 +104,13 @@ def test_bench_line_has_the_contract_fields():
     sv = ns["solve"]
     assert sv["cost_per_gn"][-1] < 0.05 * sv["cost_per_gn"][0] and sv["pcgs_cut_short_by_the_launch_budget"] == 0
     assert all(0 < n < sv["pcg_iteration_cap"] for n in sv["pcg_iterations_per_gn"])  # every PCG stopped by its tolerance
+    # the Gauss-Newton stopping rule (dfa_solve6_params.gn_tol, the reference's earlyOut): inside an outer iteration no
+    # accepted linearisation has a higher energy than the one before it (beyond gn_tol); the fixed-iteration run is beside it
+    assert sv["gn_tol"] > 0 and sv["gn_solves"] <= sv["gn_iterations"]
+    for costs in sv["cost_per_gn_by_outer_iteration"]:
+        assert all(b <= a * (1 + sv["gn_tol"]) * (1 + 1e-4) for a, b in zip(costs, costs[1:])), costs
+    fx = ns["fixed_iterations"]
+    assert fx["gn_solves"] >= sv["gn_solves"] and fx["value"] > 30.0 and sv["final_cost"] <= fx["final_cost"] * 1.02
     for e in [ns["roofline"]] + ns["roofline_other"]:
         for key in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms"):
             assert key in e, key

@@ -526,3 +526,125 @@ def test_one_plan_across_problems_of_different_size(A):
             if st["pcg_short"] == 0:
                 assert np.array_equal(got, want)
     shared.close()
+
+
+# ---------------------------------------------------------------- Gauss-Newton stopping rule + step acceptance
+_BENCH_PCG = dict(linear_iter=64, lambda_=200.0, pcg_tol=1e-3, pcg_tol_first=0.1, pcg_tol_adapt=0.9)
+
+
+def _accepted(st):
+    return [c for c, code in zip(st["cost_hist"], st["stop_hist"]) if code in (0, 1)]
+
+
+@pytest.mark.parametrize("name,frame,outer,gn", [("T1", 6, 2, 3), ("C2", 7, 1, 5), ("C3", 11, 2, 5)])
+def test_gn_stopping_rule_matches_the_oracle(A, name, frame, outer, gn):
+    """dfa_solve6_params.gn_tol (the reference runs Opt with earlyOut = true and nonLinearIter as a cap:
+    src/dynfu/dyn_fusion.cpp:183-189): with bench.py's own parameters at C2 (1 x 5) and C3 (2 x 5, Eisenstat-Walker forcing)
+    the HIP path takes the decisions of the fp64 statement slot by slot — solved / converged / rejected / skipped —, ends
+    on its energy, never lists an accepted linearisation above the one before it, and does no worse than the run that uses
+    every iteration."""
+    cfg, c, intr, depth = _scene(name, frame)
+    kw = dict(_BENCH_PCG, num_iter=outer, gn_iter=gn, gn_tol=1e-3)
+    s, dq, st, wv, wn_, dq_ref, st_ref = _solve_both(A, cfg, c, intr, depth, c["node_dq"], threads=_threads(), **kw)
+    assert st["overflow"] == 0
+    assert st["stop_hist"] == st_ref["stop_hist"], (st["stop_hist"], st_ref["stop_hist"], st["cost_hist"], st_ref["cost_hist"])
+    assert (st["gn_solves"], st["gn_rejected"], st["gn_converged"], st["gn_iters"]) == \
+           (st_ref["gn_solves"], st_ref["gn_rejected"], st_ref["gn_converged"], st_ref["gn_iters"])
+    assert st["gn_solves"] < outer * gn  # the rule has something to say on these frames
+    assert st["final_cost"] == pytest.approx(st_ref["final_cost"], rel=0.02)
+    assert st["valid_hist"][0] == st["valid_first"] and abs(st["valid_hist"][0] - st_ref["valid_hist"][0]) <= 1e-3 * st_ref["valid_hist"][0] + 2
+    for o in range(outer):
+        costs = [cst for i, (cst, code) in enumerate(zip(st["cost_hist"], st["stop_hist"])) if code in (0, 1) and i // gn == o and i < outer * gn]
+        assert all(b <= a * (1 + 1e-3) for a, b in zip(costs, costs[1:])), costs
+    assert st["final_cost"] == _accepted(st)[-1]
+    # skipped slots ran nothing
+    for i, code in enumerate(st["stop_hist"]):
+        if code != 0:
+            assert st["pcg_it_hist"][i] == 0
+    idx, wn, _ = O.graph6(c["node_pos"], c["node_w"], cfg["k"], c["verts"], threads=_threads())
+    p_ref, _ = O.warp6(dq_ref, idx, wn, c["verts"])
+    assert np.linalg.norm(wv - p_ref, axis=1).mean() < 5e-4
+    # against the run that uses every iteration: fewer solves, an energy (re-associated, fresh weights: the oracle's cost of
+    # the transforms each run returns) that is no higher
+    P, Nm = A.compute_points_normals(dev(depth), *intr)
+    s.solve(P, Nm, *intr, A.Solve6Params(**dict(kw, gn_tol=0.0)))
+    st_fix, dq_fix = s.stats(), host(s.node_dq())
+    assert st_fix["gn_solves"] == st_fix["gn_iters"] == outer * gn and st_fix["stop_hist"] == [0] * (outer * gn)
+    e_early, _ = O.cost6(c["node_pos"], dq, c["node_w"], cfg["k"], c["verts"], c["normals"], host(P), host(Nm), intr, lambda_=200.0, threads=_threads())
+    e_fix, _ = O.cost6(c["node_pos"], dq_fix, c["node_w"], cfg["k"], c["verts"], c["normals"], host(P), host(Nm), intr, lambda_=200.0, threads=_threads())
+    assert e_early <= 1.02 * e_fix, (e_early, e_fix)
+    s.close()
+
+
+def test_gn_rejected_step_is_undone_bit_for_bit(A):
+    """A rejected step leaves the transforms of the last accepted linearisation: the same bits as a solve that was only
+    given that many iterations.  A converged outer iteration keeps its last step: the bits of the solve that was given
+    exactly the iterations it used."""
+    cfg, c, intr, depth = _scene("C2", 7)
+    P, Nm = A.compute_points_normals(dev(depth), *intr)
+    s = A.Solver6(cfg["D"], len(c["verts"]), cfg["k"])
+    keep = [dev(c["node_pos"]), dev(c["node_dq"]), dev(c["node_w"]), dev(c["verts"]), dev(c["normals"])]
+    s.set_problem(*keep)
+    kw = dict(_BENCH_PCG, num_iter=1, gn_iter=5)
+    s.solve(P, Nm, *intr, A.Solve6Params(**kw, gn_tol=1e-3))
+    st, dq = s.stats(), host(s.node_dq()).copy()
+    assert 2 in st["stop_hist"], st["stop_hist"]  # this frame rejects a step (the oracle agrees: test above)
+    j = st["stop_hist"].index(2)  # slot of the rejected linearisation: j steps were applied, the last one undone
+    assert st["gn_solves"] == j and st["stop_hist"][j + 1:5] == [3] * (4 - j) and len(st["stop_hist"]) == 5
+    s.solve(P, Nm, *intr, A.Solve6Params(**dict(kw, gn_iter=j - 1)))  # j - 1 steps, every one kept
+    assert np.array_equal(host(s.node_dq()), dq)
+    st_short = s.stats()
+    assert st_short["cost_hist"] == st["cost_hist"][:j - 1]
+    # gn_tol = 0.5: the second linearisation is "converged" unless the energy halved — here the first step takes it down by
+    # more than that, the second does not
+    s.solve(P, Nm, *intr, A.Solve6Params(**kw, gn_tol=0.5))
+    st5 = s.stats()
+    assert st5["stop_hist"][:3] == [0, 0, 1] and st5["gn_converged"] == 1 and st5["gn_solves"] == 2
+    s.solve(P, Nm, *intr, A.Solve6Params(**dict(kw, gn_iter=2)))
+    dq2 = host(s.node_dq()).copy()
+    s.solve(P, Nm, *intr, A.Solve6Params(**kw, gn_tol=0.5))
+    assert np.array_equal(host(s.node_dq()), dq2)  # converged: both steps kept
+    s.close()
+
+
+def test_gn_closing_check_and_sequences(A):
+    """(a) An outer iteration that runs to its cap has its last step checked by a closing linearisation (one more history
+    slot); (b) a sequence of frames through one plan with the launch budget on gives the same bits whether or not the host
+    waits between solves, and the budget of the slots behind a stop decays instead of staying at the cap."""
+    cfg, c, intr, _ = _scene("T1", 6)
+    keep = [dev(c["node_pos"]), dev(c["node_dq"]), dev(c["node_w"]), dev(c["verts"]), dev(c["normals"])]
+    frames = [6, 6, 6, 7, 7, 7, 8, 8]
+    maps = {f: A.compute_points_normals(dev(synth.depth_frame(cfg, f)), *intr) for f in set(frames)}
+    # (a) one iteration per outer iteration: nothing to compare inside it, the closing slot decides about the last step
+    s = A.Solver6(cfg["D"], len(c["verts"]), cfg["k"])
+    s.set_problem(*keep)
+    s.solve(*maps[6], *intr, A.Solve6Params(**_BENCH_PCG, num_iter=1, gn_iter=1, gn_tol=1e-3))
+    st = s.stats()
+    assert len(st["stop_hist"]) == 2 and st["stop_hist"][0] == 0 and st["stop_hist"][1] in (1, 2) and st["gn_iters"] == 2
+    assert st["stop_hist"][1] == 1 and st["final_cost"] == st["cost_hist"][1] < 0.1 * st["cost_hist"][0]  # a first step from rest: kept
+    dq1 = host(s.node_dq()).copy()
+    s.solve(*maps[6], *intr, A.Solve6Params(**_BENCH_PCG, num_iter=1, gn_iter=1))
+    assert np.array_equal(host(s.node_dq()), dq1) and len(s.stats()["stop_hist"]) == 1
+    s.close()
+
+    # (b)
+    kw = dict(_BENCH_PCG, num_iter=2, gn_iter=4, gn_tol=1e-3, adaptive_launch=1)
+
+    def run(wait):
+        s = A.Solver6(cfg["D"], len(c["verts"]), cfg["k"])
+        s.set_problem(*keep)
+        out = []
+        for f in frames:
+            s.solve(*maps[f], *intr, A.Solve6Params(**kw))
+            if wait:
+                out.append(s.stats())
+        st, dq = s.stats(), host(s.node_dq()).copy()
+        s.close()
+        return out, st, dq
+
+    seq, st_w, dq_w = run(True)
+    _, st_a, dq_a = run(False)
+    assert np.array_equal(dq_w, dq_a) and st_w["pcg_launches"] == st_a["pcg_launches"] and st_w["stop_hist"] == st_a["stop_hist"]
+    assert all(x["gn_solves"] < 8 for x in seq)
+    # solves 0, 1: the full cap on every slot; from solve 2 on what the slots needed — the slots behind a stop next to nothing
+    assert seq[0]["pcg_launches"] == seq[1]["pcg_launches"] == 8 * 65 and all(x["pcg_launches"] < 8 * 65 // 3 for x in seq[2:])
