@@ -106,6 +106,11 @@ def parse():
                     help="launcher / process-group check without a GPU: every rank sleeps instead of running frames, the line "
                          "carries the same contract fields (tests/test_bench_contract.py)")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--dry-run-hang-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--no-rccl-selfcheck", action="store_true",
+                    help="N = 1: do not build the one-rank process group that exercises RCCL init / all-reduce / barrier")
+    ap.add_argument("--rank-timeout", type=float, default=3600.0,
+                    help="--gpus N outside torchrun: wall-clock limit of the rank processes in seconds")
     ap.add_argument("--gn-tol", type=float, default=None,
                     help="northstar: dfa_solve6_params.gn_tol (default 1e-3: stopping rule + step acceptance; 0: every "
                          "Gauss-Newton iteration runs)")
@@ -571,8 +576,10 @@ def northstar_fields(seq, st):
 
 
 def northstar_fixed_iterations(seq, f0, device, steps, warmup=3):
-    """the same sequence with gn_tol = 0 — every Gauss-Newton iteration runs, what rounds 1-4 measured — beside the default
-    (stopping rule on).  The plan's launch budget restarts by itself when the stopping rule changes."""
+    """the same frames (f0 + warmup .. f0 + warmup + steps: every frame starts from the canonical transforms, so a frame's
+    work does not depend on what ran before it) with gn_tol = 0 — every Gauss-Newton iteration runs, what rounds 1-4
+    measured — beside the default (stopping rule on).  The plan's launch budget restarts by itself when the stopping rule
+    changes."""
     import torch
     A = seq.A
     keep = seq.params
@@ -631,7 +638,7 @@ def northstar_probe(cfg_name, device, steps=30, warmup=8, cpu_frames=0):
     dt = time.perf_counter() - t0
     st, tm, fuse_ms = northstar_timed_frames(seq, warmup + steps, device)
     rl = northstar_rooflines(seq, cfg_name, st, tm, fuse_ms)
-    fixed = northstar_fixed_iterations(seq, warmup + steps + 5, device, max(5, steps // 2))
+    fixed = northstar_fixed_iterations(seq, warmup - 3, device, steps)
     out = dict(value=round(steps / dt, 2), unit="frames/s", steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 4),
                workload="%s north-star mode: at most %d GN iterations (stopping rule gn_tol = %g) x block-Jacobi PCG (inexact Newton), "
                         "6-DoF twists per node, DQ blend, projective point-to-plane data term against the live depth map, ARAP "
@@ -691,6 +698,7 @@ def main_northstar(args, torch, replicas, rank, world, device):
                                     % (args.config, dim, Wd, Hd, seq.D, seq.k, seq.N, seq.gn_total, seq.params.gn_tol, lin,
                                        northstar_fields(seq, st)["pcg_tolerance_schedule"]),
                            parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus, ranks_seen=n_gpus,
+                           rccl_selfcheck=rccl_selfcheck(),
                            streams="serial" if args.serial else ("fuse || graph build + solve on two HIP streams" if args.fuse_first else
                                                                  "graph build, then fuse || solve on two HIP streams"),
                            last_frame=northstar_fields(seq, st)),
@@ -700,7 +708,7 @@ def main_northstar(args, torch, replicas, rank, world, device):
         del seq
         torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline6(args.config, max(1, args.cpu_frames // 4), params)
-    print(json.dumps(out), flush=True)
+    emit(json.dumps(out))
     replicas.shutdown()
 
 
@@ -862,7 +870,7 @@ def config_probe(cfg_name, mode, device, steps=10, warmup=3, n_frames=6):
                                             "valid_rows", "final_cost", "cost_per_gn", "cost_of_rejected_steps", "valid_rows_per_gn",
                                             "cost_per_valid_row_per_gn")},
                    early_out=dict(value=out["value"], ms_per_step=out["ms_per_step"]),
-                   fixed_10=northstar_fixed_iterations(seq, warmup + steps + 3, device, steps), roofline=rl[0], roofline_other=rl[1:])
+                   fixed_10=northstar_fixed_iterations(seq, warmup - 3, device, steps), roofline=rl[0], roofline_other=rl[1:])
     else:
         st = seq.solver.stats()
         t_err = float((seq.solver.translations() - seq.t_true[(warmup + steps - 1) % seq.n_frames]).abs().max())
@@ -884,6 +892,28 @@ def other_configs(device):
     return out
 
 
+_LINE_OUT = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too — RCCL prints its version block through C stdio
+    when its communicator goes away, i.e. AFTER the line (seen on the first run of the one-rank self-check) — so this
+    process keeps the real stdout for the line alone and points file descriptor 1 at stderr for everything else."""
+    global _LINE_OUT
+    if _LINE_OUT is None:
+        sys.stdout.flush()
+        _LINE_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(line):
+    if _LINE_OUT is None:
+        print(line, flush=True)
+    else:
+        _LINE_OUT.write(line + "\n")
+        _LINE_OUT.flush()
+
+
 def under_profiler():
     """rocprofv3 preloads a library that initialises the GPU before this program's first line runs: starting another
     program from here would then be an exec from a process that has touched the GPU — what this pool forbids.  The children
@@ -897,28 +927,32 @@ def launch_ranks(args, argv):
     LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run would), wait for all of them, forward
     rank 0's JSON line and exit non-zero if any rank failed.  This parent never initialises the GPU (no torch import, no
     HIP call), and no process that has touched the GPU is ever re-executed: the children are new interpreters."""
-    import socket
     import subprocess
+    import tempfile
+    from dynfu_amd import replicas
     n = args.gpus
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
+    port = replicas._free_port()
+    procs, errs = [], []
+    errdir = tempfile.mkdtemp(prefix="dfa_bench_ranks_")
     for rank in range(n):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DFA_BENCH_LAUNCHED_BY="bench.py")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+        # ranks > 0: stderr into a file of their own (rank 0 keeps the terminal's), shown if the run fails
+        err = open(os.path.join(errdir, "rank%d.err" % rank), "w+") if rank > 0 else None
+        errs.append(err)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True))
-    # a rank that dies leaves the others in a barrier: poll, and end the rest as soon as one has failed
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, stderr=err, text=True))
+    # a rank that dies leaves the others in a barrier: poll, and end the rest as soon as one has failed — or when the
+    # wall-clock limit is over (a rank that hangs without failing would otherwise hold this parent for ever)
     failed, out0 = None, None
     pending = set(range(n))
     import threading
     buf = []
     reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
     reader.start()
+    deadline = time.monotonic() + args.rank_timeout
     while pending and failed is None:
         for r in sorted(pending):
             rc = procs[r].poll()
@@ -928,6 +962,8 @@ def launch_ranks(args, argv):
             if rc != 0:
                 failed = (r, rc)
                 break
+        if failed is None and pending and time.monotonic() > deadline:
+            failed = (min(pending), 124)
         time.sleep(0.05)
     if failed is not None:
         for r in pending:
@@ -937,7 +973,16 @@ def launch_ranks(args, argv):
                 procs[r].wait(timeout=10)
             except subprocess.TimeoutExpired:
                 procs[r].kill()
-        print("bench.py: rank %d of %d exited with code %d; no line is printed" % (failed[0], n, failed[1]), file=sys.stderr)
+        print("bench.py: rank %d of %d %s; no line is printed" %
+              (failed[0], n, "exited with code %d" % failed[1] if failed[1] != 124 or failed[0] not in pending
+               else "was still running after %.0f s (--rank-timeout)" % args.rank_timeout), file=sys.stderr)
+        for r, err in enumerate(errs):
+            if err is None:
+                continue
+            err.seek(0)
+            tail = err.read()[-1500:].strip()
+            if tail:
+                print("---- stderr of rank %d (%s):\n%s" % (r, err.name, tail), file=sys.stderr)
         raise SystemExit(failed[1] if 0 < failed[1] < 256 else 1)
     reader.join(timeout=30)
     out0 = buf[0] if buf else ""
@@ -950,13 +995,16 @@ def launch_ranks(args, argv):
 
 def ranks_seen(device=None):
     """number of live ranks of the process group, counted by an all-reduce (not read from the environment)"""
-    import torch
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
-        return 1
-    t = torch.ones(1, dtype=torch.int64, device=device if device is not None else "cpu")
-    dist.all_reduce(t)
-    return int(t.item())
+    from dynfu_amd import replicas
+    return replicas.count_ranks(device)
+
+
+def rccl_selfcheck():
+    """what the one-rank process group of an N = 1 run found (dynfu_amd/replicas.py: init(single_rank_group=True))"""
+    from dynfu_amd import replicas
+    return replicas.selfcheck if replicas.selfcheck is not None else dict(skipped="a process group of WORLD_SIZE ranks is in use"
+                                                                                 if int(os.environ.get("WORLD_SIZE", "1")) > 1
+                                                                                 else "--no-rccl-selfcheck")
 
 
 def main_dry_run(args):
@@ -964,18 +1012,22 @@ def main_dry_run(args):
     barrier-bracketed timed region and rank 0 prints a line with the contract's fields (tests only)."""
     from dynfu_amd import replicas
     rank, local, world = replicas.env_world()
-    replicas.init(backend=args.backend)
+    replicas.pin_to_core_slice(rank, world)
+    replicas.init(backend=args.backend, single_rank_group=not args.no_rccl_selfcheck)
     seen = ranks_seen()
     if rank == args.dry_run_fail_rank:
         os._exit(7)
+    if rank == args.dry_run_hang_rank:
+        time.sleep(1e6)
     K, Wm = args.steps, args.warmup
     dt_max = replicas.timed_region(lambda: time.sleep(0.02 * K))
     if rank == 0:
-        print(json.dumps(dict(metric="frames/sec (warp-solve + TSDF fuse), 512^3 vol / 2k nodes / VGA depth",
+        emit(json.dumps(dict(metric="frames/sec (warp-solve + TSDF fuse), 512^3 vol / 2k nodes / VGA depth",
                               value=round(seen * K / dt_max, 2), unit="frames/s", n_gpus=seen, steps=K, warmup=Wm,
                               ms_per_step=round(dt_max / K * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
                               dtype="f32", data="none (dry run: sleeps)",
                               config=dict(workload="dry run of the rank launcher (no GPU work)", ranks_seen=seen,
+                                          rccl_selfcheck=rccl_selfcheck(),
                                           parallelism="replicas x%d (one sequence per GPU, no collective; %d ranks counted by "
                                                       "all-reduce, backend %s)" % (seen, seen, args.backend)))), flush=True)
     replicas.shutdown()
@@ -987,12 +1039,15 @@ def main():
         if under_profiler():
             raise SystemExit("bench.py --gpus N starts rank processes: not under rocprofv3 (profile one rank: --gpus 1)")
         return launch_ranks(args, sys.argv[1:])
+    claim_stdout()  # (a rank process: from here on stdout carries the JSON line and nothing else)
     if args.dry_run:
         return main_dry_run(args)
     import torch
 
     from dynfu_amd import replicas
     rank, local, world = replicas.env_world()
+    if world > 1:
+        replicas.pin_to_core_slice(rank, world)  # a contiguous slice of the host's cores per rank (in-process)
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (without torchrun, `python bench.py --gpus N` starts the N ranks "
                          "itself)" % (args.gpus, world))
@@ -1003,7 +1058,7 @@ def main():
     if world == 1 and args.mode == "ref" and args.live == "targets" and not args.no_end_to_end and under_profiler():
         e2e = dict(skipped="running under rocprofv3: no child process is started from a profiled process")
     elif world == 1 and args.mode == "ref" and args.live == "targets" and not args.no_end_to_end:
-        if torch.cuda.device_count() < 1:  # does not initialise the GPU
+        if not os.path.exists("/dev/kfd"):  # (a file probe: nothing here may touch the GPU before the child has run)
             raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
         try:
             e2e = end_to_end(args.config)
@@ -1013,7 +1068,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    replicas.init(backend=args.backend, device=device)  # nccl = RCCL; only barriers, one MAX and one SUM all-reduce use it
+    # nccl = RCCL; only barriers, one MAX and one SUM all-reduce use it.  N = 1: a one-rank group runs the same calls
+    # (config.rccl_selfcheck), guarded so that a failure there costs the line nothing
+    replicas.init(backend=args.backend, device=device, single_rank_group=not args.no_rccl_selfcheck)
     n_gpus = ranks_seen(device)  # counted, not assumed
     if n_gpus != world:
         raise SystemExit("bench.py: %d ranks answered the all-reduce, WORLD_SIZE=%d" % (n_gpus, world))
@@ -1030,7 +1087,7 @@ def main():
             rec.update(metric="frames/sec (warp-solve + TSDF fuse), 512^3 vol / 2k nodes / VGA depth", value=round(n_gpus * K / dt_max, 2),
                        n_gpus=n_gpus, steps=K, warmup=args.warmup, ms_per_step=round(dt_max / K * 1e3, 4), higher_is_better=True,
                        scaling="weak", vs_baseline=None, dtype="f32", data="synthetic", config=dict(workload=rec.pop("workload")))
-            print(json.dumps(rec), flush=True)
+            emit(json.dumps(rec))
         replicas.shutdown()
         return
     seq = Sequence(args.config, device)
@@ -1151,6 +1208,7 @@ def main():
                                     "reference-parity energy (energy.t), "
                                     "lambda=200" % (args.config, dim, Wd, Hd, seq.D, seq.k, seq.N, cfg["gn_iters"]),
                            parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus, ranks_seen=n_gpus,
+                           rccl_selfcheck=rccl_selfcheck(),
                            streams="serial" if args.serial else ("fuse || graph build of frame f+1 || solve of frame f on three "
                                                                  "HIP streams, two solver plans" if args.pipeline else
                                                                  ("fuse || graph build + solve on two HIP streams" if args.fuse_first
@@ -1196,7 +1254,7 @@ def main():
             out["other_configs"] = other_configs(device)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_frames)
-    print(json.dumps(out), flush=True)
+    emit(json.dumps(out))
     replicas.shutdown()
 
 

@@ -16,18 +16,77 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend=None, device=None):
-    """Initialises the default process group when WORLD_SIZE > 1. Returns (rank, local, world)."""
+# What the single-rank self-check found (bench.py copies it into config.rccl_selfcheck): None = not attempted.
+selfcheck = None
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def init(backend=None, device=None, single_rank_group=False):
+    """Initialises the default process group when WORLD_SIZE > 1. Returns (rank, local, world).
+
+    single_rank_group: with WORLD_SIZE absent / 1 and the nccl (= RCCL) backend, build a ONE-rank process group anyway
+    (127.0.0.1, a free port, device_id) so that the N = 1 run drives the very calls the N > 1 run depends on — communicator
+    creation, a device-tensor all-reduce, the barriers of the timed region — and the first multi-GPU run is not the first RCCL
+    call of this code.  Nothing of it may cost the caller its measurement: every failure is caught and recorded in
+    `selfcheck` = {ok, init_ms, error}, and the run goes on without a group (as a single rank always could)."""
+    global selfcheck
     import torch.distributed as dist
     rank, local, world = env_world()
+    if backend is None:
+        backend = "nccl" if device is not None and device.type == "cuda" else "gloo"
     if world > 1 and not dist.is_initialized():
         kw = {}
-        if backend is None:
-            backend = "nccl" if device is not None and device.type == "cuda" else "gloo"
         if backend == "nccl" and device is not None:
             kw["device_id"] = device
         dist.init_process_group(backend, **kw)
+    elif world == 1 and single_rank_group and not dist.is_initialized() and dist.is_available():
+        import datetime
+        t0 = time.perf_counter()
+        selfcheck = dict(ok=False, backend=backend, init_ms=None, error=None)
+        try:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            kw = dict(rank=0, world_size=1, timeout=datetime.timedelta(seconds=120))
+            if backend == "nccl" and device is not None:
+                kw["device_id"] = device
+            dist.init_process_group(backend, **kw)
+            selfcheck["init_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+            selfcheck["ok"] = True
+        except Exception as e:  # noqa: BLE001 - a self-check must not take the run down
+            selfcheck["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+            _drop_group()
     return rank, local, world
+
+
+def _drop_group():
+    import torch.distributed as dist
+    try:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        pass
+
+
+def _single_rank_guard(fn, what):
+    """runs a collective of the one-rank self-check group; on failure records it, drops the group, returns False"""
+    global selfcheck
+    try:
+        fn()
+        return True
+    except Exception as e:  # noqa: BLE001
+        if selfcheck is not None:
+            selfcheck["ok"] = False
+            selfcheck["error"] = "%s in %s: %s" % (type(e).__name__, what, str(e)[:300])
+        _drop_group()
+        return False
 
 
 def assign_sequences(n_sequences, world, rank):
@@ -42,8 +101,13 @@ def barrier(device=None):
     """Barrier across ranks, then drain this rank's GPU (no-op pieces are skipped)."""
     import torch
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+    if dist.is_available() and dist.is_initialized():
+        if dist.get_world_size() > 1:
+            dist.barrier()
+        else:  # the one-rank self-check group: the same call, guarded
+            _single_rank_guard(dist.barrier, "barrier")
+            if selfcheck is not None and selfcheck.get("ok"):
+                selfcheck["barriers"] = selfcheck.get("barriers", 0) + 1
     if device is not None and device.type == "cuda":
         torch.cuda.synchronize(device)
 
@@ -58,10 +122,16 @@ def timed_region(fn, device=None):
     fn()
     barrier(device)
     dt = time.perf_counter() - t0
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         t = torch.tensor([dt], dtype=torch.float64, device=device if device is not None else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        if dist.get_world_size() > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        elif _single_rank_guard(lambda: dist.all_reduce(t, op=dist.ReduceOp.MAX), "all_reduce(MAX)"):
+            # (one rank: the maximum IS this rank's time — the reduced value is only checked, never used)
+            if selfcheck is not None:
+                selfcheck["max_allreduce_ok"] = bool(abs(float(t.item()) - dt) < 1e-12)
+                selfcheck["ok"] = selfcheck["ok"] and selfcheck["max_allreduce_ok"]
     return dt
 
 
@@ -70,7 +140,42 @@ def aggregate_throughput(units_per_rank, seconds_max, world):
     return world * units_per_rank / seconds_max
 
 
+def count_ranks(device=None):
+    """number of live ranks of the process group, counted by a SUM all-reduce of ones (not read from the environment);
+    1 without a group"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    t = torch.ones(1, dtype=torch.int64, device=device if device is not None else "cpu")
+    if dist.get_world_size() > 1:
+        dist.all_reduce(t)
+        return int(t.item())
+    if _single_rank_guard(lambda: dist.all_reduce(t), "all_reduce(SUM)") and selfcheck is not None:
+        selfcheck["ranks_seen"] = int(t.item())
+        selfcheck["ok"] = selfcheck["ok"] and selfcheck["ranks_seen"] == 1
+    return 1
+
+
+def pin_to_core_slice(rank, world):
+    """In-process CPU affinity of a rank: a contiguous slice of the cores this process may use (no `taskset`: a launcher
+    hop in front of a GPU program is what this pool forbids).  Returns the slice or None."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // world
+        if per < 1:
+            return None
+        mine = cores[rank * per:(rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        return mine
+    except (AttributeError, OSError):
+        return None
+
+
 def shutdown():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
-        dist.destroy_process_group()
+        if dist.get_world_size() > 1:
+            dist.destroy_process_group()
+        else:
+            _drop_group()
