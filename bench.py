@@ -1029,7 +1029,7 @@ def main_dry_run(args):
                               config=dict(workload="dry run of the rank launcher (no GPU work)", ranks_seen=seen,
                                           rccl_selfcheck=rccl_selfcheck(),
                                           parallelism="replicas x%d (one sequence per GPU, no collective; %d ranks counted by "
-                                                      "all-reduce, backend %s)" % (seen, seen, args.backend)))), flush=True)
+                                                      "all-reduce, backend %s)" % (seen, seen, args.backend)))))
     replicas.shutdown()
 
 
