@@ -748,16 +748,27 @@ def end_to_end(cfg_name, frames=14, skip=4):
     return out
 
 
-def cpu_baseline(cfg_name, frames):
+def host_cores():
+    """cores this process may run on (what `nproc` prints), and the machine's count"""
+    try:
+        return len(os.sched_getaffinity(0)), os.cpu_count() or 1
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1, os.cpu_count() or 1
+
+
+def cpu_baseline(cfg_name, frames, variants=True):
     """The CPU restatement (oracle/, kind "port": NOT Ceres, NOT the reference's CUDA path —
     neither exists for this path in a buildable form) timed on the host cores for `frames`
-    frames of the same workload."""
+    frames of the same workload.  SURVEY 8(d) asks for two figures — (a) a single thread, (b) OpenMP over all host cores
+    (`nproc` of this box, stated) —: both are in the record (`single_thread`, `all_cores`) beside the 16-thread figure the
+    line's `value` has carried since round 1 (the restatement's parallel regions are short — one per PCG iteration — so on a
+    many-core host more threads mostly add fork / join cost: `all_cores` shows by how much).  Also returns the oracle's node
+    translations of its last frame (a checker for the line's own solve of that frame)."""
     import oracle as O
     from dynfu_amd import synth
     cfg = synth.CONFIGS[cfg_name]
-    # OpenMP over at most 16 threads: the restatement's parallel regions are short (one per PCG
-    # iteration), on a many-core host more threads only add fork/join cost
-    threads = min(os.cpu_count() or 1, int(os.environ.get("DFA_CPU_THREADS", "16")))
+    usable, machine = host_cores()
+    threads = min(usable, int(os.environ.get("DFA_CPU_THREADS", "16")))
     fx, fy, cx, cy = synth.intrinsics(cfg)
     voxel, trunc, vol2cam, _, _ = synth.volume_params(cfg)
     dim, k = cfg["dim"], cfg["k"]
@@ -771,23 +782,39 @@ def cpu_baseline(cfg_name, frames):
     lives = [synth.live_vertices(c["verts"], idx, w, synth.true_translations(c["node_pos"], f, cfg["k"])) for f in range(frames)]
     O.tsdf_integrate(vol[:8], O.compute_dists(depths[0], fx, fy, cx, cy), voxel, trunc, 64, vol2cam, fx, fy, cx, cy,
                      threads=threads)  # warm the thread pool
-    t0 = time.perf_counter()
-    pcg = 0
-    for f in range(frames):
-        dists = O.compute_dists(depths[f], fx, fy, cx, cy)
-        O.lib().orc_tsdf_clear(vol.ctypes.data, dim, dim, dim)
-        O.tsdf_integrate(vol, dists, voxel, trunc, synth.MAX_WEIGHT, vol2cam, fx, fy, cx, cy, threads=threads)
-        _, dq, st = O.solve_ref(c["node_pos"], c["node_dq"], c["node_w"], k, c["verts"], lives[f],
-                                num_iter=cfg["gn_iters"], nonlinear_iter=1, linear_iter=256, pcg_tol=1e-6,
-                                use_double=False, threads=threads, **synth.SOLVER)
-        O.warp_to_live(c["node_pos"], dq, c["node_w"], k, c["verts"], c["normals"], threads=threads)
-        pcg += st["pcg_iters"]
-    dt = time.perf_counter() - t0
-    return dict(value=round(frames / dt, 4), unit="frames/s", cores=threads, kind="port",
-                sample="%d full frames of config %s (compute_dists, clear, integrate %d^3, k-NN graph, %d GN x PCG "
-                       "(%d PCG iterations in total), write-back, warpToLive) by the C restatement in oracle/, "
-                       "OpenMP over %d of the host's %d cores, fp32; %.1f s" % (frames, cfg_name, dim, cfg["gn_iters"],
-                                                                                pcg, threads, os.cpu_count() or 1, dt))
+
+    def run(nthreads, nframes):
+        t0 = time.perf_counter()
+        pcg, t_last = 0, None
+        for f in range(nframes):
+            dists = O.compute_dists(depths[f], fx, fy, cx, cy)
+            O.lib().orc_tsdf_clear(vol.ctypes.data, dim, dim, dim)
+            O.tsdf_integrate(vol, dists, voxel, trunc, synth.MAX_WEIGHT, vol2cam, fx, fy, cx, cy, threads=nthreads)
+            t_last, dq, st = O.solve_ref(c["node_pos"], c["node_dq"], c["node_w"], k, c["verts"], lives[f],
+                                         num_iter=cfg["gn_iters"], nonlinear_iter=1, linear_iter=256, pcg_tol=1e-6,
+                                         use_double=False, threads=nthreads, **synth.SOLVER)
+            O.warp_to_live(c["node_pos"], dq, c["node_w"], k, c["verts"], c["normals"], threads=nthreads)
+            pcg += st["pcg_iters"]
+        return time.perf_counter() - t0, pcg, t_last
+
+    dt, pcg, t_last = run(threads, frames)
+    out = dict(value=round(frames / dt, 4), unit="frames/s", cores=threads, kind="port",
+               sample="%d full frames of config %s (compute_dists, clear, integrate %d^3, k-NN graph, %d GN x PCG "
+                      "(%d PCG iterations in total), write-back, warpToLive) by the C restatement in oracle/, "
+                      "OpenMP over %d of the host's %d cores (%d usable by this process), fp32; %.1f s"
+                      % (frames, cfg_name, dim, cfg["gn_iters"], pcg, threads, machine, usable, dt),
+               host_cores=dict(nproc=usable, machine=machine))
+    if variants:
+        n1 = min(frames, 2)
+        dt1, _, _ = run(1, n1)
+        out["single_thread"] = dict(value=round(n1 / dt1, 4), unit="frames/s", cores=1, sample="%d frames, %.1f s" % (n1, dt1))
+        if usable != threads:
+            na = min(frames, 6)
+            dta, _, _ = run(usable, na)
+            out["all_cores"] = dict(value=round(na / dta, 4), unit="frames/s", cores=usable, sample="%d frames, %.1f s" % (na, dta))
+        else:
+            out["all_cores"] = dict(value=out["value"], unit="frames/s", cores=usable, sample="the 16-thread figure IS all cores here")
+    return out, t_last, frames - 1
 
 
 def raycast_probe(seq, config, reps=20):
@@ -881,8 +908,16 @@ def config_probe(cfg_name, mode, device, steps=10, warmup=3, n_frames=6):
     return out
 
 
-def other_configs(device):
+def other_configs(device, cpu=True):
     out = {}
+    # C1 IS the CPU-path configuration of BASELINE.json ("256^3, ~500 nodes, Ceres CPU solver"): its line carries the CPU
+    # restatement timed beside it (the umbrella sequence itself is not in the image: the same synthetic scene at C1's sizes)
+    try:
+        out["C1_ref"] = config_probe("C1", "ref", device, steps=20, warmup=5)
+        if cpu:
+            out["C1_ref"]["cpu_baseline"] = cpu_baseline("C1", 12)[0]
+    except Exception as e:  # noqa: BLE001
+        out["C1_ref"] = dict(error="%s: %s" % (type(e).__name__, e))
     for name in ("C3", "C4"):
         for mode in ("ref", "northstar"):
             try:
@@ -1234,12 +1269,20 @@ def main():
                 out["pipelined"] = pipelined_probe(seq, Wm + K, device)
             except Exception as e:  # noqa: BLE001
                 out["pipelined"] = dict(error="%s: %s" % (type(e).__name__, e))
+        # the frame the CPU baseline below ends on, solved here too: its translations are compared with the oracle's
+        t_cmp, f_cmp = None, args.cpu_frames - 1
+        if not args.no_cpu_baseline and not (args.pipeline or args.serial):
+            try:
+                seq.frame(f_cmp)
+                t_cmp = seq.solver.translations().cpu().numpy().copy()
+            except Exception:  # noqa: BLE001
+                t_cmp = None
         del seq
         torch.cuda.empty_cache()
         if not args.no_northstar:
             try:
                 out["northstar_mode"] = northstar_probe(args.config, device,
-                                                        cpu_frames=0 if args.no_cpu_baseline else max(1, args.cpu_frames // 8))
+                                                        cpu_frames=0 if args.no_cpu_baseline else max(1, args.cpu_frames // 4))
             except Exception as e:  # noqa: BLE001
                 out["northstar_mode"] = dict(error="%s: %s" % (type(e).__name__, e))
         if not args.no_live_depth:
@@ -1251,9 +1294,14 @@ def main():
         if e2e is not None:
             out["end_to_end"] = e2e
         if not args.no_other_configs and args.config == "C2":
-            out["other_configs"] = other_configs(device)
+            out["other_configs"] = other_configs(device, cpu=not args.no_cpu_baseline)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_frames)
+            out["cpu_baseline"], t_cpu, f_cpu = cpu_baseline(args.config, args.cpu_frames)
+            # the oracle's own answer for its last frame against this line's solve of that frame (t_cmp: above)
+            if t_cmp is not None and f_cpu == f_cmp:
+                out["config"]["max_abs_translation_diff_vs_oracle_m"] = float("%.3g" % np.abs(t_cmp - t_cpu).max())
+                out["config"]["oracle_check"] = ("frame %d solved by the HIP path and by oracle/solve_oracle (fp32 CPU restatement, the "
+                                                 "cpu_baseline leg): largest difference of a node translation component" % f_cmp)
     emit(json.dumps(out))
     replicas.shutdown()
 

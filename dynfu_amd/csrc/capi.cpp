@@ -756,7 +756,8 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
     if (rc == DFA_OK) rc = plan_alloc(s, &s->iters_total, 1);
     if (rc == DFA_OK && hipMemset(s->iters_total, 0, sizeof(long long)) != hipSuccess) rc = DFA_ERR_HIP;
     if (rc == DFA_OK && hipHostMalloc((void**)&s->host_flag, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) s->host_flag = nullptr;
-    if (rc == DFA_OK) rc = plan_alloc(s, &s->cost_partials, (R + 255) / 256 + 1);
+    // (per linearise workgroup, at most 1024 of them: its share of the energy; behind those its largest matrix addend)
+    if (rc == DFA_OK) rc = plan_alloc(s, &s->cost_partials, std::max<size_t>((R + 255) / 256 + 1, 1024) + 1024);
     if (rc == DFA_OK) rc = plan_alloc(s, &s->ticket, 64);
     if (rc == DFA_OK && hipMemset(s->ticket, 0, 64 * sizeof(unsigned int)) != hipSuccess)
         rc = fail(DFA_ERR_HIP, "hipMemset (ticket)");
@@ -822,7 +823,7 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
     REQUIRE(s->has_problem, "set_problem has not been called");
     REQUIRE(p->num_iter >= 0 && p->nonlinear_iter >= 0 && p->linear_iter >= 0, "negative iteration count");
     REQUIRE(p->tukey_offset > 0.f && p->psi_data > 0.f, "tukey_offset / psi_data must be positive");
-    REQUIRE(p->lambda >= 0.f, "lambda must be non-negative");
+    REQUIRE(p->lambda >= 0.f && std::isfinite(p->lambda), "lambda must be non-negative and finite");
     const dfa::SolveView& v = s->v;
     hipStream_t st          = S(stream);
     if (!s->just_reset) HIP_TRY(dfa::solve_reset(v, s->state, s->ticket, 64, st));  // (set_problem has just done it)

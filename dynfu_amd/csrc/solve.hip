@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256) void linearise_kernel(SolveView s, SolveState*
     }
     const size_t R = (size_t)s.N + (size_t)s.D * s.k;
     double c       = 0.0;
+    float amax     = 0.f;  // re-weighting linearisations: the largest addend tau w_a w_b any row brings to the normal matrix
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (size_t)gridDim.x * blockDim.x) {
         float tau;
         if (a.update_weights) {
@@ -266,9 +267,11 @@ __global__ __launch_bounds__(256) void linearise_kernel(SolveView s, SolveState*
                 const int nn = n[j] >= 0 ? n[j] : 0;
                 tx[j] = s.t[3 * nn], ty[j] = s.t[3 * nn + 1], tz[j] = s.t[3 * nn + 2];
             }
+            float wm = 0.f;
 #pragma unroll
             for (int j = 0; j < K; ++j)
-                if (n[j] >= 0) sx += w[j] * tx[j], sy += w[j] * ty[j], sz += w[j] * tz[j];
+                if (n[j] >= 0) sx += w[j] * tx[j], sy += w[j] * ty[j], sz += w[j] * tz[j], wm = fmaxf(wm, fabsf(w[j]));
+            amax = fmaxf(amax, tau * wm * wm);
         }
         const float ex = s.rb[3 * r] - sx, ey = s.rb[3 * r + 1] - sy, ez = s.rb[3 * r + 2] - sz;
         // tail of the packed row record (head = k ids + k weights, written once per frame)
@@ -276,7 +279,10 @@ __global__ __launch_bounds__(256) void linearise_kernel(SolveView s, SolveState*
         c += (double)tau * ((double)ex * ex + (double)ey * ey + (double)ez * ez);
     }
     c = wave_sum_all(c);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __shared__ float wmax[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c, wmax[threadIdx.x >> 6] = amax;
     __syncthreads();
     if (threadIdx.x == 0) {
         // publish the partial write-through (sc1) — no release fence, which would write back the
@@ -284,6 +290,9 @@ __global__ __launch_bounds__(256) void linearise_kernel(SolveView s, SolveState*
         // last arriver of each shard
         __hip_atomic_store(&cost_partials[blockIdx.x], (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+        if (a.update_weights)  // (the second half of the array: one maximum per workgroup)
+            __hip_atomic_store(&cost_partials[LIN_MAX_BLOCKS + blockIdx.x], (double)fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned int shard   = blockIdx.x % LIN_SHARDS;
         const unsigned int members = (gridDim.x - shard + LIN_SHARDS - 1) / LIN_SHARDS;
@@ -304,17 +313,21 @@ __global__ __launch_bounds__(256) void linearise_kernel(SolveView s, SolveState*
 
     // last workgroup: ordered sum of the partials + Gauss-Newton control
     __shared__ double sm[256];
-    double acc = 0.0;
-    for (unsigned int i = threadIdx.x; i < gridDim.x; i += 256)
+    __shared__ double smx[256];
+    double acc = 0.0, mx = 0.0;
+    for (unsigned int i = threadIdx.x; i < gridDim.x; i += 256) {
         acc += __hip_atomic_load(&cost_partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sm[threadIdx.x] = acc;
+        if (a.update_weights) mx = fmax(mx, __hip_atomic_load(&cost_partials[LIN_MAX_BLOCKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    sm[threadIdx.x] = acc, smx[threadIdx.x] = mx;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o], smx[threadIdx.x] = fmax(smx[threadIdx.x], smx[threadIdx.x + o]);
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         const double cost = sm[0];
+        if (a.update_weights) st->amax = (float)smx[0];
         if (!st->have_initial) st->initial_cost = cost, st->have_initial = 1;
         if (a.mode == 0) st->done = 0;
         // Gauss-Newton early-out: relative cost decrease of the previous step below gn_tol
@@ -401,20 +414,24 @@ constexpr int HASH_MASK = HASH - 1;
 // The hash's sums are 64-bit FIXED-POINT integers, not floats.  On gfx950 an LDS float add (ds_add_f32) executes one lane
 // after the other whatever the addresses — 192 cycles per wave instruction against 8 for ds_add_u64 without conflicts
 // (tools/microbench_lds_atomic.hip) — and 7 of them per row were 56 % of this kernel's time (C4: 345 -> 152 us with the adds
-// taken out).  An addend tau w_a w_b is a float of magnitude <= max(1, w_reg^2) (RBF weights <= 1, Tukey weights <= 1,
-// regularisation rows +-1 x w_reg^2); scaled by 2^40 / (that bound rounded up to a power of two) it is an exact integer
-// unless it is below 2^-17 of the bound (then it is cut to that grid: 2^-41 of the bound per addend).  The sum of up to
-// 2^22 rows fits 63 bits, is EXACT otherwise, and does not depend on the order of the adds.
+// taken out).  An addend tau w_a w_b is a float whose magnitude is at most `amax` = the largest tau (max_j |w_j|)^2 of any
+// row under the current robust weights (data rows: RBF and Tukey weights <= 1; regularisation rows: +-1 x w_reg^2) — found
+// by the linearisation that evaluates those weights (SolveState::amax), so the grid follows the PROBLEM's scale: weights
+// that are all tiny (sparse nodes, a narrow dg_w) or a huge lambda cost no bits.  Scaled by 2^40 / (amax rounded up to a
+// power of two) an addend is an exact integer unless it is below 2^-17 of that bound (then it is cut to the grid: 2^-41 of
+// the bound per addend).  The sum of up to 2^22 rows fits 63 bits, is EXACT otherwise, and does not depend on the order of
+// the adds.
 struct FixedScale {
     float up;     // float -> fixed: a power of two
     double down;  // fixed -> float
 };
-__host__ __device__ inline FixedScale solve_fixed_scale(float w_reg_sq) {
+__device__ __forceinline__ FixedScale solve_fixed_scale(float amax) {
     int e = 0;
-    while (e < 60 && (float)(1ull << e) < w_reg_sq) ++e;  // bound 2^e >= max(1, w_reg^2)
+    (void)frexpf(fmaxf(amax, 1e-30f), &e);  // amax < 2^e
+    e = e < -80 ? -80 : e > 100 ? 100 : e;
     FixedScale f;
-    f.up   = (float)(1ull << (40 - (e < 40 ? e : 40)));
-    f.down = 1.0 / (double)f.up;
+    f.up   = ldexpf(1.f, 40 - e);
+    f.down = ldexp(1.0, e - 40);
     return f;
 }
 // a node with more than 2^22 rows (a plan of millions of vertices on a handful of nodes) gives up one bit of the grid per
@@ -497,7 +514,7 @@ extern "C" __attribute__((visibility("default"))) int dfa_dev_asm_timing(unsigne
 #endif
 
 template <int K>
-__global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* __restrict__ st, int save_base, FixedScale fx) {
+__global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* __restrict__ st, int save_base) {
     __shared__ int key[HASH];
     __shared__ long long val[2 * HASH];  // [0, HASH): sums of the non-negative addends, [HASH, 2 HASH): of the negative ones' magnitudes
     __shared__ float gpart[4][3];
@@ -521,7 +538,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
 #endif
 
     const int beg = s.node_ptr[a], end = s.node_ptr[a + 1];
-    fx = fixed_scale_for_rows(fx, end - beg);
+    const FixedScale fx = fixed_scale_for_rows(solve_fixed_scale(st->amax), end - beg);
     float gx = 0.f, gy = 0.f, gz = 0.f, dsum = 0.f;
     for (int p = beg + (int)threadIdx.x; p < end; p += 256) {
         const uint32_t e = s.node_list[p];
@@ -692,7 +709,7 @@ __global__ __launch_bounds__(256) void sort_node_lists_kernel(const int32_t* __r
 }
 
 template <int K>
-__global__ __launch_bounds__(256) void assemble_det_kernel(SolveView s, SolveState* __restrict__ st, int save_base, FixedScale fx) {
+__global__ __launch_bounds__(256) void assemble_det_kernel(SolveView s, SolveState* __restrict__ st, int save_base) {
     __shared__ int key[HASH];
     __shared__ long long val[2 * HASH];  // fixed-point sums (see FixedScale, fixed_add): integer adds commute, any order gives the same bits
     __shared__ float gpart[4][3], dpart[4];
@@ -704,7 +721,7 @@ __global__ __launch_bounds__(256) void assemble_det_kernel(SolveView s, SolveSta
     if (threadIdx.x == 0) ovf = 0, nkeys = 0;
     __syncthreads();
     const int beg = s.node_ptr[a], end = s.node_ptr[a + 1];
-    fx = fixed_scale_for_rows(fx, end - beg);
+    const FixedScale fx = fixed_scale_for_rows(solve_fixed_scale(st->amax), end - beg);
     // pass 1: the set of columns (keys only), the gradient and the diagonal
     float gx = 0.f, gy = 0.f, gz = 0.f, dsum = 0.f;
     for (int p = beg + (int)threadIdx.x; p < end; p += 256) {
@@ -1582,9 +1599,9 @@ hipError_t solve_huber(const SolveView& s, float psi_reg, hipStream_t st) {
 }
 
 hipError_t solve_assemble(const SolveView& s, SolveState* state, int save_base, float w_reg_sq, hipStream_t st) {
-    const FixedScale fx = solve_fixed_scale(w_reg_sq);
-    if (s.deterministic) KDISPATCH(assemble_det_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base, fx));
-    else KDISPATCH(assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base, fx));
+    (void)w_reg_sq;  // (the rows carry it as their tau; the scale of the fixed-point sums comes from SolveState::amax)
+    if (s.deterministic) KDISPATCH(assemble_det_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base));
+    else KDISPATCH(assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base));
     return hipGetLastError();
 }
 
@@ -1909,7 +1926,10 @@ static bool mb_one_launch() { return dev_env_int("DFA_MB_FORM", 1) != 2; }
 // iterations [it0, it1): from the cache's graph of that range when there is (or can be) one, else launch by launch
 static hipError_t launch_mb_range(const SolveView& s, SolveState* state, int it0, int it1, float pcg_tol,
                                   MbGraphCache* gc, hipStream_t st) {
-    const int nb = solve_mb_blocks(s.D), nbu = (s.D + 255) / 256;
+    const int nb = solve_mb_blocks(s.D);
+#ifdef DFA_DEV_AB
+    const int nbu = (s.D + 255) / 256;
+#endif
     auto direct = [&](hipStream_t q) {
         for (int it = it0; it < it1; ++it) {
 #ifdef DFA_DEV_AB

@@ -35,6 +35,8 @@ struct SolveState {
     int cost_stale;  // t has moved since the last linearisation evaluated the cost (inner iterations restarted by
                      // solve_regradient): the closing evaluation must run even when the solve has converged
     float mb_rz0, mb_gamma_prev[2], mb_alpha_prev[2];
+    float amax;     // largest addend tau w_a w_b of the normal matrix under the current robust weights (the re-weighting
+                    // linearisation's last workgroup): the scale of the assembly's fixed-point sums
     long long prof[8];  // DFA_PCG_PROFILE builds: shader cycles per PCG phase (thread 0)
 };
 

@@ -176,6 +176,13 @@ def test_bench_line_has_the_contract_fields():
     assert cb6["kind"] == "port" and cb6["cores"] >= 1 and cb6["value"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    # single thread and all host cores (nproc stated) beside the 16-thread figure
+    assert cb["single_thread"]["cores"] == 1 and cb["single_thread"]["value"] > 0
+    assert cb["all_cores"]["cores"] == cb["host_cores"]["nproc"] >= 1 and cb["all_cores"]["value"] > 0
+    # the oracle's translations of the CPU sample's last frame against the HIP solve of the same frame
+    assert d["config"]["max_abs_translation_diff_vs_oracle_m"] <= 2e-5
+    c1 = d["other_configs"]["C1_ref"]  # BASELINE config 1 IS the CPU-path configuration: timed on both sides
+    assert c1["value"] > 30.0 and c1["cpu_baseline"]["value"] > 0 and c1["cpu_baseline"]["single_thread"]["cores"] == 1
     # the raycast, reported separately, priced by the work of its own rays
     rc = d["raycast"]
     assert rc["work"]["hits"] > 0.5 * 640 * 480 and rc["work"]["march_fetches"] > 10 * rc["work"]["hits"]
