@@ -88,7 +88,7 @@ def parse():
     ap.add_argument("--no-raycast", action="store_true", help="skip the raycast figures (SURVEY 8d: reported separately)")
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the DynFusion::operator() sequence (the reference's own timed region, C++ adaptor classes)")
-    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the bounded CPU sample")
+    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded CPU sample")
     ap.add_argument("--serial", action="store_true", help="run fuse and solve on one stream (A/B of the overlap)")
     ap.add_argument("--pipeline", action="store_true",
                     help="ref mode: build frame f+1's graphs (k-NN, transposition) on a third stream while frame f is "
@@ -707,7 +707,7 @@ def main_northstar(args, torch, replicas, rank, world, device):
         params = seq.params
         del seq
         torch.cuda.empty_cache()
-        out["cpu_baseline"] = cpu_baseline6(args.config, max(1, args.cpu_frames // 4), params)
+        out["cpu_baseline"] = cpu_baseline6(args.config, max(1, args.cpu_frames // 2), params)
     emit(json.dumps(out))
     replicas.shutdown()
 
@@ -809,7 +809,7 @@ def cpu_baseline(cfg_name, frames, variants=True):
         dt1, _, _ = run(1, n1)
         out["single_thread"] = dict(value=round(n1 / dt1, 4), unit="frames/s", cores=1, sample="%d frames, %.1f s" % (n1, dt1))
         if usable != threads:
-            na = min(frames, 6)
+            na = 1  # (one frame: on a 256-thread host the restatement is 30 x SLOWER on all cores than on 16 — measured, r05)
             dta, _, _ = run(usable, na)
             out["all_cores"] = dict(value=round(na / dta, 4), unit="frames/s", cores=usable, sample="%d frames, %.1f s" % (na, dta))
         else:
@@ -1037,6 +1037,10 @@ def ranks_seen(device=None):
 def rccl_selfcheck():
     """what the one-rank process group of an N = 1 run found (dynfu_amd/replicas.py: init(single_rank_group=True))"""
     from dynfu_amd import replicas
+    if replicas.selfcheck is not None and "collective_host_ms" not in replicas.selfcheck:
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device()) if replicas.selfcheck.get("backend") == "nccl" and torch.cuda.is_available() else None
+        replicas.selfcheck["collective_host_ms"] = replicas.time_collectives(dev)
     return replicas.selfcheck if replicas.selfcheck is not None else dict(skipped="a process group of WORLD_SIZE ranks is in use"
                                                                                  if int(os.environ.get("WORLD_SIZE", "1")) > 1
                                                                                  else "--no-rccl-selfcheck")
@@ -1282,7 +1286,7 @@ def main():
         if not args.no_northstar:
             try:
                 out["northstar_mode"] = northstar_probe(args.config, device,
-                                                        cpu_frames=0 if args.no_cpu_baseline else max(1, args.cpu_frames // 4))
+                                                        cpu_frames=0 if args.no_cpu_baseline else max(1, args.cpu_frames // 2))
             except Exception as e:  # noqa: BLE001
                 out["northstar_mode"] = dict(error="%s: %s" % (type(e).__name__, e))
         if not args.no_live_depth:

@@ -12,6 +12,7 @@ SYMBOLS = [
     "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_tsdf_raycast_tally", "dfa_tsdf_vertex_normals", "dfa_correspond_projective", "dfa_knn", "dfa_warp_to_live",
     "dfa_calc_dqb", "dfa_unsupported_vertices", "dfa_icp_sums", "dfa_repack_points", "dfa_compact_points", "dfa_transform_points", "dfa_warp_to_live_graph",
     "dfa_correspond", "dfa_marching_cubes", "dfa_mc_default_tables",
+    "dfa_tsdf_occupancy_bytes", "dfa_tsdf_clear_occ", "dfa_tsdf_integrate_occ", "dfa_tsdf_clear_integrate_occ", "dfa_marching_cubes_occ",
     "dfa_depth_bilateral_filter", "dfa_depth_truncate", "dfa_depth_build_pyramid", "dfa_compute_normals_mask_depth",
     "dfa_resize_depth_normals", "dfa_resize_points_normals",
     "dfa_compute_points_normals", "dfa_solver6_create", "dfa_solver6_destroy", "dfa_solver6_set_problem",
@@ -149,6 +150,11 @@ def load(path=None):
     integ = [vp, i, i, i, vp, i, i, i, vp, f, i, vp, f, f, f, f, vp]
     L.dfa_tsdf_integrate.argtypes = integ
     L.dfa_tsdf_clear_integrate.argtypes = integ
+    L.dfa_tsdf_integrate_occ.argtypes = integ[:-1] + [vp, vp]
+    L.dfa_tsdf_clear_integrate_occ.argtypes = integ[:-1] + [vp, vp]
+    L.dfa_tsdf_clear_occ.argtypes = [vp, i, i, i, vp, vp]
+    L.dfa_tsdf_occupancy_bytes.argtypes = [i, i, i]
+    L.dfa_tsdf_occupancy_bytes.restype = C.c_size_t
     ray = [vp, i, i, i, vp, f, vp, vp, f, f, f, f, f, f, vp, i, vp, i, i, i, vp]
     L.dfa_tsdf_raycast_points.argtypes = ray
     L.dfa_tsdf_raycast_depth.argtypes = ray
@@ -177,6 +183,7 @@ def load(path=None):
     L.dfa_solver6_enable_timing.argtypes = [vp, i]
     L.dfa_solver6_get_timing.argtypes = [vp, C.POINTER(_Solve6Timing), vp]
     L.dfa_marching_cubes.argtypes = [vp, i, i, i, vp, vp, vp, vp, i, vp, vp]
+    L.dfa_marching_cubes_occ.argtypes = [vp, vp, i, i, i, vp, vp, vp, vp, i, vp, vp]
     L.dfa_mc_default_tables.argtypes = [vp, vp]
     L.dfa_icp_sums.argtypes = [i, vp, i, vp, i, vp, i, vp, i, i, i, vp, f, f, f, f, f, f, vp, vp, vp]
     L.dfa_calc_dqb.argtypes = [vp, vp, vp, i, i, vp, i, vp, vp]
@@ -277,25 +284,43 @@ def _vol_dims(vol):
     return X, Y, Z
 
 
-def tsdf_clear(vol):
+def tsdf_occupancy(vol):
+    """a fresh occupancy map for `vol` (dfa_tsdf_occupancy_bytes; uint8 CUDA tensor (ceil(Z/8), ceil(Y/2), ceil(X/32)))"""
+    torch = _torch()
     X, Y, Z = _vol_dims(vol)
-    _check(load().dfa_tsdf_clear(_dev(vol), X, Y, Z, _stream()))
+    n = load().dfa_tsdf_occupancy_bytes(X, Y, Z)
+    shape = ((Z + 7) // 8, (Y + 1) // 2, (X + 31) // 32)
+    assert n == shape[0] * shape[1] * shape[2]
+    return torch.zeros(shape, dtype=torch.uint8, device=vol.device)
 
 
-def _integrate(fn, vol, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, cx, cy):
+def tsdf_clear(vol, occupancy=None):
+    X, Y, Z = _vol_dims(vol)
+    if occupancy is None:
+        _check(load().dfa_tsdf_clear(_dev(vol), X, Y, Z, _stream()))
+    else:
+        _check(load().dfa_tsdf_clear_occ(_dev(vol), X, Y, Z, _dev(occupancy, _torch().uint8, "occupancy"), _stream()))
+
+
+def _integrate(fn, vol, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, cx, cy, occupancy=None):
     torch = _torch()
     X, Y, Z = _vol_dims(vol)
     rows, cols = dists.shape
+    occ = () if occupancy is None else (_dev(occupancy, torch.uint8, "occupancy"),)
     _check(fn(_dev(dists, torch.uint16, "dists"), dists.stride(0) * 2, cols, rows, _dev(vol), X, Y, Z,
-              _farr(voxel_size, 3), trunc, max_weight, _aff12(vol2cam), fx, fy, cx, cy, _stream()))
+              _farr(voxel_size, 3), trunc, max_weight, _aff12(vol2cam), fx, fy, cx, cy, *occ, _stream()))
 
 
-def tsdf_integrate(vol, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, cx, cy):
-    _integrate(load().dfa_tsdf_integrate, vol, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, cx, cy)
+def tsdf_integrate(vol, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, cx, cy, occupancy=None):
+    L = load()
+    _integrate(L.dfa_tsdf_integrate if occupancy is None else L.dfa_tsdf_integrate_occ, vol, dists, voxel_size, trunc, max_weight,
+               vol2cam, fx, fy, cx, cy, occupancy)
 
 
-def tsdf_clear_integrate(vol, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, cx, cy):
-    _integrate(load().dfa_tsdf_clear_integrate, vol, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, cx, cy)
+def tsdf_clear_integrate(vol, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, cx, cy, occupancy=None):
+    L = load()
+    _integrate(L.dfa_tsdf_clear_integrate if occupancy is None else L.dfa_tsdf_clear_integrate_occ, vol, dists, voxel_size, trunc,
+               max_weight, vol2cam, fx, fy, cx, cy, occupancy)
 
 
 def tsdf_raycast_points(vol, voxel_size, trunc, cam2vol, Rinv, fx, fy, cx, cy, step_factor, delta_factor, points,
@@ -372,17 +397,21 @@ def mc_default_tables():
     return tri, nv
 
 
-def marching_cubes(vol, cell_size, tri_table, num_verts_table, max_vertices):
+def marching_cubes(vol, cell_size, tri_table, num_verts_table, max_vertices, occupancy=None):
     """cuda::MarchingCubes::run.  tri_table / num_verts_table: int32 CUDA tensors (256x16, 256).
     Returns (points (max_vertices, 4) float32 CUDA tensor, total int32 CUDA tensor of 1 element);
-    only the first min(total, max_vertices) points are written."""
+    only the first min(total, max_vertices) points are written.  occupancy: the volume's occupancy map (tsdf_occupancy,
+    kept by the *_occ sweeps) — the same output without reading the empty part of the volume."""
     torch = _torch()
     X, Y, Z = _vol_dims(vol)
     pts = torch.empty((max(max_vertices, 1), 4), dtype=torch.float32, device=vol.device)
     total = torch.zeros((1,), dtype=torch.int32, device=vol.device)
-    _check(load().dfa_marching_cubes(_dev(vol), X, Y, Z, _farr(cell_size, 3), _dev(tri_table, torch.int32, "tri_table"),
-                                     _dev(num_verts_table, torch.int32, "num_verts_table"),
-                                     _dev(pts) if max_vertices > 0 else None, max_vertices, _dev(total), _stream()))
+    tail = (_farr(cell_size, 3), _dev(tri_table, torch.int32, "tri_table"), _dev(num_verts_table, torch.int32, "num_verts_table"),
+            _dev(pts) if max_vertices > 0 else None, max_vertices, _dev(total), _stream())
+    if occupancy is None:
+        _check(load().dfa_marching_cubes(_dev(vol), X, Y, Z, *tail))
+    else:
+        _check(load().dfa_marching_cubes_occ(_dev(vol), _dev(occupancy, torch.uint8, "occupancy"), X, Y, Z, *tail))
     return pts, total
 
 

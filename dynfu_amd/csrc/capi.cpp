@@ -285,31 +285,61 @@ int dfa_tsdf_clear(uint32_t* volume, int X, int Y, int Z, dfa_stream_t stream) {
     return DFA_OK;
 }
 
+size_t dfa_tsdf_occupancy_bytes(int X, int Y, int Z) {
+    return X > 0 && Y > 0 && Z > 0 ? dfa::occ_dims(X, Y, Z).bytes() : 0;
+}
+
+int dfa_tsdf_clear_occ(uint32_t* volume, int X, int Y, int Z, uint8_t* occupancy, dfa_stream_t stream) {
+    REQUIRE(volume_args_ok(volume, X, Y, Z), "bad volume");
+    REQUIRE(occupancy, "null occupancy map");
+    HIP_TRY(dfa::launch_tsdf_clear(volume, X, Y, Z, S(stream)));
+    HIP_TRY(hipMemsetAsync(occupancy, 0, dfa::occ_dims(X, Y, Z).bytes(), S(stream)));
+    return DFA_OK;
+}
+
 static int integrate_common(bool fused, const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* volume,
                             int X, int Y, int Z, const float voxel_size[3], float trunc_dist, int max_weight,
-                            const float vol2cam[12], float fx, float fy, float cx, float cy, dfa_stream_t stream) {
+                            const float vol2cam[12], float fx, float fy, float cx, float cy, uint8_t* occupancy,
+                            dfa_stream_t stream) {
     REQUIRE(volume_args_ok(volume, X, Y, Z), "bad volume");
     REQUIRE(dists && cols > 0 && rows > 0 && dists_step >= cols * 2, "bad dists image");
     REQUIRE(voxel_size && vol2cam, "null parameter block");
     REQUIRE(trunc_dist > 0.f, "trunc_dist must be positive");
     REQUIRE(max_weight >= 0 && max_weight <= 65535, "max_weight must fit the 16-bit weight");
     HIP_TRY(dfa::launch_tsdf_integrate(fused, dists, dists_step, cols, rows, volume, X, Y, Z, voxel_size, trunc_dist,
-                                       max_weight, vol2cam, fx, fy, cx, cy, S(stream)));
+                                       max_weight, vol2cam, fx, fy, cx, cy, occupancy, S(stream)));
     return DFA_OK;
+}
+
+int dfa_tsdf_integrate_occ(const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* volume, int X, int Y, int Z,
+                           const float voxel_size[3], float trunc_dist, int max_weight, const float vol2cam[12], float fx,
+                           float fy, float cx, float cy, uint8_t* occupancy, dfa_stream_t stream) {
+    REQUIRE(occupancy, "null occupancy map");
+    return integrate_common(false, dists, dists_step, cols, rows, volume, X, Y, Z, voxel_size, trunc_dist, max_weight, vol2cam,
+                            fx, fy, cx, cy, occupancy, stream);
+}
+
+int dfa_tsdf_clear_integrate_occ(const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* volume, int X, int Y,
+                                 int Z, const float voxel_size[3], float trunc_dist, int max_weight,
+                                 const float vol2cam[12], float fx, float fy, float cx, float cy, uint8_t* occupancy,
+                                 dfa_stream_t stream) {
+    REQUIRE(occupancy, "null occupancy map");
+    return integrate_common(true, dists, dists_step, cols, rows, volume, X, Y, Z, voxel_size, trunc_dist, max_weight, vol2cam,
+                            fx, fy, cx, cy, occupancy, stream);
 }
 
 int dfa_tsdf_integrate(const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* volume, int X, int Y, int Z,
                        const float voxel_size[3], float trunc_dist, int max_weight, const float vol2cam[12], float fx,
                        float fy, float cx, float cy, dfa_stream_t stream) {
     return integrate_common(false, dists, dists_step, cols, rows, volume, X, Y, Z, voxel_size, trunc_dist, max_weight,
-                            vol2cam, fx, fy, cx, cy, stream);
+                            vol2cam, fx, fy, cx, cy, nullptr, stream);
 }
 
 int dfa_tsdf_clear_integrate(const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* volume, int X, int Y,
                              int Z, const float voxel_size[3], float trunc_dist, int max_weight,
                              const float vol2cam[12], float fx, float fy, float cx, float cy, dfa_stream_t stream) {
     return integrate_common(true, dists, dists_step, cols, rows, volume, X, Y, Z, voxel_size, trunc_dist, max_weight,
-                            vol2cam, fx, fy, cx, cy, stream);
+                            vol2cam, fx, fy, cx, cy, nullptr, stream);
 }
 
 int dfa_tsdf_vertex_normals(const uint32_t* volume, int X, int Y, int Z, const float voxel_size[3],
@@ -474,9 +504,9 @@ int dfa_icp_sums(int depth_variant, const void* curr, int curr_step, const float
 
 // ------------------------------------------------------------------------ marching-cubes seam
 
-int dfa_marching_cubes(const uint32_t* volume, int X, int Y, int Z, const float cell_size[3],
-                       const int32_t* tri_table, const int32_t* num_verts_table, float* out_points, int max_vertices,
-                       int32_t* total_vertices, dfa_stream_t stream) {
+static int marching_cubes_common(const uint32_t* volume, int X, int Y, int Z, const float cell_size[3],
+                                 const int32_t* tri_table, const int32_t* num_verts_table, float* out_points,
+                                 int max_vertices, int32_t* total_vertices, const uint8_t* occupancy, dfa_stream_t stream) {
     REQUIRE(volume_args_ok(volume, X, Y, Z), "bad volume");
     REQUIRE(cell_size && tri_table && num_verts_table, "null parameter block / case tables");
     REQUIRE(max_vertices >= 0 && (max_vertices == 0 || out_points), "bad output buffer");
@@ -486,9 +516,24 @@ int dfa_marching_cubes(const uint32_t* volume, int X, int Y, int Z, const float 
     McScratch& scratch = stream_scratch<McScratch>(S(stream));
     HIP_TRY(scratch.reserve(nsegs));
     HIP_TRY(dfa::launch_marching_cubes(volume, X, Y, Z, cell_size, tri_table, num_verts_table, out_points,
-                                       max_vertices, total_vertices, scratch.seg_off, scratch.chunk_sums,
+                                       max_vertices, total_vertices, scratch.seg_off, scratch.chunk_sums, occupancy,
                                        S(stream)));
     return DFA_OK;
+}
+
+int dfa_marching_cubes(const uint32_t* volume, int X, int Y, int Z, const float cell_size[3],
+                       const int32_t* tri_table, const int32_t* num_verts_table, float* out_points, int max_vertices,
+                       int32_t* total_vertices, dfa_stream_t stream) {
+    return marching_cubes_common(volume, X, Y, Z, cell_size, tri_table, num_verts_table, out_points, max_vertices,
+                                 total_vertices, nullptr, stream);
+}
+
+int dfa_marching_cubes_occ(const uint32_t* volume, const uint8_t* occupancy, int X, int Y, int Z, const float cell_size[3],
+                           const int32_t* tri_table, const int32_t* num_verts_table, float* out_points, int max_vertices,
+                           int32_t* total_vertices, dfa_stream_t stream) {
+    REQUIRE(occupancy, "null occupancy map");
+    return marching_cubes_common(volume, X, Y, Z, cell_size, tri_table, num_verts_table, out_points, max_vertices,
+                                 total_vertices, occupancy, stream);
 }
 
 int dfa_mc_default_tables(int32_t* tri_table, int32_t* num_verts_table) {

@@ -13,10 +13,20 @@ namespace dfa {
 hipError_t launch_compute_dists(const uint16_t* depth, int depth_step, uint16_t* dists, int dists_step, int cols,
                                 int rows, float fx, float fy, float cx, float cy, hipStream_t s);
 hipError_t launch_tsdf_clear(uint32_t* vol, int X, int Y, int Z, hipStream_t s);
+// Occupancy map of a volume (optional; include/dynfu_amd.h: dfa_tsdf_occupancy_bytes): one byte per box of 32 x 2 x 8 voxels
+// — the patch of columns a wave of the sweep owns times one classified run —: bit 0 if a sweep may have left a voxel with a
+// non-zero weight in it, bit 1 if one may have left a NEGATIVE distance there (a run classified FULL: FRONT runs write +1).
+// Byte ((z / 8) oy + y / 2) ox + x / 32.
+struct OccDims {
+    int ox, oy, oz;
+    __host__ __device__ size_t bytes() const { return (size_t)ox * oy * oz; }
+};
+__host__ __device__ inline OccDims occ_dims(int X, int Y, int Z) { return OccDims{(X + 31) / 32, (Y + 1) / 2, (Z + 7) / 8}; }
+// occ (may be null): fused_clear writes every byte of it (the sweep writes every voxel), the accumulating sweep only sets bytes
 hipError_t launch_tsdf_integrate(bool fused_clear, const uint16_t* dists, int dists_step, int cols, int rows,
                                  uint32_t* vol, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
                                  int max_weight, const float vol2cam[12], float fx, float fy, float cx, float cy,
-                                 hipStream_t s);
+                                 uint8_t* occ, hipStream_t s);
 hipError_t launch_vertex_normals(const uint32_t* vol, int X, int Y, int Z, const float voxel_size[3], float delta_factor,
                                  const float* points, int n, float* normals, hipStream_t s);
 hipError_t launch_raycast_points(const uint32_t* vol, int X, int Y, int Z, const float voxel_size[3],
@@ -97,7 +107,7 @@ long mc_scan_chunks(long nsegs);                   // entries of chunk_sums
 hipError_t launch_marching_cubes(const uint32_t* vol, int X, int Y, int Z, const float cell_size[3],
                                  const int32_t* tri_table, const int32_t* num_verts_table, float* out_points,
                                  int max_vertices, int32_t* total_vertices, int32_t* seg_off, int32_t* chunk_sums,
-                                 hipStream_t s);
+                                 const uint8_t* occ /* occupancy map of the volume or null */, hipStream_t s);
 void mc_default_tables(int32_t tri_table[256 * 16], int32_t num_verts_table[256]);
 
 // img.hip

@@ -42,6 +42,8 @@ struct McArgs {
     float csx, csy, csz;
     const int32_t* tri;
     const int32_t* nverts;
+    const uint8_t* occ;  // occupancy map of the volume (kernels.hpp: OccDims: a byte per 32 x 2 x 8 voxels) or null
+    int ox, oy, oz;
 };
 
 // the VX voxels a lane owns in one row plus the voxel after them; zeros (weight 0 -> "no cube",
@@ -163,9 +165,34 @@ __global__ __launch_bounds__(256) void mc_count_kernel(const McArgs a, int32_t* 
     if (y >= a.Y) return;  // whole wave
     const int z0 = blockIdx.z * a.zchunk, z1 = min(z0 + a.zchunk, a.Z - 1);
     if (z0 >= z1) return;
+    // With an occupancy map: a cube with triangles has a non-zero weight at all eight corners (:38-60) and a negative
+    // distance at one of them, so a slice pair (z, z + 1) has such cubes for this wave only if the map shows weights in BOTH
+    // slices' layers over the wave's footprint — its 64 VX voxels and the one after them in x (2 VX + 1 boxes), rows
+    // y .. y + MC_ROWS (two rows of boxes) — and a possibly negative distance in one of them.  Everything else is never
+    // loaded: all but the band around the surface.  One byte per lane and two ballots per layer of 8 slices.
+    auto layer_marks = [&](int z8) -> unsigned {  // bit 0: weights somewhere in the footprint; bit 1: negative distances possible
+        if (!a.occ) return 3u;
+        constexpr int NBX = 2 * VX + 1;
+        const int lane = threadIdx.x, by = y / 2 + lane / NBX, bx = seg * 2 * VX + lane % NBX;
+        unsigned v = 0u;
+        if (lane < 2 * NBX && by < a.oy && bx < a.ox && z8 < a.oz) v = a.occ[((size_t)z8 * a.oy + by) * a.ox + bx];
+        return (__ballot(v & 1u) != 0ull ? 1u : 0u) | (__ballot(v & 2u) != 0ull ? 2u : 0u);
+    };
+    int cur8 = z0 / 8;
+    unsigned cur = layer_marks(cur8);
+    bool lo_valid = false;
     Row<VX> lo[MC_ROWS + 1];
-    load_rows<VX, MC_ROWS + 1>(a, x0, y, z0, lo);
     for (int z = z0; z < z1; ++z) {
+        const int nxt8 = (z + 1) / 8;
+        const unsigned nxt = nxt8 == cur8 ? cur : layer_marks(nxt8);
+        const bool need = (cur & nxt & 1u) && ((cur | nxt) & 2u);  // (wave-uniform)
+        cur = nxt, cur8 = nxt8;
+        if (!need) {
+            lo_valid = false;
+            continue;
+        }
+        if (!lo_valid) load_rows<VX, MC_ROWS + 1>(a, x0, y, z, lo);
+        lo_valid = true;
         Row<VX> hi[MC_ROWS + 1];
         load_rows<VX, MC_ROWS + 1>(a, x0, y, z + 1, hi);
 #pragma unroll
@@ -373,11 +400,13 @@ long mc_scan_chunks(long nsegs) { return (nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK; 
 hipError_t launch_marching_cubes(const uint32_t* vol, int X, int Y, int Z, const float cell_size[3],
                                  const int32_t* tri_table, const int32_t* num_verts_table, float* out_points,
                                  int max_vertices, int32_t* total_vertices, int32_t* seg_off, int32_t* chunk_sums,
-                                 hipStream_t s) {
+                                 const uint8_t* occ, hipStream_t s) {
     const bool vec4 = (X % 4 == 0) && (((uintptr_t)vol & 15) == 0);
     const int vx    = vec4 ? 4 : 1;
     McArgs a;
     a.vol = vol, a.X = X, a.Y = Y, a.Z = Z;
+    const OccDims od = occ_dims(X, Y, Z);
+    a.occ = occ, a.ox = od.ox, a.oy = od.oy, a.oz = od.oz;
     a.nseg = (X + 64 * vx - 1) / (64 * vx);
     a.csx = cell_size[0], a.csy = cell_size[1], a.csz = cell_size[2];
     a.tri = tri_table, a.nverts = num_verts_table;

@@ -82,6 +82,8 @@ struct IntegrateArgs {
     Aff3 vol2cam;
     float fx, fy, cx, cy;
     int zchunk;
+    uint8_t* occ;  // occupancy map (kernels.hpp: OccDims) or null
+    int ox, oy;
     int nt;      // DFA_TSDF_NT=1 (A/B): non-temporal stores in the fused sweep
     int ablate;  // -DDFA_DEV_ABLATE builds only (DFA_TSDF_ABLATE): 1 every run SKIP, 2 FULL runs filled like FRONT, 3 no classification
 };
@@ -315,6 +317,15 @@ __global__ __launch_bounds__(256) void integrate_runs_kernel(const IntegrateArgs
 
     int z      = z0;
     RunEnd end = run_end(vc.x, vc.y, vc.z, rc, rcp_approx);
+    // occupancy map: a byte per (this wave's WX x (64 / WX) columns) x (run of 8 slices) — the launcher passes it only for
+    // WX = 32, U = 8 and chunks that start on a multiple of 8.  Written by the first live lane of the wave.
+    uint8_t* occ_cell = nullptr;
+    if (a.occ) {
+        const unsigned long long live = __ballot(1);
+        if (lane == (int)__ffsll((long long)live) - 1)
+            occ_cell = a.occ + (size_t)(x / WX) + (size_t)a.ox * ((size_t)(y / WAVE_ROWS) + (size_t)a.oy * (size_t)(z0 / U));
+    }
+    const size_t occ_layer = (size_t)a.ox * a.oy;
     for (; z + U <= z1; z += U, ptr += slice * U) {
         const f3 far     = vc + stepU;
         int cls          = RUN_SKIP;
@@ -333,6 +344,15 @@ __global__ __launch_bounds__(256) void integrate_runs_kernel(const IntegrateArgs
             end              = nxt;
         }
 #endif
+        if (a.occ) {  // (uniform) bit 0: a run of the box was not SKIP (SKIP runs are the only ones that leave, or find, no
+                      // weight); bit 1: a run was FULL — the only runs that can leave a NEGATIVE distance (FRONT runs write +1)
+            const unsigned mark = (__ballot(cls != RUN_SKIP) != 0ull ? 1u : 0u) | (__ballot(cls == RUN_FULL) != 0ull ? 2u : 0u);
+            if (occ_cell) {
+                if (FUSED_CLEAR) *occ_cell = (uint8_t)mark;
+                else if (mark) *occ_cell = (uint8_t)(*occ_cell | mark);  // (one writer per byte and launch)
+                occ_cell += occ_layer;
+            }
+        }
         f3 p[U];  // the run's voxel positions by the reference's running addition (:64)
 #pragma unroll
         for (int u = 0; u < U; ++u) p[u] = vc, vc = vc + zstep;
@@ -372,6 +392,7 @@ __global__ __launch_bounds__(256) void integrate_runs_kernel(const IntegrateArgs
             }
         }
     }
+    if (occ_cell && z < z1) *occ_cell = 3;  // (the slices of a tail: marked without looking)
     for (; z < z1; ++z, ptr += slice) {  // tail shorter than a run: per voxel
         bool changed     = FUSED_CLEAR;
         const uint32_t v = integrate_voxel<FUSED_CLEAR>(a, vc, FUSED_CLEAR ? 0u : *ptr, changed);
@@ -754,10 +775,15 @@ static int pick_zchunk(int X, int Y, int Z, int vx, bool fused_clear) {
 hipError_t launch_tsdf_integrate(bool fused_clear, const uint16_t* dists, int dists_step, int cols, int rows,
                                  uint32_t* vol, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
                                  int max_weight, const float vol2cam[12], float fx, float fy, float cx, float cy,
-                                 hipStream_t s) {
+                                 uint8_t* occ, hipStream_t s) {
     IntegrateArgs a;
     a.dists = dists, a.dists_step = dists_step, a.cols = cols, a.rows = rows;
     a.vol = vol, a.X = X, a.Y = Y, a.Z = Z;
+    const OccDims od = occ_dims(X, Y, Z);
+    a.occ = nullptr, a.ox = od.ox, a.oy = od.oy;
+    // a sweep that does not keep the map (the per-voxel sweeps below, other wave shapes / run lengths of development builds)
+    // marks everything: the map stays a superset of the voxels with a weight
+    auto occ_all = [&]() -> hipError_t { return occ ? hipMemsetAsync(occ, 3, od.bytes(), s) : hipSuccess; };
     a.vsx = voxel_size[0], a.vsy = voxel_size[1], a.vsz = voxel_size[2];
     a.trunc      = trunc_dist;
     a.trunc_inv  = 1.f / trunc_dist;  // tsdf_volume.cu:106
@@ -795,7 +821,15 @@ hipError_t launch_tsdf_integrate(bool fused_clear, const uint16_t* dists, int di
             // >= 4 096 workgroups for either sweep: the tile look-ups of a run are dependent loads that only occupancy
             // hides (512^3 fused: 0.147 ms unsplit = 1 024 workgroups, 0.117 ms with z-chunks of 128 slices)
             a.zchunk = pick_zchunk(X, Y, Z, 1, false);
+            if (occ) a.zchunk = (a.zchunk + 7) & ~7;  // chunks of whole runs: a byte of the map has one writer
             dim3 block(64, 4), grid((X + 63) / 64, (Y + 3) / 4, (Z + a.zchunk - 1) / a.zchunk);
+#ifdef DFA_DEV_AB
+            if (occ && (dev_env_int("DFA_TSDF_WAVE", 32) != 32 || run_u != 8)) {
+                const hipError_t oe = occ_all();
+                if (oe != hipSuccess) return oe;
+            } else
+#endif
+                a.occ = occ;
 #define DFA_RUNS(F, W, UU) integrate_runs_kernel<F, W, UU><<<grid, block, 0, s>>>(a, rc, front_const)
 #ifdef DFA_DEV_AB
             const int wave_x = dev_env_int("DFA_TSDF_WAVE", 32);
@@ -827,6 +861,10 @@ hipError_t launch_tsdf_integrate(bool fused_clear, const uint16_t* dists, int di
     constexpr bool vec4 = false;
 #endif
     const int vx    = vec4 ? 4 : 1;
+    {
+        const hipError_t oe = occ_all();
+        if (oe != hipSuccess) return oe;
+    }
     a.zchunk        = pick_zchunk(X, Y, Z, vx, fused_clear);
     dim3 block(64, 4), grid((X + 64 * vx - 1) / (64 * vx), (Y + 3) / 4, (Z + a.zchunk - 1) / a.zchunk);
 #ifdef DFA_DEV_AB

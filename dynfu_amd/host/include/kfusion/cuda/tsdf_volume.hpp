@@ -23,15 +23,22 @@ class TsdfVolume {
         float grad_delta    = 0.75f;                // in voxels         (:24)
     } cfg_;
     CudaData blob_;  // X*Y*Z packed voxels {fp16 tsdf, u16 weight}
+    // Occupancy map of the volume (dynfu_amd.h: dfa_tsdf_occupancy_bytes): which boxes of 32 x 2 x 8 voxels the sweeps of THIS
+    // object may have left a weight in — kept by clear / integrate / clearAndIntegrate, read by cuda::MarchingCubes::run
+    // instead of the empty voxels.  Storage that arrives from outside (swap, a writable data() handle) makes it unknown.
+    CudaData occ_;
+    bool occ_known_ = false;
 
 public:
     // --- construction / storage -----------------------------------------------------------------------------
     explicit TsdfVolume(const Vec3i& dims) { cfg_.dims = dims, create(dims); }
     virtual ~TsdfVolume() {}
     void create(const Vec3i& dims);            // allocates and clears
-    void swap(CudaData& data) { blob_.swap(data); }
-    CudaData data() { return blob_; }
+    void swap(CudaData& data) { blob_.swap(data), occ_known_ = false; }
+    CudaData data() { return occ_known_ = false, blob_; }
     const CudaData data() const { return blob_; }
+    // the occupancy map of the voxels (device) or nullptr when the voxels may have been written from outside this object
+    const unsigned char* occupancy() const { return occ_known_ ? occ_.ptr<unsigned char>() : nullptr; }
 
     // --- the GPU work -----------------------------------------------------------------------------------------
     virtual void clear();

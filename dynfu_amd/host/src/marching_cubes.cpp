@@ -32,10 +32,17 @@ dfa::DeviceArray<MarchingCubes::PointType> MarchingCubes::run(const TsdfVolume& 
     const Vec3f size = volume.getSize();
     // the reference divides by its hard-coded 128 (marching_cubes.cu:283-285) = the voxel size there
     const float cell[3] = {size[0] / dims[0], size[1] / dims[1], size[2] / dims[2]};
-    dfa::check(dfa_marching_cubes(volume.data().ptr<uint32_t>(), dims[0], dims[1], dims[2], cell, tri_dev_.ptr(),
-                                  nverts_dev_.ptr(), (float*)triangles_buffer.ptr(), (int)triangles_buffer.size(),
-                                  total_dev_.ptr(), nullptr),
-               "MarchingCubes::run");
+    // (with the volume's occupancy map, when the volume knows it: the count sweep skips what the fuse left empty)
+    if (const unsigned char* occ = volume.occupancy())
+        dfa::check(dfa_marching_cubes_occ(volume.data().ptr<uint32_t>(), occ, dims[0], dims[1], dims[2], cell, tri_dev_.ptr(),
+                                          nverts_dev_.ptr(), (float*)triangles_buffer.ptr(), (int)triangles_buffer.size(),
+                                          total_dev_.ptr(), nullptr),
+                   "MarchingCubes::run");
+    else
+        dfa::check(dfa_marching_cubes(volume.data().ptr<uint32_t>(), dims[0], dims[1], dims[2], cell, tri_dev_.ptr(),
+                                      nverts_dev_.ptr(), (float*)triangles_buffer.ptr(), (int)triangles_buffer.size(),
+                                      total_dev_.ptr(), nullptr),
+                   "MarchingCubes::run");
     std::vector<int> t;
     total_dev_.download(t);  // synchronises
     last_total_ = t[0];

@@ -22,12 +22,15 @@ TsdfVolume::Entry::half TsdfVolume::Entry::float2half(float) { throw "Not implem
 void TsdfVolume::create(const Vec3i& dims) {  // :32-38
     cfg_.dims = dims;
     blob_.create((size_t)dims[0] * dims[1] * dims[2] * sizeof(int));
+    occ_.create(dfa_tsdf_occupancy_bytes(dims[0], dims[1], dims[2]));
     setTruncDist(cfg_.trunc);
     clear();
 }
 
 void TsdfVolume::clear() {  // :74-80
-    dfa::check(dfa_tsdf_clear(blob_.ptr<uint32_t>(), cfg_.dims[0], cfg_.dims[1], cfg_.dims[2], nullptr), "TsdfVolume::clear");
+    dfa::check(dfa_tsdf_clear_occ(blob_.ptr<uint32_t>(), cfg_.dims[0], cfg_.dims[1], cfg_.dims[2], occ_.ptr<uint8_t>(), nullptr),
+               "TsdfVolume::clear");
+    occ_known_ = true;
 }
 
 void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_pose, const Intr& intr) {  // :82-93
@@ -35,10 +38,16 @@ void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_pose, cons
     float aff[12];
     vol2cam.to12(aff);
     const Vec3f vsz = getVoxelSize();
-    dfa::check(dfa_tsdf_integrate(dists.ptr(), (int)dists.step(), dists.cols(), dists.rows(), blob_.ptr<uint32_t>(),
-                                  cfg_.dims[0], cfg_.dims[1], cfg_.dims[2], vsz.v, cfg_.trunc, cfg_.max_weight, aff, intr.fx, intr.fy,
-                                  intr.cx, intr.cy, nullptr),
-               "TsdfVolume::integrate");
+    if (occ_known_)  // (the accumulating sweep only ADDS to the map: it has to be right before)
+        dfa::check(dfa_tsdf_integrate_occ(dists.ptr(), (int)dists.step(), dists.cols(), dists.rows(), blob_.ptr<uint32_t>(),
+                                          cfg_.dims[0], cfg_.dims[1], cfg_.dims[2], vsz.v, cfg_.trunc, cfg_.max_weight, aff, intr.fx,
+                                          intr.fy, intr.cx, intr.cy, occ_.ptr<uint8_t>(), nullptr),
+                   "TsdfVolume::integrate");
+    else
+        dfa::check(dfa_tsdf_integrate(dists.ptr(), (int)dists.step(), dists.cols(), dists.rows(), blob_.ptr<uint32_t>(),
+                                      cfg_.dims[0], cfg_.dims[1], cfg_.dims[2], vsz.v, cfg_.trunc, cfg_.max_weight, aff, intr.fx,
+                                      intr.fy, intr.cx, intr.cy, nullptr),
+                   "TsdfVolume::integrate");
     dfa::device_synchronize();  // the reference's device::integrate blocks (tsdf_volume.cu:120)
 }
 
@@ -47,10 +56,11 @@ void TsdfVolume::clearAndIntegrate(const Dists& dists, const Affine3f& camera_po
     float aff[12];
     vol2cam.to12(aff);
     const Vec3f vsz = getVoxelSize();
-    dfa::check(dfa_tsdf_clear_integrate(dists.ptr(), (int)dists.step(), dists.cols(), dists.rows(),
-                                        blob_.ptr<uint32_t>(), cfg_.dims[0], cfg_.dims[1], cfg_.dims[2], vsz.v, cfg_.trunc,
-                                        cfg_.max_weight, aff, intr.fx, intr.fy, intr.cx, intr.cy, nullptr),
+    dfa::check(dfa_tsdf_clear_integrate_occ(dists.ptr(), (int)dists.step(), dists.cols(), dists.rows(),
+                                            blob_.ptr<uint32_t>(), cfg_.dims[0], cfg_.dims[1], cfg_.dims[2], vsz.v, cfg_.trunc,
+                                            cfg_.max_weight, aff, intr.fx, intr.fy, intr.cx, intr.cy, occ_.ptr<uint8_t>(), nullptr),
                "TsdfVolume::clearAndIntegrate");
+    occ_known_ = true;  // (the fused sweep writes every voxel and every byte of the map)
     dfa::device_synchronize();
 }
 

@@ -117,11 +117,21 @@ def timed_region(fn, device=None):
     seconds over all ranks (every rank gets the same number)."""
     import torch
     import torch.distributed as dist
+    single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
     barrier(device)
     t0 = time.perf_counter()
     fn()
-    barrier(device)
-    dt = time.perf_counter() - t0
+    if single:
+        # one rank: there is nobody to wait for — the clock stops when this rank's GPU has drained, and the one-rank
+        # self-check group runs its barrier BEHIND the measurement (an RCCL barrier costs ~1-2 ms of host time: inside the
+        # window it took 15 % off a 20-step line)
+        if device is not None and device.type == "cuda":
+            torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        barrier(device)
+    else:
+        barrier(device)
+        dt = time.perf_counter() - t0
     if dist.is_available() and dist.is_initialized():
         t = torch.tensor([dt], dtype=torch.float64, device=device if device is not None else "cpu")
         if dist.get_world_size() > 1:
@@ -138,6 +148,31 @@ def timed_region(fn, device=None):
 def aggregate_throughput(units_per_rank, seconds_max, world):
     """whole-job units/s: every rank processed `units_per_rank` in at most `seconds_max`."""
     return world * units_per_rank / seconds_max
+
+
+def time_collectives(device=None, reps=5):
+    """host time of the collectives the timed region pays for at N > 1, measured on whatever group exists (after the
+    measurement): {"barrier_ms": [...], "allreduce_sync_ms": [...]} or None"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    out = dict(barrier_ms=[], allreduce_sync_ms=[])
+    try:
+        t = torch.zeros(1, dtype=torch.float64, device=device if device is not None else "cpu")
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            dist.barrier()
+            out["barrier_ms"].append(round((time.perf_counter() - t0) * 1e3, 3))
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            dist.all_reduce(t)
+            if device is not None and device.type == "cuda":
+                torch.cuda.synchronize(device)
+            out["allreduce_sync_ms"].append(round((time.perf_counter() - t0) * 1e3, 3))
+    except Exception as e:  # noqa: BLE001
+        out["error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
+    return out
 
 
 def count_ranks(device=None):

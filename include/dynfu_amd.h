@@ -93,6 +93,25 @@ int dfa_tsdf_clear_integrate(const uint16_t* dists, int dists_step, int cols, in
                              int Z, const float voxel_size[3], float trunc_dist, int max_weight,
                              const float vol2cam[12], float fx, float fy, float cx, float cy, dfa_stream_t stream);
 
+/* Occupancy map of a volume (optional).  The sweep classifies every run of 8 voxels of a column against the depth image
+ * before it touches it (csrc/tsdf_classify.hpp) and so knows, for free, which parts of the volume it left empty — 5/6 of a
+ * 512^3 volume fused from one depth frame.  The `_occ` entry points keep that knowledge in a byte map — one byte per box
+ * of 32 x 2 x 8 voxels (x, y, z), byte ((z / 8) ceil(Y / 2) + y / 2) ceil(X / 32) + x / 32; bit 0 = a voxel of the box MAY
+ * have a non-zero weight, bit 1 = one MAY hold a negative distance (a run the sweep had to evaluate voxel by voxel; the runs
+ * in front of the surface are filled with +1) — that dfa_marching_cubes_occ reads instead of the empty voxels (the reference's OccupiedVoxels
+ * pass reads the whole volume, src/kfusion/cuda/marching_cubes.cu:77-142).  Same volume bits, same mesh bits as the
+ * entry points without a map.  The caller owns the map (dfa_tsdf_occupancy_bytes bytes, device); the fused sweep writes
+ * all of it, dfa_tsdf_integrate_occ only sets bytes, dfa_tsdf_clear_occ zeroes volume and map. */
+size_t dfa_tsdf_occupancy_bytes(int X, int Y, int Z);
+int dfa_tsdf_clear_occ(uint32_t* volume, int X, int Y, int Z, uint8_t* occupancy, dfa_stream_t stream);
+int dfa_tsdf_integrate_occ(const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* volume, int X, int Y, int Z,
+                           const float voxel_size[3], float trunc_dist, int max_weight, const float vol2cam[12], float fx,
+                           float fy, float cx, float cy, uint8_t* occupancy, dfa_stream_t stream);
+int dfa_tsdf_clear_integrate_occ(const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* volume, int X, int Y,
+                                 int Z, const float voxel_size[3], float trunc_dist, int max_weight,
+                                 const float vol2cam[12], float fx, float fy, float cx, float cy, uint8_t* occupancy,
+                                 dfa_stream_t stream);
+
 /* Normals of surface points from the TSDF gradient (the reference extracts the mesh without
  * normals, dyn_fusion.cpp:80-88 "temporary workaround until normals are computed via mc").  The raycaster's own
  * compute_normal (tsdf_volume.cu:320-336): central differences of the trilinear interpolant, gradient_delta_factor
@@ -191,6 +210,12 @@ int dfa_icp_sums(int depth_variant, const void* curr, int curr_step, const float
 int dfa_marching_cubes(const uint32_t* volume, int X, int Y, int Z, const float cell_size[3],
                        const int32_t* tri_table, const int32_t* num_verts_table, float* out_points, int max_vertices,
                        int32_t* total_vertices, dfa_stream_t stream);
+
+/* ... with the volume's occupancy map (see dfa_tsdf_occupancy_bytes): the count sweep loads only the slices whose boxes
+ * the map marks; identical output. */
+int dfa_marching_cubes_occ(const uint32_t* volume, const uint8_t* occupancy, int X, int Y, int Z, const float cell_size[3],
+                           const int32_t* tri_table, const int32_t* num_verts_table, float* out_points, int max_vertices,
+                           int32_t* total_vertices, dfa_stream_t stream);
 
 /* A valid case table pair for callers that do not have the reference's (HOST buffers, 256 x 16
  * and 256 ints): derived from the face-by-face rule described in csrc/mc.hip.  Same corner / edge

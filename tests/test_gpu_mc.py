@@ -122,3 +122,88 @@ def test_vertex_normals_bit_exact(A, dims, delta):
     ok = ~np.isnan(ref)
     assert np.array_equal(bits(got)[ok], bits(ref)[ok])
     assert host(A.tsdf_vertex_normals(dev(vol), cell, delta, dev(pts[:0]))).shape == (0, 4)
+
+
+def _boxes(hv):
+    """the map the sweep must at least produce, per box of 32 x 2 x 8 voxels (x, y, z): (holds a voxel with a weight, holds
+    a voxel with a weight and a negative distance)"""
+    Z, Y, X = hv.shape
+    w = (hv >> 16) != 0
+    neg = w & ((hv & 0x8000) != 0) & ((hv & 0x7fff) != 0)
+
+    def boxes(b):
+        pad = np.zeros(((Z + 7) // 8 * 8, (Y + 1) // 2 * 2, (X + 31) // 32 * 32), bool)
+        pad[:Z, :Y, :X] = b
+        return pad.reshape(pad.shape[0] // 8, 8, pad.shape[1] // 2, 2, pad.shape[2] // 32, 32).any(axis=(1, 3, 5))
+
+    return boxes(w), boxes(neg)
+
+
+@pytest.mark.parametrize("name,dims", [("T1", None), ("T0", None), ("T1", (100, 77, 90)), ("C2", None)])
+def test_occupancy_map_and_marching_cubes_without_the_empty_voxels(A, name, dims):
+    """dfa_tsdf_clear_integrate_occ / dfa_tsdf_integrate_occ / dfa_tsdf_clear_occ keep a byte per box of 32 x 2 x 8 voxels;
+    dfa_marching_cubes_occ reads it instead of the empty voxels (the reference's OccupiedVoxels pass reads all of them,
+    src/kfusion/cuda/marching_cubes.cu:77-142).  The volume is the one the plain entry points write (bit for bit), the map
+    covers every voxel with a weight and is sparse, the mesh is the plain entry point's and the oracle's, bit for bit —
+    fused sweep, accumulating sweep over three frames, ragged dimensions, BASELINE size."""
+    import torch
+    cfg = synth.CONFIGS[name]
+    fx, fy, cx, cy = synth.intrinsics(cfg)
+    voxel, trunc, vol2cam, _, _ = synth.volume_params(cfg)
+    X, Y, Z = dims or (cfg["dim"],) * 3
+    if dims:
+        voxel = tuple(float(synth.VOLUME_SIZE / d) for d in dims)
+    tri, nv = default_tables()
+    dists = []
+    for f in range(3):
+        d = torch.empty((cfg["height"], cfg["width"]), dtype=torch.uint16, device="cuda")
+        A.compute_dists(dev(synth.depth_frame(cfg, f)), d, fx, fy, cx, cy)
+        dists.append(d)
+    vol = torch.empty((Z, Y, X), dtype=torch.int32, device="cuda")
+    plain = torch.empty_like(vol)
+    occ = A.tsdf_occupancy(vol)
+    assert tuple(occ.shape) == ((Z + 7) // 8, (Y + 1) // 2, (X + 31) // 32)
+    occ.fill_(7)  # the fused sweep must write every byte
+
+    def check(cap=None):
+        hv = host(vol).view(np.uint32)
+        assert np.array_equal(hv, host(plain).view(np.uint32))
+        m, full = (host(occ) & 1) != 0, (host(occ) & 2) != 0
+        need, need_neg = _boxes(hv)
+        assert not (need & ~m).any() and not (need_neg & ~full).any()  # supersets of the boxes with weights / negative distances
+        assert m.mean() < 0.5 and m.sum() < 3 * max(1, need.sum())      # ... and not much more
+        assert full.mean() < 0.2 and not (full & ~m).any()
+        ref_pts, ref_total = A.marching_cubes(plain, voxel, dev(tri), dev(nv), cap or 1)
+        total = int(host(ref_total)[0])
+        ref_pts, _ = A.marching_cubes(plain, voxel, dev(tri), dev(nv), total)
+        pts, got = A.marching_cubes(vol, voxel, dev(tri), dev(nv), total, occupancy=occ)
+        assert int(host(got)[0]) == total > 1000
+        assert np.array_equal(bits(host(pts)), bits(host(ref_pts)))
+        return hv, total, host(pts)
+
+    A.tsdf_clear_integrate(plain, dists[0], voxel, trunc, synth.MAX_WEIGHT, vol2cam, fx, fy, cx, cy)
+    A.tsdf_clear_integrate(vol, dists[0], voxel, trunc, synth.MAX_WEIGHT, vol2cam, fx, fy, cx, cy, occupancy=occ)
+    assert set(np.unique(host(occ))) <= {0, 1, 3}
+    hv, total, pts = check()
+    if X * Y * Z <= 128 ** 3:  # the CPU statement of marching cubes beside it
+        ref, rtotal, _ = O.marching_cubes(hv, np.asarray(voxel, np.float32), tri, nv)
+        assert rtotal == total and np.array_equal(bits(pts), bits(ref))
+    # the accumulating sweep: two more frames into the same volume; the map only grows
+    before = host(occ) != 0
+    for f in (1, 2):
+        A.tsdf_integrate(plain, dists[f], voxel, trunc, synth.MAX_WEIGHT, vol2cam, fx, fy, cx, cy)
+        A.tsdf_integrate(vol, dists[f], voxel, trunc, synth.MAX_WEIGHT, vol2cam, fx, fy, cx, cy, occupancy=occ)
+    assert not (before & ~(host(occ) != 0)).any()
+    check()
+    # clear: volume and map
+    A.tsdf_clear(vol, occupancy=occ)
+    assert not host(occ).any() and not host(vol).any()
+    pts, got = A.marching_cubes(vol, voxel, dev(tri), dev(nv), 16, occupancy=occ)
+    assert int(host(got)[0]) == 0
+    # a map of ones is the plain sweep
+    A.tsdf_clear_integrate(vol, dists[1], voxel, trunc, synth.MAX_WEIGHT, vol2cam, fx, fy, cx, cy)
+    A.tsdf_clear_integrate(plain, dists[1], voxel, trunc, synth.MAX_WEIGHT, vol2cam, fx, fy, cx, cy)
+    occ.fill_(3)
+    _, t1 = A.marching_cubes(vol, voxel, dev(tri), dev(nv), 1, occupancy=occ)
+    _, t0 = A.marching_cubes(plain, voxel, dev(tri), dev(nv), 1)
+    assert int(host(t1)[0]) == int(host(t0)[0]) > 1000

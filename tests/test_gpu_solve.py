@@ -638,7 +638,7 @@ def test_translations_match_oracle_at_baseline_sizes(A, name, noise):
     s.set_problem(nodes, node_dq, node_w, verts, dev(live_np))
     s.solve(_params(A, **kw))
     t, st = host(s.translations()), s.stats()
-    assert st["overflow"] == 0 and st["gn_iters"] == st_ref["gn_iters"] == cfg["gn_iters"]
+    assert st["max_row_nnz"] <= 256 and st["gn_iters"] == st_ref["gn_iters"] == cfg["gn_iters"]
     assert np.abs(t - t_ref).max() <= 2e-5, (np.abs(t - t_ref).max(), np.abs(t_ref).max())
     np.testing.assert_allclose(st["initial_cost"], st_ref["initial_cost"], rtol=1e-4)
     if noise:
@@ -679,7 +679,7 @@ def test_normal_matrix_sums_follow_the_scale_of_the_problem(A, offset):
     kw = dict(kw, lambda_=1e12)
     t_ref, _, _ = O.solve_ref(node_pos, c["node_dq"], c["node_w"], k, c["verts"], live, use_double=True, threads=8, **kw)
     s.solve(_params(A, **kw))
-    assert np.isfinite(host(s.translations())).all() and s.stats()["overflow"] == 0
+    assert np.isfinite(host(s.translations())).all() and np.isfinite(s.stats()["final_cost"])
     with pytest.raises(A.DynfuAmdError):
         s.solve(_params(A, **dict(kw, lambda_=float("inf"))))
     s.close()
