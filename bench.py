@@ -120,6 +120,51 @@ def parse():
     return ap.parse_args()
 
 
+STREAM_PROBES = []  # what concurrent_stream() found, per call (goes into config.streams_probe)
+
+
+def concurrent_stream(device, other=()):
+    """A HIP stream whose work really runs BESIDE the current stream's (and beside `other` streams').  HIP maps streams onto a
+    few hardware queues, assigned at a stream's FIRST USE; two streams on one queue serialise.  Which queue a stream lands
+    on depends on every stream the process has used before — with an RCCL communicator created first, the sweep stream of
+    the first sequence shared the solve stream's queue and the C2 frame went from 0.65 to 0.77 ms (tools/rccl_launch_tax.py,
+    tools/stream_queue_probe.py: about one stream in eight aliases the current one).  So candidates are created and used once
+    until one demonstrably overlaps: a long fill on the busy streams, a one-element kernel on the candidate that must finish
+    before the fill does."""
+    import torch
+    main = torch.cuda.current_stream(device)
+    busy = [main] + list(other)
+    big = torch.empty(96 << 20, dtype=torch.float32, device=device)  # 384 MiB: a fill is ~0.1 ms
+    one = torch.zeros(1, device=device)
+    rejected = []
+    cand = None
+    for attempt in range(8):
+        cand = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(cand):  # first use: the hardware queue is bound (and created: milliseconds) here
+            one.add_(1.0)
+        ok = True
+        for b in busy:
+            e0, e_busy, e_side = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            torch.cuda.synchronize(device)
+            with torch.cuda.stream(b):
+                e0.record(b)
+                for _ in range(4):
+                    big.fill_(1.0)
+                e_busy.record(b)
+            cand.wait_event(e0)
+            with torch.cuda.stream(cand):
+                one.add_(1.0)
+                e_side.record(cand)
+            torch.cuda.synchronize(device)
+            ok = ok and e0.elapsed_time(e_side) < 0.5 * e0.elapsed_time(e_busy)
+        if ok:
+            break
+        rejected.append(cand)  # (kept alive until the choice is made: a destroyed stream's queue slot is handed out again)
+    STREAM_PROBES.append(dict(candidates_tried=len(rejected) + 1, overlaps=bool(ok)))
+    del big
+    return cand
+
+
 class Sequence:
     """Device-resident inputs + plan of one synthetic sequence."""
 
@@ -154,7 +199,7 @@ class Sequence:
         self.solver = A.Solver(self.D, self.N, self.k)
         self.params = A.SolveParams(num_iter=cfg["gn_iters"], nonlinear_iter=1, linear_iter=256, pcg_tol=1e-6,
                                     gn_tol=0.0, **synth.SOLVER)
-        self.s_fuse = torch.cuda.Stream(device=device)
+        self.s_fuse = concurrent_stream(device)
         self.warped = None
         self.fuse_events = []
 
@@ -249,7 +294,7 @@ class Sequence:
             self.ev_pipe = [torch.cuda.Event(), torch.cuda.Event()]
             for plan in self.plans:
                 plan.set_overlap_callback(self._pipeline_shadow)
-        self.s_graph = torch.cuda.Stream()
+        self.s_graph = concurrent_stream(torch.device("cuda", torch.cuda.current_device()), other=[self.s_fuse])
         self.graph_ready = [None, None]   # event: plan i holds the graphs of its next frame
         self.plan_free = [None, None]     # event: plan i's last solve (and warp) has finished
         self.next_graph = None            # frame whose graphs plan[f % 2] holds
@@ -1247,7 +1292,7 @@ def main():
                                     "reference-parity energy (energy.t), "
                                     "lambda=200" % (args.config, dim, Wd, Hd, seq.D, seq.k, seq.N, cfg["gn_iters"]),
                            parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus, ranks_seen=n_gpus,
-                           rccl_selfcheck=rccl_selfcheck(),
+                           rccl_selfcheck=rccl_selfcheck(), streams_probe=STREAM_PROBES[:1],
                            streams="serial" if args.serial else ("fuse || graph build of frame f+1 || solve of frame f on three "
                                                                  "HIP streams, two solver plans" if args.pipeline else
                                                                  ("fuse || graph build + solve on two HIP streams" if args.fuse_first

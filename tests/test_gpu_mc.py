@@ -172,7 +172,8 @@ def test_occupancy_map_and_marching_cubes_without_the_empty_voxels(A, name, dims
         need, need_neg = _boxes(hv)
         assert not (need & ~m).any() and not (need_neg & ~full).any()  # supersets of the boxes with weights / negative distances
         assert m.mean() < 0.5 and m.sum() < 3 * max(1, need.sum())      # ... and not much more
-        assert full.mean() < 0.2 and not (full & ~m).any()
+        # (boxes of 32 x 2 x 8 voxels against a band of ~5 voxels around the surface: coarse at 128^3, fine at 512^3)
+        assert full.mean() < (0.2 if X >= 512 else 0.6) and not (full & ~m).any()
         ref_pts, ref_total = A.marching_cubes(plain, voxel, dev(tri), dev(nv), cap or 1)
         total = int(host(ref_total)[0])
         ref_pts, _ = A.marching_cubes(plain, voxel, dev(tri), dev(nv), total)
