@@ -171,9 +171,11 @@ def test_occupancy_map_and_marching_cubes_without_the_empty_voxels(A, name, dims
         m, full = (host(occ) & 1) != 0, (host(occ) & 2) != 0
         need, need_neg = _boxes(hv)
         assert not (need & ~m).any() and not (need_neg & ~full).any()  # supersets of the boxes with weights / negative distances
-        assert m.mean() < 0.5 and m.sum() < 3 * max(1, need.sum())      # ... and not much more
-        # (boxes of 32 x 2 x 8 voxels against a band of ~5 voxels around the surface: coarse at 128^3, fine at 512^3)
-        assert full.mean() < (0.2 if X >= 512 else 0.6) and not (full & ~m).any()
+        assert m.sum() < 3 * max(1, need.sum()) and not (full & ~m).any()  # ... and not much more
+        # (boxes of 32 x 2 x 8 voxels against the frustum / a band of ~5 voxels around the surface: coarse at 64^3 and
+        # 128^3, where most boxes hold something; at 512^3 a third of the volume has weights and a tenth may be negative)
+        if X >= 512:
+            assert m.mean() < 0.4 and full.mean() < 0.2, (m.mean(), full.mean())
         ref_pts, ref_total = A.marching_cubes(plain, voxel, dev(tri), dev(nv), cap or 1)
         total = int(host(ref_total)[0])
         ref_pts, _ = A.marching_cubes(plain, voxel, dev(tri), dev(nv), total)

@@ -620,8 +620,7 @@ def test_translations_match_oracle_at_baseline_sizes(A, name, noise):
     pcg_paired_kernel<1024,1,32,1>) and of C3 (4 096 nodes, k = 8, 524 288 vertices: the many-workgroup PCG) with
     bench.py's parameters — 5 / 10 outer iterations, PCG <= 256 at 1e-6, lambda = 200 — HIP against the fp64 statement
     (O.solve_ref(use_double=True): energy.t:50-55, opt_solver.cpp:204-231): node translations within 2e-5 m, energies
-    within 1e-3.  noise = 0: SURVEY 8(d)'s index-aligned zero-residual targets (the final energy is round-off on both sides:
-    compared against the initial one); noise = 1 mm on the live vertices: a fit with a residual, energies compared directly."""
+    within 1e-3.  noise = 0: SURVEY 8(d)'s index-aligned targets; noise = 1 mm on the live vertices: a fit with a residual."""
     cfg = synth.CONFIGS[name]
     c = synth.canonical(cfg)
     k, D = cfg["k"], cfg["D"]
@@ -641,10 +640,9 @@ def test_translations_match_oracle_at_baseline_sizes(A, name, noise):
     assert st["max_row_nnz"] <= 256 and st["gn_iters"] == st_ref["gn_iters"] == cfg["gn_iters"]
     assert np.abs(t - t_ref).max() <= 2e-5, (np.abs(t - t_ref).max(), np.abs(t_ref).max())
     np.testing.assert_allclose(st["initial_cost"], st_ref["initial_cost"], rtol=1e-4)
-    if noise:
-        np.testing.assert_allclose(st["final_cost"], st_ref["final_cost"], rtol=1e-3)
-    else:
-        assert st["final_cost"] < 1e-7 * st["initial_cost"] and st_ref["final_cost"] < 1e-7 * st_ref["initial_cost"]
+    # (noise = 0 is not a zero-energy fit either: lambda = 200 bends the field, the final energy is ~1e-5 of the first)
+    np.testing.assert_allclose(st["final_cost"], st_ref["final_cost"], rtol=1e-3)
+    assert st["final_cost"] < (1e-2 if noise else 1e-4) * st["initial_cost"]
     np.testing.assert_allclose(host(s.node_dq()), dq_ref, atol=2e-5)
     s.close()
 
