@@ -33,29 +33,19 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 LDS_GATHER_PEAK_GBS = 921.6  # 3 CUs x 128 B/clk x 2.4 GHz: the LDS read rate of the three CUs the reference-mode PCG runs on
 TIMING_SAMPLE = 8  # every 8th timed frame carries the hipEvent brackets of the per-kernel report
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x 2 for wide read streams + WRITE_SIZE, corrected as
-# MI355X_MICROARCH.md prescribes).  Collected offline — PMC needs its own runs — so every figure names the tracked file it
-# was read from and the commit that file was measured at: a figure older than the kernel it describes is visible as such.
-PMC_TRAFFIC = {
-    # (config, kernel key): (bytes per launch, profile file, commit of the measured tree)
-    ("C2", "fused_integrate"): (0.5417e9, "profiles/r04_pmc_c2.md", "e45c70c"),   # WRITE 524 288 KiB + 2 x FETCH 2 367 KiB
-    ("C3", "fused_integrate"): (0.5414e9, "profiles/r04_pmc_ns_c3.md", "e45c70c"),
-    ("C4", "fused_integrate"): (4.344e9, "profiles/r02_pmc_tsdf.md", "round 2"),   # 4 194 304 + 2 x 23 775 KiB
-    ("C2", "pcg"): (0.635e6, "profiles/r04_pmc_c2.md", "e45c70c"),                 # pcg_paired_kernel<1024,1,32,1>: FETCH 344.6 + WRITE 275.7 KiB
-    ("C3", "pcg"): (1.796e6, "profiles/r04_pmc_ref_c3.md", "e45c70c"),             # pcg_mb_step_kernel: FETCH 1 339 + WRITE 415 KiB per launch
-    # north-star kernels: FETCH + WRITE, uncorrected, for the gather-heavy PCG step and the gathering assembly (the x2 of
-    # wide read streams does not apply to 16-80-byte gathers); 2 x FETCH + WRITE for the streaming linearisation.
-    ("C2", "s6_assemble"): (61.44e6, "profiles/r04_pmc_ns_c2.md", "e45c70c"),
-    ("C2", "s6_linearise"): (42.13e6, "profiles/r04_pmc_ns_c2.md", "e45c70c"),
-    ("C2", "s6_pcg_step"): (1.728e6, "profiles/r04_pmc_ns_c2.md", "e45c70c"),
-    ("C3", "s6_assemble"): (249.1e6, "profiles/r04_pmc_ns_c3.md", "e45c70c"),
-    ("C3", "s6_linearise"): (104.4e6, "profiles/r04_pmc_ns_c3.md", "e45c70c"),
-    ("C3", "s6_pcg_step"): (4.058e6, "profiles/r04_pmc_ns_c3.md", "e45c70c"),
-    # raycast: FETCH + WRITE (4-byte gathers: uncorrected)
-    ("C2", "raycast_points"): ((61764 + 9600) * 1024.0, "profiles/r04_raycast.md", "e45c70c"),
-    ("C2", "raycast_depth"): ((61736 + 5458) * 1024.0, "profiles/r04_raycast.md", "e45c70c"),
-    ("C4", "raycast_points"): ((227663 + 28800) * 1024.0, "profiles/r04_raycast.md", "e45c70c"),
-    ("C4", "raycast_depth"): ((227504 + 16748) * 1024.0, "profiles/r04_raycast.md", "e45c70c"),
-}
+# MI355X_MICROARCH.md prescribes).  Collected offline — PMC needs its own runs — by tools/round5_profile.sh and written to
+# profiles/traffic.json by tools/profile_summary.py (nothing is copied by hand): every figure names the tracked file it was
+# read from and the commit that file was measured at, so a figure older than the kernel it describes is visible as such.
+def _load_traffic():
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return {}
+    return {tuple(k.split("/", 1)): (v["bytes_per_launch"], v.get("source"), v.get("commit")) for k, v in t.items()}
+
+
+PMC_TRAFFIC = _load_traffic()
 PMC_TRAFFIC_BYTES = {k: v[0] for k, v in PMC_TRAFFIC.items()}
 
 
@@ -78,6 +68,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-northstar", action="store_true", help="skip the short north-star-mode measurement of the default run")
     ap.add_argument("--no-pipelined-probe", action="store_true", help="skip the short pipelined-throughput measurement")
+    ap.add_argument("--sequences-per-gpu", type=int, nargs="*", default=[1, 2, 4],
+                    help="the multi_sequence figure: S independent sequences on this GPU, each on streams of its own (default 1 2 4)")
+    ap.add_argument("--no-multi-sequence", action="store_true", help="skip the multi_sequence figure")
+    ap.add_argument("--sequences-one-thread", action="store_true", help="multi_sequence: one host thread enqueues every sequence")
     ap.add_argument("--no-live-depth", action="store_true", help="skip the short measurement on the reference's data flow with noisy depth")
     ap.add_argument("--live", default="targets", choices=["targets", "depth"],
                     help="targets: index-aligned live vertices canon + sum w t* (SURVEY 8d, the headline workload); depth: the "
@@ -428,6 +422,80 @@ class SequenceLive(Sequence):
         self.solver.solve(self.params)
         self.warped, _ = self.solver.warp_to_live(None)
         self.live_last = live
+
+
+def multi_sequence_probe(cfg_name, device, counts=(1, 2, 4), rounds=60, warmup=8, threads=True):
+    """BASELINE config 5's workload shape on ONE device: S independent sequences (own volume, solver plan and streams), a
+    frame of each enqueued round-robin by one host thread, no synchronisation between frames.  The reference-mode PCG of a C2
+    frame holds 3 of 256 CUs for half of the frame; what a second and a fourth sequence make of the idle chip tells the
+    reader of the 1/2/4/8-GPU curve how much of a node one GPU already covers.  Reported: aggregate frames/s per S, and the
+    per-frame latency inside a sequence (hipEvents on its solve stream) — a secondary figure, NOT the headline."""
+    import torch
+    out = {}
+    seqs, streams = [], []
+    main = torch.cuda.current_stream(device)
+    for S in sorted(set(counts)):
+        while len(seqs) < S:
+            # a solve stream of its own that runs beside every stream already in use, then (inside Sequence) a sweep stream
+            # that runs beside that one
+            s_solve = concurrent_stream(device, other=streams)
+            with torch.cuda.stream(s_solve):
+                q = Sequence(cfg_name, device, n_frames=12)
+                q.fuse_first = False
+                q.enable_pcg_shadow()
+            streams += [s_solve, q.s_fuse]
+            q.s_solve = s_solve
+            seqs.append(q)
+        lat = [[] for _ in range(S)]
+
+        def one(i, q, n, f0, timed):
+            torch.cuda.set_device(device)
+            with torch.cuda.stream(q.s_solve):
+                for r in range(n):
+                    if timed:
+                        e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+                        e0.record()
+                    q.frame(f0 + r)
+                    if timed:
+                        e1.record()
+                        lat[i].append((e0, e1))
+
+        def run(n, f0, timed):
+            # a host thread per sequence (the launches of a C2 frame cost one thread ~0.45 ms: four sequences enqueued by one
+            # thread were bound by that, 2 207 frames/s; ctypes and torch release the interpreter lock inside their calls)
+            if threads and S > 1:
+                import threading
+                ts = [threading.Thread(target=one, args=(i, q, n, f0, timed)) for i, q in enumerate(seqs[:S])]
+                [t.start() for t in ts]
+                [t.join() for t in ts]
+            else:
+                for r in range(n):
+                    for i, q in enumerate(seqs[:S]):
+                        one(i, q, 1, f0 + r, timed)
+        run(warmup, 0, False)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        run(rounds, warmup, False)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        run(min(rounds, 30), warmup + rounds, True)
+        torch.cuda.synchronize(device)
+        ms = sorted(a.elapsed_time(b) for per in lat for a, b in per)
+        t_err = max(float((q.solver.translations() - q.t_true[(warmup + rounds + min(rounds, 30) - 1) % q.n_frames]).abs().max()) for q in seqs[:S])
+        out[str(S)] = dict(value=round(S * rounds / dt, 1), unit="frames/s (all sequences together)", sequences=S, rounds=rounds,
+                           ms_per_round=round(dt / rounds * 1e3, 4),
+                           frame_latency_ms=dict(median=round(ms[len(ms) // 2], 4), p95=round(ms[min(len(ms) - 1, int(0.95 * len(ms)))], 4),
+                                                 note="first to last launch of a frame on its sequence's solve stream, while the other sequences run"),
+                           max_abs_translation_error_vs_ground_truth_m=round(t_err, 6))
+    base = out[str(min(int(k) for k in out))]["value"]
+    for k in out:
+        out[k]["vs_one_sequence"] = round(out[k]["value"] / base, 3)
+    out["note"] = ("secondary figure: S self-contained C2 sequences share one GPU (2 HIP streams each, chosen by a concurrency probe), "
+                   + ("a host thread per sequence" if threads else "one host thread enqueues every launch (~45 per frame: its launch rate "
+                                                                   "is part of what saturates)"))
+    del seqs
+    torch.cuda.empty_cache()
+    return out
 
 
 def live_depth_probe(cfg_name, device, steps=30, warmup=5, seq=None):
@@ -1328,6 +1396,12 @@ def main():
                 t_cmp = None
         del seq
         torch.cuda.empty_cache()
+        if not args.no_multi_sequence and args.sequences_per_gpu:
+            try:
+                out["multi_sequence"] = multi_sequence_probe(args.config, device, counts=args.sequences_per_gpu,
+                                                             threads=not args.sequences_one_thread)
+            except Exception as e:  # noqa: BLE001
+                out["multi_sequence"] = dict(error="%s: %s" % (type(e).__name__, e))
         if not args.no_northstar:
             try:
                 out["northstar_mode"] = northstar_probe(args.config, device,

@@ -105,10 +105,14 @@ class use_library:
     def __enter__(self):
         global _LIB
         self.saved = _LIB
-        if self.path not in _LOADED:
-            _LIB = None
-            load(self.path)
-        _LIB = _LOADED[self.path]
+        try:
+            if self.path not in _LOADED:
+                _LIB = None
+                load(self.path)
+            _LIB = _LOADED[self.path]
+        except BaseException:
+            _LIB = self.saved  # (the other build is missing: the module keeps the library it had)
+            raise
         return _LIB
 
     def __exit__(self, *exc):
@@ -548,14 +552,15 @@ class Solver:
     def __init__(self, max_D, max_N, k):
         _torch()
         self._h = C.c_void_p()
+        self._L = load()  # the library that creates the plan serves it for life (use_library may swap the module's)
         self.k, self.max_D, self.max_N = k, max_D, max_N
-        _check(load().dfa_solver_create(max_D, max_N, k, C.byref(self._h)))
+        _check(self._L.dfa_solver_create(max_D, max_N, k, C.byref(self._h)))
         self._keep = None
         self.D = self.N = 0
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
-            load().dfa_solver_destroy(self._h)
+        if getattr(self, "_h", None) and self._h.value and getattr(self, "_L", None) is not None:
+            self._L.dfa_solver_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close
@@ -565,17 +570,17 @@ class Solver:
         f32 = torch.float32
         self.D, self.N = node_pos.shape[0], canon.shape[0]
         self._keep = (node_pos, node_dq, node_w, canon, live, canon_normals, live_normals)  # borrowed by the plan
-        _check(load().dfa_solver_set_problem(self._h, _dev(node_pos, f32, "node_pos"), _dev(node_dq, f32, "node_dq"),
+        _check(self._L.dfa_solver_set_problem(self._h, _dev(node_pos, f32, "node_pos"), _dev(node_dq, f32, "node_dq"),
                                              _dev(node_w, f32, "node_w"), self.D, _dev(canon, f32, "canon"),
                                              _dev(canon_normals, f32), _dev(live, f32, "live"),
                                              _dev(live_normals, f32), self.N, _stream()))
 
     def set_deterministic(self, on=True):
         """order-stable variant (dfa_solver_set_deterministic); applies from the next set_problem"""
-        _check(load().dfa_solver_set_deterministic(self._h, 1 if on else 0))
+        _check(self._L.dfa_solver_set_deterministic(self._h, 1 if on else 0))
 
     def solve(self, params):
-        _check(load().dfa_solver_solve(self._h, C.byref(params), _stream()))
+        _check(self._L.dfa_solver_solve(self._h, C.byref(params), _stream()))
         err, self._overlap_error = getattr(self, "_overlap_error", None), None
         if err is not None:
             raise err
@@ -588,7 +593,7 @@ class Solver:
             n *= d
         if n == 0:
             return torch.empty(shape, dtype=dtype, device="cuda")
-        ptr = getattr(load(), "dfa_solver_" + name)(self._h)
+        ptr = getattr(self._L, "dfa_solver_" + name)(self._h)
         typestr = {torch.float32: "<f4", torch.int32: "<i4"}[dtype]
 
         class _Holder:
@@ -625,13 +630,13 @@ class Solver:
         torch = _torch()
         out_v = torch.empty((self.N, 3), dtype=torch.float32, device="cuda")
         out_n = torch.empty_like(out_v) if normals is not None else None
-        _check(load().dfa_solver_warp_to_live(self._h, _dev(normals, torch.float32, "normals"), _dev(out_v), _dev(out_n),
+        _check(self._L.dfa_solver_warp_to_live(self._h, _dev(normals, torch.float32, "normals"), _dev(out_v), _dev(out_n),
                                               _stream()))
         return out_v, out_n
 
     def enable_timing(self, on=True):
         """True / 1 starts a new measurement, 2 resumes a paused one, False / 0 pauses"""
-        _check(load().dfa_solver_enable_timing(self._h, int(on)))
+        _check(self._L.dfa_solver_enable_timing(self._h, int(on)))
 
     def set_overlap_callback(self, fn):
         """fn(gn_iteration) (or None) is called by every following solve() right after the assembly launch of each
@@ -648,17 +653,17 @@ class Solver:
                 except BaseException as e:  # an exception cannot cross the C frame: re-raised by solve()
                     self._overlap_error = e
             self._overlap_cb = _OVERLAP_FN(trampoline)  # kept alive with the plan
-        _check(load().dfa_solver_set_overlap_callback(self._h, self._overlap_cb, None))
+        _check(self._L.dfa_solver_set_overlap_callback(self._h, self._overlap_cb, None))
 
     def timing(self):
         t = _SolveTiming()
-        _check(load().dfa_solver_get_timing(self._h, C.byref(t), _stream()))
+        _check(self._L.dfa_solver_get_timing(self._h, C.byref(t), _stream()))
         return dict(pcg_ms=t.pcg_ms, assemble_ms=t.assemble_ms, pcg_launches=t.pcg_launches,
                     assemble_launches=t.assemble_launches, matrix_nnz=t.matrix_nnz, pcg_iters=t.pcg_iters, solves=t.solves)
 
     def stats(self):
         st = _SolveStats()
-        _check(load().dfa_solver_get_stats(self._h, C.byref(st), _stream()))
+        _check(self._L.dfa_solver_get_stats(self._h, C.byref(st), _stream()))
         return dict(initial_cost=st.initial_cost, final_cost=st.final_cost, gn_iters=st.gn_iters,
                     pcg_iters=st.pcg_iters, max_row_nnz=st.max_row_nnz, gn_noop=st.gn_noop)
 
@@ -681,14 +686,15 @@ class Solver6:
     def __init__(self, max_D, max_N, k):
         _torch()
         self._h = C.c_void_p()
+        self._L = load()  # the library that creates the plan serves it for life (use_library may swap the module's)
         self.k, self.max_D, self.max_N = k, max_D, max_N
-        _check(load().dfa_solver6_create(max_D, max_N, k, C.byref(self._h)))
+        _check(self._L.dfa_solver6_create(max_D, max_N, k, C.byref(self._h)))
         self._keep = None
         self.D = self.N = 0
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
-            load().dfa_solver6_destroy(self._h)
+        if getattr(self, "_h", None) and self._h.value and getattr(self, "_L", None) is not None:
+            self._L.dfa_solver6_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close
@@ -697,24 +703,24 @@ class Solver6:
         f32 = _torch().float32
         self.D, self.N = node_pos.shape[0], canon.shape[0]
         self._keep = (node_pos, node_dq, node_w, canon, canon_normals)  # borrowed by the plan
-        _check(load().dfa_solver6_set_problem(self._h, _dev(node_pos, f32, "node_pos"), _dev(node_dq, f32, "node_dq"),
+        _check(self._L.dfa_solver6_set_problem(self._h, _dev(node_pos, f32, "node_pos"), _dev(node_dq, f32, "node_dq"),
                                               _dev(node_w, f32, "node_w"), self.D, _dev(canon, f32, "canon"),
                                               _dev(canon_normals, f32, "canon_normals"), self.N, _stream()))
 
     def set_node_transforms(self, node_dq):
         """the same graphs, new starting transforms (dfa_solver6_set_node_transforms)"""
         self._keep = self._keep[:1] + (node_dq,) + self._keep[2:]
-        _check(load().dfa_solver6_set_node_transforms(self._h, _dev(node_dq, _torch().float32, "node_dq")))
+        _check(self._L.dfa_solver6_set_node_transforms(self._h, _dev(node_dq, _torch().float32, "node_dq")))
 
     def solve(self, vmap, nmap, fx, fy, cx, cy, params):
         f32 = _torch().float32
         rows, cols = vmap.shape[:2]
-        _check(load().dfa_solver6_solve(self._h, _dev(vmap, f32, "vmap"), vmap.stride(0) * 4, _dev(nmap, f32, "nmap"),
+        _check(self._L.dfa_solver6_solve(self._h, _dev(vmap, f32, "vmap"), vmap.stride(0) * 4, _dev(nmap, f32, "nmap"),
                                         nmap.stride(0) * 4, cols, rows, fx, fy, cx, cy, C.byref(params), _stream()))
 
     def node_dq(self):
         torch = _torch()
-        ptr = load().dfa_solver6_node_dq(self._h)
+        ptr = self._L.dfa_solver6_node_dq(self._h)
 
         class _Holder:
             __cuda_array_interface__ = dict(shape=(self.D, 8), typestr="<f4", data=(int(ptr), False), version=2)
@@ -725,20 +731,20 @@ class Solver6:
         torch = _torch()
         out_v = torch.empty((self.N, 3), dtype=torch.float32, device="cuda")
         out_n = torch.empty_like(out_v) if want_normals and self._keep[4] is not None else None
-        _check(load().dfa_solver6_warp(self._h, _dev(out_v), _dev(out_n), _stream()))
+        _check(self._L.dfa_solver6_warp(self._h, _dev(out_v), _dev(out_n), _stream()))
         return out_v, out_n
 
     def enable_timing(self, on=True):
-        _check(load().dfa_solver6_enable_timing(self._h, 1 if on else 0))
+        _check(self._L.dfa_solver6_enable_timing(self._h, 1 if on else 0))
 
     def timing(self):
         t = _Solve6Timing()
-        _check(load().dfa_solver6_get_timing(self._h, C.byref(t), _stream()))
+        _check(self._L.dfa_solver6_get_timing(self._h, C.byref(t), _stream()))
         return {n: getattr(t, n) for n, _ in _Solve6Timing._fields_}
 
     def stats(self):
         st = _Solve6Stats()
-        _check(load().dfa_solver6_get_stats(self._h, C.byref(st), _stream()))
+        _check(self._L.dfa_solver6_get_stats(self._h, C.byref(st), _stream()))
         d = {n: getattr(st, n) for n, _ in _Solve6Stats._fields_}
         n = st.hist_n  # slots of the Gauss-Newton loop (gn_tol > 0: + the closing check), skipped ones included
         for name in ("cost_hist", "pcg_rel_hist", "pcg_it_hist", "pcg_tol_hist", "valid_hist", "stop_hist"):

@@ -154,17 +154,10 @@ constexpr int MC_ROWS = 2;  // rows of cubes per wave: 3 row loads per slice ser
 template <int VX>
 __global__ __launch_bounds__(256) void mc_count_kernel(const McArgs a, int32_t* __restrict__ seg_count) {
     __shared__ uint8_t ntri_lds[256];  // triangles per case
-    {
-        const int t  = threadIdx.y * 64 + threadIdx.x;
-        const int nv = a.nverts[t];
-        ntri_lds[t]  = (t == 0 || t == 255) ? 0 : (uint8_t)(min(max(nv, 0), 15) / 3);  // :99
-    }
-    __syncthreads();
+    __shared__ int wave_work[4];
     const int seg = blockIdx.x, x0 = (seg * 64 + threadIdx.x) * VX;
     const int y = (blockIdx.y * 4 + threadIdx.y) * MC_ROWS;
-    if (y >= a.Y) return;  // whole wave
     const int z0 = blockIdx.z * a.zchunk, z1 = min(z0 + a.zchunk, a.Z - 1);
-    if (z0 >= z1) return;
     // With an occupancy map: a cube with triangles has a non-zero weight at all eight corners (:38-60) and a negative
     // distance at one of them, so a slice pair (z, z + 1) has such cubes for this wave only if the map shows weights in BOTH
     // slices' layers over the wave's footprint — its 64 VX voxels and the one after them in x (2 VX + 1 boxes), rows
@@ -178,6 +171,24 @@ __global__ __launch_bounds__(256) void mc_count_kernel(const McArgs a, int32_t* 
         if (lane < 2 * NBX && by < a.oy && bx < a.ox && z8 < a.oz) v = a.occ[((size_t)z8 * a.oy + by) * a.ox + bx];
         return (__ballot(v & 1u) != 0ull ? 1u : 0u) | (__ballot(v & 2u) != 0ull ? 2u : 0u);
     };
+    // what the wave's chunk can hold at all (the layers of its first and last slice: chunks with a map are one layer long),
+    // before anything else is loaded: most workgroups of a sparse volume end here
+    bool work = y < a.Y && z0 < z1;
+    if (work && a.occ) {
+        const unsigned m0 = layer_marks(z0 / 8), m1 = z1 / 8 != z0 / 8 ? layer_marks(z1 / 8) : m0;
+        // (the steps inside the first layer need weights and a negative distance there; the step into the last layer both layers)
+        work = a.zchunk > 8 || (m0 & 3u) == 3u || ((m0 & m1 & 1u) && ((m0 | m1) & 2u));
+    }
+    if (threadIdx.x == 0) wave_work[threadIdx.y] = work;
+    __syncthreads();
+    if (!(wave_work[0] | wave_work[1] | wave_work[2] | wave_work[3])) return;  // (the whole workgroup)
+    {
+        const int t  = threadIdx.y * 64 + threadIdx.x;
+        const int nv = a.nverts[t];
+        ntri_lds[t]  = (t == 0 || t == 255) ? 0 : (uint8_t)(min(max(nv, 0), 15) / 3);  // :99
+    }
+    __syncthreads();
+    if (!work) return;  // whole wave
     int cur8 = z0 / 8;
     unsigned cur = layer_marks(cur8);
     bool lo_valid = false;
@@ -415,6 +426,10 @@ hipError_t launch_marching_cubes(const uint32_t* vol, int X, int Y, int Z, const
     const long columns = (long)a.nseg * ((Y + 4 * MC_ROWS - 1) / (4 * MC_ROWS));
     int zchunk         = Z;
     while (columns * ((Z + zchunk - 1) / zchunk) < 2048 && zchunk > 16) zchunk = (zchunk + 1) / 2;
+    // With an occupancy map the sweep is no longer a stream: the few waves that have slices to load walk them as a chain of
+    // dependent round trips (a slice per trip).  One layer of the map per workgroup: 4 x as many workgroups at 512^3, most
+    // of which return after one look at the map, and chains of 8 trips instead of 32 (count sweep 109 -> see profiles/r05).
+    if (occ) zchunk = 8;
     a.zchunk = zchunk;
     // only segments with vertices are written by the count sweep (an unconditional 4-byte store per
     // wave and slice costs 25 %: the sweep is bound by vector-memory instruction issue)

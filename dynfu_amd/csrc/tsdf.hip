@@ -513,7 +513,10 @@ __device__ __forceinline__ f3 compute_normal(const RaycastArgs& a, f3 p, RayTall
 
 // march steps whose voxels are requested together (measured at 512^3 / VGA and 1024^3 / 720p: 1 step 0.082 / 0.219 ms,
 // 2: 0.063 / 0.158, 4: 0.057 / 0.140, 6: 0.060 / 0.143, 8: 0.062 / 0.148 in the first batched form)
-constexpr int RAY_BATCH = 4;
+#ifndef DFA_RAY_BATCH  // (compile-time A/B: tools/ab_variant.sh rb8 tsdf.hip -DDFA_RAY_BATCH=8)
+#define DFA_RAY_BATCH 4
+#endif
+constexpr int RAY_BATCH = DFA_RAY_BATCH;
 
 // shared body of the two TsdfRaycaster::operator() overloads (:195-318)
 template <bool TALLY = false, bool IDX32 = false>

@@ -315,7 +315,9 @@ typedef struct {
     int linear_iter;    /* max PCG iterations per GN iteration (linearIter)                                  */
     float tukey_offset; /* CombinedSolver ctor, opt_solver.cpp:3-13                                          */
     float psi_data;
-    float lambda;
+    float lambda;  /* >= 0 and finite (anything else: DFA_ERR_INVALID).  w_reg^2 = lambda / (D k) is one of the addends of the
+                      normal matrix, whose 64-bit fixed-point sums scale themselves by the largest addend of the problem
+                      (tiny RBF weights or a huge lambda cost no bits; addends below 2^-17 of the largest lose theirs) */
     float psi_reg;
     float pcg_tol; /* relative preconditioned-residual tolerance; 0 = machine floor only */
     float gn_tol;  /* relative cost-decrease tolerance; 0 = run all GN iterations         */
@@ -362,11 +364,14 @@ int dfa_solver_set_problem(dfa_solver* s, const float* node_pos, const float* no
  * capturable into a caller's HIP graph; in the others the call blocks the calling thread (hipStreamSynchronize on
  * `stream`) between its launches, also between two invocations of the overlap callback. */
 /* Order-stable variant of the reference-parity solve: the same bits from the same inputs ("or
- * deterministic segmented reduction for bit-stable results").  The default path reduces a node's rows with LDS float
- * atomics, compacts the matrix rows in hash order and places rows of equal length by an atomic cursor: two runs of the
- * same frame differ in the last bits (measured: up to 2e-5 m in the translations after 24 x 16 iterations).  With
- * on != 0 the node lists are sorted, the assembly adds per-wave private sums in a fixed order into rows sorted by column
- * (two passes over a node's rows: ~1.3x the assembly time), and the PCG kernels keep equal-length rows in index order.
+ * deterministic segmented reduction for bit-stable results").  Both paths sum a node's rows as 64-bit fixed-point integers
+ * in LDS (exact, whatever the order of the adds: csrc/solve.hip, FixedScale) — the matrix ENTRIES are the same bits in
+ * every run.  What differs from run to run on the default path is their ORDER: the rows are compacted in hash order and
+ * rows of equal length are placed by an atomic cursor, so the float sums of the PCG's products (and the gradient's wave
+ * sums over an unsorted list) round differently in the last bit (measured in round 3, before the integer sums: up to 2e-5 m
+ * in the translations after 24 x 16 iterations; not re-measured since).  With on != 0 the node lists are sorted, the rows
+ * are written sorted by column (two passes over a node's rows: ~1.3x the assembly time), and the PCG kernels keep
+ * equal-length rows in index order: same inputs, same bits.
  * Takes effect at the next dfa_solver_set_problem.  New plans start with the value of the environment variable
  * DFA_ASSEMBLE_DETERMINISTIC (unset / 0: off). */
 int dfa_solver_set_deterministic(dfa_solver* s, int on);

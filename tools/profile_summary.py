@@ -24,7 +24,7 @@ def find(d, suffix):
 
 
 lines = []
-for d in sorted(glob.glob(os.path.join(out, tag + "_stats_*"))):
+for d in sorted(glob.glob(os.path.join(out, tag + "_stats_*")) + glob.glob(os.path.join(out, tag + "_trace_hostseq_*"))):
     if not os.path.isdir(d):
         continue
     name = os.path.basename(d)[len(tag) + 7:]
@@ -81,4 +81,44 @@ for name in names:
             mf, mw = sf / max(nf, 1), sw / max(nw, 1)
             g.write("| `%s` | %d | %.1f | %.1f | %.3f | %.3f |\n" % (kn.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:80], nf, mf, mw,
                                                                   (mf + mw) * 1024 / 1e6, (2 * mf + mw) * 1024 / 1e6))
-print("wrote", sorted(os.listdir(prof))[-12:])
+# idle-gap tables and stage clocks of the adaptor's sequence (tools/hostseq_trace.sh)
+for mode in ("ref", "northstar"):
+    for src, dst in (("%s_frame_gaps_%s.md" % (tag, mode), "%s_frame_gaps_hostseq_%s.md" % (tag, mode)),):
+        f = os.path.join(out, src)
+        if os.path.exists(f) and os.path.getsize(f) > 10:
+            open(os.path.join(prof, dst), "w").write("(rocprofv3 kernel trace of dynfu_amd/host/build/sequence_bench, 512^3, mode %s, commit %s; "
+                                                     "tools/frame_gaps.py)\n\n" % (mode, commit) + open(f).read())
+
+# ---- profiles/traffic.json: HBM bytes per launch of the kernels bench.py prices, straight from the counter passes above
+# (no hand-copied numbers).  key "<config>/<kernel key>" -> bytes, formula, source file, commit.  Entries whose pass did not
+# run this time are carried over from the existing file (their own source / commit stay with them).
+KEYS = {  # pmc run name -> config, then kernel-name fragment -> (key, formula)
+    "c2": ("C2", {"integrate_runs_kernel<true": ("fused_integrate", "2F+W"), "pcg_paired_kernel": ("pcg", "F+W")}),
+    "ref_c3": ("C3", {"integrate_runs_kernel<true": ("fused_integrate", "2F+W"), "pcg_mb_step_kernel": ("pcg", "F+W")}),
+    "ref_c4": ("C4", {"integrate_runs_kernel<true": ("fused_integrate", "2F+W"), "pcg_mb_step_kernel": ("pcg", "F+W")}),
+    "ns_c2": ("C2", {"s6_assemble2_kernel": ("s6_assemble", "F+W"), "s6_linearise_kernel": ("s6_linearise", "2F+W"), "s6_pcg_step_kernel": ("s6_pcg_step", "F+W")}),
+    "ns_c3": ("C3", {"s6_assemble2_kernel": ("s6_assemble", "F+W"), "s6_linearise_kernel": ("s6_linearise", "2F+W"), "s6_pcg_step_kernel": ("s6_pcg_step", "F+W")}),
+    "ns_c4": ("C4", {"s6_assemble2_kernel": ("s6_assemble", "F+W"), "s6_linearise_kernel": ("s6_linearise", "2F+W"), "s6_pcg_step_kernel": ("s6_pcg_step", "F+W")}),
+}
+tj = os.path.join(prof, "traffic.json")
+traffic = json.load(open(tj)) if os.path.exists(tj) else {}
+for name, (config, kmap) in KEYS.items():
+    ff = find(os.path.join(out, "%s_pmc_%s_FETCH_SIZE" % (tag, name)), "counter_collection.csv")
+    fw = find(os.path.join(out, "%s_pmc_%s_WRITE_SIZE" % (tag, name)), "counter_collection.csv")
+    if not (ff and fw):
+        continue
+    f, w = load(ff), load(fw)
+    for frag, (key, formula) in kmap.items():
+        hits = [kn for kn in f if frag in kn]
+        if not hits:
+            continue
+        kn = max(hits, key=lambda n: f[n][1])
+        mf, mw = f[kn][1] / max(f[kn][0], 1), w.get(kn, [0, 0.0])[1] / max(w.get(kn, [1, 0.0])[0], 1)
+        nbytes = ((2 * mf if formula == "2F+W" else mf) + mw) * 1024.0
+        traffic["%s/%s" % (config, key)] = dict(bytes_per_launch=round(nbytes, 1), fetch_kib=round(mf, 1), write_kib=round(mw, 1),
+                                                formula={"2F+W": "2 x FETCH_SIZE + WRITE_SIZE (wide read streams: the gfx950 correction of MI355X_MICROARCH.md)",
+                                                         "F+W": "FETCH_SIZE + WRITE_SIZE (gathers of 4-80 bytes: uncorrected)"}[formula],
+                                                source="profiles/%s_pmc_%s.md" % (tag, name), commit=commit, dispatches=f[kn][0],
+                                                kernel=kn.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:80])
+json.dump(traffic, open(tj, "w"), indent=1, sort_keys=True)
+print("wrote", sorted(os.listdir(prof))[-14:])
