@@ -71,7 +71,8 @@ def parse():
     ap.add_argument("--sequences-per-gpu", type=int, nargs="*", default=[1, 2, 4],
                     help="the multi_sequence figure: S independent sequences on this GPU, each on streams of its own (default 1 2 4)")
     ap.add_argument("--no-multi-sequence", action="store_true", help="skip the multi_sequence figure")
-    ap.add_argument("--sequences-one-thread", action="store_true", help="multi_sequence: one host thread enqueues every sequence")
+    ap.add_argument("--sequences-threads", action="store_true", help="multi_sequence: a host thread per sequence instead of one "
+                                                                     "thread enqueuing round-robin")
     ap.add_argument("--no-live-depth", action="store_true", help="skip the short measurement on the reference's data flow with noisy depth")
     ap.add_argument("--live", default="targets", choices=["targets", "depth"],
                     help="targets: index-aligned live vertices canon + sum w t* (SURVEY 8d, the headline workload); depth: the "
@@ -424,7 +425,7 @@ class SequenceLive(Sequence):
         self.live_last = live
 
 
-def multi_sequence_probe(cfg_name, device, counts=(1, 2, 4), rounds=60, warmup=8, threads=True):
+def multi_sequence_probe(cfg_name, device, counts=(1, 2, 4), rounds=60, warmup=8, threads=False):
     """BASELINE config 5's workload shape on ONE device: S independent sequences (own volume, solver plan and streams), a
     frame of each enqueued round-robin by one host thread, no synchronisation between frames.  The reference-mode PCG of a C2
     frame holds 3 of 256 CUs for half of the frame; what a second and a fourth sequence make of the idle chip tells the
@@ -461,8 +462,8 @@ def multi_sequence_probe(cfg_name, device, counts=(1, 2, 4), rounds=60, warmup=8
                         lat[i].append((e0, e1))
 
         def run(n, f0, timed):
-            # a host thread per sequence (the launches of a C2 frame cost one thread ~0.45 ms: four sequences enqueued by one
-            # thread were bound by that, 2 207 frames/s; ctypes and torch release the interpreter lock inside their calls)
+            # --sequences-threads: a host thread per sequence (measured: no better than one thread enqueuing round-robin —
+            # 2 055 against 2 200 frames/s at S = 4 —: the threads share the interpreter lock between their calls)
             if threads and S > 1:
                 import threading
                 ts = [threading.Thread(target=one, args=(i, q, n, f0, timed)) for i, q in enumerate(seqs[:S])]
@@ -476,6 +477,7 @@ def multi_sequence_probe(cfg_name, device, counts=(1, 2, 4), rounds=60, warmup=8
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         run(rounds, warmup, False)
+        t_enq = time.perf_counter() - t0  # the host is done enqueuing here; close to dt = the host is what paces the rounds
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
         run(min(rounds, 30), warmup + rounds, True)
@@ -483,7 +485,7 @@ def multi_sequence_probe(cfg_name, device, counts=(1, 2, 4), rounds=60, warmup=8
         ms = sorted(a.elapsed_time(b) for per in lat for a, b in per)
         t_err = max(float((q.solver.translations() - q.t_true[(warmup + rounds + min(rounds, 30) - 1) % q.n_frames]).abs().max()) for q in seqs[:S])
         out[str(S)] = dict(value=round(S * rounds / dt, 1), unit="frames/s (all sequences together)", sequences=S, rounds=rounds,
-                           ms_per_round=round(dt / rounds * 1e3, 4),
+                           ms_per_round=round(dt / rounds * 1e3, 4), host_enqueue_ms_per_round=round(t_enq / rounds * 1e3, 4),
                            frame_latency_ms=dict(median=round(ms[len(ms) // 2], 4), p95=round(ms[min(len(ms) - 1, int(0.95 * len(ms)))], 4),
                                                  note="first to last launch of a frame on its sequence's solve stream, while the other sequences run"),
                            max_abs_translation_error_vs_ground_truth_m=round(t_err, 6))
@@ -1399,7 +1401,7 @@ def main():
         if not args.no_multi_sequence and args.sequences_per_gpu:
             try:
                 out["multi_sequence"] = multi_sequence_probe(args.config, device, counts=args.sequences_per_gpu,
-                                                             threads=not args.sequences_one_thread)
+                                                             threads=args.sequences_threads)
             except Exception as e:  # noqa: BLE001
                 out["multi_sequence"] = dict(error="%s: %s" % (type(e).__name__, e))
         if not args.no_northstar:
