@@ -22,6 +22,9 @@ public:
     void init(float epsilon, std::vector<std::shared_ptr<Node>> nodes);
     void addNode(std::shared_ptr<Node> newNode);
     std::vector<std::shared_ptr<Node>> getNodes();
+    // the same nodes without the copy (8 k shared pointers: ~0.05 ms of reference counting per call) — for the adaptor's own
+    // per-frame loops; the reference's accessor above returns by value
+    const std::vector<std::shared_ptr<Node>>& nodesRef() const { return nodes; }
 
     std::vector<std::shared_ptr<Node>> findNeighbors(int numNeighbor, dfa::PointXYZ vertex);
     std::vector<size_t> findNeighborsIndex(int numNeighbor, dfa::PointXYZ vertex);

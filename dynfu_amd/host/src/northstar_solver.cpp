@@ -59,13 +59,12 @@ struct NorthStarSolver::Impl {
 
 NorthStarSolver::NorthStarSolver(Warpfield warpfield, NorthStarParameters params, float tukeyOffset_, float psi_data_,
                                  float lambda_, float psi_reg_)
-    : m_warpfield(warpfield), m_params(params), tukeyOffset(tukeyOffset_), psi_data(psi_data_), lambda(lambda_),
+    : m_warpfield(std::move(warpfield)), m_params(params), tukeyOffset(tukeyOffset_), psi_data(psi_data_), lambda(lambda_),
       psi_reg(psi_reg_), impl(std::make_shared<Impl>()) {}
 NorthStarSolver::~NorthStarSolver() = default;
 
 void NorthStarSolver::initializeProblemInstance(const std::shared_ptr<dynfu::Frame> canonicalFrame) {
-    auto nodes  = m_warpfield.getNodes();
-    const int D = (int)nodes.size(), N = (int)canonicalFrame->size();
+    const int D = (int)m_warpfield.nodesRef().size(), N = (int)canonicalFrame->size();
     if (D == 0) throw dfa::Error(DFA_ERR_INVALID, "NorthStarSolver: the warp field has no nodes");
     std::vector<float> pos, w, dq;
     m_warpfield.hostArrays(pos, w, dq);
@@ -158,7 +157,7 @@ void NorthStarSolver::solveAll(const kfusion::cuda::Cloud& vmap, const kfusion::
     // opt_solver.cpp:270-285; here the unknown IS the transform)
     std::vector<float> dq(8 * (size_t)I.D);
     dfa_host_copy_from_device(dq.data(), dfa_solver6_node_dq(I.plan), dq.size() * sizeof(float));
-    auto nodes = m_warpfield.getNodes();
+    const auto& nodes = m_warpfield.nodesRef();
     for (int i = 0; i < I.D; ++i) {
         const float* q = &dq[8 * (size_t)i];
         nodes[i]->setTransformation(std::make_shared<DualQuaternion<float>>(dfa::quaternion<float>(q[0], q[1], q[2], q[3]),

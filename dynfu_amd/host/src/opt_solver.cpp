@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <utility>
 #include <vector>
 
 #include <dfa_host/device.hpp>
@@ -29,15 +30,14 @@ struct CombinedSolver::Impl {
 
 CombinedSolver::CombinedSolver(Warpfield warpfield, CombinedSolverParameters params, float tukeyOffset_,
                                float psi_data_, float lambda_, float psi_reg_)
-    : m_warpfield(warpfield), m_params(params), tukeyOffset(tukeyOffset_), psi_data(psi_data_), lambda(lambda_),
+    : m_warpfield(std::move(warpfield)), m_params(params), tukeyOffset(tukeyOffset_), psi_data(psi_data_), lambda(lambda_),
       psi_reg(psi_reg_), impl(std::make_shared<Impl>()) {}
 CombinedSolver::~CombinedSolver() = default;
 
 // opt_solver.cpp:15-54 (+ resetGPUMemory :149-202): stage AoS -> SoA, upload, build the graphs
 void CombinedSolver::initializeProblemInstance(const std::shared_ptr<dynfu::Frame> canonicalFrame,
                                                const std::shared_ptr<dynfu::Frame> liveFrame, dfa::Affine3f /*affine*/) {
-    auto nodes = m_warpfield.getNodes();
-    const int D = (int)nodes.size(), N = (int)canonicalFrame->size();
+    const int D = (int)m_warpfield.nodesRef().size(), N = (int)canonicalFrame->size();
     if ((int)liveFrame->size() != N) throw dfa::Error(DFA_ERR_INVALID, "canonical / live vertex counts differ");
     std::vector<float> pos, w, dq;
     m_warpfield.hostArrays(pos, w, dq);
@@ -98,7 +98,7 @@ void CombinedSolver::solveAll() {
         extern void dfa_host_copy_from_device(void*, const void*, size_t);
         dfa_host_copy_from_device(t.data(), dfa_solver_translations(I.plan), t.size() * sizeof(float));
     }
-    auto nodes = m_warpfield.getNodes();
+    const auto& nodes = m_warpfield.nodesRef();  // (the Nodes are shared with the caller's warp field: opt_solver.cpp:5)
     for (int i = 0; i < I.D; ++i) {
         nodes[i]->updateTransformation(DualQuaternion<float>(0.f, 0.f, 0.f, t[3 * i], t[3 * i + 1], t[3 * i + 2]));
     }
