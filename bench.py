@@ -109,6 +109,9 @@ def parse():
     ap.add_argument("--gn-tol", type=float, default=None,
                     help="northstar: dfa_solve6_params.gn_tol (default 1e-3: stopping rule + step acceptance; 0: every "
                          "Gauss-Newton iteration runs)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="northstar: the sweep on a second stream beside the solve (the default of this mode is stream order: "
+                         "its kernels fill the chip)")
     ap.add_argument("--no-adaptive-launch", action="store_true",
                     help="northstar: enqueue the full PCG launch budget of every Gauss-Newton iteration (A/B of "
                          "dfa_solve6_params.adaptive_launch)")
@@ -368,6 +371,15 @@ class Sequence6(Sequence):
 
     def build_graph(self, f):
         self.solver.set_problem(self.nodes, self.node_dq, self.node_w, self.verts, self.normals)
+
+    def frame(self, f, serial=None, timed_events=None):
+        # Every kernel of this mode fills the chip (linearise, assembly, a PCG step = thousands of workgroups): a sweep on
+        # a second stream does not hide behind them, it takes their CUs — measured with streams that really overlap
+        # (concurrent_stream): C2 781 -> 845, C3 301 -> 319, C4 162 -> 165 frames/s in stream order.  The reference-mode
+        # frame (its PCG holds 3 CUs) keeps the second stream; `--overlap` gives this mode one too (A/B).
+        return super().frame(f, not self.overlap if serial is None else serial, timed_events)
+
+    overlap = False
 
     def solve(self, f, graph_built=False):
         A = self.A
@@ -725,7 +737,7 @@ def northstar_timed_frames(seq, f0, device, frames=5):
     fuse_events, tms = [], []
     seq.solver.enable_timing(True)
     for i in range(frames):
-        seq.frame(f0 + i, False, fuse_events)
+        seq.frame(f0 + i, None, fuse_events)
         torch.cuda.synchronize(device)
         tms.append(seq.solver.timing())
     st = seq.solver.stats()
@@ -782,15 +794,17 @@ def main_northstar(args, torch, replicas, rank, world, device):
         pcg["gn_tol"] = args.gn_tol
     seq = Sequence6(args.config, device, lin, pcg)
     seq.fuse_first = args.fuse_first
+    seq.overlap = args.overlap or args.fuse_first
     cfg = seq.cfg
     K, Wm = args.steps, args.warmup
+    ser = True if args.serial else None  # (None: the mode's default — stream order unless --overlap / --fuse-first)
     for f in range(Wm):
-        seq.frame(f, args.serial)
+        seq.frame(f, ser)
     fuse_events = []
 
     def timed():
         for f in range(K):
-            seq.frame(Wm + f, args.serial, fuse_events)
+            seq.frame(Wm + f, ser, fuse_events)
 
     seq.solver.enable_timing(True)
     dt_max = replicas.timed_region(timed, device)
@@ -814,8 +828,9 @@ def main_northstar(args, torch, replicas, rank, world, device):
                                        northstar_fields(seq, st)["pcg_tolerance_schedule"]),
                            parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus, ranks_seen=n_gpus,
                            rccl_selfcheck=rccl_selfcheck(),
-                           streams="serial" if args.serial else ("fuse || graph build + solve on two HIP streams" if args.fuse_first else
-                                                                 "graph build, then fuse || solve on two HIP streams"),
+                           streams="one HIP stream (every kernel of this mode fills the chip: a second stream for the sweep costs 6-8 %)"
+                                   if not seq.overlap or args.serial else ("fuse || graph build + solve on two HIP streams" if args.fuse_first else
+                                                                           "graph build, then fuse || solve on two HIP streams"),
                            last_frame=northstar_fields(seq, st)),
                roofline=rl[0], roofline_other=rl[1:])
     if not args.no_cpu_baseline and world == 1:

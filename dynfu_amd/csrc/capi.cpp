@@ -1217,7 +1217,7 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
     dfa::Solve6Image img{live_vertex_map, live_normal_map, vertex_step, normal_step, cols, rows, fx, fy, cx, cy};
     hipStream_t st = S(stream);
     s->ev_used = 0;
-    HIP_TRY(dfa::s6_begin(s->v, s->state, s->node_dq, st));
+    HIP_TRY(dfa::s6_begin(s->v, s->state, s->node_dq, early ? p.num_iter * p.gn_iter : 0, st));
     s->last_launches = 0;
     const bool no_graph = dfa::dev_env("DFA_S6_NO_GRAPH") != nullptr;  // (development builds: launches issued one by one)
     // ---- launch budget: fold the solves up to n - 2 into the history (in order, each behind its completion event)
@@ -1281,10 +1281,10 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
             };
             const int gi = outer * p.gn_iter + gn;
             mark();
-            HIP_TRY(dfa::s6_linearise(s->v, s->state, img, p, gn == 0, st));
-            // gn_tol > 0: the stopping rule, decided on the device — launches behind the end of an outer iteration return
-            // at entry (nothing comes back to the host: the launches of the whole solve are enqueued regardless)
-            if (early) HIP_TRY(dfa::s6_decide(s->v, s->state, p, gi, gn, 0, st));
+            // gn_tol > 0: the launch's last workgroup applies the stopping rule on the device — launches behind the end of an
+            // outer iteration return at entry (nothing comes back to the host: the launches of the whole solve are enqueued
+            // regardless)
+            HIP_TRY(dfa::s6_linearise(s->v, s->state, img, p, gn == 0, gi, gn, 0, st));
             mark();
             HIP_TRY(dfa::s6_assemble(s->v, s->state, p, gn, st));
             mark();
@@ -1331,8 +1331,7 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
     if (early && p.num_iter * p.gn_iter > 0) {
         // the last step of the solve, if its outer iteration ran to the cap: one closing linearisation decides whether it stays
         const int gi = p.num_iter * p.gn_iter;
-        HIP_TRY(dfa::s6_linearise(s->v, s->state, img, p, 0, st));
-        HIP_TRY(dfa::s6_decide(s->v, s->state, p, gi, p.gn_iter, 1, st));
+        HIP_TRY(dfa::s6_linearise(s->v, s->state, img, p, 0, gi, p.gn_iter, 1, st));
         HIP_TRY(dfa::s6_update(s->v, s->state, 0, p.linear_iter, nullptr, gi, 0, st));
     }
     if (mirror_slot) HIP_TRY(hipEventRecord(s->done_ev[slot], st));

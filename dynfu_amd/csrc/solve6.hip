@@ -256,7 +256,7 @@ __device__ __forceinline__ float tukey6(float err, float offset, float c) {  // 
 // first workgroup of the assembly that follows adds them up in a fixed order (s6_cost_total).  Two atomicAdds per workgroup
 // on the state block's two words — 4 000 same-address fp64 atomics per launch at C3 — cost 15-25 us of the launch
 // (C2 0.033 -> 0.017 ms, C3 0.061 -> 0.041), and their order decided the last bits of the sum.
-__device__ __forceinline__ void block_add_cost(double cost, unsigned int nvalid, const Solve6View& s) {
+__device__ __forceinline__ void block_add_cost(double cost, unsigned int nvalid, const Solve6View& s, bool through = false) {
     __shared__ double sc[8];
     __shared__ unsigned int sn[8];
     cost   = wave_sum_all(cost);
@@ -268,17 +268,27 @@ __device__ __forceinline__ void block_add_cost(double cost, unsigned int nvalid,
         double c = 0;
         unsigned int n = 0;
         for (int w = 0; w < nw; ++w) c += sc[w], n += sn[w];
-        s.cost_part[blockIdx.x] = c, s.valid_part[blockIdx.x] = n;
+        if (through) {  // read by ANOTHER workgroup of this launch (its last one): written through, past this XCD's L2
+            __hip_atomic_store(&s.cost_part[blockIdx.x], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&s.valid_part[blockIdx.x], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            s.cost_part[blockIdx.x] = c, s.valid_part[blockIdx.x] = n;
+        }
     }
 }
 __host__ __device__ inline int s6_linearise_blocks(int N, int D, int k) { return (N + 255) / 256 + (D * k + 255) / 256; }
 // by all 256 threads of one workgroup: the partial sums of the last linearisation, in a fixed order, into the state block
-__device__ __forceinline__ void s6_cost_total(const Solve6View& s, Solve6State* st) {
+__device__ __forceinline__ void s6_cost_total(const Solve6View& s, Solve6State* st, bool through = false) {
     __shared__ double tc[4];
     __shared__ unsigned long long tn[4];
     const int n = s6_linearise_blocks(s.N, s.D, s.k), tid = threadIdx.x;
     double c = 0.0;
     unsigned long long v = 0ull;
+    if (through) {  // (partials of the launch in flight: loads that do not stop at this XCD's L2)
+        for (int i = tid; i < n; i += 256)
+            c += __hip_atomic_load(&s.cost_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                v += __hip_atomic_load(&s.valid_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else
     for (int i = tid; i < n; i += 256) c += s.cost_part[i], v += s.valid_part[i];
     c = wave_sum_all(c);
     v = (unsigned long long)wave_sum_all((double)v);  // (counts below 2^53: exact)
@@ -289,14 +299,77 @@ __device__ __forceinline__ void s6_cost_total(const Solve6View& s, Solve6State* 
 
 __device__ __forceinline__ double s6_reg_edge(const Solve6View& s, int e, float wreg2, float psi_reg, int update_w);
 
+// gn_tol > 0: the Gauss-Newton stopping rule (oracle/oracle.h: orc6_params.gn_tol states it; the reference runs Opt with
+// earlyOut = true and nonLinearIter as a cap, src/dynfu/dyn_fusion.cpp:183-189) and the bookkeeping s6_bookkeeping does
+// otherwise — by ONE thread of the linearisation's last workgroup, after s6_cost_total: the assembly's workgroups, which run
+// next, must already know (a launch behind an ended outer iteration returns at entry).  Slots that are skipped write
+// nothing: s6_begin has marked every slot "skipped".
+__device__ __forceinline__ void s6_decide(Solve6State* st, const S6Decide& d) {
+    const bool in = d.gi < S6_HIST;
+    const double cost = st->cost;
+    const unsigned long long valid = st->valid;
+    if (!st->have_first) st->initial_cost = cost, st->valid_first = valid, st->have_first = 1;
+    int stop = 0;
+    if (d.gn > 0) {
+        const double ref = st->cost_ref;
+        if (cost > (1.0 + (double)d.gn_tol) * ref) stop = 2;                       // the step raised the energy: undone
+        else if (d.closing || ref - cost <= (double)d.gn_tol * ref) stop = 1;      // converged: kept, no further step
+    }
+    if (stop == 2) {
+        st->final_cost = st->cost_ref, st->valid_last = st->valid_ref, st->gn_rejected += 1;
+    } else {
+        st->final_cost = cost, st->valid_last = valid;
+        if (stop == 1) st->gn_converged += d.closing ? 0 : 1;
+        else st->cost_ref = cost, st->valid_ref = valid, st->gn_solves += 1;
+    }
+    if (in) {
+        st->cost_hist[d.gi] = cost, st->valid_hist[d.gi] = (unsigned int)valid, st->pcg_it_hist[d.gi] = 0;
+        st->pcg_rel_hist[d.gi] = stop ? 0.f : 1.f, st->pcg_tol_hist[d.gi] = stop ? 0.f : sqrtf(d.f.tol2), st->stop_hist[d.gi] = stop;
+        if (st->hist_n < d.gi + 1) st->hist_n = d.gi + 1;
+    }
+    st->gn_iters += 1, st->cur = d.gi, st->gn_stop = stop;
+    st->tol2 = d.f.tol2, st->pcg_last_it = 0, st->pcg_done = stop != 0;
+    st->ew_gamma = d.f.ew_gamma, st->ew_min2 = d.f.ew_min2, st->ew_max2 = d.f.ew_max2, st->ew_slot = d.f.ew_slot;
+}
+
+// Tail of the linearisation when it decides (gn_tol > 0): every workgroup has published its partial sums write-through
+// (block_add_cost); thread 0 waits for that store to leave, then arrives — a counter per shard, a top counter for the last
+// arriver of each shard (one word would serialise ~2 000 device-scope atomics at ~11 ns each), re-armed by whoever
+// completes them — and the LAST workgroup of the launch sums the partials in their fixed order and decides.  The pattern
+// of the reference-mode linearise_kernel (solve.hip); one launch and ~6 us less per Gauss-Newton slot than a kernel of its own.
+__device__ __forceinline__ void s6_linearise_tail(const Solve6View& s, Solve6State* st, const S6Decide& d) {
+    __shared__ int is_last;
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int shard   = blockIdx.x % S6_LIN_SHARDS;
+        const unsigned int members = (gridDim.x - shard + S6_LIN_SHARDS - 1) / S6_LIN_SHARDS;
+        const unsigned int nshards = min((unsigned int)S6_LIN_SHARDS, gridDim.x);
+        int last                   = 0;
+        if (__hip_atomic_fetch_add(&st->lin_ticket[shard], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+            __hip_atomic_store(&st->lin_ticket[shard], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(&st->lin_ticket[S6_LIN_SHARDS], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nshards - 1) {
+                __hip_atomic_store(&st->lin_ticket[S6_LIN_SHARDS], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1;
+            }
+        }
+        is_last = last;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    s6_cost_total(s, st, true);
+    if (threadIdx.x == 0) s6_decide(st, d);
+}
+
 // blocks [0, nlin): the data term, a lane per vertex; blocks from nlin on: the regulariser, a lane per edge
 template <int K>
 __global__ __launch_bounds__(256) void s6_linearise_kernel(Solve6View s, Solve6State* st, Solve6Image img,
-                                                           Solve6Params prm, int update_w, int nlin, float wreg2, int gate) {
-    if (gate && st->gn_stop) return;  // (uniform) the outer iteration has ended (s6_decide): nothing to linearise
+                                                           Solve6Params prm, int update_w, int nlin, float wreg2, int gate,
+                                                           const S6Decide dec) {
+    if (gate && st->gn_stop) return;  // (uniform) the outer iteration has ended: nothing to linearise, nothing to decide
     if ((int)blockIdx.x >= nlin) {  // (uniform)
         const int e = ((int)blockIdx.x - nlin) * 256 + (int)threadIdx.x;
-        block_add_cost(e < s.D * s.k ? s6_reg_edge(s, e, wreg2, prm.psi_reg, update_w) : 0.0, 0u, s);
+        block_add_cost(e < s.D * s.k ? s6_reg_edge(s, e, wreg2, prm.psi_reg, update_w) : 0.0, 0u, s, dec.on != 0);
+        if (dec.on) s6_linearise_tail(s, st, dec);
         return;
     }
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -387,7 +460,8 @@ __global__ __launch_bounds__(256) void s6_linearise_kernel(Solve6View s, Solve6S
         for (int q = 0; q < K / 4; ++q) rec[2 + q] = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
         rec[2 + K / 4] = make_float4(swr, 0.f, 0.f, 0.f);
     }
-    block_add_cost(cost, nvalid, s);
+    block_add_cost(cost, nvalid, s, dec.on != 0);
+    if (dec.on) s6_linearise_tail(s, st, dec);
 }
 
 __device__ __forceinline__ double s6_reg_edge(const Solve6View& s, int e, float wreg2, float psi_reg, int update_w) {
@@ -486,53 +560,6 @@ __device__ __forceinline__ void s6_bookkeeping(Solve6State* st, const S6Forcing 
     }
     st->gn_iters = h + 1, st->gn_solves = h + 1, st->cur = h;
     st->tol2 = f.tol2, st->pcg_last_it = 0, st->pcg_done = 0;
-    st->ew_gamma = f.ew_gamma, st->ew_min2 = f.ew_min2, st->ew_max2 = f.ew_max2, st->ew_slot = f.ew_slot;
-}
-
-// gn_tol > 0: the launch between the linearisation and the assembly (one workgroup).  Energy of the linearisation, the
-// Gauss-Newton stopping rule (oracle/oracle.h: orc6_params.gn_tol states it; the reference runs Opt with earlyOut = true
-// and nonLinearIter as a cap, src/dynfu/dyn_fusion.cpp:183-189), the bookkeeping s6_bookkeeping does otherwise.  Decided
-// HERE and not by the assembly's extra workgroup because the assembly's other workgroups must already know: a launch
-// behind an ended outer iteration returns at entry.
-__global__ __launch_bounds__(256) void s6_decide_kernel(Solve6View s, Solve6State* st, const S6Forcing f, int gi, int gn,
-                                                        int closing, float gn_tol) {
-    const int tid = threadIdx.x;
-    const bool in = gi < S6_HIST;
-    if (gn > 0 && st->gn_stop) {  // (uniform) the outer iteration has ended
-        if (tid == 0) {
-            if (!closing && in) {
-                st->cost_hist[gi] = 0.0, st->valid_hist[gi] = 0u, st->pcg_it_hist[gi] = 0, st->pcg_rel_hist[gi] = 0.f;
-                st->pcg_tol_hist[gi] = 0.f, st->stop_hist[gi] = 3, st->hist_n = gi + 1;
-            }
-            st->cur = gi, st->pcg_done = 1, st->pcg_last_it = 0;
-        }
-        return;
-    }
-    s6_cost_total(s, st);  // (a barrier inside: every thread has read gn_stop before thread 0 writes it below)
-    if (tid != 0) return;
-    const double cost = st->cost;
-    const unsigned long long valid = st->valid;
-    if (!st->have_first) st->initial_cost = cost, st->valid_first = valid, st->have_first = 1;
-    int stop = 0;
-    if (gn > 0) {
-        const double ref = st->cost_ref;
-        if (cost > (1.0 + (double)gn_tol) * ref) stop = 2;                            // the step raised the energy: undone
-        else if (closing || ref - cost <= (double)gn_tol * ref) stop = 1;             // converged: kept, no further step
-    }
-    if (stop == 2) {
-        st->final_cost = st->cost_ref, st->valid_last = st->valid_ref, st->gn_rejected += 1;
-    } else {
-        st->final_cost = cost, st->valid_last = valid;
-        if (stop == 1) st->gn_converged += closing ? 0 : 1;
-        else st->cost_ref = cost, st->valid_ref = valid, st->gn_solves += 1;
-    }
-    if (in) {
-        st->cost_hist[gi] = cost, st->valid_hist[gi] = (unsigned int)valid, st->pcg_it_hist[gi] = 0;
-        st->pcg_rel_hist[gi] = stop ? 0.f : 1.f, st->pcg_tol_hist[gi] = stop ? 0.f : sqrtf(f.tol2), st->stop_hist[gi] = stop;
-        st->hist_n = gi + 1;
-    }
-    st->gn_iters += 1, st->cur = gi, st->gn_stop = stop;
-    st->tol2 = f.tol2, st->pcg_last_it = 0, st->pcg_done = stop != 0;
     st->ew_gamma = f.ew_gamma, st->ew_min2 = f.ew_min2, st->ew_max2 = f.ew_max2, st->ew_slot = f.ew_slot;
 }
 
@@ -949,7 +976,7 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
     // 0.150 at C3: not kept.)
     const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
     if (a == s.D) {  // one workgroup more than nodes: the energy of the linearisation this launch follows, the state block's bookkeeping
-        if (forcing.decided) return;  // (s6_decide has done both)
+        if (forcing.decided) return;  // (the linearisation's last workgroup has done both)
         s6_cost_total(s, st);
         if (tid == 0) s6_bookkeeping(st, forcing);
         return;
@@ -1586,7 +1613,7 @@ __global__ __launch_bounds__(64 * S6_NODES_PER_BLOCK, DFA_S6_PCG_WAVES) void s6_
 __global__ __launch_bounds__(256) void s6_update_kernel(Solve6View s, Solve6State* st, int launched, int linear_iter,
                                                         int* __restrict__ mirror, int h, int apply) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    // Gauss-Newton control (written by s6_decide, by no thread of this launch): 0 = apply the step; 1 = the outer iteration
+    // Gauss-Newton control (written by the linearisation's last workgroup, by no thread of this launch): 0 = apply the step; 1 = the outer iteration
     // has ended, nothing moves; 2 = ended by a rejected step: the transforms before that step come back (every update
     // launch until the next outer iteration does this again: the same values)
     const int stop = st->gn_stop;
@@ -1662,14 +1689,19 @@ __global__ __launch_bounds__(256) void s6_warp_kernel(Solve6View s, const float*
     }
 }
 
-__global__ __launch_bounds__(256) void s6_begin_kernel(Solve6View s, Solve6State* st, const float* __restrict__ node_dq) {
+__global__ __launch_bounds__(256) void s6_begin_kernel(Solve6View s, Solve6State* st, const float* __restrict__ node_dq, int slots) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < S6_HIST) {  // gn_tol > 0: every slot the solve enqueues starts as "skipped"; the ones that run overwrite theirs
+        st->cost_hist[i] = 0.0, st->valid_hist[i] = 0u, st->pcg_it_hist[i] = 0, st->pcg_rel_hist[i] = 0.f, st->pcg_tol_hist[i] = 0.f;
+        st->stop_hist[i] = i < slots ? 3 : 0;
+    }
+    if (i <= S6_LIN_SHARDS) st->lin_ticket[i] = 0u;
     if (i == 0) {
         st->cost = 0.0, st->initial_cost = 0.0, st->final_cost = 0.0;
         st->valid = st->valid_first = st->valid_last = 0ull;
         st->have_first = 0, st->gn_iters = 0, st->pcg_iters = 0;  // overflow / max_row_blocks belong to the pattern
         st->pcg_done = 0, st->rz0 = 0.f, st->pcg_short = 0, st->rz0_gn[0] = st->rz0_gn[1] = 0.f;
-        st->cur = 0, st->hist_n = 0, st->gn_stop = 0, st->gn_solves = 0, st->gn_rejected = 0, st->gn_converged = 0;
+        st->cur = 0, st->hist_n = min(slots, S6_HIST), st->gn_stop = 0, st->gn_solves = 0, st->gn_rejected = 0, st->gn_converged = 0;
         st->cost_ref = 0.0, st->valid_ref = 0ull;
     }
     if (i < 8 * s.D) s.dq[i] = node_dq[i], s.dq_prev[i] = node_dq[i];
@@ -1738,21 +1770,22 @@ hipError_t s6_build_graph(const Solve6View& s, Solve6State* state, const float* 
     return hipGetLastError();
 }
 
-hipError_t s6_begin(const Solve6View& s, Solve6State* state, const float* node_dq, hipStream_t st) {
-    const int n = std::max(std::max(8 * s.D, s.N), s.D * s.k);
-    s6_begin_kernel<<<(n + 255) / 256, 256, 0, st>>>(s, state, node_dq);
+hipError_t s6_begin(const Solve6View& s, Solve6State* state, const float* node_dq, int slots, hipStream_t st) {
+    const int n = std::max(std::max(std::max(8 * s.D, s.N), s.D * s.k), S6_HIST + S6_LIN_SHARDS);
+    s6_begin_kernel<<<(n + 255) / 256, 256, 0, st>>>(s, state, node_dq, slots);
     return hipGetLastError();
 }
 
 hipError_t s6_linearise(const Solve6View& s, Solve6State* state, const Solve6Image& img, const Solve6Params& p,
-                        int update_weights, hipStream_t st) {
+                        int update_weights, int gi, int gn_in_outer, int closing, hipStream_t st) {
     // (g^, M of the nodes and the cleared cost accumulators come from the launch that produced the transforms:
     // s6_begin / s6_update)
     const float wreg2 = p.lambda / ((float)s.D * (float)s.k);
     const int nlin = (s.N + 255) / 256, nreg = (s.D * s.k + 255) / 256;
     // gn_tol > 0: a linearisation that does not open an outer iteration is skipped once that iteration has ended
     const int gate = p.gn_tol > 0.f && !update_weights;
-    K6DISPATCH(s6_linearise_kernel, s.k, <<<nlin + nreg, 256, 0, st>>>(s, state, img, p, update_weights, nlin, wreg2, gate));
+    const S6Decide dec{p.gn_tol > 0.f ? 1 : 0, gi, gn_in_outer, closing, p.gn_tol, s6_forcing(p, gn_in_outer)};
+    K6DISPATCH(s6_linearise_kernel, s.k, <<<nlin + nreg, 256, 0, st>>>(s, state, img, p, update_weights, nlin, wreg2, gate, dec));
     return hipGetLastError();
 }
 
@@ -1771,12 +1804,6 @@ S6Forcing s6_forcing(const Solve6Params& p, int gn_in_outer) {
         f.tol2 = eta * eta;
     }
     return f;
-}
-
-hipError_t s6_decide(const Solve6View& s, Solve6State* state, const Solve6Params& p, int gi, int gn_in_outer, int closing,
-                     hipStream_t st) {
-    s6_decide_kernel<<<1, 256, 0, st>>>(s, state, s6_forcing(p, gn_in_outer), gi, gn_in_outer, closing, p.gn_tol);
-    return hipGetLastError();
 }
 
 hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Params& p, int gn_in_outer, hipStream_t st) {

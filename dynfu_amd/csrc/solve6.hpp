@@ -16,11 +16,13 @@ struct Solve6Params {
     // of an outer iteration stops at clamp(pcg_tol_adapt (r.z)_0,i / (r.z)_0,i-1, pcg_tol, pcg_tol_first)
     float pcg_tol_adapt;
     // > 0: Gauss-Newton stopping rule + step acceptance (include/dynfu_amd.h: dfa_solve6_params.gn_tol), decided on the
-    // device by s6_decide; <= 0: every iteration runs (the launches are those of the rounds before the rule existed)
+    // device by the last workgroup of the linearisation; <= 0: every iteration runs (the launches and the bookkeeping are
+    // those of the rounds before the rule existed)
     float gn_tol;
 };
 
 constexpr int S6_HIST = 32;  // = DFA_SOLVE6_HIST of include/dynfu_amd.h
+constexpr int S6_LIN_SHARDS = 32;  // arrival counters of the linearisation (one word would serialise ~2 000 atomics at ~11 ns)
 constexpr int S6_MIRROR_SKIPPED = -(1 << 30);  // launch-budget mirror: the Gauss-Newton iteration ran no PCG (its outer iteration had ended)
 
 // Device-resident scalars of one solve
@@ -60,6 +62,7 @@ struct Solve6State {
     unsigned long long valid_ref;
     unsigned int valid_hist[S6_HIST];
     int stop_hist[S6_HIST];  // 0 solved, 1 converged here, 2 rejected here, 3 skipped
+    unsigned int lin_ticket[S6_LIN_SHARDS + 1];  // arrivals of the linearisation's workgroups (gn_tol > 0: the last one decides)
 };
 
 struct Solve6Image {  // live vertex / normal maps (borrowed): float4 pixels, NaN where undefined
@@ -144,21 +147,28 @@ __host__ __device__ inline int s6_update_blocks(int D) { return (6 * D + 255) / 
 // the k-NN pass's output for them
 hipError_t s6_build_graph(const Solve6View& s, Solve6State* state, const float* canon_user, const float* canon_n_user,
                           const float* raw_w /* N x k */, const int32_t* raw_reg /* D x (k+1) */, int kreg, hipStream_t st);
-hipError_t s6_begin(const Solve6View& s, Solve6State* state, const float* node_dq, hipStream_t st);
+// slots: history slots the solve will enqueue when gn_tol > 0 (they start as "skipped"), 0 otherwise
+hipError_t s6_begin(const Solve6View& s, Solve6State* state, const float* node_dq, int slots, hipStream_t st);
+// gn_tol > 0: the launch also sums the energy and applies the Gauss-Newton stopping rule for history slot gi (gn_in_outer:
+// index inside the outer iteration; closing: the check of the solve's last step) — by its last workgroup, which every other
+// workgroup's partial sums reach through write-through stores
 hipError_t s6_linearise(const Solve6View& s, Solve6State* state, const Solve6Image& img, const Solve6Params& p,
-                        int update_weights, hipStream_t st);
+                        int update_weights, int gi, int gn_in_outer, int closing, hipStream_t st);
 // gn_in_outer: index of the Gauss-Newton iteration inside its outer iteration (selects the PCG tolerance of the forcing schedule)
 hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Params& p, int gn_in_outer, hipStream_t st);
-struct S6Forcing {  // what the assembly launch (gn_tol > 0: s6_decide) leaves in the state block for the PCG that follows
+struct S6Forcing {  // what the assembly launch (gn_tol > 0: the linearisation) leaves in the state block for the PCG that follows
     float tol2, ew_gamma, ew_min2, ew_max2;
     int ew_slot;
-    int decided;  // s6_decide has done the bookkeeping of this linearisation: the assembly launch only assembles
+    int decided;  // the linearisation has done the bookkeeping itself (gn_tol > 0): the assembly launch only assembles
 };
 S6Forcing s6_forcing(const Solve6Params& p, int gn_in_outer);
-// gn_tol > 0, between s6_linearise and s6_assemble: sums the energy, applies the stopping rule (gn_in_outer > 0; `closing`:
-// the check of the solve's last step — no iteration follows), does the state block's bookkeeping for history slot gi
-hipError_t s6_decide(const Solve6View& s, Solve6State* state, const Solve6Params& p, int gi, int gn_in_outer, int closing,
-                     hipStream_t st);
+// gn_tol > 0: what the linearisation's last workgroup needs to decide — the history slot gi = outer * gn_iter + gn_in_outer,
+// `closing`: the check of the solve's last step (no iteration follows), the PCG parameters of the iteration
+struct S6Decide {
+    int on, gi, gn, closing;
+    float gn_tol;
+    S6Forcing f;
+};
 hipError_t s6_pcg(const Solve6View& s, Solve6State* state, const Solve6Params& p, hipStream_t st);
 // launched: step launches enqueued for this PCG (<= linear_iter); mirror: pinned host int[S6_HIST] or null — iterations of
 // every PCG of the solve as the device finishes them, negative when the PCG used every launch without converging

@@ -22,6 +22,9 @@ pmc() {
   done
 }
 ns="--mode northstar --no-cpu-baseline --no-rccl-selfcheck"
+# north-star: the default (stopping rule on: launches behind a stop return at entry and dilute every per-launch mean) for the
+# bench lines, and --gn-tol 0 (every launch does its work) for per-launch durations and traffic
+if [ "$2" != "ns-fixed-only" ]; then
 prof c2 $lite
 prof ref_c3 $lite --config C3 --steps 12
 prof ns_c2 $ns --config C2 --steps 40
@@ -30,9 +33,13 @@ prof ns_c4 $ns --config C4 --steps 10 --warmup 4
 pmc c2 $lite --steps 10 --warmup 2
 pmc ref_c3 $lite --config C3 --steps 6 --warmup 2
 pmc ref_c4 $lite --config C4 --steps 4 --warmup 2
-pmc ns_c2 $ns --config C2 --steps 6 --warmup 2
-pmc ns_c3 $ns --config C3 --steps 4 --warmup 2
-pmc ns_c4 $ns --config C4 --steps 3 --warmup 2
+fi
+prof ns_c2_fixed $ns --config C2 --steps 40 --gn-tol 0
+prof ns_c3_fixed $ns --config C3 --steps 30 --gn-tol 0
+pmc ns_c2 $ns --config C2 --steps 6 --warmup 2 --gn-tol 0
+pmc ns_c3 $ns --config C3 --steps 4 --warmup 2 --gn-tol 0
+pmc ns_c4 $ns --config C4 --steps 3 --warmup 2 --gn-tol 0
+if [ "$2" == "ns-fixed-only" ]; then exit 0; fi
 # the adaptor's sequence (DynFusion::operator(), 512^3, ~1.08 M vertices, ~8.5 k nodes): kernel statistics + idle gaps
 bash $root/tools/hostseq_trace.sh $tag 14
 # keep what the summary needs, drop the bulky traces of the stats runs
