@@ -336,7 +336,9 @@ __device__ __forceinline__ void s6_decide(Solve6State* st, const S6Decide& d) {
 // (block_add_cost); thread 0 waits for that store to leave, then arrives — a counter per shard, a top counter for the last
 // arriver of each shard (one word would serialise ~2 000 device-scope atomics at ~11 ns each), re-armed by whoever
 // completes them — and the LAST workgroup of the launch sums the partials in their fixed order and decides.  The pattern
-// of the reference-mode linearise_kernel (solve.hip); one launch and ~6 us less per Gauss-Newton slot than a kernel of its own.
+// of the reference-mode linearise_kernel (solve.hip).  One launch fewer per Gauss-Newton slot than the one-workgroup kernel
+// this replaced — which measured the same frame time (C2 841 against 845 frames/s, C3 317.5 against 316.8: that launch hid
+// in the stream's launch pipeline).
 __device__ __forceinline__ void s6_linearise_tail(const Solve6View& s, Solve6State* st, const S6Decide& d) {
     __shared__ int is_last;
     if (threadIdx.x == 0) {
