@@ -789,9 +789,28 @@ __global__ __launch_bounds__(256) void dqb_support_kernel(const float* __restric
     const bool active = v < n;
     f3 p              = mk3(0.f, 0.f, 0.f);
     if (active) p = mk3(pts[3 * (size_t)v], pts[3 * (size_t)v + 1], pts[3 * (size_t)v + 2]);
+    // the support quotient of one node (:45-46 — pow(float, int) is double arithmetic, the root is rounded to float on assignment)
+    auto quotient = [&](int m) __attribute__((always_inline)) {
+        const double dx = (double)(p.x - node_pos[3 * m]), dy = (double)(p.y - node_pos[3 * m + 1]),
+                     dz = (double)(p.z - node_pos[3 * m + 2]);
+        return (float)sqrt(dx * dx + dy * dy + dz * dz) / node_w[m];
+    };
     KnnList<K> best;
     if (GRID) {
         if (!active) return;
+        if (out_flag && !out_dq && k >= 1) {
+            // Flags only (Warpfield::getUnsupportedVertices): the NEAREST node is one of the k nearest whatever k is, so a
+            // vertex inside that node's radius is supported (min <= its quotient < 1) without the other k - 1 — the 1-NN
+            // search stops in shell 0 / 1 and keeps no sorted list.  Almost every vertex of a tracked surface ends here; the
+            // others (a farther node with a wider radius may still support them) take the full search below.
+            KnnList<1> near;
+            knn_grid_query<1, true>(*grid.desc, grid.cell_start, grid.sorted, p, near);
+            const int m = near.index(0);
+            if (m >= 0 && quotient(m) < 1.f) {
+                out_flag[v] = 0;
+                return;
+            }
+        }
         knn_grid_query<K>(*grid.desc, grid.cell_start, grid.sorted, p, best);
     } else {
         knn_scan<K>(node_pos, D, p, best, tile);
@@ -803,12 +822,7 @@ __global__ __launch_bounds__(256) void dqb_support_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             if (j < k && best.index(j) >= 0) {
-                const int m = best.index(j);
-                // :45-46 — pow(float, int) is double arithmetic, the root is rounded to float on assignment
-                const double dx = (double)(p.x - node_pos[3 * m]), dy = (double)(p.y - node_pos[3 * m + 1]),
-                             dz = (double)(p.z - node_pos[3 * m + 2]);
-                const float dist = (float)sqrt(dx * dx + dy * dy + dz * dz);
-                const float q    = dist / node_w[m];
+                const float q = quotient(best.index(j));
                 if (q <= mn) mn = q;  // :48-50
             }
         }

@@ -243,7 +243,7 @@ def test_correspond_point_grid_is_exact_on_awkward_geometry(A, kind):
 
 
 # ------------------------------------------------------------- node insertion pieces (warp_field.cpp:34-95)
-@pytest.mark.parametrize("D,k,n", [(300, 8, 20000), (2048, 8, 60000), (3, 8, 500)])
+@pytest.mark.parametrize("D,k,n", [(300, 8, 20000), (2048, 8, 60000), (3, 8, 500), (8192, 8, 150000), (4096, 4, 50000)])
 def test_unsupported_vertices_and_calc_dqb_match_the_oracle(A, D, k, n):
     rng = np.random.default_rng(D)
     nodes = rng.uniform(-1, 1, (D, 3)).astype(np.float32)
