@@ -777,7 +777,9 @@ __global__ __launch_bounds__(256) void correspond_kernel(const float* __restrict
 // Warpfield::calcDQB (warp_field.cpp:127-148) at arbitrary points: the blended transform itself (new nodes
 // are seeded with it, warp_field.cpp:78) — and Warpfield::getUnsupportedVertices (warp_field.cpp:34-62):
 // a vertex is unsupported when min_j |v - g_j| / dg_w_j >= 1 over its k nearest nodes.
-template <int K, bool GRID>
+// FLAGS_ONLY: the instantiation of Warpfield::getUnsupportedVertices (no blended transform: 117 -> ~60 VGPRs at K = 8, twice
+// the waves per SIMD for a kernel that is a chain of dependent loads)
+template <int K, bool GRID, bool FLAGS_ONLY>
 __global__ __launch_bounds__(256) void dqb_support_kernel(const float* __restrict__ node_pos,
                                                           const float* __restrict__ node_dq,
                                                           const float* __restrict__ node_w, int D, int k,
@@ -798,7 +800,7 @@ __global__ __launch_bounds__(256) void dqb_support_kernel(const float* __restric
     KnnList<K> best;
     if (GRID) {
         if (!active) return;
-        if (out_flag && !out_dq && k >= 1) {
+        if (FLAGS_ONLY && k >= 1) {
             // Flags only (Warpfield::getUnsupportedVertices): the NEAREST node is one of the k nearest whatever k is, so a
             // vertex inside that node's radius is supported (min <= its quotient < 1) without the other k - 1 — the 1-NN
             // search stops in shell 0 / 1 and keeps no sorted list.  Almost every vertex of a tracked surface ends here; the
@@ -816,7 +818,7 @@ __global__ __launch_bounds__(256) void dqb_support_kernel(const float* __restric
         knn_scan<K>(node_pos, D, p, best, tile);
         if (!active) return;
     }
-    if (out_dq) dq_store(out_dq + 8 * (size_t)v, calc_dqb<K>(best, k, node_pos, node_dq, node_w, p));
+    if (!FLAGS_ONLY && out_dq) dq_store(out_dq + 8 * (size_t)v, calc_dqb<K>(best, k, node_pos, node_dq, node_w, p));
     if (out_flag) {
         float mn = __builtin_huge_valf();  // :40
 #pragma unroll
@@ -979,8 +981,21 @@ hipError_t launch_dqb_support(const float* node_pos, const float* node_dq, const
     dim3 block(256), gridDim((n + 255) / 256);
     const bool use_grid = grid != nullptr;
     KnnGridView g       = use_grid ? *grid : KnnGridView{};
-    KGDISPATCH(dqb_support_kernel, k, use_grid,
-               <<<gridDim, block, 0, s>>>(node_pos, node_dq, node_w, D, k, pts, n, out_dq, out_flag, g));
+#define DQBK(KK, GG)                                                                                                         \
+    do {                                                                                                                    \
+        if (out_flag && !out_dq) dqb_support_kernel<KK, GG, true><<<gridDim, block, 0, s>>>(node_pos, node_dq, node_w, D, k, pts, n, out_dq, out_flag, g);  \
+        else dqb_support_kernel<KK, GG, false><<<gridDim, block, 0, s>>>(node_pos, node_dq, node_w, D, k, pts, n, out_dq, out_flag, g);                     \
+    } while (0)
+    if (use_grid) {
+        if (k <= 4) DQBK(4, true);
+        else if (k <= 8) DQBK(8, true);
+        else DQBK(16, true);
+    } else {
+        if (k <= 4) DQBK(4, false);
+        else if (k <= 8) DQBK(8, false);
+        else DQBK(16, false);
+    }
+#undef DQBK
     return hipGetLastError();
 }
 
