@@ -284,10 +284,24 @@ __device__ __forceinline__ void s6_cost_total(const Solve6View& s, Solve6State* 
     const int n = s6_linearise_blocks(s.N, s.D, s.k), tid = threadIdx.x;
     double c = 0.0;
     unsigned long long v = 0ull;
-    if (through) {  // (partials of the launch in flight: loads that do not stop at this XCD's L2)
-        for (int i = tid; i < n; i += 256)
-            c += __hip_atomic_load(&s.cost_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                v += __hip_atomic_load(&s.valid_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (through) {
+        // partials of the launch in flight: loads that do not stop at this XCD's L2 — each a round trip of ~2 us, and this is
+        // the one workgroup the whole launch waits for: eight of them in flight per thread (clamped addresses, masked sums;
+        // a loop of load-wait-add was five dependent round trips at C2: 9 us per linearisation)
+        constexpr int Q = 8;
+        for (int base = tid; base < n; base += 256 * Q) {
+            double cq[Q];
+            unsigned int vq[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int i = min(base + 256 * q, n - 1);
+                cq[q] = __hip_atomic_load(&s.cost_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vq[q] = __hip_atomic_load(&s.valid_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                if (base + 256 * q < n) c += cq[q], v += vq[q];
+        }
     } else
     for (int i = tid; i < n; i += 256) c += s.cost_part[i], v += s.valid_part[i];
     c = wave_sum_all(c);
