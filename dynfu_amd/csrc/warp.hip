@@ -27,33 +27,37 @@ namespace dfa {
 
 constexpr int KNN_TILE = 1024;
 
-// sorted (ascending by (distance, index)) list of the K nearest candidates
+// sorted (ascending by (distance, index)) list of the K nearest candidates.  An entry is ONE 64-bit key — the bits of the
+// (non-negative) squared distance above the node index — so that "(d, i) before (d', i')" is one unsigned compare and an
+// exchange is a min / max pair: the 8-NN search of 1.08 M vertices is bound by vector-ALU issue, and the insertion is most of
+// what it issues (profiles/r05_sq_hostseq_ref.md).  The order of non-negative floats is the order of their bits; +inf
+// (empty) sorts behind every finite distance, a NaN distance (a vertex with NaN coordinates) behind +inf: never inserted.
 template <int K>
 struct KnnList {
-    float d[K];
-    int i[K];
+    unsigned long long key[K];
+    static constexpr unsigned long long EMPTY = 0x7f8000007fffffffull;  // (+inf, index 0x7fffffff)
+    __device__ __forceinline__ static unsigned long long pack(float dist, int idx) {
+        return ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned int)idx;
+    }
     __device__ __forceinline__ void init() {
 #pragma unroll
-        for (int j = 0; j < K; ++j) d[j] = __builtin_inff(), i[j] = 0x7fffffff;
-    }
-    __device__ __forceinline__ static bool before(float da, int ia, float db, int ib) {
-        return da < db || (da == db && ia < ib);
+        for (int j = 0; j < K; ++j) key[j] = EMPTY;
     }
     __device__ __forceinline__ void push(float dist, int idx) {
-        if (before(dist, idx, d[K - 1], i[K - 1])) {
-            d[K - 1] = dist, i[K - 1] = idx;
+        const unsigned long long x = pack(dist, idx);
+        if (x < key[K - 1]) {
+            key[K - 1] = x;
 #pragma unroll
             for (int j = K - 1; j > 0; --j) {
-                if (before(d[j], i[j], d[j - 1], i[j - 1])) {
-                    const float td = d[j];
-                    d[j] = d[j - 1], d[j - 1] = td;
-                    const int ti = i[j];
-                    i[j] = i[j - 1], i[j - 1] = ti;
-                }
+                const unsigned long long a = key[j - 1], b = key[j];
+                key[j - 1] = a < b ? a : b, key[j] = a < b ? b : a;
             }
         }
     }
-    __device__ __forceinline__ int index(int j) const { return i[j] == 0x7fffffff ? -1 : i[j]; }
+    __device__ __forceinline__ float dist(int j) const { return __uint_as_float((unsigned int)(key[j] >> 32)); }
+    __device__ __forceinline__ int raw_index(int j) const { return (int)(unsigned int)key[j]; }  // 0x7fffffff: empty
+    __device__ __forceinline__ int index(int j) const { return raw_index(j) == 0x7fffffff ? -1 : raw_index(j); }
+    __device__ __forceinline__ void set_index(int j, int n) { key[j] = pack(__builtin_inff(), n < 0 ? 0x7fffffff : n); }
 };
 
 // L2_Simple_Adaptor::evalMetric (nanoflann.hpp:338-345): ((0 + d0^2) + d1^2) + d2^2
@@ -489,10 +493,10 @@ __device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32
         const int c0 = cx + g.dim[0] * (cy + g.dim[1] * cz);
         scan_range(cell_start[c0], cell_start[c0 + 1]);
         const float b0 = fmaxf(margin - 1e-3f, 0.f) * g.cs;
-        if (best.d[K - 1] < b0 * b0 * 0.9999f) return;
+        if (best.dist(K - 1) < b0 * b0 * 0.9999f) return;
         scan_block3();
         const float b1 = fmaxf(1.f + margin - 1e-3f, 0.f) * g.cs;
-        if (best.d[K - 1] < b1 * b1 * 0.9999f) return;
+        if (best.dist(K - 1) < b1 * b1 * 0.9999f) return;
         r_first = 2;
     }
     if (!TIGHT) {
@@ -502,7 +506,7 @@ __device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32
         // The query is a chain of dependent loads and little else (a wave of 64 queries is resident from launch to end:
         // 4 waves per SIMD at C2), so the loads are issued for memory-level parallelism (scan_block3 above).
         scan_block3();
-        if (best.d[K - 1] < g.cs * g.cs * 0.9999f) return;  // (r = 1: every node not visited is at least one cell away)
+        if (best.dist(K - 1) < g.cs * g.cs * 0.9999f) return;  // (r = 1: every node not visited is at least one cell away)
         r_first = 2;  // (a grid of at most 2 cells per axis has been visited completely: the loop below does not run)
     }
     for (int r = r_first; r < rmax; ++r) {
@@ -530,7 +534,7 @@ __device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32
         // (TIGHT: the cell coordinate of a point is rounded with an error ~1e-5 cells at 128 cells per
         // axis, twice that at 256; 1e-3 cells are taken off the bound before the relative margin)
         const float bound = TIGHT ? fmaxf((float)r + margin - 1e-3f, 0.f) * g.cs : (float)r * g.cs;
-        if (best.d[K - 1] < bound * bound * 0.9999f) break;
+        if (best.dist(K - 1) < bound * bound * 0.9999f) break;
     }
 }
 
@@ -584,7 +588,7 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
         const float bound = (float)r * g.cs, b2 = bound * bound * 0.9999f;
         int inside = 0;
 #pragma unroll
-        for (int j = 0; j < K; ++j) inside += best.d[j] < b2 ? 1 : 0;
+        for (int j = 0; j < K; ++j) inside += best.dist(j) < b2 ? 1 : 0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) inside += __shfl_xor(inside, o, 64);
         if (inside >= K) break;
@@ -592,12 +596,11 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
     // merge: K rounds of wave-min over each lane's current head
     int pos = 0;
     for (int j = 0; j < K; ++j) {
-        float hd = __builtin_inff();
-        int hi   = 0x7fffffff;
+        unsigned long long key = KnnList<K>::EMPTY;
 #pragma unroll
         for (int t = 0; t < K; ++t)
-            if (t == pos) hd = best.d[t], hi = best.i[t];
-        const unsigned long long key = ((unsigned long long)__float_as_uint(hd) << 32) | (unsigned int)hi;
+            if (t == pos) key = best.key[t];
+        const int hi = (int)(unsigned int)key;
         const unsigned long long win = wave_min_u64(key);
         if (key == win && hi != 0x7fffffff) ++pos;
         if (lane == 0 && j < k) {
@@ -730,7 +733,7 @@ __global__ __launch_bounds__(256) void warp_graph_kernel(const float* __restrict
     for (int j = 0; j < K; ++j)
         if (j < k) {
             const int n = idx[(size_t)v * k + j];
-            nb.i[j]     = n < 0 ? 0x7fffffff : n;
+            nb.set_index(j, n);
         }
     const f3 p  = mk3(verts[3 * (size_t)v], verts[3 * (size_t)v + 1], verts[3 * (size_t)v + 2]);
     const DQ dq = calc_dqb<K>(nb, k, node_pos, node_dq, node_w, p);
