@@ -228,3 +228,62 @@ def test_projective_association_oracle_obeys_its_gates():
     # without normals the third vertex is associated too
     _, _, pix2 = O.correspond_projective(v, None, P, Nm, fx, fy, cx, cy, 0.1, 0.5)
     assert pix2.tolist() == [5, -1, 15, -1, -1, -1]
+
+
+# ---------------------------------------------------------------- Gauss-Newton stopping rule (orc6_params.gn_tol)
+_PCG = dict(linear_iter=64, lambda_=200.0, pcg_tol=1e-3, pcg_tol_first=0.1, pcg_tol_adapt=0.9)
+
+
+def test_gn_stopping_rule_of_the_oracle(scene):
+    """oracle.h: gn_tol.  With the rule the oracle (a) never lists an accepted linearisation above the one before it inside
+    an outer iteration, (b) leaves, behind a rejected step, exactly the transforms of the solve that was only given the
+    accepted iterations, (c) ends on the energy of its last accepted linearisation, (d) marks what it did per slot, and (e)
+    with gn_tol = 0 is the fixed-iteration solve of before, slot for slot."""
+    cfg, c, intr, P, Nm = scene
+    k = cfg["k"]
+    args = (c["node_pos"], c["node_dq"], c["node_w"], k, c["verts"], c["normals"], P, Nm, intr)
+    dq_fix, st_fix = O.solve6(*args, num_iter=2, gn_iter=4, **_PCG)
+    assert st_fix["stop_hist"] == [0] * 8 and st_fix["gn_solves"] == st_fix["gn_iters"] == 8 and st_fix["hist_n"] == 8
+    assert st_fix["final_cost"] == st_fix["cost_hist"][-1] and st_fix["valid_hist"][0] == st_fix["valid_first"]
+    dq, st = O.solve6(*args, num_iter=2, gn_iter=4, gn_tol=1e-3, **_PCG)
+    codes = st["stop_hist"]
+    assert len(codes) in (8, 9) and set(codes) <= {0, 1, 2, 3} and st["gn_solves"] == codes.count(0) < 8
+    assert st["gn_rejected"] == codes.count(2) and st["gn_iters"] == len(codes) - codes.count(3)
+    for o in range(2):
+        slots = [i for i in range(4 * o, 4 * o + 4) if codes[i] in (0, 1)]
+        costs = [st["cost_hist"][i] for i in slots]
+        assert all(b <= a * (1 + 1e-3) for a, b in zip(costs, costs[1:])), costs
+        if 2 in codes[4 * o:4 * o + 4]:  # everything behind a rejection is skipped, and the rejected energy was higher
+            j = codes.index(2, 4 * o)
+            assert codes[j + 1:4 * o + 4] == [3] * (4 * o + 3 - j) and st["cost_hist"][j] > costs[-1] * (1 + 1e-3)
+    accepted = [st["cost_hist"][i] for i, cd in enumerate(codes) if cd in (0, 1)]
+    assert st["final_cost"] == accepted[-1]
+    # (b) one outer iteration: the solve with the rule == the fixed solve given only the accepted steps
+    dq1, st1 = O.solve6(*args, num_iter=1, gn_iter=6, gn_tol=1e-3, **_PCG)
+    c1 = st1["stop_hist"]
+    if 2 in c1:
+        j = c1.index(2)
+        dq_ref, _ = O.solve6(*args, num_iter=1, gn_iter=j - 1, **_PCG)
+    else:
+        dq_ref, _ = O.solve6(*args, num_iter=1, gn_iter=st1["gn_solves"], **_PCG)
+    assert np.array_equal(dq1, dq_ref)
+    # the returned transforms are no worse than the fixed run's (energy re-associated at fresh weights)
+    e_rule, _ = O.cost6(c["node_pos"], dq, c["node_w"], k, c["verts"], c["normals"], P, Nm, intr, lambda_=200.0)
+    e_fix, _ = O.cost6(c["node_pos"], dq_fix, c["node_w"], k, c["verts"], c["normals"], P, Nm, intr, lambda_=200.0)
+    assert e_rule <= 1.05 * e_fix
+
+
+def test_gn_closing_check_and_matrix_reuse_of_the_oracle(scene):
+    cfg, c, intr, P, Nm = scene
+    args = (c["node_pos"], c["node_dq"], c["node_w"], cfg["k"], c["verts"], c["normals"], P, Nm, intr)
+    # one iteration per outer iteration: only the closing slot can judge the step
+    dq, st = O.solve6(*args, num_iter=1, gn_iter=1, gn_tol=1e-3, **_PCG)
+    assert st["stop_hist"] == [0, 1] and st["final_cost"] == st["cost_hist"][1] < st["cost_hist"][0]
+    dq0, st0 = O.solve6(*args, num_iter=1, gn_iter=1, **_PCG)
+    assert np.array_equal(dq, dq0) and st0["stop_hist"] == [0]
+    # reuse_matrix: iteration 0 is full Gauss-Newton, so a one-iteration solve is unchanged; later iterations differ
+    dq_r1, _ = O.solve6(*args, num_iter=1, gn_iter=1, reuse_matrix=1, **_PCG)
+    assert np.array_equal(dq_r1, dq0)
+    dq_r3, st_r3 = O.solve6(*args, num_iter=1, gn_iter=3, reuse_matrix=1, **_PCG)
+    dq_f3, st_f3 = O.solve6(*args, num_iter=1, gn_iter=3, **_PCG)
+    assert st_r3["cost_hist"][:2] == st_f3["cost_hist"][:2] and not np.array_equal(dq_r3, dq_f3)
