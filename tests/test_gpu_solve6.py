@@ -648,3 +648,17 @@ def test_gn_closing_check_and_sequences(A):
     assert all(x["gn_solves"] < 8 for x in seq)
     # solves 0, 1: the full cap on every slot; from solve 2 on what the slots needed — the slots behind a stop next to nothing
     assert seq[0]["pcg_launches"] == seq[1]["pcg_launches"] == 8 * 65 and all(x["pcg_launches"] < 8 * 65 // 3 for x in seq[2:])
+
+
+def test_gn_stopping_rule_beyond_the_history_length(A):
+    """more Gauss-Newton slots (5 x 8 + the closing check) than the statistics keep (DFA_SOLVE6_HIST = 32): the rule
+    works on the state block's scalars, not on the histories — same counts and energy as the oracle, histories cut at 32."""
+    cfg, c, intr, depth = _scene("T0", 4)
+    kw = dict(_BENCH_PCG, num_iter=5, gn_iter=8, gn_tol=1e-3)
+    s, dq, st, wv, wn_, dq_ref, st_ref = _solve_both(A, cfg, c, intr, depth, c["node_dq"], **kw)
+    assert len(st["stop_hist"]) == len(st_ref["stop_hist"]) == 32 and st["stop_hist"] == st_ref["stop_hist"]
+    assert (st["gn_solves"], st["gn_rejected"], st["gn_converged"], st["gn_iters"]) == \
+           (st_ref["gn_solves"], st_ref["gn_rejected"], st_ref["gn_converged"], st_ref["gn_iters"])
+    assert st["gn_solves"] < 40 and st["final_cost"] == pytest.approx(st_ref["final_cost"], rel=0.02)
+    assert np.isfinite(dq).all()
+    s.close()
