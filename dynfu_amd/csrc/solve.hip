@@ -373,23 +373,58 @@ __global__ __launch_bounds__(256) void prepare_rows_kernel(SolveView s, SolveSta
     const int k = s.k;
     int ids[K];
     float ws[K];
+    const bool wide = k == K && K % 4 == 0;  // (uniform) the common case: every row's ids / weights / record head by 16-byte accesses
     if (r < (size_t)s.N) {  // data row: k-NN + RBF weights already in ridx / rw; b = live - canonical (energy.t:55)
 #pragma unroll
         for (int c = 0; c < 3; ++c) s.rb[3 * r + c] = s.live[3 * r + c] - s.canon[3 * r + c];
+        if (wide) load_row_graph<K>(s, r, ids, ws);
+        else {
 #pragma unroll
-        for (int j = 0; j < K; ++j)
-            if (j < k) ids[j] = s.ridx[r * k + j], ws[j] = s.rw[r * k + j];
+            for (int j = 0; j < K; ++j)
+                if (j < k) ids[j] = s.ridx[r * k + j], ws[j] = s.rw[r * k + j];
+        }
     } else {  // regularisation row N + n k + i <- {reg_idx[n][i]: -1, n: +1} (opt_solver.cpp:74-105, energy.t:75-78)
         const int e = (int)(r - (size_t)s.N), n = e / k, m = s.reg_idx[e];
 #pragma unroll
         for (int j = 0; j < K; ++j) ids[j] = -1, ws[j] = 0.f;
         if (m >= 0 && m != n) ids[0] = m, ws[0] = -1.f, ids[1] = n, ws[1] = +1.f;  // k >= 2 whenever a non-self neighbour exists
+        if (wide) {
 #pragma unroll
-        for (int j = 0; j < K; ++j)
-            if (j < k) s.ridx[r * k + j] = ids[j], s.rw[r * k + j] = ws[j];
+            for (int q = 0; q < K / 4; ++q) {
+                reinterpret_cast<int4*>(s.ridx + r * K)[q]  = make_int4(ids[4 * q], ids[4 * q + 1], ids[4 * q + 2], ids[4 * q + 3]);
+                reinterpret_cast<float4*>(s.rw + r * K)[q] = make_float4(ws[4 * q], ws[4 * q + 1], ws[4 * q + 2], ws[4 * q + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                if (j < k) s.ridx[r * k + j] = ids[j], s.rw[r * k + j] = ws[j];
+        }
         s.rb[3 * r + 0] = s.rb[3 * r + 1] = s.rb[3 * r + 2] = 0.f;
     }
     float* rec = s.re + r * (size_t)solve_rec_words(k);
+    if (wide) {  // the record's head (the words before (e, tau)) as float4 stores: a lane's record is 48 or 64 contiguous bytes
+        float4* rec4 = reinterpret_cast<float4*>(rec);
+        if (solve_rec_ids16(k)) {  // K / 2 words of 16-bit id pairs, then K weights
+            uint32_t pk[K / 2];
+#pragma unroll
+            for (int j = 0; j < K / 2; ++j) {
+                const uint32_t lo = ids[2 * j] < 0 ? 0xffffu : (uint32_t)ids[2 * j], hi = ids[2 * j + 1] < 0 ? 0xffffu : (uint32_t)ids[2 * j + 1];
+                pk[j]             = (lo & 0xffffu) | (hi << 16);
+            }
+#pragma unroll
+            for (int q = 0; q < K / 8; ++q)
+                rec4[q] = make_float4(__uint_as_float(pk[4 * q]), __uint_as_float(pk[4 * q + 1]), __uint_as_float(pk[4 * q + 2]), __uint_as_float(pk[4 * q + 3]));
+#pragma unroll
+            for (int q = 0; q < K / 4; ++q) rec4[K / 8 + q] = make_float4(ws[4 * q], ws[4 * q + 1], ws[4 * q + 2], ws[4 * q + 3]);
+        } else {  // K ids, then K weights
+#pragma unroll
+            for (int q = 0; q < K / 4; ++q)
+                rec4[q] = make_float4(__int_as_float(ids[4 * q]), __int_as_float(ids[4 * q + 1]), __int_as_float(ids[4 * q + 2]), __int_as_float(ids[4 * q + 3]));
+#pragma unroll
+            for (int q = 0; q < K / 4; ++q) rec4[K / 4 + q] = make_float4(ws[4 * q], ws[4 * q + 1], ws[4 * q + 2], ws[4 * q + 3]);
+        }
+        return;
+    }
     if (solve_rec_ids16(k)) {  // k / 2 words of 16-bit ids (0xffff = empty slot), then k weights
         uint16_t* h = reinterpret_cast<uint16_t*>(rec);
 #pragma unroll
