@@ -637,20 +637,34 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ node
         knn_scan<K>(node_pos, D, q, best, tile);
         if (!active) return;
     }
+    int out_i[K];
+    float out_w[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
+        out_i[j] = -1, out_w[j] = 0.f;
         if (j < k) {
-            const int n            = best.index(j);
-            idx[(size_t)v * k + j] = n;
-            if (weights) {
-                float w = 0.f;
-                if (n >= 0)
-                    w = transformation_weight(mk3(node_pos[3 * n], node_pos[3 * n + 1], node_pos[3 * n + 2]),
-                                              node_w[n], q);
-                weights[(size_t)v * k + j] = w;
-            }
+            const int n = best.index(j);
+            out_i[j]    = n;
+            if (weights && n >= 0)
+                out_w[j] = transformation_weight(mk3(node_pos[3 * n], node_pos[3 * n + 1], node_pos[3 * n + 2]), node_w[n], q);
         }
     }
+    // (uniform) a query's k ids / weights are 16 or 32 contiguous bytes: 16-byte stores where the caller's arrays allow them
+    if (k == K && K % 4 == 0 && ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(weights)) & 15u) == 0) {
+#pragma unroll
+        for (int h = 0; h < K / 4; ++h) {
+            reinterpret_cast<int4*>(idx + (size_t)v * K)[h] = make_int4(out_i[4 * h], out_i[4 * h + 1], out_i[4 * h + 2], out_i[4 * h + 3]);
+            if (weights)
+                reinterpret_cast<float4*>(weights + (size_t)v * K)[h] = make_float4(out_w[4 * h], out_w[4 * h + 1], out_w[4 * h + 2], out_w[4 * h + 3]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if (j < k) {
+            idx[(size_t)v * k + j] = out_i[j];
+            if (weights) weights[(size_t)v * k + j] = out_w[j];
+        }
 }
 
 // Warpfield::calcDQB (warp_field.cpp:127-148) given the neighbour list
@@ -729,12 +743,20 @@ __global__ __launch_bounds__(256) void warp_graph_kernel(const float* __restrict
     if (v >= N) return;
     KnnList<K> nb;
     nb.init();
+    if (k == K && K % 4 == 0 && (reinterpret_cast<uintptr_t>(idx) & 15u) == 0) {  // (uniform) the vertex's k neighbours by 16-byte loads
 #pragma unroll
-    for (int j = 0; j < K; ++j)
-        if (j < k) {
-            const int n = idx[(size_t)v * k + j];
-            nb.set_index(j, n);
+        for (int h = 0; h < K / 4; ++h) {
+            const int4 n4 = reinterpret_cast<const int4*>(idx + (size_t)v * K)[h];
+            nb.set_index(4 * h, n4.x), nb.set_index(4 * h + 1, n4.y), nb.set_index(4 * h + 2, n4.z), nb.set_index(4 * h + 3, n4.w);
         }
+    } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (j < k) {
+                const int n = idx[(size_t)v * k + j];
+                nb.set_index(j, n);
+            }
+    }
     const f3 p  = mk3(verts[3 * (size_t)v], verts[3 * (size_t)v + 1], verts[3 * (size_t)v + 2]);
     const DQ dq = calc_dqb<K>(nb, k, node_pos, node_dq, node_w, p);
     const f3 o  = dq_transform(dq, p);
