@@ -1687,10 +1687,20 @@ __global__ __launch_bounds__(256) void s6_warp_kernel(Solve6View s, const float*
     if (v >= s.N) return;
     int32_t idx[K];
     float wn[K];
+    if (s.k == K) {  // (uniform) 16-byte loads, as the linearisation
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        idx[j] = j < s.k ? s.idx[(size_t)v * s.k + j] : -1;
-        wn[j]  = j < s.k ? s.wn[(size_t)v * s.k + j] : 0.f;
+        for (int q = 0; q < K / 4; ++q) {
+            const int4 iv   = reinterpret_cast<const int4*>(s.idx + (size_t)v * K)[q];
+            const float4 wv = reinterpret_cast<const float4*>(s.wn + (size_t)v * K)[q];
+            idx[4 * q] = iv.x, idx[4 * q + 1] = iv.y, idx[4 * q + 2] = iv.z, idx[4 * q + 3] = iv.w;
+            wn[4 * q] = wv.x, wn[4 * q + 1] = wv.y, wn[4 * q + 2] = wv.z, wn[4 * q + 3] = wv.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            idx[j] = j < s.k ? s.idx[(size_t)v * s.k + j] : -1;
+            wn[j]  = j < s.k ? s.wn[(size_t)v * s.k + j] : 0.f;
+        }
     }
     Blend<K> B;
     blend<K>(dq, idx, wn, s.k, B);
