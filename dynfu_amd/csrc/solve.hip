@@ -72,14 +72,18 @@ __global__ __launch_bounds__(1024) void tg_count_kernel(const int32_t* __restric
 __global__ __launch_bounds__(256) void tg_colscan_kernel(int32_t* __restrict__ blk_hist /* [TG_BLOCKS + 1][D] */, int D) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D) return;
-    int h[TG_BLOCKS];
-#pragma unroll
-    for (int b = 0; b < TG_BLOCKS; ++b) h[b] = blk_hist[(size_t)b * D + i];
+    constexpr int G = 32;  // counts in flight per thread (all TG_BLOCKS at once would be 256 registers)
+    static_assert(TG_BLOCKS % G == 0, "workgroups of the counting sort in groups");
     int run = 0;
+    for (int b0 = 0; b0 < TG_BLOCKS; b0 += G) {
+        int h[G];
 #pragma unroll
-    for (int b = 0; b < TG_BLOCKS; ++b) {
-        blk_hist[(size_t)b * D + i] = run;
-        run += h[b];
+        for (int b = 0; b < G; ++b) h[b] = blk_hist[(size_t)(b0 + b) * D + i];
+#pragma unroll
+        for (int b = 0; b < G; ++b) {
+            blk_hist[(size_t)(b0 + b) * D + i] = run;
+            run += h[b];
+        }
     }
     blk_hist[(size_t)TG_BLOCKS * D + i] = run;
 }

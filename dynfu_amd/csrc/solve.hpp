@@ -99,7 +99,7 @@ struct SolveView {
     float* node_dq_out;  // D x 8
 };
 
-constexpr int SOLVE_TG_BLOCKS = 64;
+constexpr int SOLVE_TG_BLOCKS = 256;  // one workgroup of the counting sort per CU (64 until round 5: a quarter of the chip)
 // rows (regularisation rows, right-hand sides, packed record heads), reset of the unknowns / state / tickets, and the
 // node -> rows transposition of the problem in `s`
 hipError_t solve_build_graph(const SolveView& s, SolveState* state, unsigned int* ticket, int nticket, hipStream_t st);
