@@ -24,7 +24,7 @@ public:
     std::vector<std::shared_ptr<Node>> getNodes();
     // the same nodes without the copy (8 k shared pointers: ~0.05 ms of reference counting per call) — for the adaptor's own
     // per-frame loops; the reference's accessor above returns by value
-    const std::vector<std::shared_ptr<Node>>& nodesRef() const { return nodes; }
+    const std::vector<std::shared_ptr<Node>>& nodesRef() const { return *nodes; }
 
     std::vector<std::shared_ptr<Node>> findNeighbors(int numNeighbor, dfa::PointXYZ vertex);
     std::vector<size_t> findNeighborsIndex(int numNeighbor, dfa::PointXYZ vertex);
@@ -44,7 +44,16 @@ public:
 private:
     float epsilon = 0.f;
     int knn_      = KNN;
-    std::vector<std::shared_ptr<Node>> nodes;
+    // The node list is shared by the copies of a warp field until one of them changes it (copy on write): the reference
+    // hands Warpfield around BY VALUE every frame (CombinedSolver's constructor, opt_solver.cpp:3-13), and a copy of 8.5 k
+    // shared pointers — and their release when the solver goes — was 0.1 ms of each frame.  Each copy still sees its own
+    // list, the Nodes themselves were always shared.
+    using NodeList = std::vector<std::shared_ptr<Node>>;
+    std::shared_ptr<NodeList> nodes = std::make_shared<NodeList>();
+    NodeList& ownNodes() {  // before any change of the list
+        if (nodes.use_count() > 1) nodes = std::make_shared<NodeList>(*nodes);
+        return *nodes;
+    }
     struct DeviceNodes;  // device copies of node positions / weights (positions are immutable)
     std::shared_ptr<DeviceNodes> dev;
     void syncPositions();

@@ -27,19 +27,20 @@ Warpfield::~Warpfield() = default;
 
 void Warpfield::init(float epsilon_, std::vector<std::shared_ptr<Node>> nodes_) {  // warp_field.cpp:10-28
     epsilon = epsilon_;
-    nodes   = nodes_;
+    nodes   = std::make_shared<NodeList>(std::move(nodes_));
     dev     = std::make_shared<DeviceNodes>();
     syncPositions();
 }
 
 void Warpfield::addNode(std::shared_ptr<Node> newNode) {
-    nodes.emplace_back(newNode);
+    ownNodes().emplace_back(newNode);
     syncPositions();
 }
-std::vector<std::shared_ptr<Node>> Warpfield::getNodes() { return nodes; }
+std::vector<std::shared_ptr<Node>> Warpfield::getNodes() { return *nodes; }
 
 // node positions and radial basis weights never change after construction: uploaded once
 void Warpfield::syncPositions() {
+    const NodeList& nodes = *this->nodes;
     std::vector<float> p(3 * nodes.size()), w(nodes.size());
     for (size_t i = 0; i < nodes.size(); ++i) {
         const dfa::PointXYZ g = nodes[i]->getPosition();
@@ -78,7 +79,7 @@ std::vector<size_t> Warpfield::findNeighborsIndex(int numNeighbor, dfa::PointXYZ
 
 std::vector<std::shared_ptr<Node>> Warpfield::findNeighbors(int numNeighbor, dfa::PointXYZ vertex) {  // :99-109
     std::vector<std::shared_ptr<Node>> out;
-    for (size_t i : findNeighborsIndex(numNeighbor, vertex)) out.push_back(nodes[i]);
+    for (size_t i : findNeighborsIndex(numNeighbor, vertex)) out.push_back((*nodes)[i]);
     return out;
 }
 
@@ -105,11 +106,12 @@ static void pack_transforms(const std::vector<std::shared_ptr<Node>>& nodes, std
 // the nodes' current transforms dg_se3 as D x 8 floats (real w,x,y,z ; dual w,x,y,z) -> dev->dq
 void Warpfield::syncTransforms() {
     std::vector<float> hdq;
-    pack_transforms(nodes, hdq);
+    pack_transforms(*nodes, hdq);
     if (!hdq.empty()) dev->dq.upload(hdq);
 }
 
 void Warpfield::hostArrays(std::vector<float>& pos, std::vector<float>& w, std::vector<float>& dq) {
+    const NodeList& nodes = *this->nodes;
     pos.resize(3 * nodes.size()), w.resize(nodes.size());
     for (size_t i = 0; i < nodes.size(); ++i) {
         const dfa::PointXYZ g = nodes[i]->getPosition();
@@ -234,11 +236,12 @@ void Warpfield::update(std::shared_ptr<dynfu::Frame> frame) {  // :64-95
                    "Warpfield::update (calcDQB)");
         dq_out.download(hq);
     }
+    NodeList& list = ownNodes();  // (a copy of this warp field held elsewhere keeps the list it was copied with)
     for (int i = 0; i < n; ++i) {
         const float* q = &hq[8 * (size_t)i];
         auto dq = std::make_shared<DualQuaternion<float>>(dfa::quaternion<float>(q[0], q[1], q[2], q[3]),
                                                           dfa::quaternion<float>(q[4], q[5], q[6], q[7]));
-        nodes.emplace_back(std::make_shared<Node>(seeds[i], dq, 2 * epsilon));  // :79-82
+        list.emplace_back(std::make_shared<Node>(seeds[i], dq, 2 * epsilon));  // :79-82
     }
     syncPositions();  // :85-94
 }

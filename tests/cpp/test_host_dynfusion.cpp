@@ -175,6 +175,33 @@ TEST(DynFusionTest, UpdateInsertsNodesWhereTheFieldDoesNotReach) {
     ASSERT_TRUE(wf->getUnsupportedVertices(frame).empty());
 }
 
+// A warp field is handed around by value (CombinedSolver's constructor, opt_solver.cpp:3-13): every copy has its own node
+// LIST, the Nodes are shared.  The adaptor shares the list between copies until one of them changes it.
+TEST(DynFusionTest, WarpfieldCopiesShareNodesButNotTheList) {
+    Cloud canon;
+    Normals cn;
+    half_sphere(128 * 8, canon, cn);
+    DynFusion df(DynFuParams::defaultParams());
+    df.init(canon, cn);
+    Warpfield& wf = *df.getWarpfield();
+    Warpfield copy = wf;  // by value
+    const size_t n  = wf.getNodes().size();
+    ASSERT_EQ(copy.getNodes().size(), n);
+    ASSERT_TRUE(copy.getNodes()[0].get() == wf.getNodes()[0].get());  // the same Node objects
+    // a transformation written through the copy is seen through the original (shared Nodes) ...
+    copy.getNodes()[3]->setTransformation(std::make_shared<DualQuaternion<float>>(0.f, 0.f, 0.f, 0.5f, 0.f, 0.f));
+    ASSERT_NEAR(wf.getNodes()[3]->getTransformation()->getTranslation()[0], 0.5f, 1e-6);
+    // ... a node added to the copy is not (its own list), and the other way round
+    copy.addNode(std::make_shared<Node>(dfa::PointXYZ(9.f, 9.f, 9.f), std::make_shared<DualQuaternion<float>>(0.f, 0.f, 0.f, 0.f, 0.f, 0.f), 0.2f));
+    ASSERT_EQ(copy.getNodes().size(), n + 1);
+    ASSERT_EQ(wf.getNodes().size(), n);
+    wf.addNode(std::make_shared<Node>(dfa::PointXYZ(-9.f, 9.f, 9.f), std::make_shared<DualQuaternion<float>>(0.f, 0.f, 0.f, 0.f, 0.f, 0.f), 0.2f));
+    wf.addNode(std::make_shared<Node>(dfa::PointXYZ(-9.f, -9.f, 9.f), std::make_shared<DualQuaternion<float>>(0.f, 0.f, 0.f, 0.f, 0.f, 0.f), 0.2f));
+    ASSERT_EQ(wf.getNodes().size(), n + 2);
+    ASSERT_EQ(copy.getNodes().size(), n + 1);
+    ASSERT_EQ(copy.getNodes()[n]->getPosition().x, 9.f);
+}
+
 // DynFusion::operator() (dyn_fusion.cpp:48-145) on two synthetic depth frames of a sphere in front of a wall
 TEST(DynFusionTest, OperatorRunsTheWholeFrameSequence) {
     const int W = 160, H = 120;

@@ -114,7 +114,7 @@ def test_host_tsdf_volume_matches_oracle(exes):
 @pytest.mark.gpu
 def test_host_dynfusion_sequence(exes):
     out = _run(exes["test_host_dynfusion"])
-    assert "11 tests, 0 failed" in out
+    assert "12 tests, 0 failed" in out
 
 
 @pytest.mark.gpu
