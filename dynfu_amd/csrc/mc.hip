@@ -246,9 +246,21 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* in, long
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = before;
     constexpr int PER = SCAN_CHUNK / 256;
     const long first  = base + (long)threadIdx.x * PER;
+    // (a thread's 32 entries are 128 contiguous bytes: 16-byte accesses where they all exist and the arrays allow it)
+    const bool whole = first + PER <= n && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
     int loc[PER], sum = 0;
+    if (whole) {
 #pragma unroll
-    for (int j = 0; j < PER; ++j) loc[j] = first + j < n ? in[first + j] : 0, sum += loc[j];
+        for (int q = 0; q < PER / 4; ++q) {
+            const int4 c4 = reinterpret_cast<const int4*>(in + first)[q];
+            loc[4 * q] = c4.x, loc[4 * q + 1] = c4.y, loc[4 * q + 2] = c4.z, loc[4 * q + 3] = c4.w;
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) sum += loc[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) loc[j] = first + j < n ? in[first + j] : 0, sum += loc[j];
+    }
     int incl       = sum;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -260,6 +272,18 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* in, long
     __syncthreads();
     int off = sh[0] + sh[1] + sh[2] + sh[3] + incl - sum;
     for (int w = 0; w < wave; ++w) off += sh2[w];
+    if (whole) {
+        int st[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) st[j] = off, off += loc[j];
+#pragma unroll
+        for (int q = 0; q < PER / 4; ++q) reinterpret_cast<int4*>(out + first)[q] = make_int4(st[4 * q], st[4 * q + 1], st[4 * q + 2], st[4 * q + 3]);
+        if (first + PER == n) {
+            out[n] = off;
+            if (total) *total = off;
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         if (first + j < n) {
