@@ -319,9 +319,21 @@ __global__ __launch_bounds__(256) void linearise_kernel(SolveView s, SolveState*
     __shared__ double sm[256];
     __shared__ double smx[256];
     double acc = 0.0, mx = 0.0;
-    for (unsigned int i = threadIdx.x; i < gridDim.x; i += 256) {
-        acc += __hip_atomic_load(&cost_partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (a.update_weights) mx = fmax(mx, __hip_atomic_load(&cost_partials[LIN_MAX_BLOCKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    {
+        // these loads go past the L2 (~2 us each) and this is the one workgroup the launch — and the assembly behind it — waits
+        // for: all of a thread's partials in flight together (LIN_MAX_BLOCKS / 256 = 4 per array; a load-wait-add loop was four
+        // dependent round trips), clamped addresses, masked sums in the same order as before
+        constexpr int Q = LIN_MAX_BLOCKS / 256;
+        double cq[Q], mq[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const unsigned int i = min(threadIdx.x + 256u * q, gridDim.x - 1);
+            cq[q] = __hip_atomic_load(&cost_partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mq[q] = a.update_weights ? __hip_atomic_load(&cost_partials[LIN_MAX_BLOCKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+            if (threadIdx.x + 256u * q < gridDim.x) acc += cq[q], mx = fmax(mx, mq[q]);
     }
     sm[threadIdx.x] = acc, smx[threadIdx.x] = mx;
     __syncthreads();
