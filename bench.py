@@ -195,6 +195,8 @@ class Sequence:
                                  .float() for f in range(self.n_frames)])
         self.t_true = t_true
         self.solver = A.Solver(self.D, self.N, self.k)
+        if os.environ.get("DFA_BENCH_DETERMINISTIC"):  # the order-stable variant (dfa_solver_set_deterministic), for A/B runs
+            self.solver.set_deterministic(True)
         self.params = A.SolveParams(num_iter=cfg["gn_iters"], nonlinear_iter=1, linear_iter=256, pcg_tol=1e-6,
                                     gn_tol=0.0, **synth.SOLVER)
         self.s_fuse = concurrent_stream(device)

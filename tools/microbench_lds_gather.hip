@@ -118,7 +118,21 @@ void run(const char* name, const uint16_t* cols, float* out, long long* cyc, int
            per, (double)h / REP, NG, (int)hipGetLastError());
 }
 
-int main() {
+// index tables from a file ([n][NG][NT] uint16, e.g. the slot -> column assignments of a real normal matrix): names on the command line
+static void run_tables(const char* path, int argc, char** argv, float* out, long long* cyc, int D) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return;
+    std::vector<uint16_t> t(NG * NT);
+    uint16_t* d;
+    hipMalloc(&d, t.size() * 2);
+    for (int i = 0; fread(t.data(), 2, t.size(), f) == t.size(); ++i) {
+        hipMemcpy(d, t.data(), t.size() * 2, hipMemcpyHostToDevice);
+        run<1, 4>(2 + i < argc ? argv[2 + i] : "table", d, out, cyc, D);
+    }
+    fclose(f);
+}
+
+int main(int argc, char** argv) {
     const int D = 2048;
     std::vector<uint16_t> cols(NG * NT), lin(NG * NT);
     srand(1);
@@ -131,6 +145,10 @@ int main() {
     hipMalloc(&d_cols, cols.size() * 2), hipMalloc(&d_lin, cols.size() * 2), hipMalloc(&out, NT * 4), hipMalloc(&cyc, 8);
     hipMemcpy(d_cols, cols.data(), cols.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(d_lin, lin.data(), lin.size() * 2, hipMemcpyHostToDevice);
+    if (argc > 1) {
+        run_tables(argv[1], argc, argv, out, cyc, D);
+        return 0;
+    }
     run<1, 4>("b32 consecutive lanes (no conflicts)", d_lin, out, cyc, D);
     run<1, 4>("b32 random", d_cols, out, cyc, D);
     run<2, 4>("b32 random, 2 copies", d_cols, out, cyc, D);
