@@ -209,8 +209,9 @@ class Sequence:
         if timed_events is not None:
             e0, e1 = (self.torch.cuda.Event(enable_timing=True) for _ in range(2))
             e0.record()
+        # (occ: the volume's occupancy map where a marching-cubes pass follows the sweep — SequenceLive)
         A.tsdf_clear_integrate(self.vol, self.dists, self.voxel, self.trunc, self.synth.MAX_WEIGHT, self.vol2cam,
-                               *self.intr)
+                               *self.intr, occupancy=getattr(self, "occ", None), occupancy_known=getattr(self, "occ_known", False))
         if timed_events is not None:
             e1.record()
             timed_events.append((e0, e1))
@@ -410,15 +411,21 @@ class SequenceLive(Sequence):
         self.n_frames = self.N_NOISY
         tri, nv = A.mc_default_tables()
         self.tri, self.nv = torch.from_numpy(tri).to(device), torch.from_numpy(nv).to(device)
+        # the sweep records which 32 x 2 x 8-voxel boxes can hold surface; marching cubes reads only those (as the adaptor's
+        # TsdfVolume / MarchingCubes pair does)
+        self.occ = None if os.environ.get("DFA_BENCH_NO_OCCUPANCY") else A.tsdf_occupancy(self.vol)
+        # volume and map start as zeros and only the sweeps write them: the map describes the volume, and the sweep leaves
+        # the boxes of zeros that stay zeros alone (dfa_tsdf_clear_integrate_known_occ)
+        self.occ_known = self.occ is not None and not os.environ.get("DFA_BENCH_NO_KNOWN_OCCUPANCY")
         # one sizing pass (host synchronisation outside any timed region).  The soup comes out in voxel order (z-major), so
         # the object's vertices (z < 2 m) precede the background plane's (z = 2.5 m): the live cloud of the solve is a
         # strided sample of that prefix — the canonical cloud covers the object only, and a plane vertex has
         # no canonical neighbour within a metre
         self.fuse(0)
-        _, total = A.marching_cubes(self.vol, self.voxel, self.tri, self.nv, 0)
+        _, total = A.marching_cubes(self.vol, self.voxel, self.tri, self.nv, 0, occupancy=self.occ)
         self.mc_total = int(total.item())
         self.mc_cap = int(self.mc_total * 1.15) + 1024
-        pts, _ = A.marching_cubes(self.vol, self.voxel, self.tri, self.nv, self.mc_cap)
+        pts, _ = A.marching_cubes(self.vol, self.voxel, self.tri, self.nv, self.mc_cap, occupancy=self.occ)
         on_object = (pts[: self.mc_total, 2] + float(self.vol2cam[11])) < 2.0
         self.mc_object = int(on_object.sum().item())
         assert bool(on_object[: self.mc_object].all()), "the object's vertices are not a prefix of the soup"
@@ -430,7 +437,7 @@ class SequenceLive(Sequence):
     def frame(self, f, serial=True, timed_events=None):
         A = self.A
         self.fuse(f, timed_events)                                                             # dyn_fusion.cpp:58,113-114
-        pts, _ = A.marching_cubes(self.vol, self.voxel, self.tri, self.nv, self.mc_cap)         # :119-121
+        pts, _ = A.marching_cubes(self.vol, self.voxel, self.tri, self.nv, self.mc_cap, occupancy=self.occ)  # :119-121
         live = (pts[: self.stride * self.rows: self.stride, :3] + self.vol2cam_t).contiguous()  # volume -> camera frame
         corr_v, _, _ = A.correspond(self.verts, self.normals, live, want_index=False)           # :212-242
         self.solver.set_problem(self.nodes, self.node_dq, self.node_w, corr_v, live)            # opt_solver.cpp:15-54
@@ -949,6 +956,41 @@ def cpu_baseline(cfg_name, frames, variants=True):
     return out, t_last, frames - 1
 
 
+def fuse_variants_probe(seq, reps=30):
+    """The fused clear + integrate sweep of the configuration, alone on the device, three ways: every voxel stored (the
+    headline's), with the occupancy map kept beside it (dfa_tsdf_clear_integrate_occ: what a marching-cubes pass behind it
+    wants), and over a map KNOWN to describe the volume (dfa_tsdf_clear_integrate_known_occ: boxes of zeros that stay zeros are
+    not stored again).  Same volume bits each way (tests/test_gpu_mc.py); events on the launch stream."""
+    import torch
+    A, synth = seq.A, seq.synth
+    vol = torch.zeros_like(seq.vol)
+    occ = A.tsdf_occupancy(vol)
+    dists = []
+    for f in range(4):
+        d = torch.empty_like(seq.dists)
+        A.compute_dists(seq.depth[f % seq.n_frames], d, *seq.intr)
+        dists.append(d)
+    out = {}
+    for name, kw in (("every_voxel_stored", {}), ("occupancy_kept", dict(occupancy=occ)),
+                     ("occupancy_known", dict(occupancy=occ, occupancy_known=True))):
+        if name == "occupancy_known":
+            A.tsdf_clear(vol, occupancy=occ)
+        run = lambda f: A.tsdf_clear_integrate(vol, dists[f % 4], seq.voxel, seq.trunc, synth.MAX_WEIGHT, seq.vol2cam, *seq.intr, **kw)
+        for f in range(4):
+            run(f)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for f in range(reps):
+            run(f)
+        e1.record()
+        torch.cuda.synchronize()
+        out[name + "_ms"] = round(e0.elapsed_time(e1) / reps, 4)
+    out["boxes_without_weights"] = round(float((occ == 0).float().mean()), 4)
+    out["note"] = ("per call: the tile pass of the dists image + the sweep; `value` above is measured with every voxel stored; the "
+                   "live-depth flow and the C++ TsdfVolume use the map")
+    return out
+
+
 def raycast_probe(seq, config, reps=20):
     """"+ raycast, reported separately".  Both variants of the raycast (src/kfusion/tsdf_volume.cpp:95-129,
     tsdf_volume.cu:128-386) through the volume the timed frames have just fused, from the integration pose, timed with
@@ -1400,6 +1442,11 @@ def main():
                 out["raycast"] = raycast_probe(seq, args.config)
             except Exception as e:  # noqa: BLE001
                 out["raycast"] = dict(error="%s: %s" % (type(e).__name__, e))
+        if not args.no_raycast:
+            try:
+                out["fuse_variants"] = fuse_variants_probe(seq)
+            except Exception as e:  # noqa: BLE001
+                out["fuse_variants"] = dict(error="%s: %s" % (type(e).__name__, e))
         if not (args.pipeline or args.serial or args.no_pipelined_probe):
             try:
                 out["pipelined"] = pipelined_probe(seq, Wm + K, device)

@@ -12,7 +12,7 @@ SYMBOLS = [
     "dfa_tsdf_clear_integrate", "dfa_tsdf_raycast_points", "dfa_tsdf_raycast_depth", "dfa_tsdf_raycast_tally", "dfa_tsdf_vertex_normals", "dfa_correspond_projective", "dfa_knn", "dfa_warp_to_live",
     "dfa_calc_dqb", "dfa_unsupported_vertices", "dfa_icp_sums", "dfa_repack_points", "dfa_compact_points", "dfa_transform_points", "dfa_warp_to_live_graph",
     "dfa_correspond", "dfa_marching_cubes", "dfa_mc_default_tables",
-    "dfa_tsdf_occupancy_bytes", "dfa_tsdf_clear_occ", "dfa_tsdf_integrate_occ", "dfa_tsdf_clear_integrate_occ", "dfa_marching_cubes_occ",
+    "dfa_tsdf_occupancy_bytes", "dfa_tsdf_clear_occ", "dfa_tsdf_integrate_occ", "dfa_tsdf_clear_integrate_occ", "dfa_tsdf_clear_integrate_known_occ", "dfa_marching_cubes_occ",
     "dfa_depth_bilateral_filter", "dfa_depth_truncate", "dfa_depth_build_pyramid", "dfa_compute_normals_mask_depth",
     "dfa_resize_depth_normals", "dfa_resize_points_normals",
     "dfa_compute_points_normals", "dfa_solver6_create", "dfa_solver6_destroy", "dfa_solver6_set_problem",
@@ -46,7 +46,7 @@ class Solve6Params(C.Structure):
 
 
 SOLVE6_HIST = 32  # DFA_SOLVE6_HIST
-ABI_VERSION = 5   # DFA_ABI_VERSION
+ABI_VERSION = 6   # DFA_ABI_VERSION
 
 
 class _Solve6Stats(C.Structure):
@@ -156,6 +156,7 @@ def load(path=None):
     L.dfa_tsdf_clear_integrate.argtypes = integ
     L.dfa_tsdf_integrate_occ.argtypes = integ[:-1] + [vp, vp]
     L.dfa_tsdf_clear_integrate_occ.argtypes = integ[:-1] + [vp, vp]
+    L.dfa_tsdf_clear_integrate_known_occ.argtypes = integ[:-1] + [vp, vp]
     L.dfa_tsdf_clear_occ.argtypes = [vp, i, i, i, vp, vp]
     L.dfa_tsdf_occupancy_bytes.argtypes = [i, i, i]
     L.dfa_tsdf_occupancy_bytes.restype = C.c_size_t
@@ -321,10 +322,13 @@ def tsdf_integrate(vol, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, c
                vol2cam, fx, fy, cx, cy, occupancy)
 
 
-def tsdf_clear_integrate(vol, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, cx, cy, occupancy=None):
+def tsdf_clear_integrate(vol, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, cx, cy, occupancy=None, occupancy_known=False):
+    """occupancy_known: the map describes the volume as it is now (left by tsdf_clear(vol, occupancy) or an occupancy-keeping
+    sweep, nothing else has written the volume since): boxes of zeros that stay zeros are not stored again
+    (dfa_tsdf_clear_integrate_known_occ)."""
     L = load()
-    _integrate(L.dfa_tsdf_clear_integrate if occupancy is None else L.dfa_tsdf_clear_integrate_occ, vol, dists, voxel_size, trunc,
-               max_weight, vol2cam, fx, fy, cx, cy, occupancy)
+    fn = L.dfa_tsdf_clear_integrate if occupancy is None else (L.dfa_tsdf_clear_integrate_known_occ if occupancy_known else L.dfa_tsdf_clear_integrate_occ)
+    _integrate(fn, vol, dists, voxel_size, trunc, max_weight, vol2cam, fx, fy, cx, cy, occupancy)
 
 
 def tsdf_raycast_points(vol, voxel_size, trunc, cam2vol, Rinv, fx, fy, cx, cy, step_factor, delta_factor, points,

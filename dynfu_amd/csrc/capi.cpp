@@ -300,14 +300,14 @@ int dfa_tsdf_clear_occ(uint32_t* volume, int X, int Y, int Z, uint8_t* occupancy
 static int integrate_common(bool fused, const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* volume,
                             int X, int Y, int Z, const float voxel_size[3], float trunc_dist, int max_weight,
                             const float vol2cam[12], float fx, float fy, float cx, float cy, uint8_t* occupancy,
-                            dfa_stream_t stream) {
+                            dfa_stream_t stream, bool occupancy_known = false) {
     REQUIRE(volume_args_ok(volume, X, Y, Z), "bad volume");
     REQUIRE(dists && cols > 0 && rows > 0 && dists_step >= cols * 2, "bad dists image");
     REQUIRE(voxel_size && vol2cam, "null parameter block");
     REQUIRE(trunc_dist > 0.f, "trunc_dist must be positive");
     REQUIRE(max_weight >= 0 && max_weight <= 65535, "max_weight must fit the 16-bit weight");
     HIP_TRY(dfa::launch_tsdf_integrate(fused, dists, dists_step, cols, rows, volume, X, Y, Z, voxel_size, trunc_dist,
-                                       max_weight, vol2cam, fx, fy, cx, cy, occupancy, S(stream)));
+                                       max_weight, vol2cam, fx, fy, cx, cy, occupancy, occupancy_known, S(stream)));
     return DFA_OK;
 }
 
@@ -326,6 +326,15 @@ int dfa_tsdf_clear_integrate_occ(const uint16_t* dists, int dists_step, int cols
     REQUIRE(occupancy, "null occupancy map");
     return integrate_common(true, dists, dists_step, cols, rows, volume, X, Y, Z, voxel_size, trunc_dist, max_weight, vol2cam,
                             fx, fy, cx, cy, occupancy, stream);
+}
+
+int dfa_tsdf_clear_integrate_known_occ(const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* volume, int X,
+                                       int Y, int Z, const float voxel_size[3], float trunc_dist, int max_weight,
+                                       const float vol2cam[12], float fx, float fy, float cx, float cy, uint8_t* occupancy,
+                                       dfa_stream_t stream) {
+    REQUIRE(occupancy, "null occupancy map");
+    return integrate_common(true, dists, dists_step, cols, rows, volume, X, Y, Z, voxel_size, trunc_dist, max_weight, vol2cam,
+                            fx, fy, cx, cy, occupancy, stream, true);
 }
 
 int dfa_tsdf_integrate(const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* volume, int X, int Y, int Z,

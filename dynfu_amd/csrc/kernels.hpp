@@ -26,7 +26,7 @@ __host__ __device__ inline OccDims occ_dims(int X, int Y, int Z) { return OccDim
 hipError_t launch_tsdf_integrate(bool fused_clear, const uint16_t* dists, int dists_step, int cols, int rows,
                                  uint32_t* vol, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
                                  int max_weight, const float vol2cam[12], float fx, float fy, float cx, float cy,
-                                 uint8_t* occ, hipStream_t s);
+                                 uint8_t* occ, bool occ_known /* fused: the map describes the volume on entry */, hipStream_t s);
 hipError_t launch_vertex_normals(const uint32_t* vol, int X, int Y, int Z, const float voxel_size[3], float delta_factor,
                                  const float* points, int n, float* normals, hipStream_t s);
 hipError_t launch_raycast_points(const uint32_t* vol, int X, int Y, int Z, const float voxel_size[3],

@@ -84,6 +84,7 @@ struct IntegrateArgs {
     int zchunk;
     uint8_t* occ;  // occupancy map (kernels.hpp: OccDims) or null
     int ox, oy;
+    int occ_known;  // fused sweep: the map describes the volume as it is NOW — a box without weights that gets none is not written
     int nt;      // DFA_TSDF_NT=1 (A/B): non-temporal stores in the fused sweep
     int ablate;  // -DDFA_DEV_ABLATE builds only (DFA_TSDF_ABLATE): 1 every run SKIP, 2 FULL runs filled like FRONT, 3 no classification
 };
@@ -326,7 +327,20 @@ __global__ __launch_bounds__(256) void integrate_runs_kernel(const IntegrateArgs
             occ_cell = a.occ + (size_t)(x / WX) + (size_t)a.ox * ((size_t)(y / WAVE_ROWS) + (size_t)a.oy * (size_t)(z0 / U));
     }
     const size_t occ_layer = (size_t)a.ox * a.oy;
+    // The fused sweep over a volume whose map is KNOWN to describe it (dfa_tsdf_clear_integrate_known_occ): a box whose byte
+    // is 0 holds 32 x 2 x 8 zeros, and when none of its runs gets a weight now either, storing those zeros again is the
+    // 5/6 of the sweep's traffic that changes nothing.  Every lane reads the box's byte (one address per wave), a run ahead.
+    // (all of a chunk's bytes up front, as a bit mask: a load per run in front of the decision is a memory round trip per run)
+    unsigned long long clean = 0ull;  // bit r: the box of the chunk's r-th run held zeros on entry
+    if (FUSED_CLEAR && a.occ && a.occ_known) {
+        const uint8_t* occ_old = a.occ + (size_t)(x / WX) + (size_t)a.ox * ((size_t)(y / WAVE_ROWS) + (size_t)a.oy * (size_t)(z0 / U));
+        const int nruns        = min((z1 - z0) / U, 64);  // (runs past the 64th: not known to be clean)
+#pragma unroll 8
+        for (int r = 0; r < nruns; ++r) clean |= (unsigned long long)(occ_old[(size_t)r * occ_layer] == 0) << r;
+    }
     for (; z + U <= z1; z += U, ptr += slice * U) {
+        const bool was_clean = (clean & 1ull) != 0ull;
+        clean >>= 1;
         const f3 far     = vc + stepU;
         int cls          = RUN_SKIP;
 #ifdef DFA_DEV_ABLATE
@@ -344,12 +358,15 @@ __global__ __launch_bounds__(256) void integrate_runs_kernel(const IntegrateArgs
             end              = nxt;
         }
 #endif
+        bool untouched = false;  // (wave-uniform) a box of zeros that stays one
         if (a.occ) {  // (uniform) bit 0: a run of the box was not SKIP (SKIP runs are the only ones that leave, or find, no
                       // weight); bit 1: a run was FULL — the only runs that can leave a NEGATIVE distance (FRONT runs write +1)
             const unsigned mark = (__ballot(cls != RUN_SKIP) != 0ull ? 1u : 0u) | (__ballot(cls == RUN_FULL) != 0ull ? 2u : 0u);
+            untouched           = FUSED_CLEAR && was_clean && mark == 0u;
             if (occ_cell) {
-                if (FUSED_CLEAR) *occ_cell = (uint8_t)mark;
-                else if (mark) *occ_cell = (uint8_t)(*occ_cell | mark);  // (one writer per byte and launch)
+                if (FUSED_CLEAR) {
+                    if (!untouched) *occ_cell = (uint8_t)mark;
+                } else if (mark) *occ_cell = (uint8_t)(*occ_cell | mark);  // (one writer per byte and launch)
                 occ_cell += occ_layer;
             }
         }
@@ -357,6 +374,7 @@ __global__ __launch_bounds__(256) void integrate_runs_kernel(const IntegrateArgs
 #pragma unroll
         for (int u = 0; u < U; ++u) p[u] = vc, vc = vc + zstep;
         if (FUSED_CLEAR) {
+            if (untouched) continue;
             uint32_t out[U];
             const uint32_t fill = cls == RUN_FRONT ? front_const : 0u;
 #pragma unroll
@@ -778,8 +796,9 @@ static int pick_zchunk(int X, int Y, int Z, int vx, bool fused_clear) {
 hipError_t launch_tsdf_integrate(bool fused_clear, const uint16_t* dists, int dists_step, int cols, int rows,
                                  uint32_t* vol, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
                                  int max_weight, const float vol2cam[12], float fx, float fy, float cx, float cy,
-                                 uint8_t* occ, hipStream_t s) {
+                                 uint8_t* occ, bool occ_known, hipStream_t s) {
     IntegrateArgs a;
+    a.occ_known = occ && occ_known && fused_clear ? 1 : 0;
     a.dists = dists, a.dists_step = dists_step, a.cols = cols, a.rows = rows;
     a.vol = vol, a.X = X, a.Y = Y, a.Z = Z;
     const OccDims od = occ_dims(X, Y, Z);

@@ -56,11 +56,12 @@ void TsdfVolume::clearAndIntegrate(const Dists& dists, const Affine3f& camera_po
     float aff[12];
     vol2cam.to12(aff);
     const Vec3f vsz = getVoxelSize();
-    dfa::check(dfa_tsdf_clear_integrate_occ(dists.ptr(), (int)dists.step(), dists.cols(), dists.rows(),
-                                            blob_.ptr<uint32_t>(), cfg_.dims[0], cfg_.dims[1], cfg_.dims[2], vsz.v, cfg_.trunc,
-                                            cfg_.max_weight, aff, intr.fx, intr.fy, intr.cx, intr.cy, occ_.ptr<uint8_t>(), nullptr),
+    // (a map that describes the volume: boxes of zeros that stay zeros are not written again)
+    dfa::check((occ_known_ ? dfa_tsdf_clear_integrate_known_occ : dfa_tsdf_clear_integrate_occ)(
+                   dists.ptr(), (int)dists.step(), dists.cols(), dists.rows(), blob_.ptr<uint32_t>(), cfg_.dims[0], cfg_.dims[1],
+                   cfg_.dims[2], vsz.v, cfg_.trunc, cfg_.max_weight, aff, intr.fx, intr.fy, intr.cx, intr.cy, occ_.ptr<uint8_t>(), nullptr),
                "TsdfVolume::clearAndIntegrate");
-    occ_known_ = true;  // (the fused sweep writes every voxel and every byte of the map)
+    occ_known_ = true;  // (the fused sweep leaves volume and map describing each other)
     dfa::device_synchronize();
 }
 

@@ -56,7 +56,7 @@ const char* dfa_version(void);
  * DFA_ABI_VERSION changes whenever the layout of one of them does.  dfa_abi_version() is the value the LIBRARY was built
  * with, dfa_abi_struct_size(id) the sizeof it assumes (0 for an unknown id) — a caller built against another header, or a
  * binding that mirrors the structs by hand (dynfu_amd/_lib.py), compares both with its own before the first call. */
-#define DFA_ABI_VERSION 5
+#define DFA_ABI_VERSION 6
 enum {
     DFA_STRUCT_SOLVE_PARAMS  = 0, /* dfa_solve_params  */
     DFA_STRUCT_SOLVE_STATS   = 1, /* dfa_solve_stats   */
@@ -111,6 +111,14 @@ int dfa_tsdf_clear_integrate_occ(const uint16_t* dists, int dists_step, int cols
                                  int Z, const float voxel_size[3], float trunc_dist, int max_weight,
                                  const float vol2cam[12], float fx, float fy, float cx, float cy, uint8_t* occupancy,
                                  dfa_stream_t stream);
+/* dfa_tsdf_clear_integrate_occ for a map that DESCRIBES THE VOLUME ON ENTRY (a map as dfa_tsdf_clear_occ or one of the _occ
+ * sweeps left it, the volume untouched by anything else since): a box of zeros whose byte says so and that receives no weight
+ * from this frame either is not stored again — 5/6 of a 512^3 sweep's traffic.  Same volume bits and same map as
+ * dfa_tsdf_clear_integrate_occ.  With a map that does not describe the volume, boxes of the old content survive. */
+int dfa_tsdf_clear_integrate_known_occ(const uint16_t* dists, int dists_step, int cols, int rows, uint32_t* volume, int X,
+                                       int Y, int Z, const float voxel_size[3], float trunc_dist, int max_weight,
+                                       const float vol2cam[12], float fx, float fy, float cx, float cy, uint8_t* occupancy,
+                                       dfa_stream_t stream);
 
 /* Normals of surface points from the TSDF gradient (the reference extracts the mesh without
  * normals, dyn_fusion.cpp:80-88 "temporary workaround until normals are computed via mc").  The raycaster's own

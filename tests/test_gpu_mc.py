@@ -210,3 +210,68 @@ def test_occupancy_map_and_marching_cubes_without_the_empty_voxels(A, name, dims
     _, t1 = A.marching_cubes(vol, voxel, dev(tri), dev(nv), 1, occupancy=occ)
     _, t0 = A.marching_cubes(plain, voxel, dev(tri), dev(nv), 1)
     assert int(host(t1)[0]) == int(host(t0)[0]) > 1000
+
+
+@pytest.mark.parametrize("name,dims", [("T1", None), ("T1", (100, 77, 90)), ("C2", None)])
+def test_fused_sweep_over_a_known_occupancy_map_leaves_the_same_volume_and_map(A, name, dims):
+    """dfa_tsdf_clear_integrate_known_occ: with a map that describes the volume on entry, boxes of zeros that stay zeros are
+    not stored again.  Frame after frame with a moving camera — behind a clear, behind fused sweeps, behind accumulating
+    sweeps — the volume and the map are those of dfa_tsdf_clear_integrate_occ (and so of the plain fused sweep, and at the
+    small sizes of the oracle), bit for bit; the documented failure with a map that does NOT describe the volume is there
+    too (old content survives where the map says "zeros")."""
+    import torch
+    cfg = synth.CONFIGS[name]
+    fx, fy, cx, cy = synth.intrinsics(cfg)
+    voxel, trunc, vol2cam, _, _ = synth.volume_params(cfg)
+    X, Y, Z = dims or (cfg["dim"],) * 3
+    if dims:
+        voxel = tuple(float(synth.VOLUME_SIZE / d) for d in dims)
+    dists = []
+    for f in range(4):
+        d = torch.empty((cfg["height"], cfg["width"]), dtype=torch.uint16, device="cuda")
+        A.compute_dists(dev(synth.depth_frame(cfg, f)), d, fx, fy, cx, cy)
+        dists.append(d)
+
+    def pose(f):  # the camera a little to the side and back every frame: other boxes come into the frustum
+        m = np.array(vol2cam, np.float32).copy()
+        m[9] += 0.04 * f
+        m[11] += 0.03 * f
+        return m
+
+    vol = torch.empty((Z, Y, X), dtype=torch.int32, device="cuda").random_(0, 2 ** 31 - 1)
+    ref = torch.empty_like(vol)
+    occ, occ_ref = A.tsdf_occupancy(vol), A.tsdf_occupancy(vol)
+    args = (voxel, trunc, synth.MAX_WEIGHT)
+
+    def same():
+        assert np.array_equal(host(vol).view(np.uint32), host(ref).view(np.uint32))
+        assert np.array_equal(host(occ), host(occ_ref))
+
+    A.tsdf_clear(vol, occupancy=occ)  # from here on the map describes the volume
+    for f in range(4):
+        A.tsdf_clear_integrate(vol, dists[f], *args, pose(f), fx, fy, cx, cy, occupancy=occ, occupancy_known=True)
+        A.tsdf_clear_integrate(ref, dists[f], *args, pose(f), fx, fy, cx, cy, occupancy=occ_ref)
+        same()
+    skipped = float((host(occ) == 0).mean())
+    if X >= 512:
+        assert skipped > 0.6  # most of the volume is not written at all
+    if X * Y * Z <= 128 ** 3:
+        dn = host(dists[3])
+        want = np.zeros((Z, Y, X), np.uint32)
+        O.tsdf_integrate(want, dn, np.asarray(voxel, np.float32), trunc, synth.MAX_WEIGHT, pose(3), fx, fy, cx, cy)
+        assert np.array_equal(host(vol).view(np.uint32), want)
+    # behind accumulating sweeps (the map only grows there) ...
+    for f in (1, 2):
+        A.tsdf_integrate(vol, dists[f], *args, pose(f), fx, fy, cx, cy, occupancy=occ)
+        A.tsdf_integrate(ref, dists[f], *args, pose(f), fx, fy, cx, cy, occupancy=occ_ref)
+    A.tsdf_clear_integrate(vol, dists[0], *args, pose(0), fx, fy, cx, cy, occupancy=occ, occupancy_known=True)
+    A.tsdf_clear_integrate(ref, dists[0], *args, pose(0), fx, fy, cx, cy, occupancy=occ_ref)
+    same()
+    # ... and what the contract warns of: a map of zeros over a volume that is not
+    vol.fill_(0x00070001)  # (weight 7: nothing one frame writes)
+    occ.zero_()
+    A.tsdf_clear_integrate(vol, dists[0], *args, pose(0), fx, fy, cx, cy, occupancy=occ, occupancy_known=True)
+    left = host(vol).view(np.uint32) == 0x00070001
+    assert left.any() and not (left & (host(ref).view(np.uint32) != 0)).any()  # only where the frame writes zeros
+    A.tsdf_clear_integrate(vol, dists[0], *args, pose(0), fx, fy, cx, cy, occupancy=occ)  # the sweep without the promise repairs it
+    same()
