@@ -476,11 +476,18 @@ __device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32
     int cx, cy, cz;
     cell_of(g, q, cx, cy, cz);
     float margin = 0.f;  // in cells; 0 for queries outside the grid (clamped above)
+    float wall[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};  // TIGHT: distance to the low / high wall of the own cell per axis (m)
+    bool inside      = false;
     if (TIGHT) {
         const float ux = (q.x - g.bmin[0]) * g.inv_cs - (float)cx, uy = (q.y - g.bmin[1]) * g.inv_cs - (float)cy,
                     uz = (q.z - g.bmin[2]) * g.inv_cs - (float)cz;
         const float m = fminf(fminf(fminf(ux, 1.f - ux), fminf(uy, 1.f - uy)), fminf(uz, 1.f - uz));
         margin        = m > 0.f ? m : 0.f;  // negative (outside) or NaN -> 0
+        inside        = m >= 0.f;           // (false for NaN)
+        const float u[3] = {ux, uy, uz};
+        // (1e-3 cells off every wall: the rounding of the cell assignment, as in the stop bounds below)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) wall[c][0] = fmaxf(u[c] - 1e-3f, 0.f) * g.cs, wall[c][1] = fmaxf(1.f - u[c] - 1e-3f, 0.f) * g.cs;
     }
     const int rmax = max(g.dim[0], max(g.dim[1], g.dim[2]));
     int r_first    = 0;
@@ -521,7 +528,35 @@ __device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32
         scan_range(cell_start[c0], cell_start[c0 + 1]);
         const float b0 = fmaxf(margin - 1e-3f, 0.f) * g.cs;
         if (best.dist(K - 1) < b0 * b0 * 0.9999f) return;
-        scan_block3();
+        // Shell 1, without the cells that cannot hold anything nearer than what the own cell gave (d0): a query that fails
+        // the test above sits near ONE wall or edge of its cell, and of the 26 neighbours only the few across that wall are
+        // within d0 — a cell whose nearest point is farther than d0 is skipped by the rule that ends the search (strictly
+        // farther, with the same margins), so the result, ties included, is that of the full block.  The own cell is not
+        // scanned again unless both x neighbours of its row are.  On a million-point surface (~20 points per cell at the
+        // 256-cell cap) the full block is ~180 candidates; this is the part of it across the near walls.
+        {
+            const float d0 = best.dist(K - 1);
+            int rbeg[9], rend[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const int dz = i / 3 - 1, dy = i % 3 - 1, z = cz + dz, y = cy + dy;
+                const float ey = dy < 0 ? wall[1][0] : dy > 0 ? wall[1][1] : 0.f, ez = dz < 0 ? wall[2][0] : dz > 0 ? wall[2][1] : 0.f;
+                const float rb2 = ey * ey + ez * ez;
+                const bool keep = !inside || !(d0 < rb2 * 0.9999f);
+                const bool xl   = keep && (!inside || !(d0 < (rb2 + wall[0][0] * wall[0][0]) * 0.9999f));
+                const bool xr   = keep && (!inside || !(d0 < (rb2 + wall[0][1] * wall[0][1]) * 0.9999f));
+                const bool own  = dy == 0 && dz == 0;  // the row of the own cell: that cell is done
+                const bool mid  = keep && (!own || (xl && xr));
+                const bool in   = z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1] && (xl || xr || mid);
+                const int x0 = max(xl ? cx - 1 : (mid ? cx : cx + 1), 0), x1 = min(xr ? cx + 1 : (mid ? cx : cx - 1), g.dim[0] - 1);
+                const int c  = in ? g.dim[0] * (y + g.dim[1] * z) : 0;
+                const bool some = in && x0 <= x1;
+                const int b = cell_start[c + (some ? x0 : 0)], e = cell_start[c + (some ? x1 + 1 : 0)];
+                rbeg[i] = some ? b : 0, rend[i] = some ? e : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) scan_range(rbeg[i], rend[i]);
+        }
         const float b1 = fmaxf(1.f + margin - 1e-3f, 0.f) * g.cs;
         if (best.dist(K - 1) < b1 * b1 * 0.9999f) return;
         r_first = 2;
