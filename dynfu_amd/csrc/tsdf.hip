@@ -85,6 +85,7 @@ struct IntegrateArgs {
     uint8_t* occ;  // occupancy map (kernels.hpp: OccDims) or null
     int ox, oy;
     int occ_known;  // fused sweep: the map describes the volume as it is NOW — a box without weights that gets none is not written
+    int chunk_rule;  // 1: a wave first asks whether its whole z chunk is skipped (tsdf_classify.hpp: chunk_skipped)
     int nt;      // DFA_TSDF_NT=1 (A/B): non-temporal stores in the fused sweep
     int ablate;  // -DDFA_DEV_ABLATE builds only (DFA_TSDF_ABLATE): 1 every run SKIP, 2 FULL runs filled like FRONT, 3 no classification
 };
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(256) void dists_tiles_kernel(const uint16_t* __rest
 }
 
 template <bool FUSED_CLEAR, int WX, int U>
-__global__ __launch_bounds__(256) void integrate_runs_kernel(const IntegrateArgs a, const RunConsts rc,
+__global__ __launch_bounds__(256) void integrate_runs_kernel(const IntegrateArgs a, const RunConsts rc, const RunConsts rcc,
                                                              const uint32_t front_const) {
     const int lane  = threadIdx.x, wave = threadIdx.y;  // block (64, 4)
     // the block's 64 x 4 columns, WX x (64 / WX) per wave: waves side by side in x, then stacked in y
@@ -310,6 +311,25 @@ __global__ __launch_bounds__(256) void integrate_runs_kernel(const IntegrateArgs
     const f3 zstep = mk3(a.vol2cam.m[2], a.vol2cam.m[5], a.vol2cam.m[8]) * a.vsz;                  // :58
     const f3 vx    = mk3((float)x * a.vsx, (float)y * a.vsy, 0.f);                                   // :60
     f3 vc          = mulR(a.vol2cam, vx) + mk3(a.vol2cam.t[0], a.vol2cam.t[1], a.vol2cam.t[2]);      // :61
+    // (all of a chunk's map bytes up front, as a bit mask: a load per run in front of the decision is a memory round trip per run)
+    constexpr int WAVE_ROWS_ = 64 / WX;
+    const size_t occ_layer = (size_t)a.ox * a.oy;
+    unsigned long long clean = 0ull;  // bit r: the box of the chunk's r-th run held zeros on entry (fused sweep over a known map)
+    const int nruns          = (z1 - z0) / U;
+    if (FUSED_CLEAR && a.occ && a.occ_known) {
+        const uint8_t* occ_old = a.occ + (size_t)(x / WX) + (size_t)a.ox * ((size_t)(y / WAVE_ROWS_) + (size_t)a.oy * (size_t)(z0 / U));
+#pragma unroll 8
+        for (int r = 0; r < min(nruns, 64); ++r) clean |= (unsigned long long)(occ_old[(size_t)r * occ_layer] == 0) << r;  // (runs past the 64th: not known to be clean)
+    }
+    // The chunk as a whole first (tsdf_classify.hpp, chunk_skipped): when every column of the wave skips every voxel of it —
+    // half of a volume lies outside the frustum — there is nothing to classify or replay; the accumulating sweep leaves such
+    // voxels alone anyway, the fused sweep may when the map says they are zeros already (and the chunk has no tail).
+    if (a.chunk_rule && (!FUSED_CLEAR || (a.occ && a.occ_known && nruns <= 64 && nruns * U == z1 - z0 &&
+                                          clean == (nruns == 64 ? ~0ull : (1ull << nruns) - 1ull)))) {
+        const float zs[3] = {zstep.x, zstep.y, zstep.z};
+        const bool skip   = chunk_skipped(vc.x, vc.y, vc.z, zs, z0, z1, rcc, rcp_approx, half_bits_to_float_u);
+        if (__ballot(!skip) == 0ull) return;  // (a skipped chunk leaves the map's bytes as they are: nothing gained a weight)
+    }
     for (int i = 0; i < z0; ++i) vc = vc + zstep;  // replay :64 up to the chunk's first slice
 
     const size_t slice = (size_t)a.X * a.Y;
@@ -326,18 +346,9 @@ __global__ __launch_bounds__(256) void integrate_runs_kernel(const IntegrateArgs
         if (lane == (int)__ffsll((long long)live) - 1)
             occ_cell = a.occ + (size_t)(x / WX) + (size_t)a.ox * ((size_t)(y / WAVE_ROWS) + (size_t)a.oy * (size_t)(z0 / U));
     }
-    const size_t occ_layer = (size_t)a.ox * a.oy;
     // The fused sweep over a volume whose map is KNOWN to describe it (dfa_tsdf_clear_integrate_known_occ): a box whose byte
     // is 0 holds 32 x 2 x 8 zeros, and when none of its runs gets a weight now either, storing those zeros again is the
-    // 5/6 of the sweep's traffic that changes nothing.  Every lane reads the box's byte (one address per wave), a run ahead.
-    // (all of a chunk's bytes up front, as a bit mask: a load per run in front of the decision is a memory round trip per run)
-    unsigned long long clean = 0ull;  // bit r: the box of the chunk's r-th run held zeros on entry
-    if (FUSED_CLEAR && a.occ && a.occ_known) {
-        const uint8_t* occ_old = a.occ + (size_t)(x / WX) + (size_t)a.ox * ((size_t)(y / WAVE_ROWS) + (size_t)a.oy * (size_t)(z0 / U));
-        const int nruns        = min((z1 - z0) / U, 64);  // (runs past the 64th: not known to be clean)
-#pragma unroll 8
-        for (int r = 0; r < nruns; ++r) clean |= (unsigned long long)(occ_old[(size_t)r * occ_layer] == 0) << r;
-    }
+    // 5/6 of the sweep's traffic that changes nothing (`clean`, read above).
     for (; z + U <= z1; z += U, ptr += slice * U) {
         const bool was_clean = (clean & 1ull) != 0ull;
         clean >>= 1;
@@ -799,6 +810,7 @@ hipError_t launch_tsdf_integrate(bool fused_clear, const uint16_t* dists, int di
                                  uint8_t* occ, bool occ_known, hipStream_t s) {
     IntegrateArgs a;
     a.occ_known = occ && occ_known && fused_clear ? 1 : 0;
+    a.chunk_rule = 0;
     a.dists = dists, a.dists_step = dists_step, a.cols = cols, a.rows = rows;
     a.vol = vol, a.X = X, a.Y = Y, a.Z = Z;
     const OccDims od = occ_dims(X, Y, Z);
@@ -852,7 +864,10 @@ hipError_t launch_tsdf_integrate(bool fused_clear, const uint16_t* dists, int di
             } else
 #endif
                 a.occ = occ;
-#define DFA_RUNS(F, W, UU) integrate_runs_kernel<F, W, UU><<<grid, block, 0, s>>>(a, rc, front_const)
+            // the chunk-level rule: margins of Z running additions (DFA_TSDF_NO_CHUNK_RULE=1 in development builds: A/B)
+            const RunConsts rcc = make_run_consts(tiles, cols, rows, fx, fy, cx, cy, trunc_dist, zstep, Z, extent);
+            a.chunk_rule = dev_env("DFA_TSDF_NO_CHUNK_RULE") ? 0 : 1;
+#define DFA_RUNS(F, W, UU) integrate_runs_kernel<F, W, UU><<<grid, block, 0, s>>>(a, rc, rcc, front_const)
 #ifdef DFA_DEV_AB
             const int wave_x = dev_env_int("DFA_TSDF_WAVE", 32);
 #define DFA_RUNS_W(F, UU) (wave_x == 16 ? DFA_RUNS(F, 16, UU) : wave_x == 32 ? DFA_RUNS(F, 32, UU) : DFA_RUNS(F, 64, UU))

@@ -139,4 +139,19 @@ inline RunConsts make_run_consts(const uint32_t* tiles, int cols, int rows, floa
     return c;
 }
 
+// A whole z chunk of a column at once: true only when EVERY voxel of the slices [z0, z1) of the column is skipped (the run rule
+// above applied to the chunk's ends).  `p0` is the column's position at slice 0; the ends are taken from it with one
+// multiply-add each instead of the z0 running additions the sweep replays, so `cc` must carry the margins of Z additions:
+// make_run_consts(..., U = Z, ...) (its run length, the whole column, bounds the chunk's).  Half of a 512^3 volume lies outside
+// the frustum: a wave whose 64 columns all answer true has nothing to classify, replay or — in a sweep that leaves skipped
+// voxels alone — touch.
+template <class Rcp, class HalfToFloat>
+DFA_HD bool chunk_skipped(float p0x, float p0y, float p0z, const float zstep[3], int z0, int z1, const RunConsts& cc, Rcp rcp,
+                          HalfToFloat h2f) {
+    const float fa = (float)z0, fb = (float)z1;  // (the last voxel is z1 - 1: one step of slack)
+    const RunEnd a = run_end(fmaf(fa, zstep[0], p0x), fmaf(fa, zstep[1], p0y), fmaf(fa, zstep[2], p0z), cc, rcp);
+    const RunEnd b = run_end(fmaf(fb, zstep[0], p0x), fmaf(fb, zstep[1], p0y), fmaf(fb, zstep[2], p0z), cc, rcp);
+    return classify_run(a, b, cc, h2f) == RUN_SKIP;
+}
+
 }  // namespace dfa

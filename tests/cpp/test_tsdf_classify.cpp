@@ -41,6 +41,7 @@ struct Volume {
 struct Stats {
     long runs[3] = {0, 0, 0};
     long wave_full = 0, waves = 0;  // 64-lane x segments with at least one FULL run
+    long chunks_skipped = 0, columns_chunks = 0;  // (column, z chunk) pairs the chunk-level rule skipped / all of them
     std::vector<uint8_t>* classes = nullptr;  // [run][y][x] when set (stats mode)
 };
 
@@ -99,6 +100,9 @@ void model_integrate(bool fused, const Scene& s, const Volume& v, std::vector<ui
     const float zs[3] = {v.vol2cam[2] * v.voxel[2], v.vol2cam[5] * v.voxel[2], v.vol2cam[8] * v.voxel[2]};
     const dfa::RunConsts c =
         dfa::make_run_consts(tiles.data(), s.cols, s.rows, s.fx, s.fy, s.cx, s.cy, v.trunc, zs, U, extent_of(v));
+    // the chunk-level rule (a column's whole z chunk skipped at once): margins of Z running additions
+    const dfa::RunConsts cc =
+        dfa::make_run_consts(tiles.data(), s.cols, s.rows, s.fx, s.fy, s.cx, s.cy, v.trunc, zs, v.Z, extent_of(v));
     const size_t slice = (size_t)v.X * v.Y;
     // FRONT on a cleared voxel: tsdf 1, weight min(1, max_weight)
     const uint32_t front_const = (uint32_t)orc_float_to_half(1.0f) | ((uint32_t)(1 < v.max_weight ? 1 : v.max_weight) << 16);
@@ -112,8 +116,15 @@ void model_integrate(bool fused, const Scene& s, const Volume& v, std::vector<ui
                 float px = dot3(v.vol2cam[0], v.vol2cam[1], v.vol2cam[2], vx, vy, 0.f) + v.vol2cam[9];
                 float py = dot3(v.vol2cam[3], v.vol2cam[4], v.vol2cam[5], vx, vy, 0.f) + v.vol2cam[10];
                 float pz = dot3(v.vol2cam[6], v.vol2cam[7], v.vol2cam[8], vx, vy, 0.f) + v.vol2cam[11];
-                for (int i = 0; i < z0; ++i) px += zs[0], py += zs[1], pz += zs[2];
                 uint32_t* p = vol.data() + (size_t)x + (size_t)v.X * y + slice * z0;
+                if (dfa::chunk_skipped(px, py, pz, zs, z0, z1, cc, rcp_host, h2f)) {  // every voxel of the chunk is left alone
+                    if (st) st->chunks_skipped++, st->columns_chunks++, st->runs[dfa::RUN_SKIP] += (z1 - z0) / U;
+                    if (fused)
+                        for (int z = z0; z < z1; ++z, p += slice) *p = 0u;
+                    continue;
+                }
+                if (st) st->columns_chunks++;
+                for (int i = 0; i < z0; ++i) px += zs[0], py += zs[1], pz += zs[2];
                 int z = z0;
                 dfa::RunEnd a = dfa::run_end(px, py, pz, c, rcp_host);
                 for (; z + U <= z1; z += U) {
@@ -223,11 +234,14 @@ TEST(TsdfClassify, BenchSceneIdentityPose) {
     Volume v      = make_volume(128, 3.f, -1.5f, -1.5f, 0.5f);
     Stats st;
     check(s, v, 128, 8, &st);
-    check(s, v, 32, 8);
+    Stats quarter;  // (chunks of a quarter column, as the kernel cuts a 512^3 volume)
+    check(s, v, 32, 8, &quarter);
     check(s, v, 128, 4);
     const double tot = st.runs[0] + st.runs[1] + st.runs[2];
-    std::printf("    runs: skip %.1f %%  front %.1f %%  full %.1f %%; wave segments with a full run %.1f %%\n", 100 * st.runs[0] / tot,
-                100 * st.runs[1] / tot, 100 * st.runs[2] / tot, 100.0 * st.wave_full / st.waves);
+    std::printf("    runs: skip %.1f %%  front %.1f %%  full %.1f %%; wave segments with a full run %.1f %%; (column, chunk) pairs "
+                "skipped whole %.1f %%\n", 100 * st.runs[0] / tot, 100 * st.runs[1] / tot, 100 * st.runs[2] / tot,
+                100.0 * st.wave_full / st.waves, 100.0 * quarter.chunks_skipped / quarter.columns_chunks);
+    ASSERT_TRUE(quarter.chunks_skipped > 0.3 * quarter.columns_chunks);  // (half of the volume is outside the frustum)
     ASSERT_TRUE(st.runs[dfa::RUN_FULL] < 0.25 * tot);  // the point of the exercise
 }
 
