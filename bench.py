@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--no-multi-sequence", action="store_true", help="skip the multi_sequence figure")
     ap.add_argument("--sequences-threads", action="store_true", help="multi_sequence: a host thread per sequence instead of one "
                                                                      "thread enqueuing round-robin")
+    ap.add_argument("--warm-start", action="store_true", help="--mode northstar: every frame starts from the transforms the frame before solved (default: from the canonical state)")
     ap.add_argument("--no-live-depth", action="store_true", help="skip the short measurement on the reference's data flow with noisy depth")
     ap.add_argument("--live", default="targets", choices=["targets", "depth"],
                     help="targets: index-aligned live vertices canon + sum w t* (SURVEY 8d, the headline workload); depth: the "
@@ -372,8 +373,14 @@ class Sequence6(Sequence):
         self.params = A.Solve6Params(num_iter=outer, gn_iter=gn // outer, linear_iter=linear_iter, **self.pcg, **self.synth.SOLVER)
         self.gn_total = outer * (gn // outer)
 
+    warm_start = False  # --warm-start: a frame starts from the transforms the frame before solved (as a warp field does between
+                        # frames, and the C++ NorthStarSolver) instead of from the canonical state; the graphs are still rebuilt
+
     def build_graph(self, f):
-        self.solver.set_problem(self.nodes, self.node_dq, self.node_w, self.verts, self.normals)
+        dq0 = self.node_dq
+        if self.warm_start and getattr(self, "_solved", None) is not None:
+            dq0 = self._solved
+        self.solver.set_problem(self.nodes, dq0, self.node_w, self.verts, self.normals)
 
     def frame(self, f, serial=None, timed_events=None):
         # Every kernel of this mode fills the chip (linearise, assembly, a PCG step = thousands of workgroups): a sweep on
@@ -391,6 +398,8 @@ class Sequence6(Sequence):
         P, Nm = A.compute_points_normals(self.depth[f % self.n_frames], *self.intr)
         self.solver.solve(P, Nm, *self.intr, self.params)
         self.warped, self.warped_n = self.solver.warp()
+        if self.warm_start:
+            self._solved = self.solver.node_dq()  # (a copy: the next set_problem borrows its argument while the plan rewrites its own)
 
 
 class SequenceLive(Sequence):
@@ -804,6 +813,7 @@ def main_northstar(args, torch, replicas, rank, world, device):
     seq = Sequence6(args.config, device, lin, pcg)
     seq.fuse_first = args.fuse_first
     seq.overlap = args.overlap or args.fuse_first
+    seq.warm_start = bool(args.warm_start)
     cfg = seq.cfg
     K, Wm = args.steps, args.warmup
     ser = True if args.serial else None  # (None: the mode's default — stream order unless --overlap / --fuse-first)
