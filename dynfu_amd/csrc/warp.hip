@@ -517,8 +517,11 @@ __device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32
             const int b = cell_start[c + x0], e = cell_start[c + x1 + 1];
             rbeg[i] = in ? b : 0, rend[i] = in ? e : 0;
         }
+        // (the row of the query's own cell first, then the four rows that share a face with it, then the corners: the list
+        // fills with near candidates early, and a late candidate that no lane of the wave accepts skips the insertion)
+        constexpr int order[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
 #pragma unroll
-        for (int i = 0; i < 9; ++i) scan_range(rbeg[i], rend[i]);
+        for (int i = 0; i < 9; ++i) scan_range(rbeg[order[i]], rend[order[i]]);
     };
     if (TIGHT) {
         // shell 0 (the query's own cell) — a 1-NN search on a fine grid usually ends here —, then, if it does not, shells 0
@@ -555,7 +558,7 @@ __device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32
                 rbeg[i] = some ? b : 0, rend[i] = some ? e : 0;
             }
 #pragma unroll
-            for (int i = 0; i < 9; ++i) scan_range(rbeg[i], rend[i]);
+            for (int i = 0; i < 9; ++i) scan_range(rbeg[i], rend[i]);  // (one key per lane: the order does not matter here)
         }
         const float b1 = fmaxf(1.f + margin - 1e-3f, 0.f) * g.cs;
         if (best.dist(K - 1) < b1 * b1 * 0.9999f) return;
