@@ -196,3 +196,23 @@ def test_bench_line_has_the_contract_fields():
         assert "error" not in oc[key], oc[key]
         assert oc[key]["value"] > 30.0 and oc[key]["unit"] == "frames/s"
     assert oc["C3_northstar"]["solve"]["pcgs_cut_short_by_the_launch_budget"] == 0
+
+
+@pytest.mark.gpu
+def test_northstar_line_cold_and_warm_start():
+    """`--mode northstar` prints the same contract line; `--warm-start` (a frame starts from the transforms the frame before
+    solved) runs the same frames, converges, and is not slower than starting every frame from the canonical state."""
+    vals = {}
+    for name, extra in (("cold", []), ("warm", ["--warm-start"])):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "northstar", "--config", "C2", "--steps", "12",
+                            "--warmup", "4", "--no-cpu-baseline", "--no-rccl-selfcheck"] + extra, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert len(r.stdout.strip().splitlines()) == 1, r.stdout[-1500:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "roofline", "config"):
+            assert key in d, key
+        lf = d["config"]["last_frame"]
+        assert d["steps"] == 12 and d["value"] > 30.0 and lf["final_cost"] < 0.1 * max(lf["cost_per_gn"][0], 1e-3) + 0.1
+        vals[name] = (d["value"], lf)
+    assert vals["warm"][0] > 0.9 * vals["cold"][0]
+    assert vals["warm"][1]["cost_per_gn"][0] < vals["cold"][1]["cost_per_gn"][0]  # (it starts nearer to the frame's surface)
