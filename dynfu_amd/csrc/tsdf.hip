@@ -314,18 +314,23 @@ __global__ __launch_bounds__(256) void integrate_runs_kernel(const IntegrateArgs
     // (all of a chunk's map bytes up front, as a bit mask: a load per run in front of the decision is a memory round trip per run)
     constexpr int WAVE_ROWS_ = 64 / WX;
     const size_t occ_layer = (size_t)a.ox * a.oy;
-    unsigned long long clean = 0ull;  // bit r: the box of the chunk's r-th run held zeros on entry (fused sweep over a known map)
+    // bit r of (clean_hi : clean): the box of the chunk's r-th run held zeros on entry (fused sweep over a known map); 128 runs
+    // are a whole column of a 1024^3 volume, runs beyond are not known to be clean
+    unsigned long long clean = 0ull, clean_hi = 0ull;
     const int nruns          = (z1 - z0) / U;
     if (FUSED_CLEAR && a.occ && a.occ_known) {
         const uint8_t* occ_old = a.occ + (size_t)(x / WX) + (size_t)a.ox * ((size_t)(y / WAVE_ROWS_) + (size_t)a.oy * (size_t)(z0 / U));
 #pragma unroll 8
-        for (int r = 0; r < min(nruns, 64); ++r) clean |= (unsigned long long)(occ_old[(size_t)r * occ_layer] == 0) << r;  // (runs past the 64th: not known to be clean)
+        for (int r = 0; r < min(nruns, 64); ++r) clean |= (unsigned long long)(occ_old[(size_t)r * occ_layer] == 0) << r;
+#pragma unroll 8
+        for (int r = 64; r < min(nruns, 128); ++r) clean_hi |= (unsigned long long)(occ_old[(size_t)r * occ_layer] == 0) << (r - 64);
     }
     // The chunk as a whole first (tsdf_classify.hpp, chunk_skipped): when every column of the wave skips every voxel of it —
     // half of a volume lies outside the frustum — there is nothing to classify or replay; the accumulating sweep leaves such
     // voxels alone anyway, the fused sweep may when the map says they are zeros already (and the chunk has no tail).
-    if (a.chunk_rule && (!FUSED_CLEAR || (a.occ && a.occ_known && nruns <= 64 && nruns * U == z1 - z0 &&
-                                          clean == (nruns == 64 ? ~0ull : (1ull << nruns) - 1ull)))) {
+    auto ones = [](int n) { return n >= 64 ? ~0ull : n <= 0 ? 0ull : (1ull << n) - 1ull; };
+    if (a.chunk_rule && (!FUSED_CLEAR || (a.occ && a.occ_known && nruns <= 128 && nruns * U == z1 - z0 && clean == ones(nruns) &&
+                                          clean_hi == ones(nruns - 64)))) {
         const float zs[3] = {zstep.x, zstep.y, zstep.z};
         const bool skip   = chunk_skipped(vc.x, vc.y, vc.z, zs, z0, z1, rcc, rcp_approx, half_bits_to_float_u);
         if (__ballot(!skip) == 0ull) return;  // (a skipped chunk leaves the map's bytes as they are: nothing gained a weight)
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(256) void integrate_runs_kernel(const IntegrateArgs
     // 5/6 of the sweep's traffic that changes nothing (`clean`, read above).
     for (; z + U <= z1; z += U, ptr += slice * U) {
         const bool was_clean = (clean & 1ull) != 0ull;
-        clean >>= 1;
+        clean = (clean >> 1) | (clean_hi << 63), clean_hi >>= 1;
         const f3 far     = vc + stepU;
         int cls          = RUN_SKIP;
 #ifdef DFA_DEV_ABLATE
