@@ -182,6 +182,24 @@ def test_correspond_bit_exact(A, n_canon, n_live):
         assert np.all((ref[0][:, 0] == ridx[:20000]) | (np.abs(d - dm) <= 1e-12))
 
 
+@pytest.mark.parametrize("n,shift_cells", [(120000, 1.6), (120000, 2.7), (600000, 2.2), (120000, 6.0)])
+def test_correspond_a_surface_that_has_moved_by_cells(A, n, shift_cells):
+    """A live surface one to a few grid cells away from the canonical one (along its normal: the 3 x 3 x 3 block of a query
+    is then empty or holds only far points): the search leaves shells 0 / 1 and takes the exact ball of cells around the
+    query (up to four cells of reach) or, beyond that, the shell walk.  Same indices as the oracle's exhaustive scan."""
+    cv, cn, lv = _surface_clouds(n, 40000, n + int(10 * shift_cells))
+    # the grid's cell size as pgrid_finalize_kernel picks it: the cap of 128 (256 above half a million points) cells per axis
+    ext = cv.max(0) - cv.min(0)
+    cs = max((0.5 if n > 500000 else 0.7) * float(np.cbrt(ext.prod() / n)), float(ext.max()) / (256 if n > 500000 else 128))
+    d = lv - synth.SPHERE_C
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rng = np.random.default_rng(3)
+    lv = (lv + d * (shift_cells * cs * rng.uniform(0.6, 1.0, (len(lv), 1)))).astype(np.float32)
+    _, _, idx = A.correspond(dev(cv), None, dev(lv))
+    _, _, ridx = O.correspond(cv, None, lv, threads=8)
+    assert np.array_equal(host(idx), ridx)
+
+
 def test_correspond_a_million_points_against_the_reference_kd_tree(A):
     """Clouds of more than half a million points switch to the finer grid (up to 256 cells per axis): a million canonical
     points on the synthetic surface, checked against the reference's own nanoflann KD-tree (oracle/_ref) on 60 000 queries
