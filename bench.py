@@ -84,7 +84,7 @@ def parse():
     ap.add_argument("--no-raycast", action="store_true", help="skip the raycast figures (SURVEY 8d: reported separately)")
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the DynFusion::operator() sequence (the reference's own timed region, C++ adaptor classes)")
-    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded CPU sample")
+    ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the bounded CPU sample per thread count of its sweep")
     ap.add_argument("--serial", action="store_true", help="run fuse and solve on one stream (A/B of the overlap)")
     ap.add_argument("--pipeline", action="store_true",
                     help="ref mode: build frame f+1's graphs (k-NN, transposition) on a third stream while frame f is "
@@ -113,6 +113,15 @@ def parse():
     ap.add_argument("--overlap", action="store_true",
                     help="northstar: the sweep on a second stream beside the solve (the default of this mode is stream order: "
                          "its kernels fill the chip)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the barrier-bracketed timed region (the same K frames) runs this many times back to back; value / "
+                         "ms_per_step are those of the MEDIAN region (a 20-step region is 13 ms: one region alone moves by percents)")
+    ap.add_argument("--force-launcher", action="store_true",
+                    help="--gpus 1: go through the rank launcher anyway (a fresh child with WORLD_SIZE=1, its core slice, rank 0's "
+                         "line forwarded, the wall-clock limit) - the path every N > 1 run takes")
+    ap.add_argument("--detail-file", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where the full record goes (every secondary figure, per-kernel table, notes); stdout carries ONE line of "
+                         "at most 4 KB with the contract's fields")
     ap.add_argument("--no-adaptive-launch", action="store_true",
                     help="northstar: enqueue the full PCG launch budget of every Gauss-Newton iteration (A/B of "
                          "dfa_solve6_params.adaptive_launch)")
@@ -829,7 +838,7 @@ def main_northstar(args, torch, replicas, rank, world, device):
                 seq.solver.enable_timing(True)
             seq.frame(Wm + f, ser, fuse_events if f % TIMING_SAMPLE == 0 else None)
 
-    dt_max = replicas.timed_region(timed, device)
+    dt_max, regions = median_region(replicas, timed, device, args.repeats)
     st = seq.solver.stats()
     tm = seq.solver.timing()  # hipEvents on the solve stream around every launch group of the LAST timed frame
     seq.solver.enable_timing(False)
@@ -843,24 +852,24 @@ def main_northstar(args, torch, replicas, rank, world, device):
                value=round(n_gpus * K / dt_max, 2), unit="frames/s", n_gpus=n_gpus, steps=K, warmup=Wm,
                ms_per_step=round(dt_max / K * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="f32", data="synthetic",
-               config=dict(workload="%s north-star mode: %d^3 TSDF, %dx%d depth, %d nodes, k=%d, %d vertices, at most %d GN "
-                                    "iterations (gn_tol = %g) x block-Jacobi PCG<=%d (inexact Newton: %s), 6-DoF DQ-blend / projective "
-                                    "point-to-plane / ARAP energy, lambda=200"
-                                    % (args.config, dim, Wd, Hd, seq.D, seq.k, seq.N, seq.gn_total, seq.params.gn_tol, lin,
-                                       northstar_fields(seq, st)["pcg_tolerance_schedule"]),
+               config=dict(workload="%s north-star: %d^3 TSDF, %dx%d depth, %d nodes, k=%d, %d vertices, <=%d GN (gn_tol %g) x "
+                                    "block-Jacobi PCG<=%d, 6-DoF / point-to-plane / ARAP"
+                                    % (args.config, dim, Wd, Hd, seq.D, seq.k, seq.N, seq.gn_total, seq.params.gn_tol, lin),
+                           workload_detail="inexact Newton: %s; DQ blend of k-NN nodes, projective association, lambda=200"
+                                           % northstar_fields(seq, st)["pcg_tolerance_schedule"],
                            parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus, ranks_seen=n_gpus,
-                           rccl_selfcheck=rccl_selfcheck(),
+                           rccl_selfcheck=rccl_selfcheck(), repeats=len(regions), launcher=launcher_mark(),
                            streams="one HIP stream (every kernel of this mode fills the chip: a second stream for the sweep costs 6-8 %)"
                                    if not seq.overlap or args.serial else ("fuse || graph build + solve on two HIP streams" if args.fuse_first else
                                                                            "graph build, then fuse || solve on two HIP streams"),
                            last_frame=northstar_fields(seq, st)),
-               roofline=rl[0], roofline_other=rl[1:])
+               region_ms=[round(r * 1e3, 4) for r in regions], roofline=rl[0], roofline_other=rl[1:])
     if not args.no_cpu_baseline and world == 1:
         params = seq.params
         del seq
         torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline6(args.config, max(1, args.cpu_frames // 2), params)
-    emit(json.dumps(out))
+    finish(out, args)
     replicas.shutdown()
 
 
@@ -908,32 +917,33 @@ def host_cores():
         return os.cpu_count() or 1, os.cpu_count() or 1
 
 
+CPU_SWEEP_THREADS = (8, 16, 32, 64)
+
+
 def cpu_baseline(cfg_name, frames, variants=True):
-    """The CPU restatement (oracle/, kind "port": NOT Ceres, NOT the reference's CUDA path —
-    neither exists for this path in a buildable form) timed on the host cores for `frames`
-    frames of the same workload.  SURVEY 8(d) asks for two figures — (a) a single thread, (b) OpenMP over all host cores
-    (`nproc` of this box, stated) —: both are in the record (`single_thread`, `all_cores`) beside the 16-thread figure the
-    line's `value` has carried since round 1 (the restatement's parallel regions are short — one per PCG iteration — so on a
-    many-core host more threads mostly add fork / join cost: `all_cores` shows by how much).  Also returns the oracle's node
-    translations of its last frame (a checker for the line's own solve of that frame)."""
+    """The CPU restatement (oracle/, kind "port": NOT Ceres, NOT the reference's CUDA path — neither exists for this path in
+    a buildable form) timed on the host cores for `frames` frames of the same workload PER THREAD COUNT.  The thread count
+    is swept, not guessed (8 / 16 / 32 / 64, whichever this process may use): `value` is the best of them, `cores` its thread
+    count, `by_threads` the whole sweep.  SURVEY 8(d) asks for two more figures — (a) a single thread, (b) OpenMP over all
+    host cores (`nproc` of this box, stated) —: `single_thread`, `all_cores`.  Also returns the oracle's node translations
+    of the sample's last frame (a checker for the line's own solve of that frame)."""
     import oracle as O
     from dynfu_amd import synth
     cfg = synth.CONFIGS[cfg_name]
     usable, machine = host_cores()
-    threads = min(usable, int(os.environ.get("DFA_CPU_THREADS", "16")))
+    forced = os.environ.get("DFA_CPU_THREADS")
+    counts = [int(forced)] if forced else sorted({min(t, usable) for t in CPU_SWEEP_THREADS})
     fx, fy, cx, cy = synth.intrinsics(cfg)
     voxel, trunc, vol2cam, _, _ = synth.volume_params(cfg)
     dim, k = cfg["dim"], cfg["k"]
     c = synth.canonical(cfg)
     vol = np.zeros((dim, dim, dim), np.uint32)
     depths = [synth.depth_frame(cfg, f) for f in range(frames)]
-    idx = O.knn(c["node_pos"], c["verts"], k, threads=threads)
+    idx = O.knn(c["node_pos"], c["verts"], k, threads=min(usable, 16))
     w = np.zeros(idx.shape, np.float32)
     d2 = ((c["verts"][:, None, :].astype(np.float64) - c["node_pos"][idx].astype(np.float64)) ** 2).sum(-1)
     w = np.exp(-d2 / (2 * float(c["node_w"][0]) ** 2)).astype(np.float32)
     lives = [synth.live_vertices(c["verts"], idx, w, synth.true_translations(c["node_pos"], f, cfg["k"])) for f in range(frames)]
-    O.tsdf_integrate(vol[:8], O.compute_dists(depths[0], fx, fy, cx, cy), voxel, trunc, 64, vol2cam, fx, fy, cx, cy,
-                     threads=threads)  # warm the thread pool
 
     def run(nthreads, nframes):
         t0 = time.perf_counter()
@@ -949,23 +959,33 @@ def cpu_baseline(cfg_name, frames, variants=True):
             pcg += st["pcg_iters"]
         return time.perf_counter() - t0, pcg, t_last
 
-    dt, pcg, t_last = run(threads, frames)
-    out = dict(value=round(frames / dt, 4), unit="frames/s", cores=threads, kind="port",
-               sample="%d full frames of config %s (compute_dists, clear, integrate %d^3, k-NN graph, %d GN x PCG "
-                      "(%d PCG iterations in total), write-back, warpToLive) by the C restatement in oracle/, "
-                      "OpenMP over %d of the host's %d cores (%d usable by this process), fp32; %.1f s"
-                      % (frames, cfg_name, dim, cfg["gn_iters"], pcg, threads, machine, usable, dt),
+    t_total = time.perf_counter()
+    by, t_last, pcg = {}, None, 0
+    for n in counts:
+        O.tsdf_integrate(vol[:8], O.compute_dists(depths[0], fx, fy, cx, cy), voxel, trunc, 64, vol2cam, fx, fy, cx, cy,
+                         threads=n)  # warm the thread pool at this width
+        dt, pcg, t_last = run(n, frames)
+        by[str(n)] = dict(value=round(frames / dt, 4), seconds=round(dt, 2))
+    best = max(by, key=lambda n: by[n]["value"])
+    out = dict(value=by[best]["value"], unit="frames/s", cores=int(best), kind="port", by_threads=by,
+               sample="%d full frames of config %s per thread count (compute_dists, clear, integrate %d^3, k-NN graph, %d GN x PCG "
+                      "(%d PCG iterations in total), write-back, warpToLive) by the C restatement in oracle/, fp32, OpenMP over "
+                      "%s threads of the host's %d cores (%d usable by this process): `value` is the best of the sweep"
+                      % (frames, cfg_name, dim, cfg["gn_iters"], pcg, " / ".join(by), machine, usable),
+               sample_short="%d frames of %s per thread count (%s), C restatement in oracle/ (not Ceres), fp32, OpenMP; best reported"
+                            % (frames, cfg_name, "/".join(by)),
                host_cores=dict(nproc=usable, machine=machine))
     if variants:
-        n1 = min(frames, 2)
-        dt1, _, _ = run(1, n1)
-        out["single_thread"] = dict(value=round(n1 / dt1, 4), unit="frames/s", cores=1, sample="%d frames, %.1f s" % (n1, dt1))
-        if usable != threads:
-            na = 1  # (one frame: on a 256-thread host the restatement is 30 x SLOWER on all cores than on 16 — measured, r05)
-            dta, _, _ = run(usable, na)
-            out["all_cores"] = dict(value=round(na / dta, 4), unit="frames/s", cores=usable, sample="%d frames, %.1f s" % (na, dta))
+        dt1, _, _ = run(1, 1)
+        out["single_thread"] = dict(value=round(1 / dt1, 4), unit="frames/s", cores=1, sample="1 frame, %.1f s" % dt1)
+        if str(usable) in by:
+            out["all_cores"] = dict(by[str(usable)], unit="frames/s", cores=usable, sample="the %d-thread figure of the sweep IS all cores here" % usable)
         else:
-            out["all_cores"] = dict(value=out["value"], unit="frames/s", cores=usable, sample="the 16-thread figure IS all cores here")
+            dta, _, _ = run(usable, 1)
+            out["all_cores"] = dict(value=round(1 / dta, 4), unit="frames/s", cores=usable, sample="1 frame, %.1f s" % dta)
+        out["why_all_cores_loses"] = ("one short OpenMP region per PCG iteration (a 262 k-row loop, then a serial scatter): "
+                                      "fork/join over every core costs more than the loop")
+    out["seconds_total"] = round(time.perf_counter() - t_total, 1)
     return out, t_last, frames - 1
 
 
@@ -1106,7 +1126,7 @@ def other_configs(device, cpu=True):
     try:
         out["C1_ref"] = config_probe("C1", "ref", device, steps=20, warmup=5)
         if cpu:
-            out["C1_ref"]["cpu_baseline"] = cpu_baseline("C1", 12)[0]
+            out["C1_ref"]["cpu_baseline"] = cpu_baseline("C1", 4)[0]
     except Exception as e:  # noqa: BLE001
         out["C1_ref"] = dict(error="%s: %s" % (type(e).__name__, e))
     for name in ("C3", "C4"):
@@ -1138,6 +1158,146 @@ def emit(line):
     else:
         _LINE_OUT.write(line + "\n")
         _LINE_OUT.flush()
+
+
+LINE_LIMIT = 4096   # bytes of the stdout line (r05's 28 KB line outgrew the driver's reader: BENCH_r05.parsed == null)
+STRING_LIMIT = 160  # characters of any string inside it
+
+
+def _num(x, digits=4):
+    """a bare number for the line (None where the figure is missing or failed)"""
+    try:
+        x = float(x)
+    except (TypeError, ValueError):
+        return None
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (digits + 2, x)) if abs(x) < 1 else round(x, 2)
+
+
+def _val(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def _short(s, n=STRING_LIMIT):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def _slim_roofline(e):
+    """the contract's roofline object of one kernel: the HBM view first (frac = algorithmic bytes / launch time / 8 TB/s),
+    the roof that actually binds the kernel - where that is not HBM - as `other_view`"""
+    if not isinstance(e, dict):
+        return None
+    alg = e.get("algorithmic_bytes_per_launch", e.get("survey_bytes_per_launch"))
+    out = dict(kernel=_short(str(e.get("kernel", "")).split(" (")[0], 64), bound=e.get("bound"), achieved=e.get("achieved"),
+               peak=e.get("peak"), unit=e.get("unit"), frac=e.get("frac"), traffic=e.get("traffic"),
+               algorithmic_bytes_per_launch=alg,
+               traffic_over_algorithmic=(round(e["traffic"] / alg, 3) if e.get("traffic") and alg else None),
+               avg_launch_ms=e.get("avg_launch_ms"), launches_per_frame=e.get("launches_per_frame"))
+    if isinstance(e.get("lds_gather_view"), dict):
+        v = e["lds_gather_view"]
+        out["other_view"] = dict(bound=v.get("bound"), achieved=v.get("achieved"), peak=v.get("peak"), frac=v.get("frac"))
+    return out
+
+
+def contract_line(out, detail_file):
+    """The ONE stdout line: the contract's fields, `roofline` of the dominant kernel (HBM view), `cpu_baseline` as numbers,
+    every secondary figure as a bare number — at most LINE_LIMIT bytes, no string above STRING_LIMIT characters.  Everything
+    else (per-kernel tables, notes, histories) is in the detail file."""
+    cfg = out.get("config", {})
+    sc = cfg.get("rccl_selfcheck") or {}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = dict(workload=_short(cfg.get("workload", "")), parallelism=_short(cfg.get("parallelism", ""), 80),
+                          ranks_seen=cfg.get("ranks_seen"), repeats=cfg.get("repeats"),
+                          rccl_selfcheck=({k: sc.get(k) for k in ("ok", "init_ms", "backend") if k in sc} if "ok" in sc
+                                          else dict(skipped=True)),
+                          launcher=cfg.get("launcher"))
+    for k in ("max_abs_translation_error_vs_ground_truth_m", "max_abs_translation_diff_vs_oracle_m"):
+        if k in cfg:
+            line["config"][k] = cfg[k]
+    line["roofline"] = _slim_roofline(out.get("roofline"))
+    others = [e for e in out.get("roofline_other", []) if isinstance(e, dict)]
+    if others:
+        line["roofline_other"] = [{k: v for k, v in _slim_roofline(e).items()
+                                   if k in ("kernel", "frac", "achieved", "avg_launch_ms", "launches_per_frame",
+                                            "traffic_over_algorithmic")} for e in others[:3]]
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = dict(value=cb.get("value"), unit=cb.get("unit"), cores=cb.get("cores"), kind=cb.get("kind"),
+                                    sample=_short(cb.get("sample_short", cb.get("sample", ""))),
+                                    single_thread=_val(cb, "single_thread", "value"), all_cores=_val(cb, "all_cores", "value"),
+                                    host_cores=_val(cb, "host_cores", "nproc"),
+                                    by_threads={k: v.get("value") for k, v in (cb.get("by_threads") or {}).items()} or None,
+                                    why_all_cores_loses=_short(cb.get("why_all_cores_loses", "")) or None)
+    sec = {}
+    lat = out.get("frame_latency_ms")
+    if isinstance(lat, dict):
+        sec["frame_latency_ms"] = dict(median=lat.get("median"), p95=lat.get("p95"))
+    oc = out.get("other_configs")
+    if isinstance(oc, dict):
+        sec["other_configs"] = {k: _num(_val(v, "value")) for k, v in oc.items()}
+        c1 = _val(oc, "C1_ref", "cpu_baseline")
+        if isinstance(c1, dict):
+            sec["other_configs"]["C1_ref_cpu"] = dict(value=c1.get("value"), cores=c1.get("cores"),
+                                                      single_thread=_val(c1, "single_thread", "value"))
+    for key, path in (("northstar_mode", ("northstar_mode", "value")), ("northstar_fixed_iterations", ("northstar_mode", "fixed_iterations", "value")),
+                      ("northstar_cpu", ("northstar_mode", "cpu_baseline", "value")),
+                      ("live_depth_mode", ("live_depth_mode", "value")), ("pipelined", ("pipelined", "value")),
+                      ("end_to_end_ref_ms", ("end_to_end", "ref", "median_ms")),
+                      ("end_to_end_northstar_ms", ("end_to_end", "northstar", "median_ms")),
+                      ("raycast_points_ms", ("raycast", "points", "avg_launch_ms")),
+                      ("raycast_depth_ms", ("raycast", "depth", "avg_launch_ms")),
+                      ("fuse_every_voxel_ms", ("fuse_variants", "every_voxel_stored_ms")),
+                      ("fuse_known_occupancy_ms", ("fuse_variants", "occupancy_known_ms"))):
+        v = _val(out, *path)
+        if v is not None:
+            sec[key] = _num(v)
+    ms = out.get("multi_sequence")
+    if isinstance(ms, dict):
+        sec["multi_sequence"] = {k: _num(_val(v, "value")) for k, v in ms.items() if isinstance(v, dict)}
+    if sec:
+        line["secondary"] = sec
+    line["detail_file"] = detail_file
+    # the limit is a promise, not a hope: secondary figures go first, then the second-rank rooflines
+    for drop in (None, ("secondary", "multi_sequence"), ("secondary",), ("roofline_other",)):
+        if drop is not None:
+            d = line
+            for k in drop[:-1]:
+                d = d.get(k, {})
+            d.pop(drop[-1], None)
+        text = json.dumps(line, separators=(",", ":"))
+        if len(text.encode()) < LINE_LIMIT:
+            break
+    return text
+
+
+def finish(out, args):
+    """writes the full record to the detail file and prints the contract line (rank 0)"""
+    path = getattr(args, "detail_file", None)
+    shown = None
+    if path:
+        try:
+            with open(path, "w") as f:
+                json.dump(out, f, indent=1)
+                f.write("\n")
+            shown = os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT + os.sep) else path
+        except OSError as e:
+            print("bench.py: could not write %s: %s" % (path, e), file=sys.stderr)
+    emit(contract_line(out, shown))
+
+
+def median_region(replicas, fn, device, repeats):
+    """the barrier + synchronize-bracketed region `fn` `repeats` times back to back (the same frames every time);
+    returns (median seconds, [seconds of every region]) — MAX over ranks each (replicas.timed_region), so every rank gets the
+    same list"""
+    regions = [replicas.timed_region(fn, device) for _ in range(max(1, repeats))]
+    return sorted(regions)[len(regions) // 2], regions
 
 
 def under_profiler():
@@ -1219,6 +1379,13 @@ def launch_ranks(args, argv):
     print(lines[-1], flush=True)
 
 
+def launcher_mark():
+    """how this rank process was started: by bench.py's own launcher (launch_ranks), by torch.distributed.run, or directly"""
+    if os.environ.get("DFA_BENCH_LAUNCHED_BY") == "bench.py":
+        return "bench.py"
+    return "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else None
+
+
 def ranks_seen(device=None):
     """number of live ranks of the process group, counted by an all-reduce (not read from the environment)"""
     from dynfu_amd import replicas
@@ -1242,7 +1409,7 @@ def main_dry_run(args):
     barrier-bracketed timed region and rank 0 prints a line with the contract's fields (tests only)."""
     from dynfu_amd import replicas
     rank, local, world = replicas.env_world()
-    replicas.pin_to_core_slice(rank, world)
+    replicas.pin_to_core_slice()
     replicas.init(backend=args.backend, single_rank_group=not args.no_rccl_selfcheck)
     seen = ranks_seen()
     if rank == args.dry_run_fail_rank:
@@ -1250,22 +1417,22 @@ def main_dry_run(args):
     if rank == args.dry_run_hang_rank:
         time.sleep(1e6)
     K, Wm = args.steps, args.warmup
-    dt_max = replicas.timed_region(lambda: time.sleep(0.02 * K))
+    dt_max, regions = median_region(replicas, lambda: time.sleep(0.02 * K), None, args.repeats)
     if rank == 0:
-        emit(json.dumps(dict(metric="frames/sec (warp-solve + TSDF fuse), 512^3 vol / 2k nodes / VGA depth",
+        finish(dict(metric="frames/sec (warp-solve + TSDF fuse), 512^3 vol / 2k nodes / VGA depth",
                               value=round(seen * K / dt_max, 2), unit="frames/s", n_gpus=seen, steps=K, warmup=Wm,
                               ms_per_step=round(dt_max / K * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
                               dtype="f32", data="none (dry run: sleeps)",
                               config=dict(workload="dry run of the rank launcher (no GPU work)", ranks_seen=seen,
-                                          rccl_selfcheck=rccl_selfcheck(),
-                                          parallelism="replicas x%d (one sequence per GPU, no collective; %d ranks counted by "
-                                                      "all-reduce, backend %s)" % (seen, seen, args.backend)))))
+                                          rccl_selfcheck=rccl_selfcheck(), repeats=len(regions), launcher=launcher_mark(),
+                                          parallelism="replicas x%d (no collective; counted by all-reduce, %s)" % (seen, args.backend)),
+                              region_ms=[round(r * 1e3, 4) for r in regions]), args)
     replicas.shutdown()
 
 
 def main():
     args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.force_launcher) and "WORLD_SIZE" not in os.environ:
         if under_profiler():
             raise SystemExit("bench.py --gpus N starts rank processes: not under rocprofv3 (profile one rank: --gpus 1)")
         return launch_ranks(args, sys.argv[1:])
@@ -1276,8 +1443,9 @@ def main():
 
     from dynfu_amd import replicas
     rank, local, world = replicas.env_world()
-    if world > 1:
-        replicas.pin_to_core_slice(rank, world)  # a contiguous slice of the host's cores per rank (in-process)
+    launched = os.environ.get("DFA_BENCH_LAUNCHED_BY") == "bench.py"
+    if world > 1 or launched:
+        replicas.pin_to_core_slice()  # a contiguous slice of the host's cores per rank (in-process)
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (without torchrun, `python bench.py --gpus N` starts the N ranks "
                          "itself)" % (args.gpus, world))
@@ -1311,13 +1479,16 @@ def main():
         seq = SequenceLive(args.config, device)
         dt_max = replicas.timed_region(lambda: [seq.frame(f) for f in range(args.warmup)], device)  # warm-up, untimed below
         K = args.steps
-        dt_max = replicas.timed_region(lambda: [seq.frame(args.warmup + f) for f in range(K)], device)
+        dt_max, regions = median_region(replicas, lambda: [seq.frame(args.warmup + f) for f in range(K)], device, args.repeats)
         if rank == 0:
             rec = live_depth_probe(args.config, device, steps=min(K, 30), warmup=0, seq=seq)
             rec.update(metric="frames/sec (warp-solve + TSDF fuse), 512^3 vol / 2k nodes / VGA depth", value=round(n_gpus * K / dt_max, 2),
                        n_gpus=n_gpus, steps=K, warmup=args.warmup, ms_per_step=round(dt_max / K * 1e3, 4), higher_is_better=True,
-                       scaling="weak", vs_baseline=None, dtype="f32", data="synthetic", config=dict(workload=rec.pop("workload")))
-            emit(json.dumps(rec))
+                       scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                       config=dict(workload=rec.pop("workload"), ranks_seen=n_gpus, repeats=len(regions), rccl_selfcheck=rccl_selfcheck(),
+                                   parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus),
+                       region_ms=[round(r * 1e3, 4) for r in regions])
+            finish(rec, args)
         replicas.shutdown()
         return
     seq = Sequence(args.config, device)
@@ -1349,7 +1520,7 @@ def main():
             seq.frame(Wm + f, args.serial, fuse_events if sampled else None)
 
     # barrier + synchronize on both sides, MAX over ranks
-    dt_max = replicas.timed_region(timed, device)
+    dt_max, regions = median_region(replicas, timed, device, args.repeats)
     for plan in plans:
         plan.enable_timing(0)
     tm = max((plan.timing() for plan in plans), key=lambda t: t["solves"])  # sums over the sampled frames
@@ -1413,16 +1584,20 @@ def main():
         # the algorithmic bytes).  The HBM figures stay in the entry because the contract's metric is HBM-based.
         lds_bytes = 12.0 * nnz * its
         lds_gbs = lds_bytes / (pcg_total_ms * 1e-3) / 1e9 if pcg_total_ms > 0 else float("nan")
+        # `frac` is the contract's HBM view (algorithmic bytes / launch time / 8 TB/s); the LDS-gather roof that binds the
+        # kernel is the secondary view
         pcg_entry = dict(kernel="pcg_paired_kernel<..,NC=1> (Jacobi PCG, matrix in registers, 3 workgroups = 3 coordinates)",
-                         bound="lds-gather", achieved=round(lds_gbs, 1), peak=LDS_GATHER_PEAK_GBS, unit="GB/s",
-                         frac=round(lds_gbs / LDS_GATHER_PEAK_GBS, 4),
-                         peak_is="3 CUs x 128 B/clk (ds_read_b32, conflict-free) x 2.4 GHz; random 4-byte gathers of 32 lanes into 32 "
-                                 "banks measure ~6.5-7.4 clk per wave instruction against 2 (tools/microbench_lds_gather.hip)",
-                         lds_gather_bytes_per_frame=lds_bytes, hbm_achieved_gbs=round(pcg_gbs, 2),
-                         hbm_frac=round(pcg_gbs / HBM_PEAK_GBS, 6), **pcg_common)
+                         bound="hbm", achieved=round(pcg_gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                         frac=round(pcg_gbs / HBM_PEAK_GBS, 6),
+                         lds_gather_view=dict(bound="lds-gather", achieved=round(lds_gbs, 1), peak=LDS_GATHER_PEAK_GBS, unit="GB/s",
+                                              frac=round(lds_gbs / LDS_GATHER_PEAK_GBS, 4), lds_gather_bytes_per_frame=lds_bytes,
+                                              peak_is="3 CUs x 128 B/clk (ds_read_b32, conflict-free) x 2.4 GHz; random 4-byte "
+                                                      "gathers of 32 lanes into 32 banks measure ~6.5-7.4 clk per wave instruction "
+                                                      "against 2 (tools/microbench_lds_gather.hip)"),
+                         **pcg_common)
         pcg_entry["note"] = ("register/LDS-resident and synchronisation-bound by design: one workgroup per coordinate, %d "
                              "barrier-separated iterations per frame, 253 of 256 CUs idle while it runs (the fuse fills them); "
-                             "hbm_frac is the contract's HBM view of the same kernel" % round(its))
+                             "frac is the contract's HBM view, lds_gather_view the roof that binds the kernel" % round(its))
     else:
         pcg_entry = dict(kernel="pcg_mb_* (many-workgroup Jacobi PCG)", bound="hbm", achieved=round(pcg_gbs, 2), peak=HBM_PEAK_GBS,
                          unit="GB/s", frac=round(pcg_gbs / HBM_PEAK_GBS, 6), **pcg_common)
@@ -1432,13 +1607,15 @@ def main():
                value=round(n_gpus * K / dt_max, 2), unit="frames/s", n_gpus=n_gpus, steps=K, warmup=Wm,
                ms_per_step=round(dt_max / K * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="f32", data="synthetic",
-               config=dict(workload="%s: %d^3 TSDF (4 B voxels), %dx%d depth, %d nodes, k=%d, %d vertices, "
-                                    "%d GN iterations (those behind a gradient at the round-off floor are no-ops and return at "
-                                    "entry) x PCG<=256 (tol 1e-6 per linearisation, never below 1e-12 of the solve's first gradient), "
-                                    "reference-parity energy (energy.t), "
-                                    "lambda=200" % (args.config, dim, Wd, Hd, seq.D, seq.k, seq.N, cfg["gn_iters"]),
+               config=dict(workload="%s: %d^3 TSDF, %dx%d depth, %d nodes, k=%d, %d vertices, %d GN x PCG<=256 (tol 1e-6), "
+                                    "reference-parity energy (energy.t), lambda=200"
+                                    % (args.config, dim, Wd, Hd, seq.D, seq.k, seq.N, cfg["gn_iters"]),
+                           workload_detail="4 B voxels; Gauss-Newton iterations behind a gradient at the round-off floor are no-ops and "
+                                           "return at entry; PCG tolerance 1e-6 per linearisation, never below 1e-12 of the solve's "
+                                           "first gradient",
                            parallelism="replicas x%d (one sequence per GPU, no collective)" % n_gpus, ranks_seen=n_gpus,
-                           rccl_selfcheck=rccl_selfcheck(), streams_probe=STREAM_PROBES[:1],
+                           rccl_selfcheck=rccl_selfcheck(), streams_probe=STREAM_PROBES[:1], repeats=len(regions),
+                           launcher=launcher_mark(),
                            streams="serial" if args.serial else ("fuse || graph build of frame f+1 || solve of frame f on three "
                                                                  "HIP streams, two solver plans" if args.pipeline else
                                                                  ("fuse || graph build + solve on two HIP streams" if args.fuse_first
@@ -1450,6 +1627,7 @@ def main():
                            max_abs_translation_error_vs_ground_truth_m=round(t_err, 6)),
                frame_latency_ms=dict(median=round(lat[len(lat) // 2], 4), p95=round(lat[min(len(lat) - 1, int(0.95 * len(lat)))], 4),
                                      frames=len(lat), note="each frame synchronised, measured after the timed region"),
+               region_ms=[round(r * 1e3, 4) for r in regions],
                roofline=dominant, roofline_other=[other],
                solve_kernels_ms_per_frame=dict(pcg=round(pcg_total_ms, 4), assemble=round(tm["assemble_ms"] / frames_timed, 4)))
     if world == 1:
@@ -1470,7 +1648,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["pipelined"] = dict(error="%s: %s" % (type(e).__name__, e))
         # the frame the CPU baseline below ends on, solved here too: its translations are compared with the oracle's
-        t_cmp, f_cmp = None, args.cpu_frames - 1
+        t_cmp, f_cmp = None, max(1, args.cpu_frames) - 1
         if not args.no_cpu_baseline and not (args.pipeline or args.serial):
             try:
                 seq.frame(f_cmp)
@@ -1502,13 +1680,13 @@ def main():
         if not args.no_other_configs and args.config == "C2":
             out["other_configs"] = other_configs(device, cpu=not args.no_cpu_baseline)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"], t_cpu, f_cpu = cpu_baseline(args.config, args.cpu_frames)
+            out["cpu_baseline"], t_cpu, f_cpu = cpu_baseline(args.config, max(1, args.cpu_frames))
             # the oracle's own answer for its last frame against this line's solve of that frame (t_cmp: above)
             if t_cmp is not None and f_cpu == f_cmp:
                 out["config"]["max_abs_translation_diff_vs_oracle_m"] = float("%.3g" % np.abs(t_cmp - t_cpu).max())
                 out["config"]["oracle_check"] = ("frame %d solved by the HIP path and by oracle/solve_oracle (fp32 CPU restatement, the "
                                                  "cpu_baseline leg): largest difference of a node translation component" % f_cmp)
-    emit(json.dumps(out))
+    finish(out, args)
     replicas.shutdown()
 
 

@@ -192,9 +192,22 @@ def count_ranks(device=None):
     return 1
 
 
-def pin_to_core_slice(rank, world):
+def local_slot():
+    """(rank on this host, ranks on this host): LOCAL_RANK / LOCAL_WORLD_SIZE where the launcher sets them (torchrun and
+    bench.py's own launcher do), the global pair otherwise.  The core slices below are per HOST: on a multi-node run the
+    global rank would index past this host's core list."""
+    rank, local, world = env_world()
+    return (int(os.environ.get("LOCAL_RANK", rank)), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+
+
+def pin_to_core_slice(rank=None, world=None):
     """In-process CPU affinity of a rank: a contiguous slice of the cores this process may use (no `taskset`: a launcher
-    hop in front of a GPU program is what this pool forbids).  Returns the slice or None."""
+    hop in front of a GPU program is what this pool forbids).  `rank` / `world` are the rank's slot ON THIS HOST (default:
+    local_slot()).  Returns the slice or None."""
+    if rank is None or world is None:
+        rank, world = local_slot()
+    if not 0 <= rank < world:
+        return None
     try:
         cores = sorted(os.sched_getaffinity(0))
         per = len(cores) // world

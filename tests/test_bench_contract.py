@@ -3,6 +3,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -35,10 +36,72 @@ def test_bench_refuses_to_run_without_a_gpu():
     assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
 
 
+DETAIL = os.path.join(tempfile.gettempdir(), "dfa_bench_detail_%d.json" % os.getpid())
+
+
 def _bench(*argv, launcher=None, timeout=300):
-    cmd = [sys.executable] + (launcher or []) + [os.path.join(ROOT, "bench.py")] + list(argv)
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    if os.path.exists(DETAIL):
+        os.remove(DETAIL)
+    cmd = [sys.executable] + (launcher or []) + [os.path.join(ROOT, "bench.py")] + list(argv) + ["--detail-file", DETAIL]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR",
+                                                             "MASTER_PORT", "DFA_BENCH_LAUNCHED_BY")}
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def _strings(x):
+    if isinstance(x, str):
+        yield x
+    elif isinstance(x, dict):
+        for k, v in x.items():
+            yield k
+            yield from _strings(v)
+    elif isinstance(x, (list, tuple)):
+        for v in x:
+            yield from _strings(v)
+
+
+def _line(stdout):
+    """the ONE stdout line, checked against the limits the driver's reader needs (r05: a 28 KB line came back unparsed)"""
+    lines = stdout.strip().splitlines()
+    assert len(lines) == 1, stdout[-1500:]
+    assert len(lines[0].encode()) < 4096, len(lines[0])
+    d = json.loads(lines[0])
+    assert max(len(t) for t in _strings(d)) <= 160
+    return d
+
+
+def _detail():
+    with open(DETAIL) as f:
+        return json.load(f)
+
+
+def test_contract_line_of_a_fat_record_stays_under_4_kb():
+    """the line builder on the largest record this repository has produced (round 5's 28 KB line, kept under profiles/)
+    and on a record whose every secondary figure is present: under 4 KB, no long strings, the contract's fields intact"""
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r05_bench_default.json")) as f:
+        fat = json.load(f)
+    assert len(json.dumps(fat)) > 20000
+    fat["config"]["repeats"] = 5
+    for extra in ({}, {"multi_sequence": {str(i): {"value": 1234.56 + i} for i in range(400)}}):
+        text = bench.contract_line(dict(fat, **extra), "bench_detail.json")
+        assert "\n" not in text and len(text.encode()) < bench.LINE_LIMIT
+        d = json.loads(text)
+        assert max(len(t) for t in _strings(d)) <= bench.STRING_LIMIT
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                    "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "detail_file"):
+            assert key in d, key
+        assert d["value"] == fat["value"] and d["config"]["workload"] and d["config"]["rccl_selfcheck"]["ok"] is True
+        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert key in d["roofline"], key
+        cb = d["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["value"] == fat["cpu_baseline"]["value"] and cb["single_thread"] > 0 and cb["all_cores"] > 0
+    assert d.get("secondary") is None or "multi_sequence" not in d["secondary"]  # the oversized part was what went
+    text = bench.contract_line(fat, "bench_detail.json")
+    sec = json.loads(text)["secondary"]
+    assert sec["other_configs"]["C3_ref"] == fat["other_configs"]["C3_ref"]["value"]
+    assert set(sec["other_configs"]) >= {"C1_ref", "C3_ref", "C3_northstar", "C4_ref", "C4_northstar"}
 
 
 def test_gpus_2_starts_two_ranks_by_itself():
@@ -46,10 +109,9 @@ def test_gpus_2_starts_two_ranks_by_itself():
     comes from two LIVE ranks (counted by an all-reduce) — SURVEY 8(e), BASELINE config 5."""
     r = _bench("--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "5", "--warmup", "1")
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1  # one line, rank 0's
-    d = json.loads(lines[0])
+    d = _line(r.stdout)  # one line, rank 0's
     assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["steps"] == 5 and d["scaling"] == "weak"
+    assert d["config"]["launcher"] == "bench.py" and d["config"]["repeats"] == 5 and len(_detail()["region_ms"]) == 5
     # 5 steps of 20 ms on each of two ranks in the time of one: whole-job value = 2 x 5 / max time
     assert d["value"] == pytest.approx(2 * 5 / (d["ms_per_step"] * 5e-3), rel=1e-3)
     assert 40.0 < d["value"] < 100.5  # (a loaded host stretches the sleeps; never faster than the sleeps allow)
@@ -75,18 +137,30 @@ def test_single_rank_run_builds_a_one_rank_process_group():
     the N > 1 run depends on have run (gloo here; nccl = RCCL on the GPU box: config.rccl_selfcheck of the bench line)."""
     r = _bench("--gpus", "1", "--backend", "gloo", "--dry-run", "--steps", "2", "--warmup", "0")
     assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    sc = d["config"]["rccl_selfcheck"]
+    d = _line(r.stdout)
+    assert d["config"]["rccl_selfcheck"]["ok"] is True and d["config"]["launcher"] is None
+    sc = _detail()["config"]["rccl_selfcheck"]
     assert sc["ok"] is True and sc["error"] is None and sc["ranks_seen"] == 1 and sc["barriers"] >= 2 and sc["max_allreduce_ok"] is True
     assert d["n_gpus"] == 1
     r = _bench("--gpus", "1", "--backend", "gloo", "--dry-run", "--steps", "2", "--warmup", "0", "--no-rccl-selfcheck")
-    assert r.returncode == 0 and "skipped" in json.loads(r.stdout.strip().splitlines()[-1])["config"]["rccl_selfcheck"]
+    assert r.returncode == 0 and "skipped" in _line(r.stdout)["config"]["rccl_selfcheck"]
+
+
+def test_forced_launcher_with_one_rank():
+    """`--gpus 1 --force-launcher`: the N = 1 run through the rank launcher (fresh child, WORLD_SIZE=1, core slice, rank 0's
+    line forwarded) — the path every N > 1 run takes (gloo here; `-m gpu`: the same on the GPU box with RCCL)"""
+    r = _bench("--gpus", "1", "--force-launcher", "--backend", "gloo", "--dry-run", "--steps", "3", "--warmup", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 1 and d["config"]["ranks_seen"] == 1 and d["config"]["launcher"] == "bench.py"
+    assert d["config"]["rccl_selfcheck"]["ok"] is True
 
 
 def test_self_check_failure_costs_the_line_nothing():
     """the one-rank group cannot be built (its rendezvous port is taken): recorded, and the run goes on without a group"""
     import socket
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "gloo", "--dry-run", "--steps", "2", "--warmup", "0"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "gloo", "--dry-run", "--steps", "2", "--warmup", "0",
+           "--detail-file", DETAIL]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     busy = socket.socket()
     busy.bind(("127.0.0.1", 0))
@@ -97,8 +171,8 @@ def test_self_check_failure_costs_the_line_nothing():
     finally:
         busy.close()
     assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads(r.stdout.strip().splitlines()[-1])
-    assert d["config"]["rccl_selfcheck"]["ok"] is False and d["config"]["rccl_selfcheck"]["error"] and d["n_gpus"] == 1
+    d = _line(r.stdout)
+    assert d["config"]["rccl_selfcheck"]["ok"] is False and _detail()["config"]["rccl_selfcheck"]["error"] and d["n_gpus"] == 1
 
 
 def test_ranks_pin_themselves_to_disjoint_core_slices():
@@ -123,12 +197,12 @@ def test_same_line_under_torchrun():
                launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                          "--master-port", str(port)])
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["launcher"] == "torchrun"
 
 
 def test_world_size_must_match_gpus():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-run", "--backend", "gloo"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-run", "--backend", "gloo", "--detail-file", DETAIL],
                        capture_output=True, text=True, timeout=120,
                        env=dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
@@ -136,24 +210,43 @@ def test_world_size_must_match_gpus():
 
 @pytest.mark.gpu
 def test_bench_line_has_the_contract_fields():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-frames", "1"],
-                       capture_output=True, text=True, timeout=1500)
+    r = _bench("--steps", "5", "--warmup", "2", "--cpu-frames", "1", timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
-    # ONE line on stdout, the JSON one — RCCL's version block and every other library's chatter go to stderr (claim_stdout)
-    assert len(r.stdout.strip().splitlines()) == 1, r.stdout[-1500:]
-    d = json.loads(r.stdout.strip().splitlines()[-1])
+    # ONE line on stdout, the JSON one, under 4 KB with no long strings — RCCL's version block and every other library's
+    # chatter go to stderr (claim_stdout); everything beyond the contract's fields is in the detail file
+    line = _line(r.stdout)
+    d = _detail()
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert key in d, key
+        assert key in line and key in d, key
+        if key not in ("config", "roofline", "cpu_baseline"):
+            assert line[key] == d[key], key
+    assert line["detail_file"]
     assert d["steps"] == 5 and d["warmup"] == 2 and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert "workload" in d["config"] and d["value"] > 30.0  # the north-star target
+    assert "workload" in line["config"] and d["value"] > 30.0  # the north-star target
+    # value / ms_per_step are those of the median of `repeats` back-to-back regions over the same frames
+    assert line["config"]["repeats"] == 5 and len(d["region_ms"]) == 5
+    assert sorted(d["region_ms"])[2] == pytest.approx(d["ms_per_step"] * d["steps"], rel=1e-3)
     # N = 1 drives a one-rank RCCL process group: init with device_id, a device-tensor all-reduce, the timed region's barriers
     sc = d["config"]["rccl_selfcheck"]
     assert sc["ok"] is True and sc["backend"] == "nccl" and sc["ranks_seen"] == 1 and sc["barriers"] >= 2, sc
-    rf = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert key in rf, key
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert line["config"]["rccl_selfcheck"]["ok"] is True and line["config"]["rccl_selfcheck"]["init_ms"] > 0
+    # the roofline of the dominant kernel: the HBM view (algorithmic bytes / launch time / 8 TB/s), in the line and in the file
+    for rf in (line["roofline"], d["roofline"]):
+        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_per_frame",
+                    "algorithmic_bytes_per_launch"):
+            assert key in rf, key
+        assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
+        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+        assert rf["achieved"] == pytest.approx(rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9, rel=0.02)
+    assert line["roofline"]["traffic_over_algorithmic"] is None or line["roofline"]["traffic_over_algorithmic"] > 0
+    sec = line["secondary"]
+    for key in ("C1_ref", "C3_ref", "C3_northstar", "C4_ref", "C4_northstar"):
+        assert sec["other_configs"][key] == pytest.approx(d["other_configs"][key]["value"], rel=1e-3)
+    assert sec["northstar_mode"] == pytest.approx(d["northstar_mode"]["value"], rel=1e-3)
+    lcb = line["cpu_baseline"]
+    assert lcb["kind"] == "port" and lcb["value"] == d["cpu_baseline"]["value"] and lcb["cores"] == d["cpu_baseline"]["cores"]
+    assert lcb["single_thread"] > 0 and lcb["all_cores"] > 0 and lcb["host_cores"] >= 1 and lcb["sample"]
     ns = d["northstar_mode"]  # the same frame with the 6-DoF solve, a secondary figure of the default run
     assert ns["value"] > 30.0 and ns["unit"] == "frames/s"
     sv = ns["solve"]
@@ -176,7 +269,10 @@ def test_bench_line_has_the_contract_fields():
     assert cb6["kind"] == "port" and cb6["cores"] >= 1 and cb6["value"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
-    # single thread and all host cores (nproc stated) beside the 16-thread figure
+    # the thread count is swept, not guessed: `value` is the best of the sweep, `cores` its thread count
+    assert cb["by_threads"] and cb["value"] == max(v["value"] for v in cb["by_threads"].values())
+    assert str(cb["cores"]) in cb["by_threads"]
+    # single thread and all host cores (nproc stated) beside it
     assert cb["single_thread"]["cores"] == 1 and cb["single_thread"]["value"] > 0
     assert cb["all_cores"]["cores"] == cb["host_cores"]["nproc"] >= 1 and cb["all_cores"]["value"] > 0
     # the oracle's translations of the CPU sample's last frame against the HIP solve of the same frame
@@ -204,15 +300,31 @@ def test_northstar_line_cold_and_warm_start():
     solved) runs the same frames, converges, and is not slower than starting every frame from the canonical state."""
     vals = {}
     for name, extra in (("cold", []), ("warm", ["--warm-start"])):
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "northstar", "--config", "C2", "--steps", "12",
-                            "--warmup", "4", "--no-cpu-baseline", "--no-rccl-selfcheck"] + extra, capture_output=True, text=True, timeout=900)
+        r = _bench("--mode", "northstar", "--config", "C2", "--steps", "12", "--warmup", "4", "--no-cpu-baseline",
+                   "--no-rccl-selfcheck", *extra, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
-        assert len(r.stdout.strip().splitlines()) == 1, r.stdout[-1500:]
-        d = json.loads(r.stdout.strip().splitlines()[-1])
+        line = _line(r.stdout)
+        d = _detail()
         for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "roofline", "config"):
-            assert key in d, key
+            assert key in d and key in line, key
+        assert line["value"] == d["value"] and line["roofline"]["bound"] == "hbm"
         lf = d["config"]["last_frame"]
         assert d["steps"] == 12 and d["value"] > 30.0 and lf["final_cost"] < 0.1 * max(lf["cost_per_gn"][0], 1e-3) + 0.1
         vals[name] = (d["value"], lf)
     assert vals["warm"][0] > 0.9 * vals["cold"][0]
     assert vals["warm"][1]["cost_per_gn"][0] < vals["cold"][1]["cost_per_gn"][0]  # (it starts nearer to the frame's surface)
+
+
+@pytest.mark.gpu
+def test_forced_launcher_on_the_gpu_box():
+    """the rank launcher (launch_ranks: a fresh child per rank, its core slice, rank 0's stdout forwarded,
+    the wall-clock limit) had never run on a GPU box — N = 1 bypasses it.  `--force-launcher` takes the N = 1 run through it
+    with WORLD_SIZE=1 and RCCL: one line, one live rank, the self-check green."""
+    r = _bench("--gpus", "1", "--force-launcher", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-end-to-end",
+               "--no-other-configs", "--no-northstar", "--no-live-depth", "--no-multi-sequence", "--no-raycast",
+               "--no-pipelined-probe", "--rank-timeout", "600", timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _line(r.stdout)
+    assert line["n_gpus"] == 1 and line["config"]["ranks_seen"] == 1 and line["config"]["launcher"] == "bench.py"
+    assert line["config"]["rccl_selfcheck"]["ok"] is True and line["config"]["rccl_selfcheck"]["backend"] == "nccl"
+    assert line["value"] > 30.0 and line["steps"] == 5
