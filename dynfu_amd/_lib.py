@@ -21,7 +21,7 @@ SYMBOLS = [
     "dfa_solver_create", "dfa_solver_destroy", "dfa_solver_set_problem", "dfa_solver_solve", "dfa_solver_set_deterministic", "dfa_solver_matrix_entries", "dfa_solver_matrix_row_lengths", "dfa_solver_gradient",
     "dfa_solver_translations", "dfa_solver_node_dq", "dfa_solver_tukey_weights", "dfa_solver_huber_weights",
     "dfa_solver_data_graph", "dfa_solver_reg_graph", "dfa_solver_get_stats", "dfa_solver_enable_timing",
-    "dfa_solver_get_timing", "dfa_solver_warp_to_live", "dfa_solver_set_overlap_callback",
+    "dfa_solver_get_timing", "dfa_solver_warp_to_live", "dfa_solver_set_overlap_callback", "dfa_solver_team_pcg_info",
 ]
 
 
@@ -214,6 +214,7 @@ def load(path=None):
     L.dfa_solver_enable_timing.argtypes = [vp, i]
     L.dfa_solver_set_overlap_callback.argtypes = [vp, _OVERLAP_FN, vp]
     L.dfa_solver_get_timing.argtypes = [vp, C.POINTER(_SolveTiming), vp]
+    L.dfa_solver_team_pcg_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     runtimes = set()
     with open("/proc/self/maps") as maps:
         for line in maps:
@@ -664,6 +665,12 @@ class Solver:
         _check(self._L.dfa_solver_get_timing(self._h, C.byref(t), _stream()))
         return dict(pcg_ms=t.pcg_ms, assemble_ms=t.assemble_ms, pcg_launches=t.pcg_launches,
                     assemble_launches=t.assemble_launches, matrix_nnz=t.matrix_nnz, pcg_iters=t.pcg_iters, solves=t.solves)
+
+    def team_pcg_info(self):
+        """dfa_solver_team_pcg_info: {launches, aborts, disabled} of the team PCG (plans of 2 049 .. ~9 300 nodes)"""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        _check(self._L.dfa_solver_team_pcg_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(launches=a.value, aborts=b.value, disabled=bool(c.value))
 
     def stats(self):
         st = _SolveStats()

@@ -163,6 +163,7 @@ struct dfa_solver {
     size_t ev_used;
     int timed_solves = 0;
     dfa::MbGraphCache mb_graphs;  // HIP graphs of the many-workgroup PCG's launch chunks
+    dfa::TeamPcg team;            // host side of the team PCG (plans of 2 049 .. ~9 300 nodes)
     bool deterministic = false;  // order-stable variant (dfa_solver_set_deterministic), applied by the next set_problem
     bool just_reset = false;  // the unknowns and the state block were zeroed by set_problem and not touched since
     long long* iters_total = nullptr;  // device: PCG iterations of all solves since enable_timing(1)
@@ -806,6 +807,22 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
         hipError_t e = s->grid.reserve(max_D);
         if (e != hipSuccess) rc = hip_fail(e, "hipMalloc (node grid)");
     }
+    if (rc == DFA_OK && dfa::solve_team_pcg_fits(max_D)) {
+        // team PCG: control block (zeroed once: barrier rounds only ever grow), exchange buffer, the pinned abort count
+        s->v.team_stride = (max_D + 3) & ~3;
+        rc = plan_alloc(s, &s->v.team_ctl, 1);
+        const size_t areas = (size_t)3 * dfa::solve_team_pcg_rounds();  // an area per barrier round and coordinate (50 MB at 8 k nodes)
+        if (rc == DFA_OK) rc = plan_alloc(s, &s->v.team_mt, areas * s->v.team_stride);
+        if (rc == DFA_OK) rc = plan_alloc(s, &s->v.team_words, dfa::solve_team_pcg_words());
+        if (rc == DFA_OK && (hipMemset(s->v.team_ctl, 0, sizeof(dfa::TeamCtl)) != hipSuccess ||
+                             hipMemset(s->v.team_words, 0, sizeof(unsigned long long) * dfa::solve_team_pcg_words()) != hipSuccess ||
+                             hipMemset(s->v.team_mt, 0, sizeof(float2) * areas * (size_t)s->v.team_stride) != hipSuccess))
+            rc = fail(DFA_ERR_HIP, "hipMemset (team PCG)");
+        if (rc == DFA_OK && hipHostMalloc((void**)&s->team.host_abort, sizeof(int), hipHostMallocDefault) == hipSuccess) {
+            *s->team.host_abort = 0;
+            s->team.ctl = s->v.team_ctl;
+        }
+    }
     if (rc == DFA_OK) rc = plan_alloc(s, &s->state, 1);
     if (rc == DFA_OK) rc = plan_alloc(s, &s->iters_total, 1);
     if (rc == DFA_OK && hipMemset(s->iters_total, 0, sizeof(long long)) != hipSuccess) rc = DFA_ERR_HIP;
@@ -829,6 +846,7 @@ void dfa_solver_destroy(dfa_solver* s) {
     s->grid.release();
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     if (s->host_flag) (void)hipHostFree(s->host_flag);
+    if (s->team.host_abort) (void)hipHostFree(s->team.host_abort);
     s->mb_graphs.release();
     delete s;
 }
@@ -893,6 +911,7 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
     int gn_launched = 0;  // Gauss-Newton iterations whose assembly has been enqueued
     bool huber_done = false;
     const bool big_budget = (long)p->num_iter * p->nonlinear_iter > 8;
+    const bool pcg_async  = dfa::solve_pcg_is_async(v, &s->team, p->linear_iter);  // (else the PCG itself reads the flags back)
     const bool no_regradient = dfa::dev_env("DFA_NO_REGRADIENT") != nullptr;  // (development builds: the tests compare both ways)
     for (int outer = 0; outer < p->num_iter; ++outer) {
         // preNonlinearSolve (opt_solver.cpp:135-140): the Huber weights are only observable after
@@ -906,8 +925,9 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
             // Iteration budgets like the reference's (24 x 16, dyn_fusion.cpp:183-189) are ~380 iterations of which a
             // handful do anything: behind a converged one the kernels return at entry, but 4 launches x 5 us x 380 is
             // still 8 ms of stream time.  Small budgets (<= 8 iterations: bench.py's 5) stay free of any host
-            // synchronisation; larger ones read the `converged` flag back every 4th iteration.
-            if (big_budget && gn_in_outer >= 4 && gn_in_outer % 4 == 0 && s->host_flag && !s->host_flag[1] && v.D <= 2048) {
+            // synchronisation; larger ones read the `converged` flag back every 4th iteration (plans whose PCG does not
+            // synchronise by itself: the register-resident kernels and the team form).
+            if (big_budget && gn_in_outer >= 4 && gn_in_outer % 4 == 0 && s->host_flag && !s->host_flag[1] && pcg_async) {
                 HIP_TRY(hipMemcpyAsync(&s->host_flag[1], &s->state->converged, sizeof(int), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
             }
@@ -932,7 +952,7 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
                 if (s->overlap_fn) s->overlap_fn(s->overlap_user, stream, gn_launched);
                 ++gn_launched;
                 int evr = s->timing ? timing_begin(s, st) : -1;
-                HIP_TRY(dfa::solve_pcg(v, s->state, p->linear_iter, p->pcg_tol, s->host_flag, &s->mb_graphs,
+                HIP_TRY(dfa::solve_pcg(v, s->state, p->linear_iter, p->pcg_tol, s->host_flag, &s->mb_graphs, &s->team,
                                        evr >= 0 ? s->events[evr + 1] : nullptr, st));
                 if (evr >= 0) s->ev_pcg.push_back(evr);
                 continue;
@@ -949,7 +969,7 @@ int dfa_solver_solve(dfa_solver* s, const dfa_solve_params* p, dfa_stream_t stre
             if (s->overlap_fn) s->overlap_fn(s->overlap_user, stream, gn_launched);
             ++gn_launched;
             ev = s->timing ? timing_begin(s, st) : -1;  // closed behind the solving kernel, before the fallback launch
-            HIP_TRY(dfa::solve_pcg(v, s->state, p->linear_iter, p->pcg_tol, s->host_flag, &s->mb_graphs,
+            HIP_TRY(dfa::solve_pcg(v, s->state, p->linear_iter, p->pcg_tol, s->host_flag, &s->mb_graphs, &s->team,
                                    ev >= 0 ? s->events[ev + 1] : nullptr, st));
             if (ev >= 0) s->ev_pcg.push_back(ev);
         }
@@ -1005,8 +1025,8 @@ int dfa_solver_get_stats(dfa_solver* s, dfa_solve_stats* host_out, dfa_stream_t 
         fprintf(stderr, "pcg phase cycles: spmv %lld  red_pAp %lld  update %lld  red_rz %lld  p_update+barrier %lld  loop %lld  (iters %d)\n",
                 h.prof[0], h.prof[1], h.prof[2], h.prof[3], h.prof[4], h.prof[5], h.pcg_iters);
     if (dfa::dev_env("DFA_PCG_PROFILE_PRINT"))
-        fprintf(stderr, "assemble block 7 cycles: init %lld  list+hash %lld  reduce+barrier %lld  compact %lld\n",
-                h.prof[6] / 1000000, h.prof[6] % 1000000, h.prof[7] / 1000000, h.prof[7] % 1000000);
+        fprintf(stderr, "assemble block 7 cycles: init %lld  list+hash %lld  reduce+barrier %lld  compact %lld   (raw prof[6] %lld prof[7] %lld)\n",
+                h.prof[6] / 1000000, h.prof[6] % 1000000, h.prof[7] / 1000000, h.prof[7] % 1000000, h.prof[6], h.prof[7]);
     if (h.overflow)
         return fail(DFA_ERR_CAPACITY, "normal-matrix row wider than the plan's ELL capacity (%d > %d)", h.max_row_nnz,
                     s->ell_cap);
@@ -1021,6 +1041,14 @@ int dfa_solver_enable_timing(dfa_solver* s, int enable) {
         s->ev_pcg.clear(), s->ev_asm.clear();
         if (s->iters_total) HIP_TRY(hipMemset(s->iters_total, 0, sizeof(long long)));
     }
+    return DFA_OK;
+}
+
+int dfa_solver_team_pcg_info(dfa_solver* s, int* launches, int* aborts, int* disabled) {
+    REQUIRE(s, "null plan");
+    if (launches) *launches = (int)std::min<long>(s->team.launches, 0x7fffffffL);
+    if (aborts) *aborts = s->team.host_abort ? *(volatile int*)s->team.host_abort : 0;
+    if (disabled) *disabled = (!s->team.ctl || s->team.disabled) ? 1 : 0;
     return DFA_OK;
 }
 

@@ -718,7 +718,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
         if (total > s.ell_cap || ovf) st->overflow = 1;
 #ifdef DFA_PCG_PROFILE
         t4_ = clock64();
-        if (a == 7) st->prof[6] = (t1_ - t0_) * 1000000 + (t2_ - t1_), st->prof[7] = (t3_ - t2_) * 1000000 + (t4_ - t3_);
+        if (a == 7 && !s.team_ctl) st->prof[6] = (t1_ - t0_) * 1000000 + (t2_ - t1_), st->prof[7] = (t3_ - t2_) * 1000000 + (t4_ - t3_);  // (plans with a team PCG: its own counters)
         if (a < 32768) {
             unsigned long long* o = asm_tbuf + 8 * (size_t)a;
             o[0] = w0_, o[1] = wall_clock64() - w0_, o[2] = (unsigned long long)(end - beg), o[3] = (unsigned long long)total;
@@ -2078,6 +2078,484 @@ static hipError_t launch_mb_pcg(const SolveView& s, SolveState* state, int max_i
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// PCG by three TEAMS of persistent workgroups, one coordinate per team, every team confined to ONE XCD
+// (plans of 2 049 .. ~19 000 nodes: C3, C4, the adaptor's frames).
+//
+// The launched form above pays a kernel boundary per iteration: ~5.8 us for an iteration whose arithmetic takes a fraction of
+// a microsecond, and the host has to guess how many launches to enqueue (192 launches for 105 iterations per C3 frame).
+// A grid barrier across the chip costs more than the boundary (L2 write-back + invalidate between XCDs: ~15 us); a barrier
+// among workgroups that share ONE L2 does not (tools/microbench_xcd_barrier.hip).  J^T J = A (x) I_3 is three independent
+// scalar systems with the same matrix (as the register-resident kernel above solves them): coordinate c is solved by the
+// TEAM_W workgroups that the dispatcher placed on XCD c, one per CU (the launch asks for more than half a CU's LDS) — every
+// workgroup reads its XCC_ID, takes a rank in its team by an atomic counter and leaves if the team is full or the XCD is
+// not 0..2: the placement is counted, never assumed.
+//
+// One synchronisation per iteration (Chronopoulos-Gear form, the recurrences of pcg_mb_step_kernel), one gathered vector
+// pair: a member owns R = ceil(D / TEAM_W) rows; J = TEAM_NT / R threads share a row and keep their entries' values,
+// columns and the REPLICA of u at the entry's column in registers for the whole solve:
+//   wait(round i)            gamma_i, delta_i = sums of the members' partials (carried by the flag words themselves)
+//   beta_i, alpha_i          the same bits in every member (same words, same summation order)
+//   LDS <- (m_i, t_(i-1))    the pair every row owner published before it raised its flag: D x 8 bytes, coalesced, from L2
+//   per entry                t_i[col] = m_i[col] + beta_i t_(i-1)[col];  u_(i+1)[col] = u_i[col] - alpha_i t_i[col]  (replica: the
+//                            owner of row col does the same arithmetic on the same numbers);  w_(i+1)[a] += val u_(i+1)[col]
+//   row owner                p, s, x, r, t, u as in pcg_mb_step_kernel;  m_(i+1) = M^-1 w_(i+1);  partial (r, u), (w, u)
+//   publish                  (m_(i+1), t_i) of the own rows, s_waitcnt vmcnt(0), workgroup barrier, then the member's flag
+//                            words {round i + 1, partial}
+//
+// How the exchange stays inside the XCD's L2.  Agent-scope atomics (sc1) are the textbook tool and were the first version:
+// every such load is a trip over the fabric (1.2-1.5 us measured here; 2 MB of them per team and iteration for the vector
+// copy) and an iteration cost 6.7 us — no better than a launch.  An agent-scope acquire fence + plain loads: buffer_inv sc1
+// from 1 500 waves, 30 us per iteration.  `buffer_inv sc0` + plain loads: leaves the vector L1 alone outside threadgroup-split
+// mode — the pollers never saw a flag, the teams timed out and the guard launch took over (which is how that was found).
+// What works: PLAIN stores and PLAIN loads, with NO ADDRESS READ TWICE by a CU inside a launch.  A plain store is in the
+// XCD's L2 once acknowledged (the vector L1 writes through and does not allocate on stores); a plain load of an address this CU
+// has not read since the kernel began (the L1 starts a kernel empty; one workgroup per CU: nobody else fills it) misses the
+// L1 and is served by that same L2.  So every barrier round of a launch has an exchange area of its own, and a flag word
+// is stored TEAM_K times: poll attempt k reads copy k, a fresh line, and only a wait that outlasts TEAM_K attempts goes on
+// with agent-scope loads.  Flag words are self-validating ({round, value} in one 64-bit store; rounds grow from launch to
+// launch, so nothing is ever reset), and the vectors are complete when the flag is stored because every wave has waited for
+// its stores' acknowledgements (vmcnt(0): stores count in vmcnt on gfx9) before the workgroup barrier in front of it.
+// What makes this enough is that writer and reader share the L2 — which the XCC_ID census guarantees and nothing else does.
+// Every spin is bounded by the wall clock (s_memrealtime): a team that cannot assemble (placement, starvation by other
+// kernels) or a row that does not fit the register slots ABORTS before it has changed anything, and the guard launch behind
+// (pcg_team_guard_kernel: one workgroup per coordinate, returns at entry otherwise) solves that coordinate by itself; the
+// host sees the abort count in pinned memory at its next call and goes back to the launched form.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "pcg_team_kernel orders its stores with s_waitcnt vmcnt(0): gfx9 only (gfx10+ count stores in vscnt)"
+#endif
+constexpr int TEAM_W = 32;        // members per team: ONE 1024-thread workgroup per CU of a 32-CU XCD
+constexpr int TEAM_NT = 1024;
+constexpr int TEAM_E = 20;        // register slots per thread (rows of up to J x 20 entries)
+constexpr int TEAM_K = 4;         // copies of a flag word = poll attempts served by plain loads
+constexpr int TEAM_ROUNDS = 257;  // exchange areas per launch: barrier rounds 0 .. 256 (the reference's linearIter, dyn_fusion.cpp:186)
+constexpr size_t TEAM_MIN_LDS = 82 * 1024;  // more than half a CU's LDS: one member per CU, nobody else fills its L1
+constexpr long long TEAM_TICKS_FIRST = 2000000, TEAM_TICKS = 500000;  // 20 ms / 5 ms of the 100 MHz wall clock
+// flag words of one team: [round][copy][kind: (gamma | delta), joint][2 x TEAM_W]
+__host__ __device__ constexpr size_t team_words_per_round() { return (size_t)TEAM_K * 2 * 2 * TEAM_W; }
+size_t solve_team_pcg_words() { return 3 * (size_t)TEAM_ROUNDS * team_words_per_round(); }
+
+__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf; }  // HW_REG_XCC_ID[3:0]
+
+__device__ __forceinline__ void team_give_up(TeamCtl* ctl, int c, int* host_abort) {
+    if (atomicExch(&ctl->abort[c], 1u) == 0u && host_abort) atomicAdd_system(host_abort, 1);
+}
+
+// The first wave of a member polls the words of `round`: lane l reads member l & 31's gamma (l < 32) or delta word; with
+// JOINT the lanes below 32 also read the joint (r0, z0) word.  Sums in lane order by the same butterfly in every member; the
+// workgroup meets at a barrier behind it.  Called by every thread; false = timed out / the team has given up.  The wall clock
+// (s_memrealtime: a microsecond by itself) is only consulted once a wait has lasted 64 polls.
+template <bool JOINT>
+__device__ __forceinline__ bool team_wait(const unsigned long long* __restrict__ wr /* this round's words */, unsigned round,
+                                          float (&sum)[3], const unsigned* abort_flag, long long ticks, float* bc /* LDS [4] */,
+                                          long long* prof = nullptr, int rank = 0) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        long long t0 = 0;
+        unsigned long long w0 = 0, w1 = 0;
+        bool good = true;
+#ifdef DFA_PCG_PROFILE
+        const long long c0_ = clock64();
+        bool own_seen = false;
+#endif
+        for (unsigned spins = 0;; ++spins) {
+            // attempt k < TEAM_K: copy k by a plain load (a line this CU has never read: from the L2); later: copy 0, agent scope
+            const unsigned long long* p = wr + (size_t)(spins < (unsigned)TEAM_K ? spins : 0u) * (4 * TEAM_W) + lane;
+            if (spins < (unsigned)TEAM_K) {
+                // (wavefront scope = no cache-policy bits on the load; `volatile` would make it a system-scope one)
+                w0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (JOINT) w1 = __hip_atomic_load(p + 2 * TEAM_W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            } else {
+                w0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (JOINT) w1 = __hip_atomic_load(p + 2 * TEAM_W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const bool ok = (unsigned)(w0 >> 32) == round && (!JOINT || lane >= TEAM_W || (unsigned)(w1 >> 32) == round);
+#ifdef DFA_PCG_PROFILE
+            if (prof) {  // how long until this member's OWN words come back (store -> L2 -> load: no skew in it), and the polls
+                const bool mine_ok = __builtin_amdgcn_readlane((int)ok, rank);
+                if (mine_ok && !own_seen) own_seen = true, prof[0] += clock64() - c0_;
+                prof[1] += 1;
+            }
+#endif
+            if (__all((int)ok)) break;
+            if (spins >= 64u && (spins & 63u) == 0u) {
+                const long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                if (now - t0 > ticks || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    good = false;
+                    break;
+                }
+            }
+            if (spins >= (unsigned)TEAM_K) __builtin_amdgcn_s_sleep(1);
+        }
+        float v0 = __uint_as_float((unsigned)w0), v1 = JOINT && lane < TEAM_W ? __uint_as_float((unsigned)w1) : 0.f;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v0 += __shfl_xor(v0, o, 64), v1 += __shfl_xor(v1, o, 64);  // sums of each half of the wave
+        if (lane == 0) bc[0] = v0, bc[2] = v1, bc[3] = good ? 1.f : 0.f;
+        if (lane == TEAM_W) bc[1] = v0;
+    }
+    __syncthreads();
+    sum[0] = bc[0], sum[1] = bc[1], sum[2] = bc[2];
+    return bc[3] != 0.f;
+}
+
+template <int E>
+__global__ __launch_bounds__(TEAM_NT) void pcg_team_kernel(SolveView s, SolveState* __restrict__ st, unsigned epoch0, int max_iter,
+                                                           float pcg_tol, int* host_abort, int force_abort) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int rank_sh;
+    __shared__ float red[3][TEAM_NT / 64];
+    __shared__ float bc[4];
+    if (st->done) return;
+    const unsigned xcc = xcc_id();
+    if (xcc >= 3u) return;
+    const int c = (int)xcc, tid = threadIdx.x, D = s.D;
+    TeamCtl* ctl = s.team_ctl;
+    if (tid == 0) rank_sh = (int)atomicAdd(&ctl->count[c], 1u);
+    __syncthreads();
+    const int rank = rank_sh;
+    if (rank >= TEAM_W) return;  // the team is complete without this workgroup
+    if (st->converged) {         // no-op iteration (see SolveState::converged); booked once
+        if (tid == 0 && c == 0 && rank == 0) st->gn_iters += 1, st->gn_noop += 1;
+        return;
+    }
+    if ((force_abort >> c) & 1) {  // (development builds: the guard launch's test)
+        if (tid == 0) team_give_up(ctl, c, host_abort);
+        return;
+    }
+    float2* mt_s = (float2*)smem;                                      // Dpad x (m, t)
+    float* part  = (float*)(smem + sizeof(float2) * (size_t)s.Dpad);  // TEAM_NT partial row sums
+    const int R = (D + TEAM_W - 1) / TEAM_W, J = TEAM_NT / R;          // rows per member, threads per row
+    const int r0 = rank * R, nrows = max(0, min(R, D - r0));
+    const int a_loc = tid % R, j = tid / R;
+    const bool active = j < J && a_loc < nrows, owner = active && j == 0;
+    const int a = active ? r0 + a_loc : 0;  // (a valid row for the unconditional loads of the others)
+
+    // ---- this thread's entries -> registers: slot e holds entry q = j + e J of row a
+    const int cnt  = active ? min(s.ell_cnt[a], s.ell_cap) : 0;
+    const int mine = cnt > j ? (cnt - j + J - 1) / J : 0;
+    if (__syncthreads_or(mine > E)) {  // a row that does not fit: before anything has been published
+        if (tid == 0) team_give_up(ctl, c, host_abort);
+        return;
+    }
+    int emax = mine;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) emax = max(emax, __shfl_xor(emax, o, 64));
+    emax = __builtin_amdgcn_readfirstlane(emax);  // wave-uniform slot bound
+    // (batches of unconditional loads, masked after: a load under a per-slot condition makes hipcc wait for each one by
+    // itself — 48 dependent round trips, 35 us, in the first version of this prologue; in two halves: the unpacked columns of
+    // all E slots at once cost registers the loop needs)
+    float val[E], ucol[E];
+    uint32_t colp[E / 2];
+#pragma unroll
+    for (int h0 = 0; h0 < E; h0 += E / 2) {
+        int col[E / 2];
+#pragma unroll
+        for (int i = 0; i < E / 2; ++i) {
+            const int e     = h0 + i;
+            const float2 en = s.ell[(size_t)min(j + e * J, s.ell_cap - 1) * D + a];
+            const bool live = e < mine;
+            val[e] = live ? en.x : 0.f;
+            col[i] = live ? __float_as_int(en.y) : a;
+        }
+#pragma unroll
+        for (int i = 0; i < E / 2; ++i) ucol[h0 + i] = s.diag[col[i]];
+#pragma unroll
+        for (int i = 0; i < E / 2; ++i) ucol[h0 + i] = (ucol[h0 + i] > FLT_EPSILON ? 1.0f / ucol[h0 + i] : 1.0f) * s.g[3 * col[i] + c];
+#pragma unroll
+        for (int i = 0; i < E / 2; i += 2) colp[(h0 + i) / 2] = (uint32_t)col[i] | ((uint32_t)col[i + 1] << 16);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- row owners: r = g, u = M^-1 g, x = p = s = t = 0; (r0, z0) of the JOINT system scales the stopping rules
+    float minv = 0.f, r = 0.f, u = 0.f, x = 0.f, pv = 0.f, sv = 0.f, tv = 0.f, w = 0.f, m = 0.f, joint_loc = 0.f;
+    if (owner) {
+        const float d = s.diag[a];
+        minv          = d > FLT_EPSILON ? 1.0f / d : 1.0f;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            const float g = s.g[3 * a + cc];
+            joint_loc     = fmaf(g, minv * g, joint_loc);
+            if (cc == c) r = g;
+        }
+        u = minv * r;
+    }
+    // exchange area / flag words of barrier round r of THIS launch (r = 0 .. max_iter): never read twice by a CU
+    auto mt_at = [&](int rr) __attribute__((always_inline)) { return s.team_mt + ((size_t)rr * 3 + c) * s.team_stride; };
+    auto words_at = [&](int rr) __attribute__((always_inline)) {
+        return s.team_words + ((size_t)c * TEAM_ROUNDS + rr) * team_words_per_round();
+    };
+
+    // w = A u over the replicas; the row's J partial sums meet in LDS (threads of a row are R apart: any R, any J)
+    auto row_product = [&]() __attribute__((always_inline)) {
+        float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; e += 2)
+            if (e < emax) acc0 = fmaf(val[e], ucol[e], acc0), acc1 = fmaf(val[e + 1], ucol[e + 1], acc1);  // (empty slots hold val = 0)
+        part[tid] = acc0 + acc1;
+        __syncthreads();
+        float tot = 0.f;
+        if (owner) {
+            for (int j0 = 0; j0 < J; j0 += 8) {  // eight LDS reads in flight
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = part[a_loc + min(j0 + q, J - 1) * R];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) tot += j0 + q < J ? v[q] : 0.f;
+            }
+        }
+        return tot;
+    };
+    // (m, t) of the own rows and the member's partial sums for barrier round rr (tag `round`)
+    auto publish = [&](int rr, unsigned round, float gp, float dp, float jp, bool with_joint) __attribute__((always_inline)) {
+        if (owner) mt_at(rr)[a] = make_float2(m, tv);  // (a plain store: in the XCD's L2 once acknowledged)
+        const float gw = wave_total(gp), dw = wave_total(dp), jw = with_joint ? wave_total(jp) : 0.f;
+        if ((tid & 63) == 0) red[0][tid >> 6] = gw, red[1][tid >> 6] = dw, red[2][tid >> 6] = jw;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have been acknowledged by the L2
+        __syncthreads();
+        // thread (copy k, kind q): q = 0 gamma, 1 delta, 2 joint — 64-bit stores, one per copy
+        if (tid < 3 * TEAM_K) {
+            const int q = tid % 3, kk = tid / 3;
+            if (q < 2 || with_joint) {
+                float tot = 0.f;
+#pragma unroll
+                for (int i = 0; i < TEAM_NT / 64; ++i) tot += red[q][i];
+                unsigned long long* dst = words_at(rr) + (size_t)kk * (4 * TEAM_W) + (q == 2 ? 2 * TEAM_W : q * TEAM_W) + rank;
+                __hip_atomic_store(dst, ((unsigned long long)round << 32) | __float_as_uint(tot), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WAVEFRONT);  // (one 64-bit store, no cache-policy bits)
+            }
+        }
+    };
+
+#ifdef DFA_PCG_PROFILE
+    long long pc_[6] = {0, 0, 0, 0, 0, 0}, pw_[2] = {0, 0};
+    long long last_  = clock64();
+#endif
+    w = row_product();
+    m = minv * w;
+    publish(0, epoch0, r * u, w * u, joint_loc, true);
+    PROF_MARK(5);  // (prologue's product + first publication)
+
+    const float floor_ = 1e-12f;
+    const float tol2   = pcg_tol * pcg_tol > floor_ ? pcg_tol * pcg_tol : floor_;
+    float target = 0.f, gamma_old = 1.f, alpha_old = 1.f, rz0 = 0.f;
+    int it = 0;
+    bool gave_up = false;
+    while (it < max_iter) {
+        float sm[3];
+        const unsigned round = epoch0 + (unsigned)it;
+        if (it == 0) {
+            if (!team_wait<true>(words_at(0), round, sm, &ctl->abort[c], TEAM_TICKS_FIRST, bc)) { gave_up = true; break; }
+            rz0 = sm[2];
+            if (st->grad_first > 0.0 && (double)rz0 <= 1e-12 * st->grad_first) {  // the same decision in every team
+                if (tid == 0 && c == 0 && rank == 0) {
+                    st->gn_iters += 1;
+                    solve_mark_at_floor(st);
+                }
+                return;
+            }
+            target = fmaxf(tol2 * rz0, solve_floor(st)) * (1.0f / 3.0f);  // this coordinate's share of the joint target
+        } else {
+#ifdef DFA_PCG_PROFILE
+            if (!team_wait<false>(words_at(it), round, sm, &ctl->abort[c], TEAM_TICKS, bc, tid == 0 && c == 0 && rank == 0 ? pw_ : nullptr, rank)) { gave_up = true; break; }
+#else
+            if (!team_wait<false>(words_at(it), round, sm, &ctl->abort[c], TEAM_TICKS, bc)) { gave_up = true; break; }
+#endif
+        }
+        const float gamma = sm[0], delta = sm[1];
+        PROF_MARK(0);  // wait
+        if (!(gamma > target)) break;  // converged: (r, M^-1 r) of the iterate in x
+        const float beta  = it == 0 ? 0.f : gamma / gamma_old;
+        const float denom = it == 0 ? delta : delta - beta * gamma / alpha_old;
+        if (!(denom > 0.f)) break;
+        const float alpha = gamma / denom;
+        {   // the published (m_i, t_(i-1)) of every row -> LDS by plain wide loads (first and only read of round i's area by
+            // this CU: from the L2)
+            const float4* src = (const float4*)mt_at(it);
+            float4* dst       = (float4*)mt_s;
+            const int n4      = s.Dpad / 2;
+            for (int i0 = tid; i0 < n4; i0 += 4 * TEAM_NT) {  // four loads in flight per thread
+                float4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = src[min(i0 + q * TEAM_NT, n4 - 1)];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (i0 + q * TEAM_NT < n4) dst[i0 + q * TEAM_NT] = v[q];
+            }
+        }
+        __syncthreads();
+        PROF_MARK(1);  // copy
+        // four gathers in flight per step (a step under its own wave-uniform branch would wait for each gather by itself)
+#pragma unroll
+        for (int e0 = 0; e0 < E; e0 += 4)
+            if (e0 < emax) {
+                uint32_t c01 = colp[e0 / 2], c23 = colp[e0 / 2 + 1];
+                asm volatile("" : "+v"(c01), "+v"(c23));
+                const float2 g0 = mt_s[c01 & 0xffffu], g1 = mt_s[c01 >> 16], g2 = mt_s[c23 & 0xffffu], g3 = mt_s[c23 >> 16];
+                ucol[e0]     = fmaf(-alpha, fmaf(beta, g0.y, g0.x), ucol[e0]);
+                ucol[e0 + 1] = fmaf(-alpha, fmaf(beta, g1.y, g1.x), ucol[e0 + 1]);
+                ucol[e0 + 2] = fmaf(-alpha, fmaf(beta, g2.y, g2.x), ucol[e0 + 2]);
+                ucol[e0 + 3] = fmaf(-alpha, fmaf(beta, g3.y, g3.x), ucol[e0 + 3]);
+            }
+        if (owner) {
+            pv = fmaf(beta, pv, u), sv = fmaf(beta, sv, w);
+            x  = fmaf(alpha, pv, x), r = fmaf(-alpha, sv, r);
+            tv = fmaf(beta, tv, m);
+            u  = fmaf(-alpha, tv, u);
+        }
+        PROF_MARK(2);  // replicas
+        w = row_product();  // (its barrier also orders this iteration's reads of mt_s before the next copy)
+        m = minv * w;
+        ++it;
+        gamma_old = gamma, alpha_old = alpha;
+        PROF_MARK(3);  // row product
+        publish(it, epoch0 + (unsigned)it, r * u, w * u, 0.f, false);
+        PROF_MARK(4);  // publish
+    }
+#ifdef DFA_PCG_PROFILE
+    if (tid == 0 && c == 0 && rank == 0) {
+        for (int i = 0; i < 6; ++i) st->prof[i] += pc_[i];
+        st->prof[6] += pw_[0], st->prof[7] += pw_[1];
+    }
+#endif
+    if (gave_up) {  // nothing of this coordinate has been written: the guard launch solves it
+        if ((tid & 63) == 0) team_give_up(ctl, c, host_abort);
+        return;
+    }
+    if (owner) s.t[3 * a + c] += x;
+    if (tid == 0 && rank == 0) {
+        // iterations of this launch = those of its slowest coordinate; the last team (or guard workgroup) to arrive books them
+        atomicMax(&st->split_iters, it);
+        __threadfence();
+        if (atomicAdd(&st->split_ticket, 1u) == 2u) {
+            __threadfence();
+            st->pcg_iters += atomicExch(&st->split_iters, 0);
+            st->split_ticket = 0u;
+            if (st->grad_first == 0.0) st->grad_first = (double)rz0;
+            st->gn_iters += 1;
+        }
+    }
+}
+
+// The guard behind every team launch: workgroup c resets team c's arrival counter for the next launch and, if the team
+// gave up, solves coordinate c by itself — the same recurrence and stopping rules in one 1024-thread workgroup, u in LDS,
+// the matrix streamed from the ELL as assembled, the rows' vectors in the plan's mb_* buffers (component c).  Slow (tens of
+// microseconds per iteration) and rare by construction.
+__global__ __launch_bounds__(1024) void pcg_team_guard_kernel(SolveView s, SolveState* __restrict__ st, int max_iter, float pcg_tol) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float red0[16], red1[16];
+    __shared__ unsigned ab_sh;
+    const int c = blockIdx.x, tid = threadIdx.x, D = s.D;
+    TeamCtl* ctl = s.team_ctl;
+    if (tid == 0) {
+        ab_sh = ctl->abort[c];
+        ctl->abort[c] = 0u, ctl->count[c] = 0u;
+    }
+    __syncthreads();
+    if (!ab_sh || st->done || st->converged) return;
+    float* u_s = (float*)smem;  // Dpad
+    float *xs = (float*)s.mb_x + c, *rs = (float*)s.mb_r + c, *ps = (float*)s.mb_p + c, *ss = (float*)s.mb_s + c;  // [4 a]
+    float joint_loc = 0.f;
+    for (int a = tid; a < D; a += 1024) {
+        const float d    = s.diag[a];
+        const float minv = d > FLT_EPSILON ? 1.0f / d : 1.0f;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            const float g = s.g[3 * a + cc];
+            joint_loc     = fmaf(g, minv * g, joint_loc);
+        }
+        const float g = s.g[3 * a + c];
+        xs[4 * a] = 0.f, rs[4 * a] = g, ps[4 * a] = 0.f, ss[4 * a] = 0.f;
+        u_s[a] = minv * g;
+    }
+    const float rz0 = block_sum_f<16>(joint_loc, red0);  // (its barrier publishes u_s)
+    if (st->grad_first > 0.0 && (double)rz0 <= 1e-12 * st->grad_first) {
+        if (tid == 0 && c == 0) {
+            st->gn_iters += 1;
+            solve_mark_at_floor(st);
+        }
+        return;
+    }
+    const float floor_ = 1e-12f;
+    const float tol2   = pcg_tol * pcg_tol > floor_ ? pcg_tol * pcg_tol : floor_;
+    const float target = fmaxf(tol2 * rz0, solve_floor(st)) * (1.0f / 3.0f);
+    float gamma_old = 1.f, alpha_old = 1.f;
+    int it = 0;
+    __syncthreads();
+    while (it < max_iter) {
+        float g_loc = 0.f, d_loc = 0.f;
+        for (int a = tid; a < D; a += 1024) {
+            const int cnt = min(s.ell_cnt[a], s.ell_cap);
+            float w = 0.f;
+            for (int q = 0; q < cnt; ++q) {
+                const float2 en = s.ell[(size_t)q * D + a];
+                w = fmaf(en.x, u_s[__float_as_int(en.y)], w);
+            }
+            ((float*)s.mb_w)[4 * a + c] = w;
+            g_loc = fmaf(rs[4 * a], u_s[a], g_loc), d_loc = fmaf(w, u_s[a], d_loc);
+        }
+        const float gw = wave_total(g_loc), dw = wave_total(d_loc);
+        if ((tid & 63) == 0) red0[tid >> 6] = gw, red1[tid >> 6] = dw;
+        __syncthreads();
+        float gamma = 0.f, delta = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gamma += red0[i], delta += red1[i];
+        if (!(gamma > target)) break;
+        const float beta  = it == 0 ? 0.f : gamma / gamma_old;
+        const float denom = it == 0 ? delta : delta - beta * gamma / alpha_old;
+        if (!(denom > 0.f)) break;
+        const float alpha = gamma / denom;
+        for (int a = tid; a < D; a += 1024) {
+            const float d    = s.diag[a];
+            const float minv = d > FLT_EPSILON ? 1.0f / d : 1.0f;
+            const float p = fmaf(beta, ps[4 * a], u_s[a]), sn = fmaf(beta, ss[4 * a], ((float*)s.mb_w)[4 * a + c]);
+            const float rn = fmaf(-alpha, sn, rs[4 * a]);
+            ps[4 * a] = p, ss[4 * a] = sn, xs[4 * a] = fmaf(alpha, p, xs[4 * a]), rs[4 * a] = rn;
+            u_s[a] = minv * rn;  // (own row only; the gathers of this iteration are behind the reduction's barrier)
+        }
+        ++it;
+        gamma_old = gamma, alpha_old = alpha;
+        __syncthreads();
+    }
+    for (int a = tid; a < D; a += 1024) s.t[3 * a + c] += xs[4 * a];
+    if (tid == 0) {
+        atomicMax(&st->split_iters, it);
+        __threadfence();
+        if (atomicAdd(&st->split_ticket, 1u) == 2u) {
+            __threadfence();
+            st->pcg_iters += atomicExch(&st->split_iters, 0);
+            st->split_ticket = 0u;
+            if (st->grad_first == 0.0) st->grad_first = (double)rz0;
+            st->gn_iters += 1;
+        }
+    }
+}
+
+// plans the team form can serve: (m, t) of every row + the partial sums in one CU's LDS, a member's rows on its threads (it
+// is USED above the register-resident kernels: more than 2 048 nodes)
+bool solve_team_pcg_fits(int D) {
+    return sizeof(float2) * (size_t)((D + 3) & ~3) + sizeof(float) * TEAM_NT + 1024 <= 158 * 1024 && (D + TEAM_W - 1) / TEAM_W <= TEAM_NT;
+}
+int solve_team_pcg_rounds() { return TEAM_ROUNDS; }
+
+template <class Kernel>
+static hipError_t allow_big_lds(Kernel* k);
+
+static hipError_t launch_team_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, TeamPcg* tp, hipStream_t st) {
+    hipError_t e = allow_big_lds(pcg_team_kernel<TEAM_E>);
+    if (e == hipSuccess) e = allow_big_lds(pcg_team_guard_kernel);
+    if (e != hipSuccess) return e;
+    const unsigned epoch0 = tp->epoch;
+    tp->epoch += (unsigned)max_iter + 8u;
+    if (tp->epoch < epoch0 || tp->epoch == 0u) tp->epoch = 1u;  // (wrapped: never round 0, the value of a word nobody has written)
+    const size_t lds = std::max(sizeof(float2) * (size_t)s.Dpad + sizeof(float) * TEAM_NT, TEAM_MIN_LDS);
+    if (max_iter + 1 > TEAM_ROUNDS) return hipErrorInvalidValue;  // (route_pcg asks solve_team_pcg_fits first)
+    pcg_team_kernel<TEAM_E><<<8 * TEAM_W, TEAM_NT, lds, st>>>(s, state, epoch0, max_iter, pcg_tol, tp->host_abort,
+                                                             dev_env_int("DFA_MB_TEAM_ABORT", 0));
+    pcg_team_guard_kernel<<<3, 1024, sizeof(float) * (size_t)s.Dpad, st>>>(s, state, max_iter, pcg_tol);
+    tp->launches += 1;
+    return hipGetLastError();
+}
+
 int solve_pcg_max_nodes() { return 32768; }  // bounded by the transposition's LDS histogram (4 B x D)
 
 template <class Kernel>
@@ -2130,11 +2608,14 @@ static void sync_floor_switch() {
 // in ONE workgroup (shared CG scalars, as the oracle), 2 / 5 its 512-thread flavours, 3 many-workgroup at any size,
 // 4 streaming up to 8 192 nodes.
 static hipError_t route_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag, MbGraphCache* gc,
-                            hipEvent_t& main_done, hipStream_t st) {
+                            TeamPcg* team, hipEvent_t& main_done, hipStream_t st) {
     const int D = s.D;
 #ifdef DFA_DEV_AB
     sync_floor_switch();
     const int v2 = dev_env_int("DFA_PCG_VARIANT", -1);
+    if (dev_env_int("DFA_MB_TEAM", 1) == 2 && team && team->ctl && !team->disabled && solve_team_pcg_fits(D) && max_iter < TEAM_ROUNDS &&
+        !(team->host_abort && *(volatile int*)team->host_abort != 0))
+        return launch_team_pcg(s, state, max_iter, pcg_tol, team, st);
     if (v2 == 3) return launch_mb_pcg(s, state, max_iter, pcg_tol, host_flag, gc, st);
     if (D <= 2048 && v2 != 0) {
         // 512 threads leave 256 VGPRs per lane (64 slots per row pair: k = 8 rows fit), 1024 threads 128 VGPRs (32 slots: k = 4)
@@ -2154,12 +2635,28 @@ static hipError_t route_pcg(const SolveView& s, SolveState* state, int max_iter,
     if (D <= 1024) return launch_paired_pcg<512, 1, 64, 1>(s, state, max_iter, pcg_tol, st);
     if (D <= 2048) return launch_paired_pcg<1024, 1, 32, 1>(s, state, max_iter, pcg_tol, st);
 #endif
+    // (development builds: DFA_MB_TEAM=0 the launched form, =2 the team form at any size)
+    if (team && team->ctl && !team->disabled && solve_team_pcg_fits(D) && max_iter < TEAM_ROUNDS && dev_env_int("DFA_MB_TEAM", 1) != 0) {
+        // a team that gave up in an earlier launch (placement, starvation, a row too long) has said so in pinned memory: from
+        // then on this plan takes the launched form (no synchronisation: the word is read as it stands)
+        if (team->host_abort && *(volatile int*)team->host_abort != 0) team->disabled = true;
+        else return launch_team_pcg(s, state, max_iter, pcg_tol, team, st);
+    }
     return launch_mb_pcg(s, state, max_iter, pcg_tol, host_flag, gc, st);
 }
 
+// does the PCG of this plan run without any host synchronisation (the register-resident kernels, the team form)?  The
+// launched many-workgroup form reads its stop flag back once per chunk of launches — and the plan's `converged` flag with it.
+bool solve_pcg_is_async(const SolveView& s, const TeamPcg* team, int max_iter) {
+    if (s.D <= 2048) return dev_env_int("DFA_PCG_VARIANT", -1) != 3;
+    return team && team->ctl && !team->disabled && solve_team_pcg_fits(s.D) && max_iter < TEAM_ROUNDS &&
+           dev_env_int("DFA_MB_TEAM", 1) != 0 && dev_env_int("DFA_PCG_VARIANT", -1) != 3 &&
+           !(team->host_abort && *(volatile int*)team->host_abort != 0);
+}
+
 hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag, MbGraphCache* gc,
-                     hipEvent_t main_done, hipStream_t st) {
-    const hipError_t e = route_pcg(s, state, max_iter, pcg_tol, host_flag, gc, main_done, st);
+                     TeamPcg* team, hipEvent_t main_done, hipStream_t st) {
+    const hipError_t e = route_pcg(s, state, max_iter, pcg_tol, host_flag, gc, team, main_done, st);
     if (main_done) (void)hipEventRecord(main_done, st);  // paths without a fallback launch
     return e;
 }

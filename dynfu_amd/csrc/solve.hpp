@@ -54,6 +54,12 @@ __device__ __forceinline__ void solve_mark_at_floor(SolveState* st) {
     else if (!st->converged) st->converged = 2;
 }
 
+// control block of the team PCG (pcg_team_kernel): device memory of the plan, zeroed once
+struct TeamCtl {
+    unsigned int count[3];                  // workgroups of team c that have arrived in the launch in flight (zeroed by the guard launch)
+    unsigned int abort[3];                  // team c gave up in the launch in flight: the guard launch solves its coordinate
+};
+
 struct SolveView {
     int N, D, k, Dpad, ell_cap;
     // Order-stable variant of the solve (dfa_solver_set_deterministic / DFA_ASSEMBLE_DETERMINISTIC=1): node lists sorted,
@@ -94,6 +100,11 @@ struct SolveView {
     // multi-workgroup PCG (more than 8192 nodes): vectors as float4 per node, ping-pong where other rows read them
     float4 *mb_x, *mb_r, *mb_p, *mb_s, *mb_w, *mb_u[2], *mb_m[2], *mb_t[2];
     float *mb_gpart[2], *mb_dpart[2];  // per-workgroup partial (r, u), (w, u)
+    // team PCG: control block, and the (m, t) pairs the row owners publish: [barrier round of the launch][coordinate][team_stride]
+    TeamCtl* team_ctl;
+    float2* team_mt;
+    unsigned long long* team_words;  // flag words {round, partial sum}: [coordinate][barrier round][copy][kind][member]
+    int team_stride;
     float* t;            // D x 3
     float* huber;        // D
     float* node_dq_out;  // D x 8
@@ -150,9 +161,22 @@ struct MbGraphCache {
     void release();
 };
 
+// host side of the team PCG of one plan (the device side is in the view)
+struct TeamPcg {
+    TeamCtl* ctl    = nullptr;  // == SolveView::team_ctl (null: no team PCG for this plan)
+    int* host_abort = nullptr;  // pinned: teams that have given up so far, written by the device
+    unsigned epoch  = 1;        // first barrier round of the next launch (rounds only ever grow: no flag is ever reset)
+    long launches   = 0;
+    bool disabled   = false;    // a team has given up before: the launched form from now on
+};
+bool solve_team_pcg_fits(int D);
+int solve_team_pcg_rounds();
+size_t solve_team_pcg_words();  // 64-bit flag words a plan holds  // exchange areas a plan holds (barrier rounds of one launch)
+
+bool solve_pcg_is_async(const SolveView& s, const TeamPcg* team, int max_iter);
 // `main_done` (optional) is recorded behind the solving kernel(s), before the fallback launch that usually returns at once
 hipError_t solve_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, int* host_flag /* pinned int[4] or null */,
-                     MbGraphCache* graphs /* or null */, hipEvent_t main_done,
+                     MbGraphCache* graphs /* or null */, TeamPcg* team /* or null */, hipEvent_t main_done,
                      hipStream_t st);
 // books n Gauss-Newton iterations that the host did not launch because the plan had converged (SolveState::converged)
 hipError_t solve_count_noop(SolveState* state, int n, hipStream_t st);

@@ -447,6 +447,15 @@ typedef void (*dfa_overlap_fn)(void* user, dfa_stream_t solve_stream, int gn_ite
 int dfa_solver_set_overlap_callback(dfa_solver* s, dfa_overlap_fn fn, void* user);
 int dfa_solver_get_timing(dfa_solver* s, dfa_solve_timing* host_out, dfa_stream_t stream);
 
+/* The PCG of plans with 2 049 .. ~9 300 nodes runs as three teams of persistent workgroups (one coordinate each, each team
+ * on one XCD: no kernel boundary per iteration).  A team that cannot assemble, or meets a row of the normal
+ * matrix too long for its register slots, gives up before it has changed anything; the guard launch behind it solves that
+ * coordinate and the plan takes the launch-per-iteration form from its next PCG on.  This reports what has happened so far
+ * (no synchronisation; counts of the calling thread's view): team launches enqueued, teams that gave up, whether the plan
+ * has gone back to the launched form (1 also for plans the team form does not serve).  Replaces nothing in the reference:
+ * Opt's solver (src/dynfu/utils/opt_solver.cpp:107-147) reports no such thing. */
+int dfa_solver_team_pcg_info(dfa_solver* s, int* launches, int* aborts, int* disabled);
+
 /* ===================================================================================== */
 /* North-star solver — the 6-DoF mode BASELINE.json:north_star asks for; NOT in the          */
 /* reference's code (its energy.t solves translations only).  Formulas: DESIGN.md §4.5.     */

@@ -307,6 +307,8 @@ def test_more_than_8192_nodes(A):
                                    tukey_offset=synth.SOLVER["tukey_offset"], psi_data=synth.SOLVER["psi_data"],
                                    psi_reg=synth.SOLVER["psi_reg"])
     assert np.abs(t - t_ref).max() <= 5e-5
+    info = s.team_pcg_info()  # (98 KB of (m, t) pairs per member: the team PCG, 384 rows per member, two threads per row)
+    assert info["launches"] >= 2 and info["aborts"] == 0 and not info["disabled"], info
     s.close()
 
 
@@ -614,10 +616,11 @@ def _threads():
     return max(1, min(16, os.cpu_count() or 1))
 
 
-@pytest.mark.parametrize("name,noise", [("C2", 0.0), ("C2", 1e-3), ("C3", 0.0), ("C3", 1e-3)])
+@pytest.mark.parametrize("name,noise", [("C2", 0.0), ("C2", 1e-3), ("C3", 0.0), ("C3", 1e-3), ("C4", 0.0)])
 def test_translations_match_oracle_at_baseline_sizes(A, name, noise):
     """One frame of BASELINE config C2 (2 048 nodes, k = 4, 262 144 vertices: the headline's own kernel instantiation,
-    pcg_paired_kernel<1024,1,32,1>) and of C3 (4 096 nodes, k = 8, 524 288 vertices: the many-workgroup PCG) with
+    pcg_paired_kernel<1024,1,32,1>), of C3 (4 096 nodes, k = 8, 524 288 vertices) and of C4 (8 192 nodes, 1 048 576
+    vertices: both the team PCG, pcg_team_kernel — three teams of persistent workgroups, a coordinate per XCD) with
     bench.py's parameters — 5 / 10 outer iterations, PCG <= 256 at 1e-6, lambda = 200 — HIP against the fp64 statement
     (O.solve_ref(use_double=True): energy.t:50-55, opt_solver.cpp:204-231): node translations within 2e-5 m, energies
     within 1e-3.  noise = 0: SURVEY 8(d)'s index-aligned targets; noise = 1 mm on the live vertices: a fit with a residual."""
@@ -644,7 +647,107 @@ def test_translations_match_oracle_at_baseline_sizes(A, name, noise):
     np.testing.assert_allclose(st["final_cost"], st_ref["final_cost"], rtol=1e-3)
     assert noise or st["final_cost"] < 1e-4 * st["initial_cost"]
     np.testing.assert_allclose(host(s.node_dq()), dq_ref, atol=2e-5)
+    info = s.team_pcg_info()
+    if D > 2048:  # the team form ran every PCG, no team gave up, the plan has not gone back to a launch per iteration
+        assert info["launches"] >= st["gn_iters"] - st["gn_noop"] and info["aborts"] == 0 and not info["disabled"], info
+    else:
+        assert info["launches"] == 0
     s.close()
+
+
+def _c3_problem(A, frame=7):
+    cfg = synth.CONFIGS["C3"]
+    c = synth.canonical(cfg)
+    k = cfg["k"]
+    nodes, node_w, node_dq, verts = (dev(c[n]) for n in ("node_pos", "node_w", "node_dq", "verts"))
+    idx, w = A.knn(nodes, node_w, verts, k)
+    live = dev(synth.live_vertices(c["verts"], host(idx), host(w), synth.true_translations(c["node_pos"], frame, k)))
+    kw = dict(num_iter=cfg["gn_iters"], nonlinear_iter=1, linear_iter=256, pcg_tol=1e-6, **synth.SOLVER)
+    return cfg, (nodes, node_dq, node_w, verts, live), kw
+
+
+def test_team_pcg_against_a_launch_per_iteration(A, devlib, monkeypatch):
+    """The team PCG (pcg_team_kernel: no kernel boundary per iteration) against the launched form it replaces
+    (pcg_mb_step_kernel, DFA_MB_TEAM=0 in the development library) on a C3 frame with the bench's parameters: the same
+    Gauss-Newton iterations, PCG iteration counts within 10 % (per-coordinate stopping instead of the joint one), node
+    translations within 1e-6 m; then 200 solves in a row without a team giving up (every spin is bounded: a hang would show
+    as aborts and a plan that went back to launches)."""
+    cfg, prob, kw = _c3_problem(A)
+    res = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("DFA_MB_TEAM", form)
+        s = A.Solver(cfg["D"], prob[3].shape[0], cfg["k"])
+        s.set_problem(*prob)
+        s.solve(_params(A, **kw))
+        res[form] = (host(s.translations()), s.stats(), s.team_pcg_info())
+        if form == "1":
+            for _ in range(200):
+                s.solve(_params(A, **kw))
+            t200, info200 = host(s.translations()), s.team_pcg_info()
+        s.close()
+    monkeypatch.delenv("DFA_MB_TEAM")
+    (t0, st0, i0), (t1, st1, i1) = res["0"], res["1"]
+    assert i0["launches"] == 0 and i1["launches"] > 0 and i1["aborts"] == 0
+    assert st0["gn_iters"] == st1["gn_iters"] and st0["gn_noop"] == st1["gn_noop"]
+    assert abs(st1["pcg_iters"] - st0["pcg_iters"]) <= 0.1 * st0["pcg_iters"] + 3, (st0["pcg_iters"], st1["pcg_iters"])
+    assert np.abs(t1 - t0).max() <= 1e-6
+    np.testing.assert_allclose(st1["final_cost"], st0["final_cost"], rtol=1e-3)
+    assert info200["aborts"] == 0 and not info200["disabled"] and info200["launches"] >= 200
+    assert np.array_equal(t200, t1)  # the same solve, the same bits: sums in a fixed order, no atomics on data
+
+
+@pytest.mark.parametrize("mask", [2, 7])
+def test_team_pcg_guard_solves_what_a_team_gave_up(A, devlib, monkeypatch, mask):
+    """DFA_MB_TEAM_ABORT (development builds) makes the teams of the masked coordinates give up at entry, as a team does
+    that cannot assemble on its XCD or meets a row too long for its register slots: the guard launch behind solves those
+    coordinates by itself (same recurrence, one workgroup), the answer is the team's, the abort is counted in pinned memory and
+    the plan takes a launch per iteration from its next solve on — and still gives the same answer."""
+    cfg, prob, kw = _c3_problem(A, frame=4)
+    s = A.Solver(cfg["D"], prob[3].shape[0], cfg["k"])
+    s.set_problem(*prob)
+    s.solve(_params(A, **kw))
+    t_team, st_team = host(s.translations()), s.stats()
+    s.close()
+    monkeypatch.setenv("DFA_MB_TEAM_ABORT", str(mask))
+    s = A.Solver(cfg["D"], prob[3].shape[0], cfg["k"])
+    s.set_problem(*prob)
+    s.solve(_params(A, **kw))
+    t_guard, st_guard, info = host(s.translations()), s.stats(), s.team_pcg_info()
+    assert info["aborts"] >= 1 and info["launches"] >= 1
+    assert np.abs(t_guard - t_team).max() <= 1e-6 and st_guard["gn_iters"] == st_team["gn_iters"]
+    assert abs(st_guard["pcg_iters"] - st_team["pcg_iters"]) <= 0.1 * st_team["pcg_iters"] + 3
+    monkeypatch.delenv("DFA_MB_TEAM_ABORT")
+    launches = info["launches"]
+    s.solve(_params(A, **kw))  # the host has seen the abort count: this solve is launched iteration by iteration
+    info = s.team_pcg_info()
+    assert info["disabled"] and info["launches"] == launches
+    assert np.abs(host(s.translations()) - t_team).max() <= 1e-6
+    s.close()
+
+
+@pytest.mark.parametrize("name,k", [("T0", 4), ("T1", 4), ("T1", 8)])
+def test_team_pcg_on_small_problems_matches_the_oracle(A, devlib, monkeypatch, name, k):
+    """DFA_MB_TEAM=2 (development builds) routes plans of any size to the team PCG: 64 and 512 nodes — fewer rows than a
+    team has members' threads, members without a row — against the fp64 statement, 2e-5 m"""
+    cfg, c, verts, live, t_true = _problem(name)
+    if k != cfg["k"]:
+        cfg = dict(cfg, k=k)
+        idx = O.knn(c["node_pos"], verts, k, threads=8)
+        d2 = ((verts[:, None, :].astype(np.float64) - c["node_pos"][idx].astype(np.float64)) ** 2).sum(-1)
+        w = np.exp(-d2 / (2 * float(c["node_w"][0]) ** 2)).astype(np.float32)
+        live = synth.live_vertices(verts, idx, w, t_true)
+    kw = dict(num_iter=3, nonlinear_iter=2, linear_iter=200, lambda_=200.0, pcg_tol=1e-6)
+    t_ref, _, st_ref = O.solve_ref(c["node_pos"], c["node_dq"], c["node_w"], k, verts, live, use_double=True, threads=8, **kw)
+    monkeypatch.setenv("DFA_MB_TEAM", "2")
+    s = A.Solver(cfg["D"], len(verts), k)
+    s.set_problem(dev(c["node_pos"]), dev(c["node_dq"]), dev(c["node_w"]), dev(verts), dev(live))
+    s.solve(_params(A, **kw))
+    t, st, info = host(s.translations()), s.stats(), s.team_pcg_info()
+    s.close()
+    monkeypatch.delenv("DFA_MB_TEAM")
+    assert info["launches"] > 0 and info["aborts"] == 0
+    assert np.abs(t - t_ref).max() <= 2e-5 and st["gn_iters"] == st_ref["gn_iters"]
+    np.testing.assert_allclose(st["final_cost"], st_ref["final_cost"], rtol=1e-3, atol=1e-9)
 
 
 @pytest.mark.parametrize("offset", [0.31, 0.4])
