@@ -565,7 +565,7 @@ extern "C" __attribute__((visibility("default"))) int dfa_dev_asm_timing(unsigne
 #endif
 
 template <int K>
-__global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* __restrict__ st, int save_base) {
+__global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* __restrict__ st, int save_base, int xcd_map) {
     __shared__ int key[HASH];
     __shared__ long long val[2 * HASH];  // [0, HASH): sums of the non-negative addends, [HASH, 2 HASH): of the negative ones' magnitudes
     __shared__ float gpart[4][3];
@@ -575,7 +575,10 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
     // (workgroup -> node in launch order.  A contiguous node range per XCD — so that the rows a node shares with its
     // neighbours are fetched into one L2 instead of up to eight — left the launch at 345 us at C4: it was never bound by
     // the fetches.)
-    const int a    = blockIdx.x;
+    int a = blockIdx.x;
+#ifdef DFA_DEV_AB  // DFA_XCD_MAP=1: the experiment above, kept for its counters (profiles/r06_xcd_map.md)
+    if (xcd_map && (s.D & 7) == 0) a = (a & 7) * (s.D >> 3) + (a >> 3);
+#endif
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #ifdef DFA_PCG_PROFILE
     long long t0_ = clock64(), t1_, t2_, t3_, t4_;
@@ -1652,7 +1655,7 @@ hipError_t solve_huber(const SolveView& s, float psi_reg, hipStream_t st) {
 hipError_t solve_assemble(const SolveView& s, SolveState* state, int save_base, float w_reg_sq, hipStream_t st) {
     (void)w_reg_sq;  // (the rows carry it as their tau; the scale of the fixed-point sums comes from SolveState::amax)
     if (s.deterministic) KDISPATCH(assemble_det_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base));
-    else KDISPATCH(assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base));
+    else KDISPATCH(assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base, dev_env_int("DFA_XCD_MAP", 0)));
     return hipGetLastError();
 }
 

@@ -968,7 +968,7 @@ constexpr size_t s6_assemble_lds(int K, int RC) {  // dynamic segment: the stage
 }
 template <int K, int S6_RC, bool KEXACT>  // KEXACT: k == K (the common case: divisions by k are shifts)
 __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6View s, Solve6State* st, float wreg2, float damping,
-                                                                         const S6Forcing forcing) {
+                                                                         const S6Forcing forcing, int xcd_map) {
     extern __shared__ __attribute__((aligned(16))) char s6_dyn[];
     // a staged row = the vertex's record as s6_linearise wrote it: l = (lW, lD) (32 bytes) | h_j = sqrt(rho) f_j, j < K |
     // sqrt(rho) r, -, -, - : RS bytes, in the order of the 16-byte chunks the row is fetched in (the LDS-DMA writes a wave's 64
@@ -990,7 +990,11 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
     // (workgroup -> node in launch order.  Consecutive nodes on one XCD — node (b mod 8) D / 8 + b / 8 for workgroup b, so that
     // a vertex record is fetched into one L2 instead of up to k — measured 0.048 against 0.050 ms at C2 and 0.156 against
     // 0.150 at C3: not kept.)
-    const int a = blockIdx.x, tid = threadIdx.x, k = s.k;
+    int a = blockIdx.x;
+    const int tid = threadIdx.x, k = s.k;
+#ifdef DFA_DEV_AB  // DFA_XCD_MAP=1: the experiment above, kept for its counters (profiles/r06_xcd_map.md)
+    if (xcd_map && a < s.D && (s.D & 7) == 0) a = (a & 7) * (s.D >> 3) + (a >> 3);
+#endif
     if (a == s.D) {  // one workgroup more than nodes: the energy of the linearisation this launch follows, the state block's bookkeeping
         if (forcing.decided) return;  // (the linearisation's last workgroup has done both)
         s6_cost_total(s, st);
@@ -1852,7 +1856,7 @@ hipError_t s6_assemble(const Solve6View& s, Solve6State* state, const Solve6Para
             const hipError_t ae = allow_dynamic_lds((const void*)s6_assemble2_kernel<KK, RC, EX>, (int)sh);         \
             if (ae != hipSuccess) return ae;                                                                      \
         }                                                                                                         \
-        s6_assemble2_kernel<KK, RC, EX><<<s.D + 1, 256, sh, st>>>(s, state, wreg2, p.damping, f);                    \
+        s6_assemble2_kernel<KK, RC, EX><<<s.D + 1, 256, sh, st>>>(s, state, wreg2, p.damping, f, dev_env_int("DFA_XCD_MAP", 0)); \
     } while (0)
         if (s.k <= 4) {
             if (rc <= 320) S6A2(4, 320);

@@ -27,6 +27,8 @@ public:
         std::swap(size_, o.size_);
     }
     bool empty() const { return !data_; }
+    // no other handle (copy of this object, a CudaData taken from its owner) refers to the same storage
+    bool unique() const { return data_.use_count() <= 1; }
     size_t sizeBytes() const { return size_; }
     template <class T>
     T* ptr() {

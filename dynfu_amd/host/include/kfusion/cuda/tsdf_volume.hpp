@@ -25,20 +25,30 @@ class TsdfVolume {
     CudaData blob_;  // X*Y*Z packed voxels {fp16 tsdf, u16 weight}
     // Occupancy map of the volume (dynfu_amd.h: dfa_tsdf_occupancy_bytes): which boxes of 32 x 2 x 8 voxels the sweeps of THIS
     // object may have left a weight in — kept by clear / integrate / clearAndIntegrate, read by cuda::MarchingCubes::run
-    // instead of the empty voxels.  Storage that arrives from outside (swap, a writable data() handle) makes it unknown.
+    // instead of the empty voxels.  The map is only trusted while THIS object is the sole owner of the voxels and of the
+    // map: CudaData handles and copies of a TsdfVolume share storage (ref-counted, as the reference's DeviceMemory), so a
+    // writable data() handle, a swap, a copy of the object (either side may write afterwards) or a sweep run while another
+    // handle is alive all make it unknown until the next clear / fused sweep by a sole owner.
     CudaData occ_;
-    bool occ_known_ = false;
+    mutable bool occ_known_ = false;  // (mutable: copying a volume makes the SOURCE's map unknown too)
+    bool soleOwner() const { return blob_.unique() && occ_.unique(); }
+    bool mapTrusted() const { return occ_known_ && soleOwner(); }
 
 public:
     // --- construction / storage -----------------------------------------------------------------------------
     explicit TsdfVolume(const Vec3i& dims) { cfg_.dims = dims, create(dims); }
+    TsdfVolume(const TsdfVolume& o) : cfg_(o.cfg_), blob_(o.blob_), occ_(o.occ_) { o.occ_known_ = false; }
+    TsdfVolume& operator=(const TsdfVolume& o) {
+        if (this != &o) cfg_ = o.cfg_, blob_ = o.blob_, occ_ = o.occ_, occ_known_ = false, o.occ_known_ = false;
+        return *this;
+    }
     virtual ~TsdfVolume() {}
     void create(const Vec3i& dims);            // allocates and clears
     void swap(CudaData& data) { blob_.swap(data), occ_known_ = false; }
     CudaData data() { return occ_known_ = false, blob_; }
     const CudaData data() const { return blob_; }
     // the occupancy map of the voxels (device) or nullptr when the voxels may have been written from outside this object
-    const unsigned char* occupancy() const { return occ_known_ ? occ_.ptr<unsigned char>() : nullptr; }
+    const unsigned char* occupancy() const { return mapTrusted() ? occ_.ptr<unsigned char>() : nullptr; }
 
     // --- the GPU work -----------------------------------------------------------------------------------------
     virtual void clear();

@@ -30,7 +30,7 @@ void TsdfVolume::create(const Vec3i& dims) {  // :32-38
 void TsdfVolume::clear() {  // :74-80
     dfa::check(dfa_tsdf_clear_occ(blob_.ptr<uint32_t>(), cfg_.dims[0], cfg_.dims[1], cfg_.dims[2], occ_.ptr<uint8_t>(), nullptr),
                "TsdfVolume::clear");
-    occ_known_ = true;
+    occ_known_ = soleOwner();  // (a handle that is alive now may write the voxels later: no promise then)
 }
 
 void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_pose, const Intr& intr) {  // :82-93
@@ -38,7 +38,7 @@ void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_pose, cons
     float aff[12];
     vol2cam.to12(aff);
     const Vec3f vsz = getVoxelSize();
-    if (occ_known_)  // (the accumulating sweep only ADDS to the map: it has to be right before)
+    if (mapTrusted())  // (the accumulating sweep only ADDS to the map: it has to be right before)
         dfa::check(dfa_tsdf_integrate_occ(dists.ptr(), (int)dists.step(), dists.cols(), dists.rows(), blob_.ptr<uint32_t>(),
                                           cfg_.dims[0], cfg_.dims[1], cfg_.dims[2], vsz.v, cfg_.trunc, cfg_.max_weight, aff, intr.fx,
                                           intr.fy, intr.cx, intr.cy, occ_.ptr<uint8_t>(), nullptr),
@@ -57,11 +57,11 @@ void TsdfVolume::clearAndIntegrate(const Dists& dists, const Affine3f& camera_po
     vol2cam.to12(aff);
     const Vec3f vsz = getVoxelSize();
     // (a map that describes the volume: boxes of zeros that stay zeros are not written again)
-    dfa::check((occ_known_ ? dfa_tsdf_clear_integrate_known_occ : dfa_tsdf_clear_integrate_occ)(
+    dfa::check((mapTrusted() ? dfa_tsdf_clear_integrate_known_occ : dfa_tsdf_clear_integrate_occ)(
                    dists.ptr(), (int)dists.step(), dists.cols(), dists.rows(), blob_.ptr<uint32_t>(), cfg_.dims[0], cfg_.dims[1],
                    cfg_.dims[2], vsz.v, cfg_.trunc, cfg_.max_weight, aff, intr.fx, intr.fy, intr.cx, intr.cy, occ_.ptr<uint8_t>(), nullptr),
                "TsdfVolume::clearAndIntegrate");
-    occ_known_ = true;  // (the fused sweep leaves volume and map describing each other)
+    occ_known_ = soleOwner();  // (the fused sweep leaves volume and map describing each other — while nobody else can write)
     dfa::device_synchronize();
 }
 

@@ -113,6 +113,40 @@ TEST(TsdfVolumeTest, IntegrateAndRaycastMatchTheOracleBitExactly) {
 
 // cuda::MarchingCubes::run as DynFusion::operator() calls it (dyn_fusion.cpp:73-75,119-121): mesh of an
 // integrated depth frame, bit-exact against the oracle given the same case tables
+// The occupancy map is trusted only while the volume object is the sole owner of its storage: a handle taken
+// BEFORE a clear can write the voxels after it; a copy of the volume shares the map it may clear.
+TEST(TsdfVolumeTest, OccupancyMapIsOnlyTrustedBySoleOwners) {
+    cuda::TsdfVolume vol(Vec3i::all(32));
+    ASSERT_TRUE(vol.occupancy() != nullptr);  // created and cleared by this object alone
+    {
+        cuda::CudaData h = vol.data();             // a writable handle ...
+        ASSERT_TRUE(vol.occupancy() == nullptr);
+        vol.clear();                          // ... that outlives a clear: the voxels can still change behind the map
+        ASSERT_TRUE(vol.occupancy() == nullptr);
+    }
+    ASSERT_TRUE(vol.occupancy() == nullptr);  // (what the handle wrote meanwhile is unknown)
+    vol.clear();
+    ASSERT_TRUE(vol.occupancy() != nullptr);  // sole owner again, and swept
+    {
+        const cuda::TsdfVolume& cv = vol;
+        const cuda::CudaData ro = cv.data();        // a const handle: untrusted while it lives, nothing lost afterwards
+        ASSERT_TRUE(vol.occupancy() == nullptr);
+    }
+    ASSERT_TRUE(vol.occupancy() != nullptr);
+    {
+        cuda::TsdfVolume copy(vol);           // shares voxels AND map
+        ASSERT_TRUE(vol.occupancy() == nullptr && copy.occupancy() == nullptr);
+        copy.clear();
+        ASSERT_TRUE(copy.occupancy() == nullptr);
+    }
+    ASSERT_TRUE(vol.occupancy() == nullptr);  // the copy may have written: unknown until this object sweeps again
+    vol.clear();
+    ASSERT_TRUE(vol.occupancy() != nullptr);
+    cuda::CudaData other((size_t)32 * 32 * 32 * sizeof(int));
+    vol.swap(other);
+    ASSERT_TRUE(vol.occupancy() == nullptr);
+}
+
 TEST(MarchingCubesTest, RunMatchesTheOracleBitExactly) {
     const int W = 160, H = 120, DIM = 64;
     const Intr intr(131.25f, 131.25f, W / 2 - 0.5f, H / 2 - 0.5f);

@@ -247,10 +247,28 @@ def test_fused_sweep_over_a_known_occupancy_map_leaves_the_same_volume_and_map(A
         assert torch.equal(vol, ref) and torch.equal(occ, occ_ref)
 
     A.tsdf_clear(vol, occupancy=occ)  # from here on the map describes the volume
+    occ_first = None
     for f in range(4):
         A.tsdf_clear_integrate(vol, dists[f], *args, pose(f), fx, fy, cx, cy, occupancy=occ, occupancy_known=True)
         A.tsdf_clear_integrate(ref, dists[f], *args, pose(f), fx, fy, cx, cy, occupancy=occ_ref)
         same()
+        if f == 0:
+            occ_first = occ.clone()
+    if X >= 1024:
+        # The one place where "old content survives" would show, against the ORACLE (the comparison above is with the plain
+        # HIP sweep): the 32 slices with the most boxes that frame 0 wrote and frame 3 — the camera has moved — left alone
+        # because their byte said zeros... which they are only if frames 1-3 put the zeros back when the boxes fell out of
+        # the frustum.  orc_tsdf_integrate_slab (tsdf_volume.cu:11-22 clear + :43-96) on zeros = what a cleared volume
+        # holds after frame 3.
+        gone = ((occ_first != 0) & (occ == 0)).sum(dim=(1, 2))  # per layer of 8 slices
+        win = gone.unfold(0, 4, 1).sum(1)                        # per window of four layers
+        assert int(win.max()) > 1000, int(win.max())             # (thousands of boxes left the frustum)
+        z0 = 8 * int(win.argmax())
+        slab = np.zeros((32, Y, X), np.uint32)
+        O.tsdf_integrate_slab(slab, z0, host(dists[3]), np.asarray(voxel, np.float32), trunc, synth.MAX_WEIGHT, pose(3), fx, fy, cx, cy,
+                              threads=8)
+        assert np.array_equal(host(vol[z0:z0 + 32]).view(np.uint32), slab), z0
+        assert (slab >> 16 != 0).any()  # (not an empty slab: part of it is inside the frustum of frame 3)
     skipped = float((occ == 0).float().mean())
     if X >= 512:
         assert skipped > 0.6  # most of the volume is not written at all
