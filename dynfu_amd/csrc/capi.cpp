@@ -180,6 +180,7 @@ struct dfa_solver6 {
     float* raw_w;       // N x k un-normalised weights of the k-NN pass
     int32_t* raw_reg;   // D x (k + 1)
     const float* node_dq;  // borrowed: transforms at set_problem time
+    int32_t* xcd_perm = nullptr;  // (development builds, DFA_XCD_MAP=2: Morton order of the nodes — an experiment's scratch)
     std::vector<void*> blocks;
     GridScratch grid;
     bool has_problem;
@@ -197,6 +198,7 @@ struct dfa_solver6 {
     int slot_gn[S6_RING] = {};                    // Gauss-Newton iterations solve n enqueued
     unsigned long long solve_seq = 0, folded = 0;  // solves started; solves whose counts are in the history
     int pred[dfa::S6_HIST] = {};                  // iterations per Gauss-Newton iteration: raised at once, lowered by one per solve
+    int seen_last[dfa::S6_HIST] = {};             // ... and what the slot needed in the solve folded last (0: unknown, < 0: skipped)
     struct BudgetKey { int D, N, num_iter, gn_iter, linear_iter; float tol, tol_first, tol_decay, tol_adapt, gn_tol; } budget_key = {};
     bool graph_disabled = false;
     hipStream_t capture_stream = nullptr;  // capture is not allowed on the legacy default stream
@@ -1198,6 +1200,7 @@ void dfa_solver6_destroy(dfa_solver6* s) {
     if (s->capture_stream) (void)hipStreamDestroy(s->capture_stream);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     for (void* p : s->blocks) (void)hipFree(p);
+    if (s->xcd_perm) (void)hipFree(s->xcd_perm);
     s->grid.release();
     delete s;
 }
@@ -1222,6 +1225,37 @@ int dfa_solver6_set_problem(dfa_solver6* s, const float* node_pos, const float* 
     const int kreg = s->k + 1;
     HIP_TRY(dfa::launch_knn(node_pos, node_w, D, node_pos, D, kreg, s->raw_reg, nullptr, grid, S(stream)));
     HIP_TRY(dfa::s6_build_graph(v, s->state, canon_vertices, canon_normals, s->raw_w, s->raw_reg, kreg, S(stream)));
+    v.xcd_perm = nullptr;
+    if (dfa::kDevAB && dfa::dev_env_int("DFA_XCD_MAP", 0) == 2) {
+        // (experiment only, profiles/r06_xcd_map.md: the nodes along a Morton curve of their positions, sorted on the host —
+        // a synchronisation per graph build that a product form would replace by a device sort)
+        std::vector<float> pos((size_t)3 * D);
+        HIP_TRY(hipMemcpyAsync(pos.data(), node_pos, sizeof(float) * pos.size(), hipMemcpyDeviceToHost, S(stream)));
+        HIP_TRY(hipStreamSynchronize(S(stream)));
+        float lo[3] = {pos[0], pos[1], pos[2]}, hi[3] = {pos[0], pos[1], pos[2]};
+        for (int i = 0; i < D; ++i)
+            for (int a = 0; a < 3; ++a) lo[a] = std::min(lo[a], pos[3 * i + a]), hi[a] = std::max(hi[a], pos[3 * i + a]);
+        auto spread = [](uint64_t x) {  // 21 bits -> every third bit
+            x &= 0x1fffff, x = (x | x << 32) & 0x1f00000000ffffull, x = (x | x << 16) & 0x1f0000ff0000ffull;
+            x = (x | x << 8) & 0x100f00f00f00f00full, x = (x | x << 4) & 0x10c30c30c30c30c3ull, x = (x | x << 2) & 0x1249249249249249ull;
+            return x;
+        };
+        std::vector<std::pair<uint64_t, int32_t>> key((size_t)D);
+        for (int i = 0; i < D; ++i) {
+            uint64_t m = 0;
+            for (int a = 0; a < 3; ++a) {
+                const float u = (pos[3 * i + a] - lo[a]) / std::max(hi[a] - lo[a], 1e-12f);
+                m |= spread((uint64_t)(u * 1048575.f)) << a;
+            }
+            key[i] = {m, i};
+        }
+        std::sort(key.begin(), key.end());
+        std::vector<int32_t> perm((size_t)D);
+        for (int i = 0; i < D; ++i) perm[i] = key[i].second;
+        if (!s->xcd_perm) HIP_TRY(hipMalloc((void**)&s->xcd_perm, sizeof(int32_t) * (size_t)s->max_D));
+        HIP_TRY(hipMemcpy(s->xcd_perm, perm.data(), sizeof(int32_t) * perm.size(), hipMemcpyHostToDevice));
+        v.xcd_perm = s->xcd_perm;
+    }
     s->has_problem = true;
     return DFA_OK;
 }
@@ -1278,13 +1312,23 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
                 int& pred      = s->pred[gi];
                 // (an iteration behind the end of its outer iteration ran no PCG: its budget decays like one that needed
                 // little — the launches enqueued for it are no-ops every time it is skipped again — but stays known)
-                if (seen == dfa::S6_MIRROR_SKIPPED) pred = pred > 1 ? pred - 1 : 1;  // (never back to 0 = unknown = the full cap)
-                else if (seen > 0) pred = std::max(seen, pred - 1);
-                else if (seen < 0) pred = std::max(pred, -2 * seen);  // cut short: twice as many
+                int& last = s->seen_last[gi];
+                if (seen == dfa::S6_MIRROR_SKIPPED) {
+                    pred = pred > 1 ? pred - 1 : 1;  // (never back to 0 = unknown = the full cap)
+                    last = last < 0 ? -2 : -1;       // skipped once / twice in a row
+                } else if (seen > 0) {
+                    // a count that repeats (within one) from solve to solve needs no decaying maximum above it
+                    pred = last > 0 && std::abs(seen - last) <= 1 ? std::max(seen, last) : std::max(seen, pred - 1);
+                    last = seen;
+                } else if (seen < 0) {
+                    pred = std::max(pred, -2 * seen);  // cut short: twice as many
+                    last = 0;
+                }
             }
         }
         if (reset) {  // another problem (or other stopping rules): what the previous one needed says nothing
             std::memset(s->pred, 0, sizeof(s->pred));
+            std::memset(s->seen_last, 0, sizeof(s->seen_last));
             s->folded = n;  // (solves n - 2, n - 1 of the old problem are never folded)
         }
     } else {
@@ -1330,8 +1374,14 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
             // C3 over 30-frame sequences: consecutive frames move a count by up to 2 where it is small and by up to a
             // quarter where it is 30-40; one launch of slack instead of two cut 1-2 PCGs short in a fifth of the frames.)
             int launches = p.linear_iter;
-            if (adaptive && gi < dfa::S6_HIST && s->pred[gi] > 0)
-                launches = std::min(p.linear_iter, s->pred[gi] + std::max(2, s->pred[gi] / 4));
+            if (adaptive && gi < dfa::S6_HIST && s->pred[gi] > 0) {
+                // slack: two launches, a quarter where the counts are large — ONE where the slot's count has just repeated
+                // (within one) in two solves running, and a slot skipped twice running gets one launch in all (40-49 % of the
+                // launches of a C2 / C3 frame returned at entry with two everywhere: VERDICT r05)
+                const int last  = s->seen_last[gi];
+                const int slack = last > 0 && s->pred[gi] <= last + 1 && s->pred[gi] < 16 ? 1 : std::max(2, s->pred[gi] / 4);
+                launches = last == -2 ? 1 : std::min(p.linear_iter, s->pred[gi] + slack);
+            }
             // the PCG launches of one Gauss-Newton iteration are replayed as a HIP graph (one per launch count); if capture
             // is not possible here (it never is on some stream configurations) the launches are issued one by one
             bool replayed = false;

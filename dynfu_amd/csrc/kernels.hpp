@@ -131,6 +131,13 @@ hipError_t launch_icp_sums(bool depth_variant, const void* curr, int curr_step, 
                            float* partial, float* sums27, unsigned int* matched, hipStream_t s);
 
 
+// Several kernels publish partial results with write-through stores and then arrive at a ticket / raise a flag word, ordering
+// the two by `s_waitcnt vmcnt(0)` (solve.hip: linearise tail, team PCG; solve6.hip: linearise tail).  That is an ordering
+// on gfx9 parts only, where stores count in vmcnt; gfx10 and later track them in vscnt.  This library is built for gfx950.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "dynfu_amd orders published stores with s_waitcnt vmcnt(0): gfx90a / gfx942 / gfx950 only"
+#endif
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is an attribute of a kernel ON A DEVICE: the opt-in to more than 48 KiB of
 // dynamic LDS is made once per (device, kernel), under a lock (the C ABI serves several devices and host threads)
 inline hipError_t allow_dynamic_lds(const void* kernel, int bytes) {

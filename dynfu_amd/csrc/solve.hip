@@ -565,7 +565,8 @@ extern "C" __attribute__((visibility("default"))) int dfa_dev_asm_timing(unsigne
 #endif
 
 template <int K>
-__global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* __restrict__ st, int save_base, int xcd_map) {
+__global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* __restrict__ st, int save_base, int xcd_map,
+                                                       float amax_unset) {
     __shared__ int key[HASH];
     __shared__ long long val[2 * HASH];  // [0, HASH): sums of the non-negative addends, [HASH, 2 HASH): of the negative ones' magnitudes
     __shared__ float gpart[4][3];
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(SolveView s, SolveState* 
 #endif
 
     const int beg = s.node_ptr[a], end = s.node_ptr[a + 1];
-    const FixedScale fx = fixed_scale_for_rows(solve_fixed_scale(st->amax), end - beg);
+    const FixedScale fx = fixed_scale_for_rows(solve_fixed_scale(st->amax > 0.f ? st->amax : amax_unset), end - beg);
     float gx = 0.f, gy = 0.f, gz = 0.f, dsum = 0.f;
     for (int p = beg + (int)threadIdx.x; p < end; p += 256) {
         const uint32_t e = s.node_list[p];
@@ -763,7 +764,7 @@ __global__ __launch_bounds__(256) void sort_node_lists_kernel(const int32_t* __r
 }
 
 template <int K>
-__global__ __launch_bounds__(256) void assemble_det_kernel(SolveView s, SolveState* __restrict__ st, int save_base) {
+__global__ __launch_bounds__(256) void assemble_det_kernel(SolveView s, SolveState* __restrict__ st, int save_base, float amax_unset) {
     __shared__ int key[HASH];
     __shared__ long long val[2 * HASH];  // fixed-point sums (see FixedScale, fixed_add): integer adds commute, any order gives the same bits
     __shared__ float gpart[4][3], dpart[4];
@@ -775,7 +776,7 @@ __global__ __launch_bounds__(256) void assemble_det_kernel(SolveView s, SolveSta
     if (threadIdx.x == 0) ovf = 0, nkeys = 0;
     __syncthreads();
     const int beg = s.node_ptr[a], end = s.node_ptr[a + 1];
-    const FixedScale fx = fixed_scale_for_rows(solve_fixed_scale(st->amax), end - beg);
+    const FixedScale fx = fixed_scale_for_rows(solve_fixed_scale(st->amax > 0.f ? st->amax : amax_unset), end - beg);
     // pass 1: the set of columns (keys only), the gradient and the diagonal
     float gx = 0.f, gy = 0.f, gz = 0.f, dsum = 0.f;
     for (int p = beg + (int)threadIdx.x; p < end; p += 256) {
@@ -1653,9 +1654,13 @@ hipError_t solve_huber(const SolveView& s, float psi_reg, hipStream_t st) {
 }
 
 hipError_t solve_assemble(const SolveView& s, SolveState* state, int save_base, float w_reg_sq, hipStream_t st) {
-    (void)w_reg_sq;  // (the rows carry it as their tau; the scale of the fixed-point sums comes from SolveState::amax)
-    if (s.deterministic) KDISPATCH(assemble_det_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base));
-    else KDISPATCH(assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base, dev_env_int("DFA_XCD_MAP", 0)));
+    // The rows carry w_reg^2 as their tau; the scale of the fixed-point sums comes from SolveState::amax, which the
+    // re-weighting linearisation in front of this launch has found.  Should no such linearisation have stored one (amax is
+    // still the 0 of solve_reset — nothing in the driver does that today), the sums take the bound every addend obeys,
+    // max(1, w_reg^2), instead of a grid for addends of 1e-30 that the first real one would overflow.
+    const float amax_unset = std::max(1.0f, w_reg_sq);
+    if (s.deterministic) KDISPATCH(assemble_det_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base, amax_unset));
+    else KDISPATCH(assemble_kernel, s.k, <<<s.D, 256, 0, st>>>(s, state, save_base, dev_env_int("DFA_XCD_MAP", 0), amax_unset));
     return hipGetLastError();
 }
 

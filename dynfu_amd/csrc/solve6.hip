@@ -993,7 +993,10 @@ __global__ __launch_bounds__(256, DFA_S6_WAVES) void s6_assemble2_kernel(Solve6V
     int a = blockIdx.x;
     const int tid = threadIdx.x, k = s.k;
 #ifdef DFA_DEV_AB  // DFA_XCD_MAP=1: the experiment above, kept for its counters (profiles/r06_xcd_map.md)
-    if (xcd_map && a < s.D && (s.D & 7) == 0) a = (a & 7) * (s.D >> 3) + (a >> 3);
+    if (xcd_map && a < s.D && (s.D & 7) == 0) {
+        a = (a & 7) * (s.D >> 3) + (a >> 3);           // a contiguous eighth of the order per XCD ...
+        if (xcd_map == 2 && s.xcd_perm) a = s.xcd_perm[a];  // ... of the Morton order of the node positions
+    }
 #endif
     if (a == s.D) {  // one workgroup more than nodes: the energy of the linearisation this launch follows, the state block's bookkeeping
         if (forcing.decided) return;  // (the linearisation's last workgroup has done both)

@@ -75,6 +75,7 @@ struct Solve6Image {  // live vertex / normal maps (borrowed): float4 pixels, Na
 
 struct Solve6View {
     int N, D, k, cap;  // cap = 6x6 blocks per block row (slot 0 = diagonal)
+    const int32_t* xcd_perm;  // development builds, DFA_XCD_MAP=2: nodes along a Morton curve of their positions (else null)
     // problem (borrowed)
     const float* node_pos;  // D x 3
     const float* node_w;    // D

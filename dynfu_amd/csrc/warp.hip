@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void pgrid_scan_kernel(const KnnGridDesc* __re
 // shell 0 / 1 of a fine grid.  Same result either way — the bound only decides when to stop.
 template <int K, bool TIGHT = false>
 __device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32_t* __restrict__ cell_start,
-                                               const float4* __restrict__ sorted, f3 q, KnnList<K>& best) {
+                                               const float4* __restrict__ sorted, f3 q, KnnList<K>& best, bool rescan = false) {
     // TIGHT scans the query's own cell twice (alone, then inside the 3 x 3 x 3 block): harmless for K = 1, where a repeated
     // candidate cannot displace anything, but a K > 1 list would hold the same node twice
     static_assert(!TIGHT || K == 1, "the tight stop bound re-scans the own cell: 1-NN only");
@@ -573,10 +573,14 @@ __device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32
         constexpr int RB = 4;
         auto reach = [&](float r, float w) { return r > w ? (int)fminf((r - w) * g.inv_cs, 1e6f) + 1 : 0; };
         // (nothing within the block: the ball is tried at two cells and grown by one until it holds a point — then that point,
-        // or one nearer inside the same ball, is the answer)
+        // or one nearer inside the same ball, is the answer.  A ball that holds a known point settles at once, so only the
+        // balls that were EMPTY grow — and a grown ball scans only the cells the larger radius adds: per row the two ends of
+        // its x range beyond the range of the ball before, nothing of which held a point.  The first form scanned the whole
+        // ball again on every growth; `rescan` — development builds — keeps that form for the comparison.)
         float rad   = best.dist(K - 1) < 3.0e38f ? sqrtf(best.dist(K - 1)) * 1.0001f : 2.f * g.cs;
         bool settled = false;
         for (int attempt = 0; attempt < RB; ++attempt) {
+            const float rad_p = attempt > 0 && !rescan ? rad - g.cs : -1.f;  // the (empty) ball this lane scanned before
             const int nzl = reach(rad, wall[2][0]), nzh = reach(rad, wall[2][1]), nyl = reach(rad, wall[1][0]), nyh = reach(rad, wall[1][1]);
             const bool ball = inside && !settled && max(max(nzl, nzh), max(nyl, nyh)) <= RB &&
                               max(reach(rad, wall[0][0]), reach(rad, wall[0][1])) <= RB;
@@ -591,7 +595,7 @@ __device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32
                 const int dz = (sz & 1) ? (sz + 1) / 2 : -(sz / 2);
                 if (dz > zh || -dz > zl) continue;  // (wave-uniform)
                 const float ez = dz == 0 ? 0.f : (dz < 0 ? wall[2][0] : wall[2][1]) + (float)(abs(dz) - 1) * g.cs;
-                int rb[2 * RB + 1], re[2 * RB + 1];
+                int rb[2 * RB + 1], re[2 * RB + 1], pb[2 * RB + 1], pe[2 * RB + 1];
 #pragma unroll
                 for (int i = 0; i <= 2 * RB; ++i) {
                     const int dy   = i - RB;
@@ -604,10 +608,17 @@ __device__ __forceinline__ void knn_grid_query(const KnnGridDesc& g, const int32
                     const int x0 = max(cx - reach(sx, wall[0][0]), 0), x1 = min(cx + reach(sx, wall[0][1]), g.dim[0] - 1);
                     const int c  = row ? g.dim[0] * (y + g.dim[1] * z) : 0;
                     const int b = cell_start[c + (row ? x0 : 0)], e = cell_start[c + (row ? x1 + 1 : 0)];
+                    // the part of this row the ball before covered (same formulas at the radius before: a sub-range)
+                    const float remp = rad_p * rad_p - ey * ey - ez * ez;
+                    const bool prow  = row && rad_p > 0.f && remp >= 0.f;
+                    const float sxp  = sqrtf(fmaxf(remp, 0.f));
+                    const int x0p = max(cx - reach(sxp, wall[0][0]), x0), x1p = min(cx + reach(sxp, wall[0][1]), x1);
+                    const int bp = cell_start[c + (prow ? x0p : 0)], ep = cell_start[c + (prow ? x1p + 1 : 0)];
                     rb[i] = row ? b : 0, re[i] = row ? e : 0;
+                    pb[i] = prow ? bp : re[i], pe[i] = prow ? ep : re[i];  // (no ball before: [rb, re) and an empty second part)
                 }
 #pragma unroll
-                for (int i = 0; i <= 2 * RB; ++i) scan_range(rb[i], re[i]);
+                for (int i = 0; i <= 2 * RB; ++i) scan_range(rb[i], pb[i]), scan_range(pe[i], re[i]);
             }
             // every point within `rad` of the query has been looked at: a best inside the ball is the nearest point
             if (ball && best.dist(K - 1) <= rad * rad * 0.9999f) settled = true;
@@ -893,7 +904,7 @@ __global__ __launch_bounds__(256) void correspond_kernel(const float* __restrict
                                                          const float* __restrict__ canon_n, int n_canon,
                                                          const float* __restrict__ live_v, int n_live,
                                                          float* __restrict__ out_v, float* __restrict__ out_n,
-                                                         int32_t* __restrict__ out_idx, KnnGridView grid) {
+                                                         int32_t* __restrict__ out_idx, KnnGridView grid, bool rescan) {
     __shared__ float4 tile[GRID ? 1 : KNN_TILE];
     const int v       = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = v < n_live;
@@ -902,7 +913,7 @@ __global__ __launch_bounds__(256) void correspond_kernel(const float* __restrict
     KnnList<1> best;
     if (GRID) {
         if (!active) return;
-        knn_grid_query<1, true>(*grid.desc, grid.cell_start, grid.sorted, q, best);
+        knn_grid_query<1, true>(*grid.desc, grid.cell_start, grid.sorted, q, best, rescan);
     } else {
         knn_scan<1>(canon_v, n_canon, q, best, tile);
         if (!active) return;
@@ -1110,8 +1121,9 @@ hipError_t launch_correspond(const float* canon_v, const float* canon_n, int n_c
                              hipStream_t s) {
     if (n_live == 0) return hipSuccess;
     dim3 block(256), gridDim((n_live + 255) / 256);
-    if (grid) correspond_kernel<true><<<gridDim, block, 0, s>>>(canon_v, canon_n, n_canon, live_v, n_live, out_v, out_n, out_idx, *grid);
-    else correspond_kernel<false><<<gridDim, block, 0, s>>>(canon_v, canon_n, n_canon, live_v, n_live, out_v, out_n, out_idx, KnnGridView{});
+    const bool rescan = dev_env("DFA_BALL_RESCAN") != nullptr;  // (development builds: a grown ball scans all of its cells again)
+    if (grid) correspond_kernel<true><<<gridDim, block, 0, s>>>(canon_v, canon_n, n_canon, live_v, n_live, out_v, out_n, out_idx, *grid, rescan);
+    else correspond_kernel<false><<<gridDim, block, 0, s>>>(canon_v, canon_n, n_canon, live_v, n_live, out_v, out_n, out_idx, KnnGridView{}, false);
     return hipGetLastError();
 }
 

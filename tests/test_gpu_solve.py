@@ -750,6 +750,25 @@ def test_team_pcg_on_small_problems_matches_the_oracle(A, devlib, monkeypatch, n
     np.testing.assert_allclose(st["final_cost"], st_ref["final_cost"], rtol=1e-3, atol=1e-9)
 
 
+def test_every_row_rejected_and_no_regulariser_leaves_the_nodes_alone(A):
+    """lambda = 0 and live vertices a metre away: every Tukey weight is 0, no row adds anything to the normal matrix, the
+    largest addend the re-weighting linearisation finds (SolveState::amax) is 0 — the assembly's fixed-point grid then comes
+    from the bound every addend obeys instead of from a grid for addends of 1e-30: finite energies, t = 0."""
+    cfg, c, verts, live, _ = _problem("T1")
+    far = (live + np.float32(1.0)).astype(np.float32)
+    s = A.Solver(cfg["D"], len(verts), cfg["k"])
+    s.set_problem(dev(c["node_pos"]), dev(c["node_dq"]), dev(c["node_w"]), dev(verts), dev(far))
+    s.solve(_params(A, num_iter=2, nonlinear_iter=2, linear_iter=50, lambda_=0.0))
+    st = s.stats()
+    assert float(s.tukey_weights().abs().max()) == 0.0
+    assert np.isfinite(st["final_cost"]) and float(s.translations().abs().max()) == 0.0
+    # the same plan, a well-posed problem next: the scale is found again
+    s.set_problem(dev(c["node_pos"]), dev(c["node_dq"]), dev(c["node_w"]), dev(verts), dev(live))
+    s.solve(_params(A, num_iter=2, nonlinear_iter=2, linear_iter=200, lambda_=200.0, pcg_tol=1e-6))
+    assert s.stats()["final_cost"] < 1e-3 * s.stats()["initial_cost"]
+    s.close()
+
+
 @pytest.mark.parametrize("offset", [0.31, 0.4])
 def test_normal_matrix_sums_follow_the_scale_of_the_problem(A, offset):
     """The assembly adds tau w_a w_b as 64-bit fixed point (LDS float adds run a lane at a time on gfx950).  Its grid comes

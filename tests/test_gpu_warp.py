@@ -200,6 +200,39 @@ def test_correspond_a_surface_that_has_moved_by_cells(A, n, shift_cells):
     assert np.array_equal(host(idx), ridx)
 
 
+def test_correspond_a_sparse_neighbourhood_grows_its_ball_without_scanning_it_again(A, devlib, monkeypatch):
+    """Queries two to four cells away from the cloud find their 3 x 3 x 3 block EMPTY: the ball of cells starts at two cells
+    and grows by one until it holds a point, and a grown ball scans only what the larger radius adds (the first
+    form scanned the whole ball again on every growth — DFA_BALL_RESCAN=1 in the development library keeps it).  Same indices
+    as the oracle's exhaustive scan and as the first form; not slower than it."""
+    import torch
+    n = 600000
+    cv, cn, lv = _surface_clouds(n, 200000, n + 5)
+    ext = cv.max(0) - cv.min(0)
+    cs = max(0.5 * float(np.cbrt(ext.prod() / n)), float(ext.max()) / 256)
+    d = lv - synth.SPHERE_C
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rng = np.random.default_rng(9)
+    lv = (lv + d * (cs * rng.uniform(2.2, 4.4, (len(lv), 1)))).astype(np.float32)  # every block empty, two to three growths
+    _, _, ridx = O.correspond(cv, None, lv, threads=8)
+    dcv, dlv = dev(cv), dev(lv)
+    ms = {}
+    for form in ("grow", "rescan"):
+        if form == "rescan":
+            monkeypatch.setenv("DFA_BALL_RESCAN", "1")
+        _, _, idx = A.correspond(dcv, None, dlv)
+        assert np.array_equal(host(idx), ridx), form
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            A.correspond(dcv, None, dlv)
+        e1.record()
+        torch.cuda.synchronize()
+        ms[form] = e0.elapsed_time(e1) / 5
+    monkeypatch.delenv("DFA_BALL_RESCAN")
+    assert ms["grow"] <= 1.1 * ms["rescan"], ms
+
+
 def test_correspond_a_million_points_against_the_reference_kd_tree(A):
     """Clouds of more than half a million points switch to the finer grid (up to 256 cells per axis): a million canonical
     points on the synthetic surface, checked against the reference's own nanoflann KD-tree (oracle/_ref) on 60 000 queries

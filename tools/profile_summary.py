@@ -94,8 +94,10 @@ for mode in ("ref", "northstar"):
 # run this time are carried over from the existing file (their own source / commit stay with them).
 KEYS = {  # pmc run name -> config, then kernel-name fragment -> (key, formula)
     "c2": ("C2", {"integrate_runs_kernel<true": ("fused_integrate", "2F+W"), "pcg_paired_kernel": ("pcg", "F+W")}),
-    "ref_c3": ("C3", {"integrate_runs_kernel<true": ("fused_integrate", "2F+W"), "pcg_mb_step_kernel": ("pcg", "F+W")}),
-    "ref_c4": ("C4", {"integrate_runs_kernel<true": ("fused_integrate", "2F+W"), "pcg_mb_step_kernel": ("pcg", "F+W")}),
+    "ref_c3": ("C3", {"integrate_runs_kernel<true": ("fused_integrate", "2F+W"), "pcg_mb_step_kernel": ("pcg", "F+W"), "pcg_team_kernel": ("pcg", "F+W")}),
+    "ref_c4": ("C4", {"integrate_runs_kernel<true": ("fused_integrate", "2F+W"), "pcg_mb_step_kernel": ("pcg", "F+W"), "pcg_team_kernel": ("pcg", "F+W")}),
+    "raycast_C2": ("C2", {"raycast_points_kernel": ("raycast_points", "F+W"), "raycast_depth_kernel": ("raycast_depth", "F+W")}),
+    "raycast_C4": ("C4", {"raycast_points_kernel": ("raycast_points", "F+W"), "raycast_depth_kernel": ("raycast_depth", "F+W")}),
     "ns_c2": ("C2", {"s6_assemble2_kernel": ("s6_assemble", "F+W"), "s6_linearise_kernel": ("s6_linearise", "2F+W"), "s6_pcg_step_kernel": ("s6_pcg_step", "F+W")}),
     "ns_c3": ("C3", {"s6_assemble2_kernel": ("s6_assemble", "F+W"), "s6_linearise_kernel": ("s6_linearise", "2F+W"), "s6_pcg_step_kernel": ("s6_pcg_step", "F+W")}),
     "ns_c4": ("C4", {"s6_assemble2_kernel": ("s6_assemble", "F+W"), "s6_linearise_kernel": ("s6_linearise", "2F+W"), "s6_pcg_step_kernel": ("s6_pcg_step", "F+W")}),

@@ -12,12 +12,13 @@ cd /tmp && export TMPDIR=/tmp
 export DFA_LIB_PATH=$root/dynfu_amd/libdynfu_amd_dev.so
 lite="--no-cpu-baseline --no-northstar --no-pipelined-probe --no-live-depth --no-end-to-end --no-other-configs --no-multi-sequence --no-raycast --no-rccl-selfcheck --repeats 1"
 ns="--mode northstar --no-cpu-baseline --no-rccl-selfcheck --gn-tol 0 --repeats 1"
-for m in 0 1; do
+for m in ${XCD_MODES:-0 1 2}; do   # 2: the contiguous eighths of the MORTON order of the nodes (north-star assembly only)
   export DFA_XCD_MAP=$m
   for cfg in C3 C4; do
     steps=6; [ $cfg == C4 ] && steps=4
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_xcd_stats_ns_${cfg}_$m -o k -- python3 $root/bench.py $ns --config $cfg --steps $((steps*3)) --warmup 3 > $out/${tag}_xcd_stats_ns_${cfg}_$m.log 2>&1
     timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${tag}_xcd_pmc_ns_${cfg}_$m -o k -- python3 $root/bench.py $ns --config $cfg --steps $steps --warmup 2 > $out/${tag}_xcd_pmc_ns_${cfg}_$m.log 2>&1
+    [ $m == 2 ] && continue
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_xcd_stats_ref_${cfg}_$m -o k -- python3 $root/bench.py $lite --config $cfg --steps $((steps*3)) --warmup 3 > $out/${tag}_xcd_stats_ref_${cfg}_$m.log 2>&1
     timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${tag}_xcd_pmc_ref_${cfg}_$m -o k -- python3 $root/bench.py $lite --config $cfg --steps $steps --warmup 2 > $out/${tag}_xcd_pmc_ref_${cfg}_$m.log 2>&1
   done
