@@ -198,7 +198,6 @@ struct dfa_solver6 {
     int slot_gn[S6_RING] = {};                    // Gauss-Newton iterations solve n enqueued
     unsigned long long solve_seq = 0, folded = 0;  // solves started; solves whose counts are in the history
     int pred[dfa::S6_HIST] = {};                  // iterations per Gauss-Newton iteration: raised at once, lowered by one per solve
-    int seen_last[dfa::S6_HIST] = {};             // ... and what the slot needed in the solve folded last (0: unknown, < 0: skipped)
     struct BudgetKey { int D, N, num_iter, gn_iter, linear_iter; float tol, tol_first, tol_decay, tol_adapt, gn_tol; } budget_key = {};
     bool graph_disabled = false;
     hipStream_t capture_stream = nullptr;  // capture is not allowed on the legacy default stream
@@ -1312,23 +1311,13 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
                 int& pred      = s->pred[gi];
                 // (an iteration behind the end of its outer iteration ran no PCG: its budget decays like one that needed
                 // little — the launches enqueued for it are no-ops every time it is skipped again — but stays known)
-                int& last = s->seen_last[gi];
-                if (seen == dfa::S6_MIRROR_SKIPPED) {
-                    pred = pred > 1 ? pred - 1 : 1;  // (never back to 0 = unknown = the full cap)
-                    last = last < 0 ? -2 : -1;       // skipped once / twice in a row
-                } else if (seen > 0) {
-                    // a count that repeats (within one) from solve to solve needs no decaying maximum above it
-                    pred = last > 0 && std::abs(seen - last) <= 1 ? std::max(seen, last) : std::max(seen, pred - 1);
-                    last = seen;
-                } else if (seen < 0) {
-                    pred = std::max(pred, -2 * seen);  // cut short: twice as many
-                    last = 0;
-                }
+                if (seen == dfa::S6_MIRROR_SKIPPED) pred = pred > 1 ? pred - 1 : 1;  // (never back to 0 = unknown = the full cap)
+                else if (seen > 0) pred = std::max(seen, pred - 1);
+                else if (seen < 0) pred = std::max(pred, -2 * seen);  // cut short: twice as many
             }
         }
         if (reset) {  // another problem (or other stopping rules): what the previous one needed says nothing
             std::memset(s->pred, 0, sizeof(s->pred));
-            std::memset(s->seen_last, 0, sizeof(s->seen_last));
             s->folded = n;  // (solves n - 2, n - 1 of the old problem are never folded)
         }
     } else {
@@ -1374,14 +1363,13 @@ int dfa_solver6_solve(dfa_solver6* s, const float* live_vertex_map, int vertex_s
             // C3 over 30-frame sequences: consecutive frames move a count by up to 2 where it is small and by up to a
             // quarter where it is 30-40; one launch of slack instead of two cut 1-2 PCGs short in a fifth of the frames.)
             int launches = p.linear_iter;
-            if (adaptive && gi < dfa::S6_HIST && s->pred[gi] > 0) {
-                // slack: two launches, a quarter where the counts are large — ONE where the slot's count has just repeated
-                // (within one) in two solves running, and a slot skipped twice running gets one launch in all (40-49 % of the
-                // launches of a C2 / C3 frame returned at entry with two everywhere: VERDICT r05)
-                const int last  = s->seen_last[gi];
-                const int slack = last > 0 && s->pred[gi] <= last + 1 && s->pred[gi] < 16 ? 1 : std::max(2, s->pred[gi] / 4);
-                launches = last == -2 ? 1 : std::min(p.linear_iter, s->pred[gi] + slack);
-            }
+            // (VERDICT r05 item 7 — one launch of slack where a slot's count had repeated in two solves running, one launch for a
+            // slot skipped twice running — was built and measured in round 6: 58 launches for 41 iterations instead of 60 for 36
+            // at C2, 83 for 53 instead of 92 for 47 at C3, and the frames/s inside the run-to-run spread (863.6 against 860,
+            // 331 against 343 over the whole period): a launch that returns at entry costs 3.5 us, a dozen of them 3 % of a
+            // C2 frame.  Not kept.)
+            if (adaptive && gi < dfa::S6_HIST && s->pred[gi] > 0)
+                launches = std::min(p.linear_iter, s->pred[gi] + std::max(2, s->pred[gi] / 4));
             // the PCG launches of one Gauss-Newton iteration are replayed as a HIP graph (one per launch count); if capture
             // is not possible here (it never is on some stream configurations) the launches are issued one by one
             bool replayed = false;
