@@ -2266,10 +2266,11 @@ __global__ __launch_bounds__(TEAM_NT) void pcg_team_kernel(SolveView s, SolveSta
             val[e] = live ? en.x : 0.f;
             col[i] = live ? __float_as_int(en.y) : a;
         }
+        float gcol[E / 2];
 #pragma unroll
-        for (int i = 0; i < E / 2; ++i) ucol[h0 + i] = s.diag[col[i]];
+        for (int i = 0; i < E / 2; ++i) ucol[h0 + i] = s.diag[col[i]], gcol[i] = s.g[3 * col[i] + c];  // (both in one round trip)
 #pragma unroll
-        for (int i = 0; i < E / 2; ++i) ucol[h0 + i] = (ucol[h0 + i] > FLT_EPSILON ? 1.0f / ucol[h0 + i] : 1.0f) * s.g[3 * col[i] + c];
+        for (int i = 0; i < E / 2; ++i) ucol[h0 + i] = (ucol[h0 + i] > FLT_EPSILON ? 1.0f / ucol[h0 + i] : 1.0f) * gcol[i];
 #pragma unroll
         for (int i = 0; i < E / 2; i += 2) colp[(h0 + i) / 2] = (uint32_t)col[i] | ((uint32_t)col[i + 1] << 16);
         __builtin_amdgcn_sched_barrier(0);
