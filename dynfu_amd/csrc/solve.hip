@@ -31,6 +31,8 @@
 #include <cstring>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 
 #include <float.h>
 
@@ -2558,11 +2560,32 @@ static hipError_t launch_team_pcg(const SolveView& s, SolveState* state, int max
     if (tp->epoch < epoch0 || tp->epoch == 0u) tp->epoch = 1u;  // (wrapped: never round 0, the value of a word nobody has written)
     const size_t lds = std::max(sizeof(float2) * (size_t)s.Dpad + sizeof(float) * TEAM_NT, TEAM_MIN_LDS);
     if (max_iter + 1 > TEAM_ROUNDS) return hipErrorInvalidValue;  // (route_pcg asks solve_team_pcg_fits first)
+    // Two team launches of different plans must not share the device: each wants every CU of XCDs 0-2 for its members, and
+    // two half-assembled teams would wait for each other until both time out (correct — the guard launches take over — but
+    // 20 ms lost).  Launches on ONE stream are ordered anyway; a launch on another stream first waits for the event behind
+    // the team launch before it.  Per device, under a lock: plans may be driven from several host threads.
+    struct Turn {
+        hipEvent_t ev      = nullptr;
+        hipStream_t stream = nullptr;
+        bool any           = false;
+    };
+    static std::mutex mu;
+    static std::map<int, Turn> turns;
+    int dev = 0;
+    e       = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    Turn& turn = turns[dev];
+    if (!turn.ev && (e = hipEventCreateWithFlags(&turn.ev, hipEventDisableTiming)) != hipSuccess) return e;
+    if (turn.any && turn.stream != st && (e = hipStreamWaitEvent(st, turn.ev, 0)) != hipSuccess) return e;
     pcg_team_kernel<TEAM_E><<<8 * TEAM_W, TEAM_NT, lds, st>>>(s, state, epoch0, max_iter, pcg_tol, tp->host_abort,
                                                              dev_env_int("DFA_MB_TEAM_ABORT", 0));
     pcg_team_guard_kernel<<<3, 1024, sizeof(float) * (size_t)s.Dpad, st>>>(s, state, max_iter, pcg_tol);
     tp->launches += 1;
-    return hipGetLastError();
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    e           = hipEventRecord(turn.ev, st);
+    turn.stream = st, turn.any = true;
+    return e;
 }
 
 int solve_pcg_max_nodes() { return 32768; }  // bounded by the transposition's LDS histogram (4 B x D)
