@@ -108,7 +108,7 @@ def test_host_combined_solver_runs_reference_opttests(exes):
 @pytest.mark.gpu
 def test_host_tsdf_volume_matches_oracle(exes):
     out = _run(exes["test_host_tsdf"])
-    assert "4 tests, 0 failed" in out
+    assert "5 tests, 0 failed" in out
 
 
 @pytest.mark.gpu
