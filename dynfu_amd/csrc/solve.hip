@@ -2225,12 +2225,18 @@ __global__ __launch_bounds__(TEAM_NT) void pcg_team_kernel(SolveView s, SolveSta
     __syncthreads();
     const int rank = rank_sh;
     if (rank >= TEAM_W) return;  // the team is complete without this workgroup
+    // (ctl->handled[c]: team c has dealt with its coordinate — solved it, or found there was nothing to solve.  The guard
+    // launch solves every coordinate nobody has dealt with: a team that gave up, and a team that never existed — a device
+    // whose XCC_IDs are not 0, 1, 2, a partition mode with fewer XCDs)
     if (st->converged) {         // no-op iteration (see SolveState::converged); booked once
-        if (tid == 0 && c == 0 && rank == 0) st->gn_iters += 1, st->gn_noop += 1;
+        if (tid == 0 && rank == 0) {
+            ctl->handled[c] = 1u;
+            if (c == 0) st->gn_iters += 1, st->gn_noop += 1;
+        }
         return;
     }
-    if ((force_abort >> c) & 1) {  // (development builds: the guard launch's test)
-        if (tid == 0) team_give_up(ctl, c, host_abort);
+    if ((force_abort >> c) & 1) {  // (development builds: the guard launch's test; 8 + mask: leave without a word, as a team that never existed)
+        if (tid == 0 && !(force_abort & 8)) team_give_up(ctl, c, host_abort);
         return;
     }
     float2* mt_s = (float2*)smem;                                      // Dpad x (m, t)
@@ -2358,9 +2364,12 @@ __global__ __launch_bounds__(TEAM_NT) void pcg_team_kernel(SolveView s, SolveSta
             if (!team_wait<true>(words_at(0), round, sm, &ctl->abort[c], TEAM_TICKS_FIRST, bc)) { gave_up = true; break; }
             rz0 = sm[2];
             if (st->grad_first > 0.0 && (double)rz0 <= 1e-12 * st->grad_first) {  // the same decision in every team
-                if (tid == 0 && c == 0 && rank == 0) {
-                    st->gn_iters += 1;
-                    solve_mark_at_floor(st);
+                if (tid == 0 && rank == 0) {
+                    ctl->handled[c] = 1u;
+                    if (c == 0) {
+                        st->gn_iters += 1;
+                        solve_mark_at_floor(st);
+                    }
                 }
                 return;
             }
@@ -2434,6 +2443,7 @@ __global__ __launch_bounds__(TEAM_NT) void pcg_team_kernel(SolveView s, SolveSta
     }
     if (owner) s.t[3 * a + c] += x;
     if (tid == 0 && rank == 0) {
+        ctl->handled[c] = 1u;  // (every member is past the last barrier and adds its rows' x: done when the kernel is)
         // iterations of this launch = those of its slowest coordinate; the last team (or guard workgroup) to arrive books them
         atomicMax(&st->split_iters, it);
         __threadfence();
@@ -2451,18 +2461,27 @@ __global__ __launch_bounds__(TEAM_NT) void pcg_team_kernel(SolveView s, SolveSta
 // gave up, solves coordinate c by itself — the same recurrence and stopping rules in one 1024-thread workgroup, u in LDS,
 // the matrix streamed from the ELL as assembled, the rows' vectors in the plan's mb_* buffers (component c).  Slow (tens of
 // microseconds per iteration) and rare by construction.
-__global__ __launch_bounds__(1024) void pcg_team_guard_kernel(SolveView s, SolveState* __restrict__ st, int max_iter, float pcg_tol) {
+__global__ __launch_bounds__(1024) void pcg_team_guard_kernel(SolveView s, SolveState* __restrict__ st, int max_iter, float pcg_tol,
+                                                              int* host_abort) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float red0[16], red1[16];
-    __shared__ unsigned ab_sh;
+    __shared__ unsigned todo_sh;
     const int c = blockIdx.x, tid = threadIdx.x, D = s.D;
     TeamCtl* ctl = s.team_ctl;
     if (tid == 0) {
-        ab_sh = ctl->abort[c];
-        ctl->abort[c] = 0u, ctl->count[c] = 0u;
+        // the coordinate is this workgroup's if nobody has dealt with it: its team gave up (abort: counted by the team), or no
+        // workgroup of the team launch ever took it (counted here: the plan goes back to the launched form)
+        const unsigned handled = ctl->handled[c], gave_up = ctl->abort[c];
+        todo_sh = st->done ? 0u : !handled;
+        if (todo_sh && !gave_up && host_abort) atomicAdd_system(host_abort, 1);
+        ctl->abort[c] = 0u, ctl->count[c] = 0u, ctl->handled[c] = 0u;
     }
     __syncthreads();
-    if (!ab_sh || st->done || st->converged) return;
+    if (!todo_sh) return;
+    if (st->converged) {  // no-op iteration, booked once — by whoever deals with coordinate 0
+        if (tid == 0 && c == 0) st->gn_iters += 1, st->gn_noop += 1;
+        return;
+    }
     float* u_s = (float*)smem;  // Dpad
     float *xs = (float*)s.mb_x + c, *rs = (float*)s.mb_r + c, *ps = (float*)s.mb_p + c, *ss = (float*)s.mb_s + c;  // [4 a]
     float joint_loc = 0.f;
@@ -2562,12 +2581,14 @@ static hipError_t launch_team_pcg(const SolveView& s, SolveState* state, int max
     if (max_iter + 1 > TEAM_ROUNDS) return hipErrorInvalidValue;  // (route_pcg asks solve_team_pcg_fits first)
     // Two team launches of different plans must not share the device: each wants every CU of XCDs 0-2 for its members, and
     // two half-assembled teams would wait for each other until both time out (correct — the guard launches take over — but
-    // 20 ms lost).  Launches on ONE stream are ordered anyway; a launch on another stream first waits for the event behind
-    // the team launch before it.  Per device, under a lock: plans may be driven from several host threads.
+    // 20 ms lost).  Launches on ONE stream are ordered anyway, and a process that only ever uses one stream for them pays
+    // nothing here.  The first launch on a SECOND stream waits for the device once; from then on every team launch records
+    // an event behind itself and a launch on another stream than the one before waits for it.  Per device, under a lock:
+    // plans may be driven from several host threads.
     struct Turn {
         hipEvent_t ev      = nullptr;
         hipStream_t stream = nullptr;
-        bool any           = false;
+        bool any = false, several = false;
     };
     static std::mutex mu;
     static std::map<int, Turn> turns;
@@ -2576,14 +2597,21 @@ static hipError_t launch_team_pcg(const SolveView& s, SolveState* state, int max
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lock(mu);
     Turn& turn = turns[dev];
-    if (!turn.ev && (e = hipEventCreateWithFlags(&turn.ev, hipEventDisableTiming)) != hipSuccess) return e;
-    if (turn.any && turn.stream != st && (e = hipStreamWaitEvent(st, turn.ev, 0)) != hipSuccess) return e;
+    if (turn.any && turn.stream != st) {
+        if (!turn.several) {
+            if ((e = hipEventCreateWithFlags(&turn.ev, hipEventDisableTiming)) != hipSuccess) return e;
+            if ((e = hipDeviceSynchronize()) != hipSuccess) return e;  // (once per process and device: no event behind the launches so far)
+            turn.several = true;
+        } else if ((e = hipStreamWaitEvent(st, turn.ev, 0)) != hipSuccess) {
+            return e;
+        }
+    }
     pcg_team_kernel<TEAM_E><<<8 * TEAM_W, TEAM_NT, lds, st>>>(s, state, epoch0, max_iter, pcg_tol, tp->host_abort,
                                                              dev_env_int("DFA_MB_TEAM_ABORT", 0));
-    pcg_team_guard_kernel<<<3, 1024, sizeof(float) * (size_t)s.Dpad, st>>>(s, state, max_iter, pcg_tol);
+    pcg_team_guard_kernel<<<3, 1024, sizeof(float) * (size_t)s.Dpad, st>>>(s, state, max_iter, pcg_tol, tp->host_abort);
     tp->launches += 1;
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    e           = hipEventRecord(turn.ev, st);
+    if (turn.several) e = hipEventRecord(turn.ev, st);
     turn.stream = st, turn.any = true;
     return e;
 }

@@ -58,6 +58,7 @@ __device__ __forceinline__ void solve_mark_at_floor(SolveState* st) {
 struct TeamCtl {
     unsigned int count[3];                  // workgroups of team c that have arrived in the launch in flight (zeroed by the guard launch)
     unsigned int abort[3];                  // team c gave up in the launch in flight: the guard launch solves its coordinate
+    unsigned int handled[3];                // team c has dealt with its coordinate in the launch in flight (the guard launch takes what nobody has)
 };
 
 struct SolveView {

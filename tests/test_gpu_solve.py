@@ -729,12 +729,14 @@ def test_team_pcg_of_two_plans_on_two_streams(A):
         s.close()
 
 
-@pytest.mark.parametrize("mask", [2, 7])
+@pytest.mark.parametrize("mask", [2, 7, 8 + 4, 8 + 7])
 def test_team_pcg_guard_solves_what_a_team_gave_up(A, devlib, monkeypatch, mask):
     """DFA_MB_TEAM_ABORT (development builds) makes the teams of the masked coordinates give up at entry, as a team does
-    that cannot assemble on its XCD or meets a row too long for its register slots: the guard launch behind solves those
-    coordinates by itself (same recurrence, one workgroup), the answer is the team's, the abort is counted in pinned memory and
-    the plan takes a launch per iteration from its next solve on — and still gives the same answer."""
+    that cannot assemble on its XCD or meets a row too long for its register slots — with 8 added they leave without a word,
+    as on a device where no workgroup ever lands on that team's XCD (another partition mode, other XCC_IDs): the guard launch
+    behind solves every coordinate nobody has dealt with (same recurrence, one workgroup), the answer is the team's, the event
+    is counted in pinned memory and the plan takes a launch per iteration from its next solve on — and still gives the same
+    answer."""
     cfg, prob, kw = _c3_problem(A, frame=4)
     s = A.Solver(cfg["D"], prob[3].shape[0], cfg["k"])
     s.set_problem(*prob)
