@@ -2579,6 +2579,12 @@ static hipError_t launch_team_pcg(const SolveView& s, SolveState* state, int max
     if (tp->epoch < epoch0 || tp->epoch == 0u) tp->epoch = 1u;  // (wrapped: never round 0, the value of a word nobody has written)
     const size_t lds = std::max(sizeof(float2) * (size_t)s.Dpad + sizeof(float) * TEAM_NT, TEAM_MIN_LDS);
     if (max_iter + 1 > TEAM_ROUNDS) return hipErrorInvalidValue;  // (route_pcg asks solve_team_pcg_fits first)
+    {   // The barrier rounds of a launch are numbered from `epoch0`, a kernel ARGUMENT: a captured launch replayed from a HIP
+        // graph would meet its own flag words of the replay before and sail through its barriers.  Refused loudly (the
+        // launched form above 2 048 nodes synchronises with its stream and was never capturable either).
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return hipErrorStreamCaptureUnsupported;
+    }
     // Two team launches of different plans must not share the device: each wants every CU of XCDs 0-2 for its members, and
     // two half-assembled teams would wait for each other until both time out (correct — the guard launches take over — but
     // 20 ms lost).  Launches on ONE stream are ordered anyway, and a process that only ever uses one stream for them pays

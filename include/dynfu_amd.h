@@ -366,10 +366,14 @@ int dfa_solver_set_problem(dfa_solver* s, const float* node_pos, const float* no
  * the outer iteration's first linearisation and restart the PCG on g - A (t - t_0) when lambda > 0 and gn_tol = 0; the
  * call reads the plan's `converged` flag back every 4th iteration of an outer iteration and stops launching its
  * remaining (or all remaining) iterations once it is set (the iterations not launched are booked as no-ops, like those
- * whose kernels return at entry); larger problems use a many-workgroup
- * PCG whose launches go out in chunks, and the call waits for `stream` about once per Gauss-Newton iteration to read
- * the stop flag.  Only the first case (<= 2048 nodes and <= 8 Gauss-Newton iterations) is therefore asynchronous and
- * capturable into a caller's HIP graph; in the others the call blocks the calling thread (hipStreamSynchronize on
+ * whose kernels return at entry).  Plans of 2 049 .. ~19 000 nodes run their PCG as three teams of persistent workgroups
+ * (a coordinate per XCD, one barrier per iteration through that XCD's L2: DESIGN.md 4.3) — also without any host
+ * synchronisation up to 8 Gauss-Newton iterations, with the same read-back every 4th iteration beyond —; a plan whose
+ * team has given up once (dfa_solver_team_pcg_info), larger plans, and linear_iter > 256 use a many-workgroup PCG whose
+ * launches go out in chunks, and the call then waits for `stream` about once per Gauss-Newton iteration to read the stop
+ * flag.  Capturable into a caller's HIP graph: only <= 2048 nodes with <= 8 Gauss-Newton iterations.  The team PCG
+ * numbers its barrier rounds by a launch argument and REFUSES a capturing stream (DFA_ERR_HIP: a replayed launch would meet
+ * the flag words of the replay before); the many-workgroup form blocks the calling thread (hipStreamSynchronize on
  * `stream`) between its launches, also between two invocations of the overlap callback. */
 /* Order-stable variant of the reference-parity solve: the same bits from the same inputs ("or
  * deterministic segmented reduction for bit-stable results").  Both paths sum a node's rows as 64-bit fixed-point integers
