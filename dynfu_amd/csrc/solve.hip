@@ -2136,7 +2136,8 @@ static hipError_t launch_mb_pcg(const SolveView& s, SolveState* state, int max_i
 #endif
 constexpr int TEAM_W = 32;        // members per team: ONE 1024-thread workgroup per CU of a 32-CU XCD
 constexpr int TEAM_NT = 1024;
-constexpr int TEAM_E = 20;        // register slots per thread (rows of up to J x 20 entries)
+constexpr int TEAM_E = 20;        // register slots per thread (rows of up to J x 20 entries) ...
+constexpr int TEAM_E_TREG = 16;   // ... and of the form that keeps t's replica in registers (rows of up to J x 16)
 constexpr int TEAM_K = 4;         // copies of a flag word = poll attempts served by plain loads
 constexpr int TEAM_ROUNDS = 257;  // exchange areas per launch: barrier rounds 0 .. 256 (the reference's linearIter, dyn_fusion.cpp:186)
 constexpr size_t TEAM_MIN_LDS = 82 * 1024;  // more than half a CU's LDS: one member per CU, nobody else fills its L1
@@ -2209,37 +2210,15 @@ __device__ __forceinline__ bool team_wait(const unsigned long long* __restrict__
     return bc[3] != 0.f;
 }
 
-template <int E>
-__global__ __launch_bounds__(TEAM_NT) void pcg_team_kernel(SolveView s, SolveState* __restrict__ st, unsigned epoch0, int max_iter,
-                                                           float pcg_tol, int* host_abort, int force_abort) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int rank_sh;
-    __shared__ float red[3][TEAM_NT / 64];
-    __shared__ float bc[4];
-    if (st->done) return;
-    const unsigned xcc = xcc_id();
-    if (xcc >= 3u) return;
-    const int c = (int)xcc, tid = threadIdx.x, D = s.D;
-    TeamCtl* ctl = s.team_ctl;
-    if (tid == 0) rank_sh = (int)atomicAdd(&ctl->count[c], 1u);
-    __syncthreads();
-    const int rank = rank_sh;
-    if (rank >= TEAM_W) return;  // the team is complete without this workgroup
-    // (ctl->handled[c]: team c has dealt with its coordinate — solved it, or found there was nothing to solve.  The guard
-    // launch solves every coordinate nobody has dealt with: a team that gave up, and a team that never existed — a device
-    // whose XCC_IDs are not 0, 1, 2, a partition mode with fewer XCDs)
-    if (st->converged) {         // no-op iteration (see SolveState::converged); booked once
-        if (tid == 0 && rank == 0) {
-            ctl->handled[c] = 1u;
-            if (c == 0) st->gn_iters += 1, st->gn_noop += 1;
-        }
-        return;
-    }
-    if ((force_abort >> c) & 1) {  // (development builds: the guard launch's test; 8 + mask: leave without a word, as a team that never existed)
-        if (tid == 0 && !(force_abort & 8)) team_give_up(ctl, c, host_abort);
-        return;
-    }
-    float2* mt_s = (float2*)smem;                                      // Dpad x (m, t)
+// a member's solve: E register slots per thread; TREG: the replica of t at the entry's column lives in a register too, and the
+// exchange carries m alone (4 bytes per row instead of the (m, t) pair: half the copy, 4-byte LDS gathers) — the form for
+// plans whose longest row fits 16 slots per thread
+template <int E, bool TREG>
+__device__ __forceinline__ void team_member(const SolveView& s, SolveState* __restrict__ st, TeamCtl* ctl, char* smem, float (&red)[3][TEAM_NT / 64],
+                                            float* bc, int c, int rank, unsigned epoch0, int max_iter, float pcg_tol, int* host_abort) {
+    const int tid = threadIdx.x, D = s.D;
+    float2* mt_s = (float2*)smem;                                      // Dpad x (m, t) ...
+    float* m_s   = (float*)smem;                                       // ... TREG: Dpad x m
     float* part  = (float*)(smem + sizeof(float2) * (size_t)s.Dpad);  // TEAM_NT partial row sums
     const int R = (D + TEAM_W - 1) / TEAM_W, J = TEAM_NT / R;          // rows per member, threads per row
     const int r0 = rank * R, nrows = max(0, min(R, D - r0));
@@ -2261,8 +2240,10 @@ __global__ __launch_bounds__(TEAM_NT) void pcg_team_kernel(SolveView s, SolveSta
     // (batches of unconditional loads, masked after: a load under a per-slot condition makes hipcc wait for each one by
     // itself — 48 dependent round trips, 35 us, in the first version of this prologue; in two halves: the unpacked columns of
     // all E slots at once cost registers the loop needs)
-    float val[E], ucol[E];
+    float val[E], ucol[E], tcol[TREG ? E : 1];
     uint32_t colp[E / 2];
+#pragma unroll
+    for (int e = 0; e < (TREG ? E : 1); ++e) tcol[e] = 0.f;
 #pragma unroll
     for (int h0 = 0; h0 < E; h0 += E / 2) {
         int col[E / 2];
@@ -2324,7 +2305,11 @@ __global__ __launch_bounds__(TEAM_NT) void pcg_team_kernel(SolveView s, SolveSta
     };
     // (m, t) of the own rows and the member's partial sums for barrier round rr (tag `round`)
     auto publish = [&](int rr, unsigned round, float gp, float dp, float jp, bool with_joint) __attribute__((always_inline)) {
-        if (owner) mt_at(rr)[a] = make_float2(m, tv);  // (a plain store: in the XCD's L2 once acknowledged)
+        // (a plain store: in the XCD's L2 once acknowledged)
+        if (owner) {
+            if (TREG) ((float*)mt_at(rr))[a] = m;
+            else mt_at(rr)[a] = make_float2(m, tv);
+        }
         const float gw = wave_total(gp), dw = wave_total(dp), jw = with_joint ? wave_total(jp) : 0.f;
         if ((tid & 63) == 0) red[0][tid >> 6] = gw, red[1][tid >> 6] = dw, red[2][tid >> 6] = jw;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have been acknowledged by the L2
@@ -2392,7 +2377,7 @@ __global__ __launch_bounds__(TEAM_NT) void pcg_team_kernel(SolveView s, SolveSta
             // this CU: from the L2)
             const float4* src = (const float4*)mt_at(it);
             float4* dst       = (float4*)mt_s;
-            const int n4      = s.Dpad / 2;
+            const int n4      = TREG ? s.Dpad / 4 : s.Dpad / 2;
             for (int i0 = tid; i0 < n4; i0 += 4 * TEAM_NT) {  // four loads in flight per thread
                 float4 v[4];
 #pragma unroll
@@ -2410,11 +2395,24 @@ __global__ __launch_bounds__(TEAM_NT) void pcg_team_kernel(SolveView s, SolveSta
             if (e0 < emax) {
                 uint32_t c01 = colp[e0 / 2], c23 = colp[e0 / 2 + 1];
                 asm volatile("" : "+v"(c01), "+v"(c23));
-                const float2 g0 = mt_s[c01 & 0xffffu], g1 = mt_s[c01 >> 16], g2 = mt_s[c23 & 0xffffu], g3 = mt_s[c23 >> 16];
-                ucol[e0]     = fmaf(-alpha, fmaf(beta, g0.y, g0.x), ucol[e0]);
-                ucol[e0 + 1] = fmaf(-alpha, fmaf(beta, g1.y, g1.x), ucol[e0 + 1]);
-                ucol[e0 + 2] = fmaf(-alpha, fmaf(beta, g2.y, g2.x), ucol[e0 + 2]);
-                ucol[e0 + 3] = fmaf(-alpha, fmaf(beta, g3.y, g3.x), ucol[e0 + 3]);
+                if (TREG) {  // t's replica in a register: the same fmaf on the same numbers as the row's owner
+                    const float g0 = m_s[c01 & 0xffffu], g1 = m_s[c01 >> 16], g2 = m_s[c23 & 0xffffu], g3 = m_s[c23 >> 16];
+                    const int t0 = TREG ? e0 : 0;  // (tcol has one element in the other form: never indexed there)
+                    tcol[t0]                  = fmaf(beta, tcol[t0], g0);
+                    tcol[TREG ? e0 + 1 : 0]   = fmaf(beta, tcol[TREG ? e0 + 1 : 0], g1);
+                    tcol[TREG ? e0 + 2 : 0]   = fmaf(beta, tcol[TREG ? e0 + 2 : 0], g2);
+                    tcol[TREG ? e0 + 3 : 0]   = fmaf(beta, tcol[TREG ? e0 + 3 : 0], g3);
+                    ucol[e0]     = fmaf(-alpha, tcol[t0], ucol[e0]);
+                    ucol[e0 + 1] = fmaf(-alpha, tcol[TREG ? e0 + 1 : 0], ucol[e0 + 1]);
+                    ucol[e0 + 2] = fmaf(-alpha, tcol[TREG ? e0 + 2 : 0], ucol[e0 + 2]);
+                    ucol[e0 + 3] = fmaf(-alpha, tcol[TREG ? e0 + 3 : 0], ucol[e0 + 3]);
+                } else {
+                    const float2 g0 = mt_s[c01 & 0xffffu], g1 = mt_s[c01 >> 16], g2 = mt_s[c23 & 0xffffu], g3 = mt_s[c23 >> 16];
+                    ucol[e0]     = fmaf(-alpha, fmaf(beta, g0.y, g0.x), ucol[e0]);
+                    ucol[e0 + 1] = fmaf(-alpha, fmaf(beta, g1.y, g1.x), ucol[e0 + 1]);
+                    ucol[e0 + 2] = fmaf(-alpha, fmaf(beta, g2.y, g2.x), ucol[e0 + 2]);
+                    ucol[e0 + 3] = fmaf(-alpha, fmaf(beta, g3.y, g3.x), ucol[e0 + 3]);
+                }
             }
         if (owner) {
             pv = fmaf(beta, pv, u), sv = fmaf(beta, sv, w);
@@ -2455,6 +2453,43 @@ __global__ __launch_bounds__(TEAM_NT) void pcg_team_kernel(SolveView s, SolveSta
             st->gn_iters += 1;
         }
     }
+}
+
+__global__ __launch_bounds__(TEAM_NT) void pcg_team_kernel(SolveView s, SolveState* __restrict__ st, unsigned epoch0, int max_iter,
+                                                           float pcg_tol, int* host_abort, int force_abort) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int rank_sh;
+    __shared__ float red[3][TEAM_NT / 64];
+    __shared__ float bc[4];
+    if (st->done) return;
+    const unsigned xcc = xcc_id();
+    if (xcc >= 3u) return;
+    const int c = (int)xcc, tid = threadIdx.x, D = s.D;
+    TeamCtl* ctl = s.team_ctl;
+    if (tid == 0) rank_sh = (int)atomicAdd(&ctl->count[c], 1u);
+    __syncthreads();
+    const int rank = rank_sh;
+    if (rank >= TEAM_W) return;  // the team is complete without this workgroup
+    // (ctl->handled[c]: team c has dealt with its coordinate — solved it, or found there was nothing to solve.  The guard
+    // launch solves every coordinate nobody has dealt with: a team that gave up, and a team that never existed — a device
+    // whose XCC_IDs are not 0, 1, 2, a partition mode with fewer XCDs)
+    if (st->converged) {         // no-op iteration (see SolveState::converged); booked once
+        if (tid == 0 && rank == 0) {
+            ctl->handled[c] = 1u;
+            if (c == 0) st->gn_iters += 1, st->gn_noop += 1;
+        }
+        return;
+    }
+    if ((force_abort >> c) & 1) {  // (development builds: the guard launch's test; 8 + mask: leave without a word, as a team that never existed)
+        if (tid == 0 && !(force_abort & 8)) team_give_up(ctl, c, host_abort);
+        return;
+    }
+    // which form: the longest row of the matrix (SolveState::max_row_nnz, raised by the assembly in front of this launch: the
+    // same value in every workgroup) against the 16 slots per thread of the form that keeps t's replica in registers
+    const int rows_ = (D + TEAM_W - 1) / TEAM_W, j_ = TEAM_NT / rows_;
+    const bool treg = st->max_row_nnz <= j_ * TEAM_E_TREG && !(force_abort & 16);  // (development builds: 16 = the (m, t) form always)
+    if (treg) team_member<TEAM_E_TREG, true>(s, st, ctl, smem, red, bc, c, rank, epoch0, max_iter, pcg_tol, host_abort);
+    else team_member<TEAM_E, false>(s, st, ctl, smem, red, bc, c, rank, epoch0, max_iter, pcg_tol, host_abort);
 }
 
 // The guard behind every team launch: workgroup c resets team c's arrival counter for the next launch and, if the team
@@ -2571,7 +2606,7 @@ template <class Kernel>
 static hipError_t allow_big_lds(Kernel* k);
 
 static hipError_t launch_team_pcg(const SolveView& s, SolveState* state, int max_iter, float pcg_tol, TeamPcg* tp, hipStream_t st) {
-    hipError_t e = allow_big_lds(pcg_team_kernel<TEAM_E>);
+    hipError_t e = allow_big_lds(pcg_team_kernel);
     if (e == hipSuccess) e = allow_big_lds(pcg_team_guard_kernel);
     if (e != hipSuccess) return e;
     const unsigned epoch0 = tp->epoch;
@@ -2612,7 +2647,7 @@ static hipError_t launch_team_pcg(const SolveView& s, SolveState* state, int max
             return e;
         }
     }
-    pcg_team_kernel<TEAM_E><<<8 * TEAM_W, TEAM_NT, lds, st>>>(s, state, epoch0, max_iter, pcg_tol, tp->host_abort,
+    pcg_team_kernel<<<8 * TEAM_W, TEAM_NT, lds, st>>>(s, state, epoch0, max_iter, pcg_tol, tp->host_abort,
                                                              dev_env_int("DFA_MB_TEAM_ABORT", 0));
     pcg_team_guard_kernel<<<3, 1024, sizeof(float) * (size_t)s.Dpad, st>>>(s, state, max_iter, pcg_tol, tp->host_abort);
     tp->launches += 1;

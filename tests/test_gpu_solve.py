@@ -666,7 +666,8 @@ def _c3_problem(A, frame=7):
     return cfg, (nodes, node_dq, node_w, verts, live), kw
 
 
-def test_team_pcg_against_a_launch_per_iteration(A, devlib, monkeypatch):
+@pytest.mark.parametrize("pair_form", [False, True])
+def test_team_pcg_against_a_launch_per_iteration(A, devlib, monkeypatch, pair_form):
     """The team PCG (pcg_team_kernel: no kernel boundary per iteration) against the launched form it replaces
     (pcg_mb_step_kernel, DFA_MB_TEAM=0 in the development library) on a C3 frame with the bench's parameters: the same
     Gauss-Newton iterations, PCG iteration counts within 10 % (per-coordinate stopping instead of the joint one), node
@@ -674,6 +675,10 @@ def test_team_pcg_against_a_launch_per_iteration(A, devlib, monkeypatch):
     as aborts and a plan that went back to launches)."""
     cfg, prob, kw = _c3_problem(A)
     res = {}
+    # two forms of the team PCG: t's replica in registers and m alone exchanged (rows that fit 16 slots per thread: this
+    # problem), or (m, t) pairs exchanged (longer rows; DFA_MB_TEAM_ABORT=16 selects it at any row length)
+    if pair_form:
+        monkeypatch.setenv("DFA_MB_TEAM_ABORT", "16")
     for form in ("0", "1"):
         monkeypatch.setenv("DFA_MB_TEAM", form)
         s = A.Solver(cfg["D"], prob[3].shape[0], cfg["k"])
@@ -686,6 +691,7 @@ def test_team_pcg_against_a_launch_per_iteration(A, devlib, monkeypatch):
             t200, info200 = host(s.translations()), s.team_pcg_info()
         s.close()
     monkeypatch.delenv("DFA_MB_TEAM")
+    monkeypatch.delenv("DFA_MB_TEAM_ABORT", raising=False)
     (t0, st0, i0), (t1, st1, i1) = res["0"], res["1"]
     assert i0["launches"] == 0 and i1["launches"] > 0 and i1["aborts"] == 0
     assert st0["gn_iters"] == st1["gn_iters"] and st0["gn_noop"] == st1["gn_noop"]

@@ -34,8 +34,13 @@ def main():
     with _lib.use_library(_lib.dev_lib_path()):
         for name in args.configs:
             rec = {}
-            for form, env in (("launched", "0"), ("team", "1")):
+            # team_pair: the form that exchanges (m, t) pairs at any row length (DFA_MB_TEAM_ABORT=16); team: t's replica in
+            # registers where the longest row fits 16 slots per thread
+            for form, env, flag in (("launched", "0", None), ("team_pair", "1", "16"), ("team", "1", None)):
                 os.environ["DFA_MB_TEAM"] = env
+                os.environ.pop("DFA_MB_TEAM_ABORT", None)
+                if flag:
+                    os.environ["DFA_MB_TEAM_ABORT"] = flag
                 seq = bench.Sequence(name, dev, n_frames=6)
                 seq.fuse_first = False
                 for f in range(5):
@@ -84,6 +89,7 @@ def main():
                     s2.close()
                 del seq
                 torch.cuda.empty_cache()
+            rec["max_abs_diff_team_forms_m"] = float(np.abs(rec["team_t"] - rec.pop("team_pair_t")).max())  # (round-off: the assembly's order)
             rec["max_abs_diff_team_vs_launched_m"] = float(np.abs(rec.pop("team_t") - rec.pop("launched_t")).max())
             out[name] = rec
             print(name, json.dumps(rec), flush=True)
