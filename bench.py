@@ -571,6 +571,26 @@ def live_depth_probe(cfg_name, device, steps=30, warmup=5, seq=None):
     return out
 
 
+def cpu_quota():
+    """CPUs' worth of time the cgroup grants this process (cpu.max of cgroup v2, cfs quota / period of v1), or None: on the
+    GPU boxes of this pool nproc and the affinity mask say 256 while the quota is 16 — 256 OpenMP threads then time-slice
+    each other on 16 CPUs' worth of time, which is what made round 5's `all_cores` figure 25 x slower than 16 threads"""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = float(f.read())
+        return quota / period if quota > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline6(cfg_name, frames, params):
     """CPU statement of the north-star frame (oracle/solve6_oracle.c, double precision) on the host cores."""
     import oracle as O
@@ -930,9 +950,11 @@ def cpu_baseline(cfg_name, frames, variants=True):
     import oracle as O
     from dynfu_amd import synth
     cfg = synth.CONFIGS[cfg_name]
-    usable, machine = host_cores()
+    nproc, machine = host_cores()
+    quota = cpu_quota()
+    usable = max(1, min(nproc, int(quota + 0.5))) if quota else nproc  # CPUs this process can really keep busy
     forced = os.environ.get("DFA_CPU_THREADS")
-    counts = [int(forced)] if forced else sorted({min(t, usable) for t in CPU_SWEEP_THREADS})
+    counts = [int(forced)] if forced else sorted({min(t, nproc) for t in CPU_SWEEP_THREADS} | {usable})
     fx, fy, cx, cy = synth.intrinsics(cfg)
     voxel, trunc, vol2cam, _, _ = synth.volume_params(cfg)
     dim, k = cfg["dim"], cfg["k"]
@@ -970,11 +992,11 @@ def cpu_baseline(cfg_name, frames, variants=True):
     out = dict(value=by[best]["value"], unit="frames/s", cores=int(best), kind="port", by_threads=by,
                sample="%d full frames of config %s per thread count (compute_dists, clear, integrate %d^3, k-NN graph, %d GN x PCG "
                       "(%d PCG iterations in total), write-back, warpToLive) by the C restatement in oracle/, fp32, OpenMP over "
-                      "%s threads of the host's %d cores (%d usable by this process): `value` is the best of the sweep"
-                      % (frames, cfg_name, dim, cfg["gn_iters"], pcg, " / ".join(by), machine, usable),
+                      "%s threads of the host's %d cores (affinity mask %d, cgroup quota %s CPUs): `value` is the best of the sweep"
+                      % (frames, cfg_name, dim, cfg["gn_iters"], pcg, " / ".join(by), machine, nproc, "%.0f" % quota if quota else "none"),
                sample_short="%d frames of %s per thread count (%s), C restatement in oracle/ (not Ceres), fp32, OpenMP; best reported"
                             % (frames, cfg_name, "/".join(by)),
-               host_cores=dict(nproc=usable, machine=machine))
+               host_cores=dict(nproc=nproc, machine=machine, cgroup_quota_cpus=quota, usable=usable))
     if variants:
         dt1, _, _ = run(1, 1)
         out["single_thread"] = dict(value=round(1 / dt1, 4), unit="frames/s", cores=1, sample="1 frame, %.1f s" % dt1)
@@ -983,8 +1005,11 @@ def cpu_baseline(cfg_name, frames, variants=True):
         else:
             dta, _, _ = run(usable, 1)
             out["all_cores"] = dict(value=round(1 / dta, 4), unit="frames/s", cores=usable, sample="1 frame, %.1f s" % dta)
-        out["why_all_cores_loses"] = ("one short OpenMP region per PCG iteration (a 262 k-row loop, then a serial scatter): "
-                                      "fork/join over every core costs more than the loop")
+        # `all_cores` = every CPU this process can keep busy: the cgroup quota where there is one (threads beyond it only
+        # time-slice each other), else the affinity mask
+        out["cores_note"] = (("cgroup quota: %.0f CPUs' worth of time on a %d-thread host (threads beyond it time-slice each other); "
+                              % (quota, machine) if quota and quota < nproc else "") +
+                             "one short OpenMP region per PCG iteration, then a serial scatter")
     out["seconds_total"] = round(time.perf_counter() - t_total, 1)
     return out, t_last, frames - 1
 
@@ -1232,9 +1257,9 @@ def contract_line(out, detail_file):
         line["cpu_baseline"] = dict(value=cb.get("value"), unit=cb.get("unit"), cores=cb.get("cores"), kind=cb.get("kind"),
                                     sample=_short(cb.get("sample_short", cb.get("sample", ""))),
                                     single_thread=_val(cb, "single_thread", "value"), all_cores=_val(cb, "all_cores", "value"),
-                                    host_cores=_val(cb, "host_cores", "nproc"),
+                                    host_cores=_val(cb, "host_cores", "nproc"), cpu_quota=_val(cb, "host_cores", "cgroup_quota_cpus"),
                                     by_threads={k: v.get("value") for k, v in (cb.get("by_threads") or {}).items()} or None,
-                                    why_all_cores_loses=_short(cb.get("why_all_cores_loses", "")) or None)
+                                    cores_note=_short(cb.get("cores_note", "")) or None)
     sec = {}
     lat = out.get("frame_latency_ms")
     if isinstance(lat, dict):

@@ -274,7 +274,10 @@ def test_bench_line_has_the_contract_fields():
     assert str(cb["cores"]) in cb["by_threads"]
     # single thread and all host cores (nproc stated) beside it
     assert cb["single_thread"]["cores"] == 1 and cb["single_thread"]["value"] > 0
-    assert cb["all_cores"]["cores"] == cb["host_cores"]["nproc"] >= 1 and cb["all_cores"]["value"] > 0
+    # "all cores" = every CPU the process can keep busy: the cgroup quota where the box sets one (16 of 256 on this pool)
+    hc = cb["host_cores"]
+    assert cb["all_cores"]["cores"] == hc["usable"] >= 1 and cb["all_cores"]["value"] > 0
+    assert hc["usable"] <= hc["nproc"] and (hc["cgroup_quota_cpus"] is None or hc["usable"] <= hc["cgroup_quota_cpus"] + 0.5)
     # the oracle's translations of the CPU sample's last frame against the HIP solve of the same frame
     assert d["config"]["max_abs_translation_diff_vs_oracle_m"] <= 2e-5
     c1 = d["other_configs"]["C1_ref"]  # BASELINE config 1 IS the CPU-path configuration: timed on both sides
