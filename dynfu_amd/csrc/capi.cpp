@@ -808,7 +808,8 @@ int dfa_solver_create(int max_D, int max_N, int k, dfa_solver** out) {
         hipError_t e = s->grid.reserve(max_D);
         if (e != hipSuccess) rc = hip_fail(e, "hipMalloc (node grid)");
     }
-    if (rc == DFA_OK && dfa::solve_team_pcg_fits(max_D)) {
+    // (plans of up to 2 048 nodes solve in the register-resident kernels: no team buffers for them outside development builds)
+    if (rc == DFA_OK && dfa::solve_team_pcg_fits(max_D) && (max_D > 2048 || dfa::kDevAB)) {
         // team PCG: control block (zeroed once: barrier rounds only ever grow), exchange buffer, the pinned abort count
         s->v.team_stride = (max_D + 3) & ~3;
         rc = plan_alloc(s, &s->v.team_ctl, 1);
