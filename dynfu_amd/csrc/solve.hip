@@ -2112,6 +2112,8 @@ static hipError_t launch_mb_pcg(const SolveView& s, SolveState* state, int max_i
 //   row owner                p, s, x, r, t, u as in pcg_mb_step_kernel;  m_(i+1) = M^-1 w_(i+1);  partial (r, u), (w, u)
 //   publish                  (m_(i+1), t_i) of the own rows, s_waitcnt vmcnt(0), workgroup barrier, then the member's flag
 //                            words {round i + 1, partial}
+// Where the longest row of the matrix fits TEAM_E_TREG slots per thread, t's replica at the entry's column lives in a register
+// as well and m ALONE is exchanged (half the copy, 4-byte gathers): team_member<16, true>; longer rows: team_member<20, false>.
 //
 // How the exchange stays inside the XCD's L2.  Agent-scope atomics (sc1) are the textbook tool and were the first version:
 // every such load is a trip over the fabric (1.2-1.5 us measured here; 2 MB of them per team and iteration for the vector
@@ -2129,8 +2131,9 @@ static hipError_t launch_mb_pcg(const SolveView& s, SolveState* state, int max_i
 // What makes this enough is that writer and reader share the L2 — which the XCC_ID census guarantees and nothing else does.
 // Every spin is bounded by the wall clock (s_memrealtime): a team that cannot assemble (placement, starvation by other
 // kernels) or a row that does not fit the register slots ABORTS before it has changed anything, and the guard launch behind
-// (pcg_team_guard_kernel: one workgroup per coordinate, returns at entry otherwise) solves that coordinate by itself; the
-// host sees the abort count in pinned memory at its next call and goes back to the launched form.
+// (pcg_team_guard_kernel: one workgroup per coordinate, returns at entry otherwise) solves every coordinate nobody has dealt
+// with — a team that gave up, a team no workgroup ever joined — by itself; the host sees the count in pinned memory at its
+// next call and goes back to the launched form.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
 #error "pcg_team_kernel orders its stores with s_waitcnt vmcnt(0): gfx9 only (gfx10+ count stores in vscnt)"
 #endif
