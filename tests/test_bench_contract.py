@@ -331,3 +331,19 @@ def test_forced_launcher_on_the_gpu_box():
     assert line["n_gpus"] == 1 and line["config"]["ranks_seen"] == 1 and line["config"]["launcher"] == "bench.py"
     assert line["config"]["rccl_selfcheck"]["ok"] is True and line["config"]["rccl_selfcheck"]["backend"] == "nccl"
     assert line["value"] > 30.0 and line["steps"] == 5
+
+
+@pytest.mark.gpu
+def test_c3_line_prices_the_team_pcg():
+    """`--config C3` (4 096 nodes: above the register-resident kernels): the dominant kernel of the line is the team PCG
+    (pcg_team_kernel: three teams of persistent workgroups, a coordinate per XCD), priced on the HBM view like every other; no
+    team gave up during the run."""
+    r = _bench("--config", "C3", "--steps", "8", "--warmup", "3", "--no-cpu-baseline", "--no-end-to-end", "--no-other-configs",
+               "--no-northstar", "--no-live-depth", "--no-multi-sequence", "--no-raycast", "--no-pipelined-probe", timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line, d = _line(r.stdout), _detail()
+    rf = d["roofline"]
+    assert "pcg_team_kernel" in rf["kernel"] and line["roofline"]["kernel"].startswith("pcg_team_kernel")
+    assert rf["team_pcg"]["aborts"] == 0 and not rf["team_pcg"]["disabled"] and rf["team_pcg"]["launches"] > 0
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["launches_per_frame"] == 10
+    assert line["value"] > 30.0 and line["config"]["max_abs_translation_error_vs_ground_truth_m"] < 1e-4
