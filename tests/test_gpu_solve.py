@@ -284,9 +284,13 @@ def test_multi_workgroup_pcg_matches_the_oracle_and_the_single_workgroup_kernels
         np.testing.assert_allclose(short[v]["final_cost"], short["1"]["final_cost"], rtol=1e-3)
 
 
-def test_more_than_8192_nodes(A):
-    """12 288 nodes: beyond the single-workgroup PCG; the ground-truth field is recovered"""
-    cfg = dict(synth.CONFIGS["T1"], D=12288, k=4)
+@pytest.mark.parametrize("D,k", [(9216, 4), (12288, 4), (12288, 8)])
+def test_more_than_8192_nodes(A, D, k):
+    """9 216 / 12 288 nodes: beyond the single-workgroup PCG (the team PCG: 288 / 384 rows per member, three / two threads per
+    row); the ground-truth field is recovered.  k = 8 at 12 288 nodes: rows of the normal matrix may be longer than the 2 x 20
+    register slots two threads hold — then the teams give up before they have written anything, the guard launch solves the
+    system, the plan goes on with a launch per iteration: the answer is the same either way."""
+    cfg = dict(synth.CONFIGS["T1"], D=D, k=k)
     c = synth.canonical(cfg)
     k = cfg["k"]
     verts = c["verts"][::8].copy()  # 16 vertices per node
@@ -308,7 +312,11 @@ def test_more_than_8192_nodes(A):
                                    psi_reg=synth.SOLVER["psi_reg"])
     assert np.abs(t - t_ref).max() <= 5e-5
     info = s.team_pcg_info()  # (98 KB of (m, t) pairs per member: the team PCG, 384 rows per member, two threads per row)
-    assert info["launches"] >= 2 and info["aborts"] == 0 and not info["disabled"], info
+    rows = (D + 31) // 32
+    if st["max_row_nnz"] <= (1024 // rows) * 20:
+        assert info["launches"] >= 2 and info["aborts"] == 0 and not info["disabled"], info
+    else:  # a row too long for the slots: every team said so, the guard launch solved, the host has seen it
+        assert info["launches"] >= 1 and info["aborts"] >= 1, (info, st["max_row_nnz"])
     s.close()
 
 
